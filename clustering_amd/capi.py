@@ -1,0 +1,74 @@
+"""ctypes binding of the C ABI in include/dc_density.h (clustering_amd/lib/libdcdensity.so).
+
+There is deliberately no fallback: if the HIP library is missing or cannot be loaded,
+importing this module raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C clustering_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdcdensity.so")
+
+DC_OK = 0
+VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA = 0, 1, 2
+VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA}
+
+# every symbol include/dc_density.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = (
+    "dc_hip_last_error", "dc_hip_abi_version", "dc_hip_device_count", "dc_hip_workspace_bytes",
+    "dc_hip_populations_dev", "dc_hip_free_energies_dev", "dc_hip_nearest_neighbors_dev",
+    "dc_hip_sigma2_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
+)
+
+
+class DensityLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise DensityLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()). "
+            "clustering_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    lib.dc_hip_last_error.restype = C.c_char_p
+    lib.dc_hip_last_error.argtypes = []
+    lib.dc_hip_abi_version.restype = i32
+    lib.dc_hip_device_count.restype = i32
+    lib.dc_hip_workspace_bytes.restype = sz
+    lib.dc_hip_workspace_bytes.argtypes = [sz, sz, sz]
+    lib.dc_hip_populations_dev.restype = i32
+    lib.dc_hip_populations_dev.argtypes = [vp, sz, sz, C.POINTER(C.c_float), sz, sz, sz, vp, vp, sz,
+                                           i32, vp]
+    lib.dc_hip_free_energies_dev.restype = i32
+    lib.dc_hip_free_energies_dev.argtypes = [vp, sz, vp, C.POINTER(C.c_uint32), vp]
+    lib.dc_hip_nearest_neighbors_dev.restype = i32
+    lib.dc_hip_nearest_neighbors_dev.argtypes = [vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, vp, sz,
+                                                 i32, vp]
+    lib.dc_hip_sigma2_dev.restype = i32
+    lib.dc_hip_sigma2_dev.argtypes = [vp, sz, C.POINTER(C.c_double), vp]
+    lib.dc_hip_populations.restype = i32
+    lib.dc_hip_populations.argtypes = [vp, sz, sz, vp, sz, sz, sz, i32, vp]
+    lib.dc_hip_nearest_neighbors.restype = i32
+    lib.dc_hip_nearest_neighbors.argtypes = [vp, sz, sz, vp, sz, sz, i32, vp, vp, vp, vp]
+    lib.dc_hip_density_all.restype = i32
+    lib.dc_hip_density_all.argtypes = [vp, sz, sz, vp, sz, sz, i32, vp, vp, vp, vp, vp, vp]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != DC_OK:
+        msg = lib.dc_hip_last_error().decode("utf-8", "replace")
+        raise DensityLibraryError(f"{what or 'dc_hip call'} failed (status {rc}): {msg}")
+
+
+def device_count():
+    n = lib.dc_hip_device_count()
+    if n < 0:
+        check(n, "dc_hip_device_count")
+    return n

@@ -1,0 +1,472 @@
+// dc_capi.hip -- the C ABI of include/dc_density.h on top of the HIP kernels (gfx950).
+// Host-side orchestration only: argument checks, memsets, launches, the host-libm free-energy
+// table and the host-pointer convenience wrappers that mirror the reference's per-GPU functions
+// (density_clustering_cuda.cu:45-137, :184-284).  No CPU implementation of the sweeps exists
+// here: without a HIP device every compute entry point fails with DC_ERR_NO_DEVICE / DC_ERR_HIP.
+#include "../../include/dc_density.h"
+#include "dc_common.hpp"
+#include "dc_mfma.hpp"
+
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define DC_HIP_TRY(expr)                                                                   \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(DC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                               \
+  } while (0)
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return DC_OK;
+}
+
+int check_sizes(size_t n_rows, size_t n_cols, size_t i_from, size_t i_to) {
+  if (n_cols == 0) return fail(DC_ERR_INVALID_ARGUMENT, "n_cols must be >= 1");
+  if (n_rows + 1 > (size_t)UINT32_MAX)
+    return fail(DC_ERR_TOO_LARGE, "n_rows=%zu: frame ids must fit uint32", n_rows);
+  if (n_rows * n_cols > (size_t)UINT32_MAX * 4ull)
+    return fail(DC_ERR_TOO_LARGE, "n_rows*n_cols=%zu too large", n_rows * n_cols);
+  if (i_from > i_to || i_to > n_rows)
+    return fail(DC_ERR_INVALID_ARGUMENT, "row range [%zu, %zu) outside [0, %zu)", i_from, i_to,
+                n_rows);
+  if (n_cols > (size_t)dc::kMaxColsGeneric)
+    return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported (max %d)", n_cols,
+                dc::kMaxColsGeneric);
+  return DC_OK;
+}
+
+// fe value of one population, exactly as the reference binary computes it
+// (density_clustering.cpp:201-209 under -ffast-math: reciprocal hoisted, double libm log).
+inline float fe_of_pop(uint32_t pop, float rec) {
+  const float q = (float)pop * rec;
+  return (float)(-log((double)q));
+}
+
+void fill_fe_table(std::vector<float>& table, uint32_t max_pop) {
+  const float rec = 1.0f / (float)max_pop;
+  const size_t n = table.size();
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nt = (n < (1u << 16)) ? 1u : std::min(hw, 16u);
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t p = lo; p < hi; ++p) table[p] = fe_of_pop((uint32_t)p, rec);
+  };
+  if (nt == 1) {
+    work(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t lo = t * chunk, hi = std::min(n, lo + chunk);
+    if (lo < hi) th.emplace_back(work, lo, hi);
+  }
+  for (auto& x : th) x.join();
+}
+
+bool want_mfma(int variant, size_t n_cols) {
+  if (variant == DC_VARIANT_DIRECT) return false;
+  return dc::mfma_supports(n_cols);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dc_hip_last_error(void) { return g_last_error.c_str(); }
+
+int dc_hip_abi_version(void) { return 1; }
+
+int dc_hip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e == hipErrorNoDevice) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(DC_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  return n;
+}
+
+size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radii) {
+  (void)n_radii;
+  return dc::mfma_workspace_bytes(n_rows, n_cols);
+}
+
+int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, const float* radii,
+                           size_t n_radii, size_t i_from, size_t i_to, uint32_t* d_pops,
+                           void* d_workspace, size_t workspace_bytes, int variant, void* stream) {
+  if (int rc = check_sizes(n_rows, n_cols, i_from, i_to)) return rc;
+  if (n_radii == 0 || n_rows == 0) return DC_OK;
+  if (!d_coords || !radii || !d_pops) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_radii * n_rows, s));
+  if (i_from == i_to) return DC_OK;
+  const bool mfma = want_mfma(variant, n_cols);
+  if (variant == DC_VARIANT_MFMA && !mfma)
+    return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
+  if (mfma) {
+    if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
+      return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
+                  dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
+    if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, s))
+      return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
+  }
+  for (size_t r0 = 0; r0 < n_radii; r0 += dc::kMaxRadiiPerLaunch) {
+    const int n_rad = (int)std::min((size_t)dc::kMaxRadiiPerLaunch, n_radii - r0);
+    dc::Rad2 rad2;
+    for (int r = 0; r < dc::kMaxRadiiPerLaunch; ++r)
+      rad2.v[r] = (r < n_rad) ? radii[r0 + r] * radii[r0 + r] : -1.0f;  // fl32(r*r), :137-140
+    uint32_t* out = d_pops + r0 * n_rows;
+    if (mfma) {
+      dc::launch_pop_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
+                          (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
+    } else if (!dc::launch_pop_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols,
+                                      (uint32_t)i_from, (uint32_t)i_to, rad2, n_rad, out, s)) {
+      return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported", n_cols);
+    }
+    if (int rc = check_launch("population sweep launch")) return rc;
+  }
+  return DC_OK;
+}
+
+int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
+                             uint32_t* max_pop_out, void* stream) {
+  if (n_rows == 0) {
+    if (max_pop_out) *max_pop_out = 0;
+    return DC_OK;
+  }
+  if (!d_pops || !d_fe) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n_rows + 1 > (size_t)UINT32_MAX) return fail(DC_ERR_TOO_LARGE, "n_rows too large");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* d_max = nullptr;
+  DC_HIP_TRY(hipMalloc((void**)&d_max, sizeof(uint32_t)));
+  dc::launch_max_u32(d_pops, (uint32_t)n_rows, d_max, s);
+  uint32_t max_pop = 0;
+  hipError_t e = hipMemcpyAsync(&max_pop, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_max);
+  if (e != hipSuccess) return fail(DC_ERR_HIP, "max population: %s", hipGetErrorString(e));
+  if (max_pop_out) *max_pop_out = max_pop;
+  // one double log per DISTINCT population value, evaluated by the host libm like the
+  // reference (which computes every FE on the host, density_clustering.cpp:687)
+  std::vector<float> table((size_t)max_pop + 1);
+  fill_fe_table(table, max_pop);
+  float* d_table = nullptr;
+  DC_HIP_TRY(hipMalloc((void**)&d_table, sizeof(float) * table.size()));
+  e = hipMemcpyAsync(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    dc::launch_fe_gather(d_pops, (uint32_t)n_rows, d_table, d_fe, s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_table);
+  if (e != hipSuccess) return fail(DC_ERR_HIP, "free-energy gather: %s", hipGetErrorString(e));
+  return DC_OK;
+}
+
+int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                 const float* d_fe, size_t i_from, size_t i_to, uint32_t* d_nn_idx,
+                                 float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
+                                 void* d_workspace, size_t workspace_bytes, int variant,
+                                 void* stream) {
+  if (int rc = check_sizes(n_rows, n_cols, i_from, i_to)) return rc;
+  if (n_rows == 0) return DC_OK;
+  if (!d_coords || !d_fe || !d_nn_idx || !d_nn_d2 || !d_hd_idx || !d_hd_d2)
+    return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (i_from != 0 || i_to != n_rows)
+    dc::launch_nn_init((uint32_t)n_rows, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, s);
+  if (i_from == i_to) return check_launch("nn init");
+  const bool mfma = want_mfma(variant, n_cols);
+  if (variant == DC_VARIANT_MFMA && !mfma)
+    return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
+  if (mfma) {
+    if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
+      return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
+                  dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
+    if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, s))
+      return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
+    dc::launch_nn_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
+                       (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
+  } else if (!dc::launch_nn_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe,
+                                   (uint32_t)i_from, (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx,
+                                   d_hd_d2, s)) {
+    return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported", n_cols);
+  }
+  return check_launch("nearest-neighbour sweep launch");
+}
+
+int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2_out, void* stream) {
+  if (!sigma2_out) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n_rows == 0) {
+    *sigma2_out = 0.0 / 0.0;  // the reference divides by nh.size() == 0
+    return DC_OK;
+  }
+  std::vector<float> h(n_rows);
+  hipStream_t s = (hipStream_t)stream;
+  DC_HIP_TRY(hipMemcpyAsync(h.data(), d_nn_d2, sizeof(float) * n_rows, hipMemcpyDeviceToHost, s));
+  DC_HIP_TRY(hipStreamSynchronize(s));
+  double acc = 0.0;  // frame order, double: density_clustering.cpp:334-343
+  for (size_t i = 0; i < n_rows; ++i) acc += (double)h[i];
+  *sigma2_out = acc / (double)n_rows;
+  return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-pointer wrappers
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct DeviceJob {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  float* d_coords = nullptr;
+  float* d_fe = nullptr;
+  uint32_t* d_pops = nullptr;
+  uint32_t* d_idx = nullptr;  // [2][n_rows]
+  float* d_d2 = nullptr;      // [2][n_rows]
+  void* d_ws = nullptr;
+  size_t ws_bytes = 0;
+  void release() {
+    (void)hipSetDevice(device);
+    if (d_coords) (void)hipFree(d_coords);
+    if (d_fe) (void)hipFree(d_fe);
+    if (d_pops) (void)hipFree(d_pops);
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_d2) (void)hipFree(d_d2);
+    if (d_ws) (void)hipFree(d_ws);
+    if (stream) (void)hipStreamDestroy(stream);
+    *this = DeviceJob();
+  }
+};
+
+int job_open(DeviceJob& j, int device, const float* coords, size_t n_rows, size_t n_cols) {
+  int n = dc_hip_device_count();
+  if (n < 0) return n;
+  if (n == 0) return fail(DC_ERR_NO_DEVICE, "no HIP device found");
+  if (device < 0 || device >= n)
+    return fail(DC_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, n);
+  j.device = device;
+  DC_HIP_TRY(hipSetDevice(device));
+  DC_HIP_TRY(hipStreamCreate(&j.stream));
+  DC_HIP_TRY(hipMalloc((void**)&j.d_coords, sizeof(float) * std::max<size_t>(1, n_rows * n_cols)));
+  DC_HIP_TRY(hipMemcpyAsync(j.d_coords, coords, sizeof(float) * n_rows * n_cols,
+                            hipMemcpyHostToDevice, j.stream));
+  j.ws_bytes = dc_hip_workspace_bytes(n_rows, n_cols, 1);
+  if (j.ws_bytes) DC_HIP_TRY(hipMalloc(&j.d_ws, j.ws_bytes));
+  return DC_OK;
+}
+
+}  // namespace
+
+int dc_hip_populations(const float* coords, size_t n_rows, size_t n_cols, const float* radii,
+                       size_t n_radii, size_t i_from, size_t i_to, int device, uint32_t* pops) {
+  if (int rc = check_sizes(n_rows, n_cols, i_from, i_to)) return rc;
+  if (n_rows == 0 || n_radii == 0) return DC_OK;
+  if (!coords || !radii || !pops) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  DeviceJob j;
+  int rc = job_open(j, device, coords, n_rows, n_cols);
+  if (rc == DC_OK) {
+    hipError_t e = hipMalloc((void**)&j.d_pops, sizeof(uint32_t) * n_radii * n_rows);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "hipMalloc pops: %s", hipGetErrorString(e));
+  }
+  if (rc == DC_OK)
+    rc = dc_hip_populations_dev(j.d_coords, n_rows, n_cols, radii, n_radii, i_from, i_to, j.d_pops,
+                                j.d_ws, j.ws_bytes, DC_VARIANT_AUTO, j.stream);
+  if (rc == DC_OK) {
+    hipError_t e = hipMemcpyAsync(pops, j.d_pops, sizeof(uint32_t) * n_radii * n_rows,
+                                  hipMemcpyDeviceToHost, j.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(j.stream);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "population sweep: %s", hipGetErrorString(e));
+  }
+  j.release();
+  return rc;
+}
+
+int dc_hip_nearest_neighbors(const float* coords, size_t n_rows, size_t n_cols, const float* fe,
+                             size_t i_from, size_t i_to, int device, uint32_t* nn_idx, float* nn_d2,
+                             uint32_t* hd_idx, float* hd_d2) {
+  if (int rc = check_sizes(n_rows, n_cols, i_from, i_to)) return rc;
+  if (n_rows == 0) return DC_OK;
+  if (!coords || !fe || !nn_idx || !nn_d2 || !hd_idx || !hd_d2)
+    return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  DeviceJob j;
+  int rc = job_open(j, device, coords, n_rows, n_cols);
+  hipError_t e = hipSuccess;
+  if (rc == DC_OK) {
+    e = hipMalloc((void**)&j.d_fe, sizeof(float) * n_rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&j.d_idx, sizeof(uint32_t) * 2 * n_rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&j.d_d2, sizeof(float) * 2 * n_rows);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(j.d_fe, fe, sizeof(float) * n_rows, hipMemcpyHostToDevice, j.stream);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "nn setup: %s", hipGetErrorString(e));
+  }
+  if (rc == DC_OK)
+    rc = dc_hip_nearest_neighbors_dev(j.d_coords, n_rows, n_cols, j.d_fe, i_from, i_to, j.d_idx,
+                                      j.d_d2, j.d_idx + n_rows, j.d_d2 + n_rows, j.d_ws,
+                                      j.ws_bytes, DC_VARIANT_AUTO, j.stream);
+  if (rc == DC_OK) {
+    e = hipMemcpyAsync(nn_idx, j.d_idx, sizeof(uint32_t) * n_rows, hipMemcpyDeviceToHost, j.stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(hd_idx, j.d_idx + n_rows, sizeof(uint32_t) * n_rows, hipMemcpyDeviceToHost,
+                         j.stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(nn_d2, j.d_d2, sizeof(float) * n_rows, hipMemcpyDeviceToHost, j.stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(hd_d2, j.d_d2 + n_rows, sizeof(float) * n_rows, hipMemcpyDeviceToHost,
+                         j.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(j.stream);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "nn sweep: %s", hipGetErrorString(e));
+  }
+  j.release();
+  return rc;
+}
+
+int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const float* radii,
+                       size_t n_radii, size_t fe_radius_index, int n_devices, uint32_t* pops,
+                       float* fe, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2) {
+  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
+  if (!coords || !radii || !pops || n_radii == 0)
+    return fail(DC_ERR_INVALID_ARGUMENT, "coords, radii and pops are required");
+  if (fe_radius_index >= n_radii) return fail(DC_ERR_INVALID_ARGUMENT, "fe_radius_index");
+  const bool want_nn = nn_idx != nullptr;
+  if (want_nn && (!fe || !nn_d2 || !hd_idx || !hd_d2))
+    return fail(DC_ERR_INVALID_ARGUMENT, "nn outputs incomplete");
+  int avail = dc_hip_device_count();
+  if (avail < 0) return avail;
+  if (avail == 0) return fail(DC_ERR_NO_DEVICE, "no HIP device found");
+  if (n_devices <= 0) n_devices = avail;
+  if (n_devices > avail)
+    return fail(DC_ERR_INVALID_ARGUMENT, "%d devices requested, %d present", n_devices, avail);
+  if (n_rows == 0) return DC_OK;
+
+  // row blocks exactly as density_clustering_cuda.cu:149,165-169 / :293,305-308
+  const size_t range = n_rows / (size_t)n_devices;
+  auto row_from = [&](int g) { return (size_t)g * range; };
+  auto row_to = [&](int g) { return g == n_devices - 1 ? n_rows : (size_t)(g + 1) * range; };
+
+  std::vector<DeviceJob> jobs(n_devices);
+  std::vector<std::vector<uint32_t>> part(n_devices);
+  int rc = DC_OK;
+  auto cleanup = [&]() {
+    for (auto& j : jobs) j.release();
+  };
+  // phase 1: populations, all devices in flight at once
+  for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
+    rc = job_open(jobs[g], g, coords, n_rows, n_cols);
+    if (rc != DC_OK) break;
+    hipError_t e = hipMalloc((void**)&jobs[g].d_pops, sizeof(uint32_t) * n_radii * n_rows);
+    if (e != hipSuccess) {
+      rc = fail(DC_ERR_HIP, "hipMalloc pops: %s", hipGetErrorString(e));
+      break;
+    }
+    rc = dc_hip_populations_dev(jobs[g].d_coords, n_rows, n_cols, radii, n_radii, row_from(g),
+                                row_to(g), jobs[g].d_pops, jobs[g].d_ws, jobs[g].ws_bytes,
+                                DC_VARIANT_AUTO, jobs[g].stream);
+    if (rc != DC_OK) break;
+    part[g].resize(n_radii * n_rows);
+    e = hipMemcpyAsync(part[g].data(), jobs[g].d_pops, sizeof(uint32_t) * n_radii * n_rows,
+                       hipMemcpyDeviceToHost, jobs[g].stream);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "pops D2H: %s", hipGetErrorString(e));
+  }
+  for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
+    (void)hipSetDevice(g);
+    hipError_t e = hipStreamSynchronize(jobs[g].stream);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "population sweep (device %d): %s", g,
+                                   hipGetErrorString(e));
+  }
+  if (rc != DC_OK) {
+    cleanup();
+    return rc;
+  }
+  // merge = sum of the zero-padded partials (density_clustering_cuda.cu:171-180)
+  std::fill(pops, pops + n_radii * n_rows, 0u);
+  for (int g = 0; g < n_devices; ++g)
+    for (size_t k = 0; k < n_radii * n_rows; ++k) pops[k] += part[g][k];
+  part.clear();
+
+  if (fe) {
+    const uint32_t* p = pops + fe_radius_index * n_rows;
+    const uint32_t max_pop = *std::max_element(p, p + n_rows);
+    const float rec = 1.0f / (float)max_pop;
+    for (size_t i = 0; i < n_rows; ++i) fe[i] = fe_of_pop(p[i], rec);
+  }
+  if (want_nn) {
+    std::vector<std::vector<uint32_t>> pidx(n_devices);
+    std::vector<std::vector<float>> pd2(n_devices);
+    for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
+      DeviceJob& j = jobs[g];
+      (void)hipSetDevice(g);
+      hipError_t e = hipMalloc((void**)&j.d_fe, sizeof(float) * n_rows);
+      if (e == hipSuccess) e = hipMalloc((void**)&j.d_idx, sizeof(uint32_t) * 2 * n_rows);
+      if (e == hipSuccess) e = hipMalloc((void**)&j.d_d2, sizeof(float) * 2 * n_rows);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(j.d_fe, fe, sizeof(float) * n_rows, hipMemcpyHostToDevice, j.stream);
+      if (e != hipSuccess) {
+        rc = fail(DC_ERR_HIP, "nn setup (device %d): %s", g, hipGetErrorString(e));
+        break;
+      }
+      rc = dc_hip_nearest_neighbors_dev(j.d_coords, n_rows, n_cols, j.d_fe, row_from(g), row_to(g),
+                                        j.d_idx, j.d_d2, j.d_idx + n_rows, j.d_d2 + n_rows, j.d_ws,
+                                        j.ws_bytes, DC_VARIANT_AUTO, j.stream);
+      if (rc != DC_OK) break;
+      pidx[g].resize(2 * n_rows);
+      pd2[g].resize(2 * n_rows);
+      e = hipMemcpyAsync(pidx[g].data(), j.d_idx, sizeof(uint32_t) * 2 * n_rows,
+                         hipMemcpyDeviceToHost, j.stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(pd2[g].data(), j.d_d2, sizeof(float) * 2 * n_rows, hipMemcpyDeviceToHost,
+                           j.stream);
+      if (e != hipSuccess) rc = fail(DC_ERR_HIP, "nn D2H: %s", hipGetErrorString(e));
+    }
+    for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
+      (void)hipSetDevice(g);
+      hipError_t e = hipStreamSynchronize(jobs[g].stream);
+      if (e != hipSuccess)
+        rc = fail(DC_ERR_HIP, "nn sweep (device %d): %s", g, hipGetErrorString(e));
+    }
+    if (rc == DC_OK) {
+      // every row is owned by exactly one device (density_clustering_cuda.cu:311-326)
+      for (int g = 0; g < n_devices; ++g)
+        for (size_t i = row_from(g); i < row_to(g); ++i) {
+          nn_idx[i] = pidx[g][i];
+          nn_d2[i] = pd2[g][i];
+          hd_idx[i] = pidx[g][n_rows + i];
+          hd_d2[i] = pd2[g][n_rows + i];
+        }
+    }
+  }
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"

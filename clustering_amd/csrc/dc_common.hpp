@@ -1,0 +1,112 @@
+// dc_common.hpp -- shared declarations of the HIP density kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// The canonical distance is a specification of individual float roundings
+// (SURVEY.md Appendix B): never let the compiler fuse a multiply into an add.
+#pragma clang fp contract(off)
+
+namespace dc {
+
+constexpr int kMaxColsTemplated = 32;   // n_cols with a register-resident kernel instance
+constexpr int kMaxColsGeneric = 400;    // n_cols the LDS-resident generic kernel can hold
+constexpr int kMaxRadiiPerLaunch = 8;   // radii swept per launch (more radii -> several launches)
+
+// squared radii of one launch, passed by value (kernarg segment -> SGPRs)
+struct Rad2 {
+  float v[kMaxRadiiPerLaunch];
+};
+
+// ---- launchers implemented in dc_direct.hip -------------------------------------------
+// pops: [n_radii_total][n_rows] radius-major; this launch fills radius rows
+// r_first .. r_first+n_rad-1 for query rows [i_from, i_to).  Returns false if n_cols is unsupported.
+bool launch_pop_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
+                       uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
+                       hipStream_t stream);
+
+bool launch_nn_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
+                      uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
+                      uint32_t* d_hd_idx, float* d_hd_d2, hipStream_t stream);
+
+// fills idx[i] = n_rows+1, d2[i] = FLT_MAX for all rows (density_clustering.cpp:242-245)
+void launch_nn_init(uint32_t n_rows, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                    float* d_hd_d2, hipStream_t stream);
+
+// fe[i] = table[pops[i]]
+void launch_fe_gather(const uint32_t* d_pops, uint32_t n_rows, const float* d_table, float* d_fe,
+                      hipStream_t stream);
+// *d_out = max(pops)
+void launch_max_u32(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_out, hipStream_t stream);
+
+// ---- canonical squared distance, compile-time D ----------------------------------------
+// q: this lane's query row (registers); r: reference row (registers, wave-uniform values).
+// Order of operations = SURVEY.md Appendix B = what the reference binary computes
+// (density_clustering.cpp:171-176, 263-268 under -O3 -ffast-math, SSE2).
+template <int D>
+__device__ __forceinline__ float dist2_canon(const float (&q)[D], const float (&r)[D]) {
+  float p[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const float c = q[k] - r[k];
+    p[k] = c * c;
+  }
+  if constexpr (D <= 3) {
+    float s = p[0];
+#pragma unroll
+    for (int k = 1; k < D; ++k) s = s + p[k];
+    return s;
+  } else {
+    constexpr int V = 4 * (D / 4);
+    // lane accumulators start at +0; 0 + p == p exactly (p is a square: never -0)
+    float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+#pragma unroll
+    for (int k0 = 4; k0 < V; k0 += 4) {
+      a0 = a0 + p[k0 + 0];
+      a1 = a1 + p[k0 + 1];
+      a2 = a2 + p[k0 + 2];
+      a3 = a3 + p[k0 + 3];
+    }
+    float s = (a0 + a2) + (a1 + a3);
+    if constexpr (D - V >= 2) {
+      s = s + (p[V] + p[V + 1]);
+      if constexpr (D - V == 3) s = s + p[V + 2];
+    } else if constexpr (D - V == 1) {
+      s = s + p[V];
+    }
+    return s;
+  }
+}
+
+// run-time D version of the same order; x, y: any addressable rows with strides sx, sy (elements)
+__device__ __forceinline__ float dist2_canon_rt(const float* x, int sx, const float* y, int sy,
+                                                int D) {
+  auto sq = [&](int k) {
+    const float c = x[k * sx] - y[k * sy];
+    return c * c;
+  };
+  if (D <= 3) {
+    float s = sq(0);
+    for (int k = 1; k < D; ++k) s = s + sq(k);
+    return s;
+  }
+  const int V = 4 * (D / 4);
+  float a0 = sq(0), a1 = sq(1), a2 = sq(2), a3 = sq(3);
+  for (int k0 = 4; k0 < V; k0 += 4) {
+    a0 = a0 + sq(k0 + 0);
+    a1 = a1 + sq(k0 + 1);
+    a2 = a2 + sq(k0 + 2);
+    a3 = a3 + sq(k0 + 3);
+  }
+  float s = (a0 + a2) + (a1 + a3);
+  int k = V;
+  if (D - k >= 2) {
+    s = s + (sq(k) + sq(k + 1));
+    k += 2;
+  }
+  if (D - k == 1) s = s + sq(k);
+  return s;
+}
+
+}  // namespace dc

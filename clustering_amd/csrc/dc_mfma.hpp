@@ -1,0 +1,21 @@
+// dc_mfma.hpp -- fp32-MFMA (Gram form + guard band + canonical re-check) variants.
+#pragma once
+#include "dc_common.hpp"
+
+namespace dc {
+
+// true if the MFMA kernels handle this n_cols
+bool mfma_supports(size_t n_cols);
+// bytes of device scratch (operand images, norms) for a problem size; 0 if unsupported
+size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols);
+// builds the operand images of d_coords in the workspace; returns 0 on success
+int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
+                 hipStream_t stream);
+void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
+                     uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
+                     void* d_ws, hipStream_t stream);
+void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
+                    uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
+                    uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
+
+}  // namespace dc

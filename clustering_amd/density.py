@@ -1,0 +1,138 @@
+"""Host-side Python mirror of the reference's density hot-path interface
+(Clustering::Density::CUDA::*, density_clustering_cuda.hpp:13-54) over the C ABI.
+
+torch is used here only as plumbing: device memory (tensors), streams and, in
+clustering_amd.distributed, torch.distributed.  All compute goes through
+libdcdensity.so; nothing in this package computes distances on the CPU or in torch.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def get_num_gpus():
+    """Clustering::Density::CUDA::get_num_gpus (density_clustering_cuda.cu:32-43): raises if none."""
+    n = capi.device_count()
+    if n == 0:
+        raise capi.DensityLibraryError("error: no HIP-compatible GPUs found")
+    return n
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class Workspace:
+    """Device scratch for the sweeps (MFMA operand images); grown on demand, reused across calls."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, n_rows, n_cols, n_radii=1):
+        need = int(capi.lib.dc_hip_workspace_bytes(n_rows, n_cols, n_radii))
+        if need == 0:
+            return C.c_void_p(0), 0
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return _dev(self.buf), int(self.buf.numel())
+
+
+_workspaces = {}
+
+
+def _workspace(device):
+    key = str(device)
+    if key not in _workspaces:
+        _workspaces[key] = Workspace(device)
+    return _workspaces[key]
+
+
+def _check_coords(coords):
+    if not (isinstance(coords, torch.Tensor) and coords.is_cuda and coords.dtype == torch.float32
+            and coords.dim() == 2 and coords.is_contiguous()):
+        raise ValueError("coords must be a contiguous float32 CUDA tensor [n_rows, n_cols]")
+    return coords.shape[0], coords.shape[1]
+
+
+def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="auto", out=None):
+    """Per-GPU partial of calculate_populations (density_clustering_cuda.cu:45-137).
+
+    coords: float32 CUDA tensor [n_rows, n_cols]; radii: sequence of float.
+    -> torch.int32 [n_radii, n_rows] (the ABI's uint32 bit pattern; populations are <= n_rows
+    < 2^31 whenever the tensor itself is addressable), radius-major in the order of ``radii``,
+    zero outside [i_from, i_to).
+    """
+    n_rows, n_cols = _check_coords(coords)
+    i_to = n_rows if i_to is None else i_to
+    rad = np.ascontiguousarray(radii, dtype=np.float32).reshape(-1)
+    if out is None:
+        out = torch.empty((rad.size, n_rows), dtype=torch.int32, device=coords.device)
+    assert out.shape == (rad.size, n_rows) and out.dtype == torch.int32 and out.is_contiguous()
+    with torch.cuda.device(coords.device):
+        ws, ws_bytes = _workspace(coords.device).get(n_rows, n_cols, rad.size)
+        rc = capi.lib.dc_hip_populations_dev(
+            _dev(coords), n_rows, n_cols, rad.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
+            i_from, i_to, _dev(out), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+    capi.check(rc, "dc_hip_populations_dev")
+    return out
+
+
+def calculate_free_energies(pops):
+    """calculate_free_energies (density_clustering.cpp:197-212) for one radius. pops: int32 CUDA [n_rows]."""
+    assert pops.is_cuda and pops.dtype == torch.int32 and pops.dim() == 1 and pops.is_contiguous()
+    fe = torch.empty(pops.shape[0], dtype=torch.float32, device=pops.device)
+    mx = C.c_uint32(0)
+    with torch.cuda.device(pops.device):
+        rc = capi.lib.dc_hip_free_energies_dev(_dev(pops), pops.shape[0], _dev(fe), C.byref(mx),
+                                               _stream_ptr())
+    capi.check(rc, "dc_hip_free_energies_dev")
+    return fe
+
+
+def nearest_neighbors_partial(coords, fe, i_from=0, i_to=None, variant="auto"):
+    """Per-GPU partial of nearest_neighbors (density_clustering_cuda.cu:184-284).
+
+    -> (nn_idx int32, nn_d2 float32, hd_idx int32, hd_d2 float32), each [n_rows]; rows outside the
+    range hold the reference's "none" value (n_rows+1, FLT_MAX)."""
+    n_rows, n_cols = _check_coords(coords)
+    i_to = n_rows if i_to is None else i_to
+    assert fe.is_cuda and fe.dtype == torch.float32 and fe.shape == (n_rows,) and fe.is_contiguous()
+    dev = coords.device
+    nn_idx = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    hd_idx = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    nn_d2 = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    hd_d2 = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
+        rc = capi.lib.dc_hip_nearest_neighbors_dev(
+            _dev(coords), n_rows, n_cols, _dev(fe), i_from, i_to, _dev(nn_idx), _dev(nn_d2),
+            _dev(hd_idx), _dev(hd_d2), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+    capi.check(rc, "dc_hip_nearest_neighbors_dev")
+    return nn_idx, nn_d2, hd_idx, hd_d2
+
+
+def compute_sigma2(nn_d2):
+    """compute_sigma2 (density_clustering.cpp:334-343)."""
+    out = C.c_double(0.0)
+    with torch.cuda.device(nn_d2.device):
+        rc = capi.lib.dc_hip_sigma2_dev(_dev(nn_d2), nn_d2.shape[0], C.byref(out), _stream_ptr())
+    capi.check(rc, "dc_hip_sigma2_dev")
+    return out.value
+
+
+def shard_rows(n_rows, n_shards, shard):
+    """Row block of one device, exactly as density_clustering_cuda.cu:149,165-169."""
+    rng = n_rows // n_shards
+    lo = shard * rng
+    hi = n_rows if shard == n_shards - 1 else (shard + 1) * rng
+    return lo, hi

@@ -1,0 +1,155 @@
+/*
+ * dc_density.h -- C ABI of the MI355X-native `clustering density` hot path.
+ *
+ * Drop-in boundary for moldyn/Clustering's GPU plug-in surface.  Every entry
+ * point names the reference interface it replaces (paths relative to the
+ * reference's src/).  The reference selects its GPU path at compile time
+ * (-DUSE_CUDA) and calls the free functions of density_clustering_cuda.hpp; the
+ * C++ shim in clustering_amd/csrc/density_clustering_hip.{hpp,cpp} re-creates
+ * exactly those signatures (namespace Clustering::Density::CUDA) on top of this
+ * C ABI.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch types cross this boundary.
+ *   - every function returns 0 on success or a negative dc_status; the message
+ *     is available from dc_hip_last_error() (thread-local).  Nothing here prints
+ *     or exits -- the C++ shim restores the reference's "message on stderr, then
+ *     exit(EXIT_FAILURE)" convention (density_clustering_cuda.cu:21-30).
+ *   - coords: row-major float32 [n_rows][n_cols], as read_coords() produces
+ *     (tools.hxx:39-111).  Frame ids are 0-based.
+ *   - populations are uint32 on the device like the reference's
+ *     (density_clustering_cuda.cu:64,120), laid out radius-major
+ *     pops[r*n_rows + i] (density_clustering_cuda.cu:130) IN THE ORDER OF THE
+ *     radii ARGUMENT; rows outside [i_from, i_to) are written 0, so that
+ *     per-device partials merge by summation (density_clustering_cuda.cu:171-180).
+ *   - results follow the reference's OpenMP CPU path bit for bit (the parity
+ *     target named by BASELINE.json; density_clustering.cpp:126-288):
+ *       pop_r[i] = 1 + #{ j != i : d2(i,j) <  fl32(r*r) }      (strict)
+ *       nn[i]    = lexicographic min over j != i of (d2(i,j), j)
+ *       nn_hd[i] = same over { j : fe[j] < fe[i] }; empty -> (n_rows+1, FLT_MAX)
+ *     with d2 in the reference binary's float summation order.
+ *   - "_dev" functions take DEVICE pointers, run on the given hipStream_t
+ *     (passed as void*; NULL = the default stream) and are asynchronous unless
+ *     stated otherwise.  Functions without the suffix take HOST pointers, manage
+ *     device memory themselves and are synchronous -- they mirror the
+ *     reference's per-GPU host functions.
+ */
+#ifndef DC_DENSITY_H
+#define DC_DENSITY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define DC_API __attribute__((visibility("default")))
+#else
+#define DC_API
+#endif
+
+typedef enum dc_status {
+  DC_OK = 0,
+  DC_ERR_INVALID_ARGUMENT = -1,
+  DC_ERR_NO_DEVICE = -2,      /* reference: "no CUDA-compatible GPUs found", cuda.cu:37-40 */
+  DC_ERR_HIP = -3,            /* a HIP runtime call failed; see dc_hip_last_error() */
+  DC_ERR_TOO_LARGE = -4,      /* n_rows + 1 does not fit the uint32 index type */
+  DC_ERR_WORKSPACE = -5       /* workspace missing or too small */
+} dc_status;
+
+/* kernel family selector for the two pairwise sweeps */
+typedef enum dc_variant {
+  DC_VARIANT_AUTO = 0,        /* MFMA when n_cols allows, else direct */
+  DC_VARIANT_DIRECT = 1,      /* VALU, direct differences in the canonical order: exact by construction */
+  DC_VARIANT_MFMA = 2         /* fp32 MFMA Gram form + guard band + canonical re-check: same results */
+} dc_variant;
+
+/* message of the last failing call on this thread ("" if none). */
+DC_API const char* dc_hip_last_error(void);
+
+/* library/ABI version, bumped on any signature change. */
+DC_API int dc_hip_abi_version(void);
+
+/* replaces Clustering::Density::CUDA::get_num_gpus() (density_clustering_cuda.hpp:16-17,
+ * density_clustering_cuda.cu:32-43).  Returns the device count (>= 0) or a negative status;
+ * 0 devices is NOT an error here (the C++ shim turns it into the reference's exit). */
+DC_API int dc_hip_device_count(void);
+
+/* ---------------------------------------------------------------------------------------
+ * device-pointer entry points (inputs already resident in HBM)
+ * ------------------------------------------------------------------------------------- */
+
+/* bytes of scratch the _dev sweeps may need for this problem size (MFMA operand images,
+ * norms; 0-filled by the callee as needed).  Pass a buffer at least this large. */
+DC_API size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radii);
+
+/* replaces the kernel loop of calculate_populations_per_gpu (density_clustering_cuda.cu:45-137;
+ * kernel population_count, density_clustering_cuda_kernels.cu:9-56): ONE launch sweeps all
+ * n_rows reference frames for the query rows [i_from, i_to).
+ *   d_coords  [n_rows*n_cols] float32, device
+ *   radii     [n_radii] float32, HOST (tiny; the reference also passes them from the host)
+ *   d_pops    [n_radii*n_rows] uint32, device, fully overwritten (0 outside the row range) */
+DC_API int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                  const float* radii, size_t n_radii, size_t i_from, size_t i_to,
+                                  uint32_t* d_pops, void* d_workspace, size_t workspace_bytes,
+                                  int variant, void* stream);
+
+/* replaces Clustering::Density::calculate_free_energies (density_clustering.cpp:197-212), which the
+ * reference runs on the host in both builds.  fe[i] = (float)-log((double)((float)pop[i] * (1.0f/max)))
+ * -- the double log is evaluated by the HOST libm (one value per distinct population, then gathered
+ * on the device) so the bits equal the reference's.  Synchronises the stream once (reads max_pop).
+ *   d_pops [n_rows] uint32 device (one radius), d_fe [n_rows] float32 device.
+ * max_pop_out (optional, host) receives the maximum population. */
+DC_API int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
+                                    uint32_t* max_pop_out, void* stream);
+
+/* replaces the kernel loop of nearest_neighbors_per_gpu (density_clustering_cuda.cu:184-284; kernel
+ * nearest_neighbor_search, density_clustering_cuda_kernels.cu:58-130) for query rows [i_from, i_to).
+ *   d_fe      [n_rows] float32 device
+ *   d_nn_idx / d_hd_idx [n_rows] uint32, d_nn_d2 / d_hd_d2 [n_rows] float32, device; rows outside the
+ *   range are written with the "none" value (n_rows+1, FLT_MAX) of density_clustering.cpp:242-245. */
+DC_API int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                        const float* d_fe, size_t i_from, size_t i_to,
+                                        uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                                        float* d_hd_d2, void* d_workspace, size_t workspace_bytes,
+                                        int variant, void* stream);
+
+/* replaces Clustering::Density::compute_sigma2 (density_clustering.cpp:334-343): mean of the nearest-
+ * neighbour d2 accumulated in double IN FRAME ORDER (bit-stable), on the device (one block, fixed
+ * reduction tree would change bits -- so this is a single ordered pass over a device->host copy).
+ * Synchronises the stream. */
+DC_API int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * host-pointer entry points (mirror the reference's per-GPU host functions)
+ * ------------------------------------------------------------------------------------- */
+
+/* replaces calculate_populations_per_gpu(coords, n_rows, n_cols, radii, i_from, i_to, i_gpu)
+ * (density_clustering_cuda.cu:45-52; declared as calculate_populations_partial in
+ * density_clustering_cuda.hpp:21-30).  pops: HOST [n_radii*n_rows] uint32. */
+DC_API int dc_hip_populations(const float* coords, size_t n_rows, size_t n_cols, const float* radii,
+                              size_t n_radii, size_t i_from, size_t i_to, int device, uint32_t* pops);
+
+/* replaces nearest_neighbors_per_gpu(coords, n_rows, n_cols, free_energy, i_from, i_to, i_gpu)
+ * (density_clustering_cuda.cu:184-191).  All outputs HOST [n_rows]. */
+DC_API int dc_hip_nearest_neighbors(const float* coords, size_t n_rows, size_t n_cols, const float* fe,
+                                    size_t i_from, size_t i_to, int device, uint32_t* nn_idx,
+                                    float* nn_d2, uint32_t* hd_idx, float* hd_d2);
+
+/* whole path on n_devices GPUs of this process (devices 0..n_devices-1), coords uploaded once per
+ * device and kept resident across pop -> FE -> NN.  Row blocks as
+ * density_clustering_cuda.cu:149,165-169 (last device takes the remainder); partial populations are
+ * summed and neighbour blocks concatenated on the host exactly as cuda.cu:171-180 / :311-326 do.
+ * radii: n_radii values; FE and NN are computed from radius index fe_radius_index (NN skipped if
+ * nn_idx == NULL).  pops HOST [n_radii*n_rows]; fe, nn_*, hd_* HOST [n_rows]. */
+DC_API int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const float* radii,
+                              size_t n_radii, size_t fe_radius_index, int n_devices, uint32_t* pops,
+                              float* fe, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
+                              float* hd_d2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DC_DENSITY_H */

@@ -1,0 +1,50 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dc_density.h declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dc_density.h")).read()
+    return sorted(set(re.findall(r"DC_API\s+[\w\s\*]+?\b(dc_hip_\w+)\s*\(", text)))
+
+
+def test_header_declares_expected_set():
+    from clustering_amd import capi
+    assert declared_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from clustering_amd import capi
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert capi.lib.dc_hip_abi_version() == 1
+    assert capi.lib.dc_hip_last_error() is not None
+
+
+def test_no_device_is_a_status_not_a_crash():
+    from clustering_amd import capi
+    import torch
+    if torch.cuda.is_available():
+        return
+    assert capi.device_count() == 0
+    import numpy as np, ctypes as C
+    c = np.zeros((4, 3), np.float32)
+    pops = np.zeros(4, np.uint32)
+    r = np.array([1.0], np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = capi.lib.dc_hip_populations(vp(c), 4, 3, vp(r), 1, 0, 4, 0, vp(pops))
+    assert rc in (-2, -3)          # DC_ERR_NO_DEVICE / DC_ERR_HIP: the product has no CPU path
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "clustering_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "capi.py" and False, (dirpath, f)

@@ -1,0 +1,220 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs -- bit-exact populations, neighbour indices and
+d2 bits; free energies bit-exact as well (same host libm), asserted within the 1e-5 relative
+tolerance BASELINE.json states plus bitwise as a stronger check."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from clustering_amd.synth import gaussian_blobs
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "kat_cases.json")))["cases"]
+FLT_MAX = np.finfo(np.float32).max
+VARIANTS = ["direct", "mfma"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def dens():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from clustering_amd import density
+    return density
+
+
+def _supported(variant, n_cols):
+    if variant == "direct":
+        return True
+    from clustering_amd import capi
+    return capi.lib.dc_hip_workspace_bytes(64, n_cols, 1) > 0
+
+
+def run_gpu(dens, c, radii, fe_from, variant, i_from=0, i_to=None):
+    import torch
+    ct = torch.from_numpy(c).cuda()
+    pops = dens.calculate_populations_partial(ct, radii, i_from, i_to, variant=variant)
+    fe = dens.calculate_free_energies(pops[fe_from].contiguous())
+    return pops.cpu().numpy().astype(np.uint32), fe, ct
+
+
+def check_full(dens, oracle, c, radii, variant, fe_from=0):
+    import torch
+    pops, fe, ct = run_gpu(dens, c, radii, fe_from, variant)
+    want = oracle.populations(c, radii)
+    assert (pops.astype(np.uint64) == want).all(), f"pops mismatch ({variant})"
+    fe_want = oracle.free_energies(want[fe_from])
+    fe_got = fe.cpu().numpy()
+    np.testing.assert_allclose(fe_got, fe_want, rtol=1e-5, atol=1e-7)   # north_star tolerance
+    assert (bits(fe_got) == bits(fe_want)).all()                        # and in fact bit-exact
+    nn = dens.nearest_neighbors_partial(ct, fe, variant=variant)
+    exp = oracle.nearest_neighbors(c, fe_want)
+    got = [t.cpu().numpy() for t in nn]
+    assert (got[0].astype(np.uint32).astype(np.uint64) == exp[0]).all(), f"nn idx ({variant})"
+    assert (got[2].astype(np.uint32).astype(np.uint64) == exp[2]).all(), f"hd idx ({variant})"
+    assert (bits(got[1]) == bits(exp[1])).all(), f"nn d2 bits ({variant})"
+    assert (bits(got[3]) == bits(exp[3])).all(), f"hd d2 bits ({variant})"
+    s2 = dens.compute_sigma2(nn[1])
+    assert s2 == oracle.sigma2(exp[1])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", KATS, ids=[c["name"] for c in KATS])
+def test_kat(dens, case, variant):
+    import torch
+    c = np.array(case["coords"], dtype=np.float32)
+    if not _supported(variant, c.shape[1]):
+        pytest.skip("variant does not support this n_cols")
+    radii = case["radii"]
+    sel = radii.index(case["fe_from_radius"])
+    pops, fe, ct = run_gpu(dens, c, radii, sel, variant)
+    assert pops.tolist() == case["pops"]
+    nn = [t.cpu().numpy() for t in dens.nearest_neighbors_partial(ct, fe, variant=variant)]
+    assert nn[0].tolist() == case["nn_idx"] and nn[2].tolist() == case["hd_idx"]
+    assert (bits(nn[1]) == bits(np.array(case["nn_d2"], np.float32))).all()
+    assert (bits(nn[3]) == bits(np.array(case["hd_d2"], np.float32))).all()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 7, 10, 12, 13, 16, 24, 25, 30, 32])
+def test_parity_templated_dims(dens, oracle, D, variant):
+    if not _supported(variant, D):
+        pytest.skip("variant does not support this n_cols")
+    c = gaussian_blobs(3000, D, seed=1000 + D)
+    radii = [0.2] if D <= 10 else [0.08 * np.sqrt(2.0 * D)]
+    check_full(dens, oracle, c, radii, variant)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("D", [33, 40, 100])
+def test_parity_generic_dims(dens, oracle, D, variant):
+    if not _supported(variant, D):
+        pytest.skip("variant does not support this n_cols")
+    c = gaussian_blobs(1500, D, seed=2000 + D)
+    check_full(dens, oracle, c, [0.08 * np.sqrt(2.0 * D), 0.1 * np.sqrt(2.0 * D)], variant, fe_from=1)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n_radii", [1, 2, 3, 4, 5, 8, 9, 17])
+def test_parity_multi_radius(dens, oracle, n_radii, variant):
+    c = gaussian_blobs(2500, 10, seed=31)
+    radii = list(np.linspace(0.35, 0.05, n_radii).astype(np.float32))  # descending, as -R sorts them
+    if n_radii >= 3:
+        radii[0], radii[2] = radii[2], radii[0]                        # and unsorted input order
+    import torch
+    pops = dens.calculate_populations_partial(torch.from_numpy(c).cuda(), radii, variant=variant)
+    assert (pops.cpu().numpy().astype(np.uint32).astype(np.uint64) == oracle.populations(c, radii)).all()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_parity_c1_config(dens, oracle, variant):
+    """BASELINE.json configs[0]: 10k x 5, single radius 0.1 -- full path, plus the reference-run
+    statistics of BASELINE.md (mean pop 73.6, max 314)."""
+    c = gaussian_blobs(10000, 5)
+    check_full(dens, oracle, c, [0.1], variant)
+    pops = oracle.populations(c, [0.1])[0]
+    assert pops.max() == 314 and round(float(pops.mean()), 1) == 73.6
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_ragged_sizes_and_row_ranges(dens, oracle, variant):
+    import torch
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 1023, 1025):
+        c = gaussian_blobs(n, 10, seed=500 + n)
+        want = oracle.populations(c, [0.2, 0.3])
+        ct = torch.from_numpy(c).cuda()
+        got = dens.calculate_populations_partial(ct, [0.2, 0.3], variant=variant).cpu().numpy()
+        assert (got.astype(np.uint32).astype(np.uint64) == want).all(), n
+        fe = oracle.free_energies(want[0])
+        nn = dens.nearest_neighbors_partial(ct, torch.from_numpy(fe).cuda(), variant=variant)
+        exp = oracle.nearest_neighbors(c, fe)
+        assert (nn[0].cpu().numpy().astype(np.uint32).astype(np.uint64) == exp[0]).all(), n
+        assert (nn[2].cpu().numpy().astype(np.uint32).astype(np.uint64) == exp[2]).all(), n
+        assert (bits(nn[1].cpu().numpy()) == bits(exp[1])).all(), n
+        assert (bits(nn[3].cpu().numpy()) == bits(exp[3])).all(), n
+    # partial row ranges: zero / "none" outside, partials merge by sum / by ownership
+    c = gaussian_blobs(1500, 10, seed=77)
+    ct = torch.from_numpy(c).cuda()
+    full = oracle.populations(c, [0.2])
+    fe = oracle.free_energies(full[0])
+    fet = torch.from_numpy(fe).cuda()
+    exp = oracle.nearest_neighbors(c, fe)
+    acc = np.zeros_like(full)
+    for lo, hi in ((0, 0), (0, 500), (500, 501), (501, 1500)):
+        p = dens.calculate_populations_partial(ct, [0.2], lo, hi, variant=variant).cpu().numpy()
+        p = p.astype(np.uint32).astype(np.uint64)
+        assert (p[:, :lo] == 0).all() and (p[:, hi:] == 0).all()
+        acc += p
+        nn = [t.cpu().numpy() for t in dens.nearest_neighbors_partial(ct, fet, lo, hi, variant=variant)]
+        idx = nn[0].astype(np.uint32).astype(np.uint64)
+        assert (idx[lo:hi] == exp[0][lo:hi]).all()
+        assert (idx[:lo] == 1501).all() and (idx[hi:] == 1501).all()
+        assert (nn[1][:lo] == FLT_MAX).all() and (nn[3][hi:] == FLT_MAX).all()
+        assert (nn[2].astype(np.uint32).astype(np.uint64)[lo:hi] == exp[2][lo:hi]).all()
+    assert (acc == full).all()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_duplicates_and_offset_data(dens, oracle, variant):
+    """duplicated frames (d2 == 0 neighbours), exact ties, and data far from the origin (large
+    |x|^2 stresses the Gram-form guard band of the MFMA variant)."""
+    rng = np.random.default_rng(5)
+    base = gaussian_blobs(700, 10, seed=9)
+    c = np.concatenate([base, base[:300], base[100:150]]).astype(np.float32)   # duplicates
+    c = c[rng.permutation(c.shape[0])]
+    check_full(dens, oracle, c, [0.2, 0.25], variant)
+    lattice = rng.integers(0, 4, (1200, 6)).astype(np.float32) * 0.25        # massive exact ties
+    check_full(dens, oracle, lattice, [0.25, 0.5, 0.3535534], variant)
+    shifted = (gaussian_blobs(1500, 10, seed=10) + np.float32(37.5)).astype(np.float32)
+    check_full(dens, oracle, shifted, [0.2], variant)
+
+
+def test_host_pointer_entry_points(oracle):
+    """dc_hip_populations / dc_hip_nearest_neighbors / dc_hip_density_all with HOST pointers."""
+    from clustering_amd import capi
+    c = gaussian_blobs(2000, 10, seed=3)
+    n, d = c.shape
+    radii = np.array([0.2, 0.1], dtype=np.float32)
+    pops = np.zeros((2, n), dtype=np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    capi.check(capi.lib.dc_hip_populations(vp(c), n, d, vp(radii), 2, 100, 1900, 0, vp(pops)))
+    want = oracle.populations(c, radii, 100, 1900)
+    assert (pops.astype(np.uint64) == want).all()
+    full = oracle.populations(c, radii)
+    fe = oracle.free_energies(full[0])
+    out = [np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros(n, np.uint32), np.zeros(n, np.float32)]
+    capi.check(capi.lib.dc_hip_nearest_neighbors(vp(c), n, d, vp(fe), 0, n, 0, *[vp(a) for a in out]))
+    exp = oracle.nearest_neighbors(c, fe)
+    assert (out[0].astype(np.uint64) == exp[0]).all() and (out[2].astype(np.uint64) == exp[2]).all()
+    assert (bits(out[1]) == bits(exp[1])).all() and (bits(out[3]) == bits(exp[3])).all()
+    # whole path, one device
+    pops2 = np.zeros((2, n), dtype=np.uint32)
+    fe2 = np.zeros(n, np.float32)
+    out2 = [np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros(n, np.uint32), np.zeros(n, np.float32)]
+    capi.check(capi.lib.dc_hip_density_all(vp(c), n, d, vp(radii), 2, 0, 1, vp(pops2), vp(fe2),
+                                           *[vp(a) for a in out2]))
+    assert (pops2.astype(np.uint64) == full).all()
+    assert (bits(fe2) == bits(fe)).all()
+    assert (out2[0].astype(np.uint64) == exp[0]).all() and (bits(out2[3]) == bits(exp[3])).all()
+
+
+def test_errors_are_codes_not_exits():
+    from clustering_amd import capi
+    c = np.zeros((4, 3), np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    pops = np.zeros(4, np.uint32)
+    r = np.array([1.0], np.float32)
+    rc = capi.lib.dc_hip_populations(vp(c), 4, 3, vp(r), 1, 3, 2, 0, vp(pops))   # i_from > i_to
+    assert rc == -1 and b"row range" in capi.lib.dc_hip_last_error()
+    rc = capi.lib.dc_hip_populations(vp(c), 4, 3, vp(r), 1, 0, 4, 99, vp(pops))  # bad device
+    assert rc == -1
+    rc = capi.lib.dc_hip_populations(vp(c), 4, 0, vp(r), 1, 0, 4, 0, vp(pops))   # n_cols == 0
+    assert rc == -1
