@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- the `clustering density` hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one synthetic trajectory:
+    populations (one sweep over all radii) -> free energies -> nearest neighbour / nearest
+    neighbour with lower free energy, with coordinates already resident in HBM and all outputs
+    left resident in HBM (after the RCCL all-reduce / all-gather when N > 1).
+Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one GPU):
+    1 000 000 frames x 10 dims, 3-Gaussian-blob generator of SURVEY.md 8(d) (seed 20240), r = 0.2.
+Metric: frame-pairs/s (density pop+nn) = 2*N^2 / t_step  (ordered pairs of both sweeps per second).
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+    "roofline":     dominant kernel vs the fp32 MFMA/VALU peak (157.3 TFLOP/s), 2*D flop per evaluated pair
+    "cpu_baseline": the CPU restatement (oracle, fast build, all host threads) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-rows", type=int, default=1_000_000)
+    ap.add_argument("--n-cols", type=int, default=10)
+    ap.add_argument("--radii", type=float, nargs="+", default=[0.2])
+    ap.add_argument("--variant", default="auto", choices=["auto", "direct", "mfma"])
+    ap.add_argument("--cpu-sample", type=int, default=40000,
+                    help="rows of the workload the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--no-nn", action="store_true", help="populations + free energies only (C2-style)")
+    return ap.parse_args()
+
+
+def cpu_baseline(coords_np, radii, sample_rows, want_nn):
+    """Times the CPU restatement (oracle/dc_oracle.c, DCO_FAST build: -O3 -ffast-math -mavx2 -mfma,
+    OpenMP over all host threads; box-grid pruned i<j populations + brute-force neighbours -- the
+    reference's own algorithm, density_clustering.cpp:126-288) on the first sample_rows rows."""
+    from oracle.oracle import Oracle, build
+    build()
+    o = Oracle(fast=True)
+    c = coords_np[:sample_rows]
+    n = c.shape[0]
+    t0 = time.perf_counter()
+    pops = o.populations(c, radii, boxgrid=True)
+    t1 = time.perf_counter()
+    fe = o.free_energies(pops[0])
+    t2 = time.perf_counter()
+    if want_nn:
+        o.nearest_neighbors(c, fe)
+    t3 = time.perf_counter()
+    sweeps = 2 if want_nn else 1
+    return {
+        "value": sweeps * float(n) * n / (t3 - t0),
+        "unit": "frame-pairs/s",
+        "cores": o.threads,
+        "kind": "port",
+        "sample": f"first {n} rows of the workload ({n}x{c.shape[1]}, radii {list(radii)}): "
+                  f"pops {t1 - t0:.2f}s (box grid, i<j) + fe {t2 - t1:.3f}s"
+                  + (f" + nn {t3 - t2:.2f}s (brute force)" if want_nn else "")
+                  + "; rate = sweeps*n^2/t at THIS n (the pruned pop sweep gets relatively cheaper as n grows)",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the density path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from clustering_amd import density
+    from clustering_amd.distributed import HipBackend, ShardedDensity
+    from clustering_amd.rows import shard_rows
+    from clustering_amd.synth import gaussian_blobs
+
+    n, d = args.n_rows, args.n_cols
+    want_nn = not args.no_nn
+    coords_np = gaussian_blobs(n, d)            # same seed on every rank: coordinates are replicated
+    coords = torch.from_numpy(coords_np).to(dev)
+    backend = HipBackend(args.variant)
+    job = ShardedDensity(backend)
+    lo, hi = shard_rows(n, world, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # per-kernel HIP events (torch events record on the current stream, which is the stream the
+    # C ABI launches on: clustering_amd.density passes torch.cuda.current_stream()).
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    pop_ms, nn_ms = [], []
+
+    def step(timed):
+        if timed:
+            ev[0].record()
+        pops = backend.populations_partial(coords, args.radii, lo, hi)
+        if timed:
+            ev[1].record()
+        if world > 1:
+            dist.all_reduce(pops, op=dist.ReduceOp.SUM)
+        fe = backend.free_energies(pops[0].contiguous())
+        res = None
+        if want_nn:
+            if timed:
+                ev[2].record()
+            res = backend.nearest_neighbors_partial(coords, fe, lo, hi)
+            if timed:
+                ev[3].record()
+        return pops, fe, res
+
+    for _ in range(args.warmup):
+        job.run(coords, args.radii, 0, want_nn)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = job.run(coords, args.radii, 0, want_nn)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # kernel durations for the roofline entry: same calls, outside the whole-job timed region
+    for _ in range(max(1, min(args.steps, 3))):
+        step(True)
+        torch.cuda.synchronize()
+        pop_ms.append(ev[0].elapsed_time(ev[1]))
+        if want_nn:
+            nn_ms.append(ev[2].elapsed_time(ev[3]))
+
+    sweeps = 2 if want_nn else 1
+    pairs_per_step = sweeps * float(n) * float(n)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = pairs_per_step / (elapsed / args.steps)
+
+    if rank == 0:
+        pop_t = float(np.mean(pop_ms)) * 1e-3
+        nn_t = float(np.mean(nn_ms)) * 1e-3 if want_nn else 0.0
+        local_rows = hi - lo
+        # dominant kernel = the longer of the two sweeps on this rank; every ordered (query, reference)
+        # pair is evaluated (no i<j symmetry, no pruning), 2*D flop each.
+        dom, dom_t = ("nearest_neighbor_search", nn_t) if nn_t > pop_t else ("population_count", pop_t)
+        flops = float(local_rows) * n * 2.0 * d
+        achieved = flops / dom_t / 1e12
+        pop_sum = int(out["pops"][0].sum(dtype=torch.int64).item())
+        line = {
+            "metric": "frame-pairs/s (density pop+nn)" if want_nn else "frame-pairs/s (density pop)",
+            "value": value,
+            "unit": "frame-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n} frames x {d} dims, 3-Gaussian-blob (sigma 0.08, seed 20240), radii {args.radii}, "
+                            + ("pop + free energy + nn/nn_hd" if want_nn else "pop + free energy"),
+                "n_rows": n, "n_cols": d, "radii": args.radii, "variant": args.variant,
+                "parallelism": f"rows sharded over {world} GPU(s), coords replicated; all-reduce(pops) + all-gather(nn)",
+            },
+            "phases_ms": {"pop_kernel": 1e3 * pop_t, "nn_kernel": 1e3 * nn_t,
+                          "other (fe, collectives, host)": ms_per_step - 1e3 * (pop_t + nn_t)},
+            "check": {"mean_pop_r0": pop_sum / n, "max_pop_r0": int(out["pops"][0].max().item())},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": None,
+                "flop_per_pair": 2 * d,
+                "pairs_per_launch": float(local_rows) * n,
+                "launch_ms": 1e3 * dom_t,
+            },
+        }
+        if args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(coords_np, args.radii, min(args.cpu_sample, n), want_nn)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import capi
+from .rows import shard_rows  # noqa: F401  (re-export)
 
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -128,11 +129,3 @@ def compute_sigma2(nn_d2):
         rc = capi.lib.dc_hip_sigma2_dev(_dev(nn_d2), nn_d2.shape[0], C.byref(out), _stream_ptr())
     capi.check(rc, "dc_hip_sigma2_dev")
     return out.value
-
-
-def shard_rows(n_rows, n_shards, shard):
-    """Row block of one device, exactly as density_clustering_cuda.cu:149,165-169."""
-    rng = n_rows // n_shards
-    lo = shard * rng
-    hi = n_rows if shard == n_shards - 1 else (shard + 1) * rng
-    return lo, hi

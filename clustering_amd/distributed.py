@@ -1,0 +1,82 @@
+"""Row-sharded density path over torch.distributed (one process per GPU; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" for the CPU tests of this host logic).
+
+Sharding and merging follow the reference's multi-GPU host code:
+  - contiguous row blocks [g*floor(N/G), (g+1)*floor(N/G)), the last rank takes the remainder
+    (density_clustering_cuda.cu:149,165-169 / :293,305-308); coordinates are replicated;
+  - populations: every rank holds [n_radii][N], zero outside its rows; the reference sums the
+    partials on the host (density_clustering_cuda.cu:171-180) -> here ONE all-reduce(sum) of
+    n_radii*N int32 (exact);
+  - free energies: every rank computes all N values locally from the reduced populations;
+  - neighbours: the reference overwrites row by row from each partial (cuda.cu:311-326) -> here
+    ONE all-gather of per-rank blocks [4][block] (nn_idx, nn_d2 bits, hd_idx, hd_d2 bits), blocks
+    padded to the largest (= last) shard.
+"""
+import torch
+import torch.distributed as dist
+
+from .rows import shard_rows
+
+
+class HipBackend:
+    """The product compute backend: libdcdensity.so through clustering_amd.density (no fallback)."""
+
+    def __init__(self, variant="auto"):
+        from . import density
+        self._d = density
+        self.variant = variant
+
+    def populations_partial(self, coords, radii, lo, hi):
+        return self._d.calculate_populations_partial(coords, radii, lo, hi, variant=self.variant)
+
+    def free_energies(self, pops_row):
+        return self._d.calculate_free_energies(pops_row)
+
+    def nearest_neighbors_partial(self, coords, fe, lo, hi):
+        return self._d.nearest_neighbors_partial(coords, fe, lo, hi, variant=self.variant)
+
+
+class ShardedDensity:
+    """pop -> FE -> NN for the rows of this rank, merged across ranks with two collectives."""
+
+    def __init__(self, backend=None, group=None):
+        self.backend = backend if backend is not None else HipBackend()
+        self.group = group
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
+
+    def run(self, coords, radii, fe_radius_index=0, want_nn=True):
+        """coords: [N, D] float32 on this rank's device (replicated).  Returns a dict of tensors on
+        that device: pops int32 [n_radii, N], fe float32 [N], and if want_nn nn_idx/hd_idx int32 [N],
+        nn_d2/hd_d2 float32 [N] -- identical on every rank."""
+        rank, world = self._world()
+        n_rows = coords.shape[0]
+        lo, hi = shard_rows(n_rows, world, rank)
+        pops = self.backend.populations_partial(coords, radii, lo, hi)
+        if world > 1:
+            dist.all_reduce(pops, op=dist.ReduceOp.SUM, group=self.group)
+        fe = self.backend.free_energies(pops[fe_radius_index].contiguous())
+        out = {"pops": pops, "fe": fe}
+        if not want_nn:
+            return out
+        nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.nearest_neighbors_partial(coords, fe, lo, hi)
+        if world > 1:
+            block = n_rows - (world - 1) * (n_rows // world)        # largest shard (the last one)
+            send = torch.zeros((4, block), dtype=torch.int32, device=coords.device)
+            send[0, :hi - lo] = nn_idx[lo:hi]
+            send[1, :hi - lo] = nn_d2[lo:hi].view(torch.int32)
+            send[2, :hi - lo] = hd_idx[lo:hi]
+            send[3, :hi - lo] = hd_d2[lo:hi].view(torch.int32)
+            recv = torch.empty((world, 4, block), dtype=torch.int32, device=coords.device)
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+            for g in range(world):
+                glo, ghi = shard_rows(n_rows, world, g)
+                nn_idx[glo:ghi] = recv[g, 0, :ghi - glo]
+                nn_d2[glo:ghi] = recv[g, 1, :ghi - glo].view(torch.float32)
+                hd_idx[glo:ghi] = recv[g, 2, :ghi - glo]
+                hd_d2[glo:ghi] = recv[g, 3, :ghi - glo].view(torch.float32)
+        out.update(nn_idx=nn_idx, nn_d2=nn_d2, hd_idx=hd_idx, hd_d2=hd_d2)
+        return out
