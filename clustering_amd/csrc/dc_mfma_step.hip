@@ -1,0 +1,29 @@
+// dc_mfma_step.hip -- instantiates the MFMA sweeps for ONE K-step count (compile with -DDC_STEP=n,
+// n = ceil(n_cols/2)); see dc_mfma_kernels.hpp.
+#include "dc_mfma_kernels.hpp"
+
+#ifndef DC_STEP
+#error "compile with -DDC_STEP=<number of K-steps>"
+#endif
+#define DC_CAT2(a, b) a##b
+#define DC_CAT(a, b) DC_CAT2(a, b)
+
+namespace dc {
+
+void DC_CAT(pop_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
+                                     void* d_ws, uint32_t i_from, uint32_t i_to, const Rad2& rad2,
+                                     int n_rad, uint32_t* pops, hipStream_t s) {
+  const Layout L = make_layout(n_rows, n_cols);
+  pop_dispatch<DC_STEP>(coords, n_rows, n_cols, ws_ptrs(d_ws, L), L.T, i_from, i_to, rad2, n_rad,
+                        pops, s);
+}
+
+void DC_CAT(nn_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
+                                    void* d_ws, uint32_t i_from, uint32_t i_to, uint32_t* nn_idx,
+                                    float* nn_d2, uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
+  const Layout L = make_layout(n_rows, n_cols);
+  nn_dispatch<DC_STEP>(coords, n_rows, n_cols, ws_ptrs(d_ws, L), L.T, i_from, i_to, nn_idx, nn_d2,
+                       hd_idx, hd_d2, s);
+}
+
+}  // namespace dc
