@@ -146,13 +146,16 @@ int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, 
     for (int r = 0; r < dc::kMaxRadiiPerLaunch; ++r)
       rad2.v[r] = (r < n_rad) ? radii[r0 + r] * radii[r0 + r] : -1.0f;  // fl32(r*r), :137-140
     uint32_t* out = d_pops + r0 * n_rows;
-    if (mfma) {
+    // MFMA variant: the MFMA kernel runs unless the operand-image pass flagged the data
+    // (non-finite / overflow-prone rows), in which case the gated direct kernel does the work;
+    // both are enqueued, the choice is made on the device (no host synchronisation).
+    if (mfma)
       dc::launch_pop_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                           (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
-    } else if (!dc::launch_pop_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols,
-                                      (uint32_t)i_from, (uint32_t)i_to, rad2, n_rad, out, s)) {
+    if (!dc::launch_pop_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
+                               (uint32_t)i_to, rad2, n_rad, out,
+                               mfma ? (const uint32_t*)d_workspace : nullptr, s))
       return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported", n_cols);
-    }
     if (int rc = check_launch("population sweep launch")) return rc;
   }
   return DC_OK;
@@ -217,11 +220,11 @@ int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
     dc::launch_nn_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
                        (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
-  } else if (!dc::launch_nn_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe,
-                                   (uint32_t)i_from, (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx,
-                                   d_hd_d2, s)) {
-    return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported", n_cols);
   }
+  if (!dc::launch_nn_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
+                            (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2,
+                            mfma ? (const uint32_t*)d_workspace : nullptr, s))
+    return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported", n_cols);
   return check_launch("nearest-neighbour sweep launch");
 }
 

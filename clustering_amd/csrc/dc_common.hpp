@@ -22,13 +22,15 @@ struct Rad2 {
 // ---- launchers implemented in dc_direct.hip -------------------------------------------
 // pops: [n_radii_total][n_rows] radius-major; this launch fills radius rows
 // r_first .. r_first+n_rad-1 for query rows [i_from, i_to).  Returns false if n_cols is unsupported.
+// gate: optional device pointer to the MFMA workspace header; when given, the kernel runs only if
+// gate[1] != 0 (the operand-image pass flagged data the MFMA kernels must not touch).
 bool launch_pop_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
-                       hipStream_t stream);
+                       const uint32_t* gate, hipStream_t stream);
 
 bool launch_nn_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
-                      uint32_t* d_hd_idx, float* d_hd_d2, hipStream_t stream);
+                      uint32_t* d_hd_idx, float* d_hd_d2, const uint32_t* gate, hipStream_t stream);
 
 // fills idx[i] = n_rows+1, d2[i] = FLT_MAX for all rows (density_clustering.cpp:242-245)
 void launch_nn_init(uint32_t n_rows, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,

@@ -69,8 +69,10 @@ template <int D, int NR>
 __global__ __launch_bounds__(kBlock) void pop_direct_kernel(const float* __restrict__ coords,
                                                             uint32_t n_rows, uint32_t i_from,
                                                             uint32_t i_to, Rad2 rad2, int n_rad,
-                                                            uint32_t* __restrict__ pops) {
+                                                            uint32_t* __restrict__ pops,
+                                                            const uint32_t* __restrict__ gate) {
   constexpr int S = Cfg<D>::S, Q = Cfg<D>::Q;
+  if (gate && gate[1] == 0) return;
   __shared__ __attribute__((aligned(16))) float tile[kTile * S];
   const uint32_t qbase = i_from + blockIdx.x * (kBlock * Q);
 
@@ -157,8 +159,9 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void nn_direct_kernel(
     const float* __restrict__ coords, uint32_t n_rows, const float* __restrict__ fe,
     uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
-    uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+    uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, const uint32_t* __restrict__ gate) {
   constexpr int S = Cfg<D>::S, Q = Cfg<D>::Q;
+  if (gate && gate[1] == 0) return;
   __shared__ __attribute__((aligned(16))) float tile[kTile * S];
   __shared__ float tile_fe[kTile];
   const uint32_t qbase = i_from + blockIdx.x * (kBlock * Q);
@@ -212,7 +215,9 @@ __global__ __launch_bounds__(kGBlock) void pop_generic_kernel(const float* __res
                                                               uint32_t n_rows, uint32_t D,
                                                               uint32_t i_from, uint32_t i_to,
                                                               Rad2 rad2, int n_rad,
-                                                              uint32_t* __restrict__ pops) {
+                                                              uint32_t* __restrict__ pops,
+                                                              const uint32_t* __restrict__ gate) {
+  if (gate && gate[1] == 0) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qs = smem;                        // [D][kGBlock]
   float* tile = smem + (size_t)D * kGBlock;  // [kGTile][D]
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(kGBlock) void pop_generic_kernel(const float* __res
 __global__ __launch_bounds__(kGBlock) void nn_generic_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t D, const float* __restrict__ fe,
     uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
-    uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+    uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, const uint32_t* __restrict__ gate) {
+  if (gate && gate[1] == 0) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qs = smem;
   float* tile = smem + (size_t)D * kGBlock;
@@ -313,26 +319,27 @@ __global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint3
 
 // ---- dispatch tables over n_cols ---------------------------------------------------------
 using PopLaunch = void (*)(const float*, uint32_t, uint32_t, uint32_t, const Rad2&, int, uint32_t*,
-                           hipStream_t);
+                           const uint32_t*, hipStream_t);
 using NnLaunch = void (*)(const float*, uint32_t, const float*, uint32_t, uint32_t, uint32_t*,
-                          float*, uint32_t*, float*, hipStream_t);
+                          float*, uint32_t*, float*, const uint32_t*, hipStream_t);
 
 template <int D, int NR>
 void pop_launch(const float* c, uint32_t n, uint32_t i_from, uint32_t i_to, const Rad2& rad2,
-                int n_rad, uint32_t* pops, hipStream_t s) {
+                int n_rad, uint32_t* pops, const uint32_t* gate, hipStream_t s) {
   const uint32_t per_block = kBlock * Cfg<D>::Q;
   const uint32_t grid = (i_to - i_from + per_block - 1) / per_block;
   hipLaunchKernelGGL((pop_direct_kernel<D, NR>), dim3(grid), dim3(kBlock), 0, s, c, n, i_from,
-                     i_to, rad2, n_rad, pops);
+                     i_to, rad2, n_rad, pops, gate);
 }
 
 template <int D>
 void nn_launch(const float* c, uint32_t n, const float* fe, uint32_t i_from, uint32_t i_to,
-               uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
+               uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2, const uint32_t* gate,
+               hipStream_t s) {
   const uint32_t per_block = kBlock * Cfg<D>::Q;
   const uint32_t grid = (i_to - i_from + per_block - 1) / per_block;
   hipLaunchKernelGGL((nn_direct_kernel<D>), dim3(grid), dim3(kBlock), 0, s, c, n, fe, i_from, i_to,
-                     nn_idx, nn_d2, hd_idx, hd_d2);
+                     nn_idx, nn_d2, hd_idx, hd_d2, gate);
 }
 
 template <int NR, int... Ds>
@@ -354,12 +361,12 @@ const auto kNn = make_nn_table(DSeq{});
 
 bool launch_pop_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops,
-                       hipStream_t stream) {
+                       const uint32_t* gate, hipStream_t stream) {
   if (i_to <= i_from || n_rad <= 0) return true;
   if (n_cols >= 1 && n_cols <= (uint32_t)kMaxColsTemplated) {
     // instances exist for 1, 4 and 8 radius slots; unused slots hold -1 ("d < -1" is never true)
     const auto& tab = (n_rad == 1) ? kPop1 : (n_rad <= 4 ? kPop4 : kPop8);
-    tab[n_cols - 1](d_coords, n_rows, i_from, i_to, rad2, n_rad, d_pops, stream);
+    tab[n_cols - 1](d_coords, n_rows, i_from, i_to, rad2, n_rad, d_pops, gate, stream);
     return true;
   }
   if (n_cols > (uint32_t)kMaxColsTemplated && n_cols <= (uint32_t)kMaxColsGeneric) {
@@ -368,7 +375,7 @@ bool launch_pop_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pop_generic_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(pop_generic_kernel, dim3(grid), dim3(kGBlock), smem, stream, d_coords,
-                       n_rows, n_cols, i_from, i_to, rad2, n_rad, d_pops);
+                       n_rows, n_cols, i_from, i_to, rad2, n_rad, d_pops, gate);
     return true;
   }
   return false;
@@ -376,11 +383,11 @@ bool launch_pop_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
 
 bool launch_nn_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
-                      uint32_t* d_hd_idx, float* d_hd_d2, hipStream_t stream) {
+                      uint32_t* d_hd_idx, float* d_hd_d2, const uint32_t* gate, hipStream_t stream) {
   if (i_to <= i_from) return true;
   if (n_cols >= 1 && n_cols <= (uint32_t)kMaxColsTemplated) {
     kNn[n_cols - 1](d_coords, n_rows, d_fe, i_from, i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2,
-                    stream);
+                    gate, stream);
     return true;
   }
   if (n_cols > (uint32_t)kMaxColsTemplated && n_cols <= (uint32_t)kMaxColsGeneric) {
@@ -389,7 +396,7 @@ bool launch_nn_direct(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_generic_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(nn_generic_kernel, dim3(grid), dim3(kGBlock), smem, stream, d_coords,
-                       n_rows, n_cols, d_fe, i_from, i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
+                       n_rows, n_cols, d_fe, i_from, i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, gate);
     return true;
   }
   return false;

@@ -55,9 +55,15 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_rows, 
     img[((size_t)t * S + (k >> 1)) * 64 + (k & 1) * 32 + c] = v;
     nrm += (double)v * (double)v;
   }
+  // (a non-finite coordinate makes nrm non-finite, which raises the flag below)
   float nf = (row < n_rows) ? (float)nrm : INFINITY;    // pad rows can never be "inside"
   norms[row] = nf;
-  if (row < n_rows && nf == nf) atomicMax(maxnorm_bits, __float_as_uint(nf));  // NaN rows skipped
+  if (row < n_rows) {
+    if (nf <= kNormLimit)
+      atomicMax(maxnorm_bits, __float_as_uint(nf));
+    else
+      atomicOr(maxnorm_bits + 1, 1u);   // NaN / inf / overflow-prone row: MFMA kernels stand down
+  }
 }
 
 __global__ void fe_pad_kernel(const float* __restrict__ fe, uint32_t n_rows, uint32_t T,

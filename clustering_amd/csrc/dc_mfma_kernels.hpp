@@ -1,4 +1,6 @@
-// dc_mfma.hip -- fp32-MFMA variants of the two pairwise sweeps (gfx950, v_mfma_f32_32x32x2_f32).
+// dc_mfma_kernels.hpp -- fp32-MFMA variants of the two pairwise sweeps (gfx950,
+// v_mfma_f32_32x32x2_f32).  Included by dc_mfma.hip (host side) and dc_mfma_step.hip (one
+// translation unit per K-step count).
 //
 // Idea.  The N x D . D x N distance block is a dense contraction:
 //     d2(x, y) = |x|^2 + |y|^2 - 2 x.y
@@ -12,7 +14,7 @@
 //                            the ORIGINAL coordinates, in-kernel, by the lane that owns it.
 // A handful of pairs per frame fall in the band (|d2 - r^2| < ~1e-5), so the re-check costs ~1 %.
 // The nearest-neighbour sweep uses the same band around the running minimum: every reference frame
-// whose MFMA distance is within 2 eps of the running minimum is evaluated exactly and merged
+// whose MFMA distance is within 2.5 eps of the running minimum is evaluated exactly and merged
 // lexicographically on (d2, index), which reproduces "lowest index wins ties" (:270) exactly.
 //
 // Mapping (one wave = TQ query tiles of 32 frames, swept against all reference tiles of 32 frames):
@@ -21,10 +23,20 @@
 //     A = centred reference coordinates   y'[i][k]            (streamed, one dword per K-step)
 //     B = -2 * centred query coordinates  x'[j][k]            (resident in VGPRs for the whole sweep)
 //     C = |y'_i|^2 broadcast along the row                     (initial accumulator, 4 x dwordx4)
-//   => acc = |y'|^2 - 2 x'.y' ; the query norm moves into the per-lane threshold r^2 - |x'|^2 -+ eps.
+//   => acc = |y'|^2 - 2 x'.y' ; the query norm moves into the per-lane threshold r^2 - |x'|^2 - eps.
 // Queries sit on the lane axis, so populations / running minima are per-lane registers; the two
 // half-waves (h = 0/1) see disjoint reference rows of the same 32 queries and are merged by one
 // __shfl_xor(.., 32) at the very end.
+//
+// Schedule.  The S MFMAs of chain k are interleaved in program order with the VALU epilogue of
+// chain k-1 (two accumulator tiles ping-pong), so a single wave keeps the matrix pipe busy and the
+// second wave of the SIMD fills the gaps.  The epilogues use no compare masks at all (no SGPR
+// hand-offs between VALU and SALU): with t = acc - lo,
+//     inside  <=>  sign bit of t               -> shifted into a bit string (v_alignbit), v_bcnt
+//     in band <=>  bits(t) <u bits(2 eps)      -> unsigned min (v_min3_u32), one test per chain
+// which is valid because the MFMA kernels only run on finite data (the operand-image pass raises
+// a flag for non-finite or overflow-prone rows; the flagged case runs the direct kernels instead,
+// both launches are gated on the device so no host synchronisation is needed).
 //
 // Operand images (built once per call by mfma_prepare in the caller's workspace):
 //   img   [T][S][64]  A fragments in lane order: img[(t*S+s)*64 + l] = y'[32t + (l&31)][2s + (l>>5)]
@@ -45,8 +57,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxSteps = 16;          // K-steps of two columns -> n_cols <= 32
-constexpr size_t kHdrBytes = 1024;     // [0] max norm (float bits); [256..] column sums (double)
-constexpr size_t kHdrSums = 256;
+constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits); word 1: non-finite flag;
+constexpr size_t kHdrSums = 256;       // byte 256..: column sums (double) for the centring
+constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram form -> flagged
 
 struct Layout {
   uint32_t T, S;
@@ -65,11 +78,24 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   return L;
 }
 
+struct Ptrs {
+  const uint32_t* hdr;   // [0] max norm bits, [1] non-finite flag
+  const double* sums;
+  const float* img;
+  const float* norms;
+  const float* fe;
+};
+
+inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
+  char* p = (char*)d_ws;
+  return Ptrs{(const uint32_t*)p, (const double*)(p + kHdrSums), (const float*)(p + L.off_img),
+              (const float*)(p + L.off_norm), (const float*)(p + L.off_fe)};
+}
+
 // ---------------------------------------------------------------------------------------------
 // guard band (DESIGN.md "guard band"): |acc + |x'|^2 - d2_canonical| <= eps for every pair whose
 // canonical d2 is <= d2cap, given M = max |x'|^2, K = 2S fused multiply-adds in the MFMA chain.
 //   eps = 1.25 * u * [ (4K + 10) * M + (D/4 + 12) * d2cap ],  u = 2^-24, rounded up.
-// Non-finite M  ->  +inf  ->  every pair takes the exact path (slow, still correct).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float guard_eps(float M, float d2cap, int K, int D) {
   const double u = 5.9604644775390625e-8;
@@ -92,6 +118,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ img,
   for (int g = 0; g < 4; ++g) nv[g] = np[2 * g];        // rows 8g + 4h .. +3  <->  registers 4g .. 4g+3
 }
 
+__device__ __forceinline__ void load_frag(const float* __restrict__ rowvals, uint32_t t, int h,
+                                          float4 (&v)[4]) {
+  const float4* p = reinterpret_cast<const float4*>(rowvals + (size_t)t * 32 + 4 * h);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) v[g] = p[2 * g];
+}
+
 __device__ __forceinline__ f32x16 frag16(const float4 (&v)[4]) {
   f32x16 o;
 #pragma unroll
@@ -104,29 +137,110 @@ __device__ __forceinline__ f32x16 frag16(const float4 (&v)[4]) {
   return o;
 }
 
-template <int S>
-__device__ __forceinline__ f32x16 gram_tile(const float (&a)[S], const float (&b)[S],
-                                            const f32x16& c0) {
-  f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
-#pragma unroll
-  for (int s = 1; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-  return acc;
-}
-
 // row of reference tile t held by register r of a lane in half h
 __device__ __forceinline__ uint32_t tile_row(uint32_t t, int r, int h) {
   return 32u * t + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);
 }
 
-// ---------------------------------------------------------------------------------------------
+// canonical d2 of two rows of the ORIGINAL coordinate matrix (the only arithmetic that decides)
+__device__ __attribute__((noinline)) float exact_d2(const float* __restrict__ coords,
+                                                   uint32_t n_cols, uint32_t jq, uint32_t i) {
+  return dist2_canon_rt(coords + (size_t)jq * n_cols, 1, coords + (size_t)i * n_cols, 1,
+                        (int)n_cols);
+}
+
+// =============================================================================================
 // population count
-// ---------------------------------------------------------------------------------------------
+// =============================================================================================
+template <int NR>
+struct PopQ {            // per query tile, per lane
+  float lo[NR];          // r^2 - |x'|^2 - eps ; -inf for lanes that own no live query
+  uint32_t cnt[NR];
+};
+
+template <int NR>
+struct PopAcc {          // per chain scratch
+  uint32_t bits[NR];     // sign bits of (acc - lo), one per element, shifted in from the right
+  uint32_t tmin;         // unsigned min over elements and radii of bits(acc - lo)
+};
+
+template <int NR, int R0, int R1>
+__device__ __forceinline__ void pop_epi(const f32x16& acc, const PopQ<NR>& q, PopAcc<NR>& e) {
+#pragma unroll
+  for (int r = R0; r < R1; ++r) {
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      const uint32_t tb = __float_as_uint(acc[r] - q.lo[rr]);
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], tb, 31);   // (bits << 1) | sign(t)
+      e.tmin = min(e.tmin, tb);                                     // negative t: huge unsigned
+    }
+  }
+}
+
+template <int NR>
+__device__ __forceinline__ void pop_epi_begin(PopAcc<NR>& e) {
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) e.bits[rr] = 0;
+  e.tmin = 0xFFFFFFFFu;
+}
+
+template <int NR>
+struct PopDelta {
+  uint32_t d[NR];
+};
+
+// rare: exact re-check of the band pairs of one accumulator tile.  Everything by value and a
+// returned delta, so that neither the accumulators nor the per-query state ever get an address
+// (an escaping reference would park them in scratch for the whole hot loop).
+template <int NR>
+__device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restrict__ coords,
+                                                          uint32_t n_rows, uint32_t n_cols,
+                                                          Rad2 rad2, f32x16 acc, PopQ<NR> q,
+                                                          uint32_t wbits, uint32_t jq, uint32_t t,
+                                                          int h) {
+  PopDelta<NR> out;
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) out.d[rr] = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    bool any = false;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) any = any || (__float_as_uint(acc[r] - q.lo[rr]) < wbits);
+    const uint32_t i = tile_row(t, r, h);
+    if (any && i < n_rows) {
+      const float d2c = exact_d2(coords, n_cols, jq, i);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr)
+        if (__float_as_uint(acc[r] - q.lo[rr]) < wbits) out.d[rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
+    }
+  }
+  return out;
+}
+
+// MFMA chain into acc_new, interleaved with the epilogue of acc_old (query state q_old)
+template <int S, int NR, int SI = 0>
+__device__ __forceinline__ void pop_chain(const float (&a)[S], const float (&b)[S],
+                                          const f32x16& c0, f32x16& acc_new,
+                                          const f32x16& acc_old, const PopQ<NR>& q_old,
+                                          PopAcc<NR>& e) {
+  if constexpr (SI < S) {
+    if constexpr (SI == 0)
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
+    else
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
+    pop_epi<NR, (16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, q_old, e);
+    pop_chain<S, NR, SI + 1>(a, b, c0, acc_new, acc_old, q_old, e);
+  }
+}
+
 template <int S, int NR, int TQ>
 __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ img, const float* __restrict__ norms,
-    const uint32_t* __restrict__ maxnorm_bits, uint32_t T, uint32_t i_from, uint32_t i_to,
-    Rad2 rad2, int n_rad, uint32_t* __restrict__ pops) {
+    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to, Rad2 rad2,
+    int n_rad, uint32_t* __restrict__ pops) {
+  static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+  if (hdr[1] != 0) return;   // non-finite / overflow-prone data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t qt0 = i_from / 32 + wave * TQ;
@@ -135,95 +249,104 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
   float r2max = rad2.v[0];
 #pragma unroll
   for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
-  const float eps = guard_eps(__uint_as_float(*maxnorm_bits), r2max, 2 * S, (int)n_cols);
+  const float eps = guard_eps(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
+  // band width 2*eps as an unsigned key; +1 ulp. eps = +inf (never for flagged-free data) -> all
+  const uint32_t wbits = __float_as_uint(2.0f * eps) + 1u;
 
-  float b[TQ][S], lo[TQ][NR], hi[TQ][NR];
-  uint32_t cnt[TQ][NR], jq[TQ];
-  bool live[TQ];
+  float b[TQ][S];
+  PopQ<NR> q[TQ];
+  uint32_t jq[TQ];
+  uint64_t livemask[TQ];
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
     const uint32_t tile = qt0 + qt;
     jq[qt] = tile * 32 + c;
-    live[qt] = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
+    const bool live = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
+    livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
     const float nx = norms[tl * 32 + c];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-      lo[qt][rr] = live[qt] ? (rad2.v[rr] - nx) - eps : -INFINITY;
-      hi[qt][rr] = live[qt] ? (rad2.v[rr] - nx) + eps : -INFINITY;
-      cnt[qt][rr] = 0;
+      q[qt].lo[rr] = live ? (rad2.v[rr] - nx) - eps : -INFINITY;
+      q[qt].cnt[rr] = 0;
     }
   }
 
-  float a[S];
-  float4 nv[4];
-  load_tile<S>(img, norms, 0, lane, h, a, nv);
-  for (uint32_t t = 0; t < T; ++t) {
-    float an[S];
-    float4 nvn[4];
-    load_tile<S>(img, norms, (t + 1 < T) ? t + 1 : t, lane, h, an, nvn);   // prefetch
+  // accumulator ping-pong: B starts as "+inf everywhere" = contributes nothing
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
+  uint32_t tB = 0;   // reference tile accB belongs to
+
+  float a0[S], a1[S];
+  float4 n0[4], n1[4];
+  load_tile<S>(img, norms, 0, lane, h, a0, n0);
+
+  auto finish = [&](const f32x16& acc, int qi, PopAcc<NR>& e, uint32_t t) {
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+    const bool band = e.tmin < wbits;
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
+      const PopDelta<NR> dl = pop_fix<NR>(coords, n_rows, n_cols, rad2, acc, q[qi], wbits, jq[qi], t, h);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += ((livemask[qi] >> lane) & 1) ? dl.d[rr] : 0u;
+    }
+  };
+
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);
 #pragma unroll
-    for (int qt = 0; qt < TQ; ++qt) {
-      const f32x16 acc = gram_tile<S>(a, b[qt], c0);
-      bool band = false;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-          const bool in = acc[r] < lo[qt][rr];
-          const bool nout = !(acc[r] >= hi[qt][rr]);      // true for NaN: undecidable -> exact path
-          cnt[qt][rr] += in ? 1u : 0u;
-          band = band || (nout && !in);
-        }
-      }
-      band = band && live[qt];
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(band) != 0, 0)) {
-        // exact re-check of the pairs inside a guard band (rare)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          bool any = false;
-#pragma unroll
-          for (int rr = 0; rr < NR; ++rr)
-            any = any || (!(acc[r] >= hi[qt][rr]) && !(acc[r] < lo[qt][rr]));
-          const uint32_t i = tile_row(t, r, h);
-          if (any && live[qt] && i < n_rows) {
-            const float d2c = dist2_canon_rt(coords + (size_t)jq[qt] * n_cols, 1,
-                                             coords + (size_t)i * n_cols, 1, (int)n_cols);
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr)
-              if (!(acc[r] >= hi[qt][rr]) && !(acc[r] < lo[qt][rr]))
-                cnt[qt][rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
-          }
-        }
-      }
+    for (int qt = 0; qt < TQ; qt += 2) {
+      // chain qt -> accA while finishing accB (= query tile TQ-1 of the previous reference tile
+      // when qt == 0, else qt-1 of this one)
+      constexpr int kLast = TQ - 1;
+      const int qb = (qt == 0) ? kLast : qt - 1;
+      PopAcc<NR> e;
+      pop_epi_begin<NR>(e);
+      pop_chain<S, NR>(a, b[qt], c0, accA, accB, q[qb], e);
+      finish(accB, qb, e, tB);
+      pop_epi_begin<NR>(e);
+      pop_chain<S, NR>(a, b[qt + 1], c0, accB, accA, q[qt], e);
+      finish(accA, qt, e, t);
+      tB = t;
     }
-#pragma unroll
-    for (int s = 0; s < S; ++s) a[s] = an[s];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) nv[g] = nvn[g];
+  };
+
+  for (uint32_t t = 0; t < T; t += 2) {
+    load_tile<S>(img, norms, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
+    tile_body(a0, n0, t);
+    if (t + 1 < T) {
+      load_tile<S>(img, norms, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
+      tile_body(a1, n1, t + 1);
+    }
+  }
+  {  // drain: epilogue of the last accB
+    PopAcc<NR> e;
+    pop_epi_begin<NR>(e);
+    pop_epi<NR, 0, 16>(accB, q[TQ - 1], e);
+    finish(accB, TQ - 1, e, tB);
   }
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
+    const bool live = (livemask[qt] >> lane) & 1;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-      const uint32_t total = cnt[qt][rr] + (uint32_t)__shfl_xor((int)cnt[qt][rr], 32, 64);
-      if (h == 0 && live[qt] && rr < n_rad) {
+      const uint32_t total = q[qt].cnt[rr] + (uint32_t)__shfl_xor((int)q[qt].cnt[rr], 32, 64);
+      if (h == 0 && live && rr < n_rad) {
         // the sweep met the self pair and counted it iff d2(i,i) < rad2; the reference starts at 1
-        const float* x = coords + (size_t)jq[qt] * n_cols;
-        const float dself = dist2_canon_rt(x, 1, x, 1, (int)n_cols);
+        const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
         pops[(size_t)rr * n_rows + jq[qt]] = total + 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
       }
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------------
+// =============================================================================================
 // nearest neighbour / nearest neighbour with lower free energy
-// ---------------------------------------------------------------------------------------------
+// =============================================================================================
 __device__ __forceinline__ void lexi_update(bool cond, float& bd, uint32_t& bj, float d,
                                             uint32_t j, uint32_t n_rows) {
   // strict '<' on d2 scanning ascending j  ==  lexicographic min on (d2, j); a tie only counts
@@ -235,143 +358,211 @@ __device__ __forceinline__ void lexi_update(bool cond, float& bd, uint32_t& bj, 
   bj = take ? j : bj;
 }
 
+struct NnQ {             // per query tile, per lane
+  float feq;             // free energy of this lane's query
+  float m_nn, m_hd;      // running minima of the MFMA values (this lane's reference rows only)
+  float bd_nn, bd_hd;    // exact incumbents
+  uint32_t bj_nn, bj_hd;
+};
+
+struct NnBest {
+  float bd_nn, bd_hd;
+  uint32_t bj_nn, bj_hd;
+};
+
+template <int R0, int R1>
+__device__ __forceinline__ void nn_epi(const f32x16& acc, const f32x16& fef, float feq,
+                                       float& tmin, float& hmin) {
+#pragma unroll
+  for (int r = R0; r < R1; ++r) {
+    tmin = fminf(tmin, acc[r]);
+    hmin = fminf(hmin, (fef[r] < feq) ? acc[r] : INFINITY);
+  }
+}
+
+// rare: exact evaluation of the candidates of one accumulator tile (values within the band of the
+// running minimum), merged lexicographically on (d2, index)
+__device__ __attribute__((noinline)) NnBest nn_fix(const float* __restrict__ coords,
+                                                   uint32_t n_rows, uint32_t n_cols, f32x16 acc,
+                                                   f32x16 fef, float feq, float bn, float bh,
+                                                   NnBest best, uint32_t jq, uint32_t t, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const bool cn = acc[r] < bn;
+    const bool ch = (fef[r] < feq) && (acc[r] < bh);
+    const uint32_t i = tile_row(t, r, h);
+    if ((cn || ch) && i < n_rows) {
+      const float d2c = exact_d2(coords, n_cols, jq, i);
+      lexi_update(cn, best.bd_nn, best.bj_nn, d2c, i, n_rows);
+      lexi_update(ch, best.bd_hd, best.bj_hd, d2c, i, n_rows);
+    }
+  }
+  return best;
+}
+
+template <int S, int SI = 0>
+__device__ __forceinline__ void nn_chain(const float (&a)[S], const float (&b)[S],
+                                         const f32x16& c0, f32x16& acc_new, const f32x16& acc_old,
+                                         const f32x16& fef_old, float feq_old, float& tmin,
+                                         float& hmin) {
+  if constexpr (SI < S) {
+    if constexpr (SI == 0)
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
+    else
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
+    nn_epi<(16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, fef_old, feq_old, tmin, hmin);
+    nn_chain<S, SI + 1>(a, b, c0, acc_new, acc_old, fef_old, feq_old, tmin, hmin);
+  }
+}
+
 template <int S, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ img, const float* __restrict__ norms,
-    const float* __restrict__ fe_pad, const uint32_t* __restrict__ maxnorm_bits, uint32_t T,
+    const float* __restrict__ fe_pad, const uint32_t* __restrict__ hdr, uint32_t T,
     uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
     uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+  static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+  if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t qt0 = i_from / 32 + wave * TQ;
   if (qt0 * 32 >= i_to) return;
 
-  const float M = __uint_as_float(*maxnorm_bits);
+  const float M = __uint_as_float(hdr[0]);
   // candidates can be as far apart as 2*sqrt(M): d2cap = 4M
   const float eps = guard_eps(M, 4.0f * M, 2 * S, (int)n_cols);
   const float eps2 = 2.5f * eps;
 
-  float b[TQ][S], feq[TQ], m_nn[TQ], m_hd[TQ], bd_nn[TQ], bd_hd[TQ];
-  uint32_t jq[TQ], bj_nn[TQ], bj_hd[TQ];
-  bool live[TQ];
+  float b[TQ][S];
+  NnQ q[TQ];
+  uint32_t jq[TQ];
+  uint64_t livemask[TQ];
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
     const uint32_t tile = qt0 + qt;
     jq[qt] = tile * 32 + c;
-    live[qt] = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
+    const bool live = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
+    livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
-    feq[qt] = fe_pad[tl * 32 + c];
-    m_nn[qt] = INFINITY;
-    m_hd[qt] = INFINITY;
-    bd_nn[qt] = FLT_MAX;
-    bd_hd[qt] = FLT_MAX;
-    bj_nn[qt] = n_rows + 1;
-    bj_hd[qt] = n_rows + 1;
+    q[qt].feq = fe_pad[tl * 32 + c];
+    q[qt].m_nn = INFINITY;
+    q[qt].m_hd = INFINITY;
+    q[qt].bd_nn = FLT_MAX;
+    q[qt].bd_hd = FLT_MAX;
+    q[qt].bj_nn = n_rows + 1;
+    q[qt].bj_hd = n_rows + 1;
   }
 
-  float a[S];
-  float4 nv[4], fv[4];
-  load_tile<S>(img, norms, 0, lane, h, a, nv);
-  {
-    const float4* fp = reinterpret_cast<const float4*>(fe_pad + 4 * h);
+  f32x16 accA, accB, fefB;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) fv[g] = fp[2 * g];
+  for (int r = 0; r < 16; ++r) {
+    accB[r] = INFINITY;
+    fefB[r] = INFINITY;
   }
-  for (uint32_t t = 0; t < T; ++t) {
-    float an[S];
-    float4 nvn[4], fvn[4];
-    const uint32_t tn = (t + 1 < T) ? t + 1 : t;
-    load_tile<S>(img, norms, tn, lane, h, an, nvn);
-    {
-      const float4* fp = reinterpret_cast<const float4*>(fe_pad + (size_t)tn * 32 + 4 * h);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) fvn[g] = fp[2 * g];
+  uint32_t tB = 0;
+
+  float a0[S], a1[S];
+  float4 n0[4], n1[4], f0[4], f1[4];
+  load_tile<S>(img, norms, 0, lane, h, a0, n0);
+  load_frag(fe_pad, 0, h, f0);
+
+  // finish one accumulator tile: band test against the running minima, rare exact path, update
+  auto finish = [&](f32x16 acc, const f32x16& fef, int qi, float tmin, float hmin, uint32_t t) {
+    NnQ& Q = q[qi];
+    const bool trig = (tmin < Q.m_nn + eps2) || (hmin < Q.m_hd + eps2);
+    const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(trig) & livemask[qi]) != 0, 0)) {
+      NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
+      best = nn_fix(coords, n_rows, n_cols, acc, fef, Q.feq, new_nn + eps2, new_hd + eps2, best,
+                    jq[qi], t, h);
+      const bool live = (livemask[qi] >> lane) & 1;
+      Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
+      Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
+      Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
+      Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
     }
+    Q.m_nn = new_nn;
+    Q.m_hd = new_hd;
+  };
+  // the tile that contains the queries themselves: drop i == j (:262)
+  auto mask_self = [&](f32x16& acc, int qi, uint32_t t) {
+    if (t == qt0 + qi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((r & 3) + 8 * (r >> 2) + 4 * h == c) acc[r] = INFINITY;
+    }
+  };
+
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], const float4 (&fv)[4],
+                       uint32_t t) {
     const f32x16 c0 = frag16(nv);
     const f32x16 fef = frag16(fv);
 #pragma unroll
-    for (int qt = 0; qt < TQ; ++qt) {
-      f32x16 acc = gram_tile<S>(a, b[qt], c0);
-      // nn: lanes also hold the norm |x'|^2 implicitly: acc = d2 - |x'|^2, same offset for every
-      // reference of this lane, so minima and bands can be taken on acc directly.
-      if (t == qt0 + qt) {   // the tile that contains the queries themselves: drop i == j (:262)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if ((r & 3) + 8 * (r >> 2) + 4 * h == c) acc[r] = INFINITY;
-      }
-      float tmin = acc[0], hmin = INFINITY;
-#pragma unroll
-      for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hmin = fminf(hmin, (fef[r] < feq[qt]) ? acc[r] : INFINITY);
-      const bool trig = live[qt] && ((tmin < m_nn[qt] + eps2) || (hmin < m_hd[qt] + eps2));
-      const float new_nn = fminf(m_nn[qt], tmin), new_hd = fminf(m_hd[qt], hmin);
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
-        const float bn = new_nn + eps2, bh = new_hd + eps2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool cn = acc[r] < bn;
-          const bool ch = (fef[r] < feq[qt]) && (acc[r] < bh);
-          const uint32_t i = tile_row(t, r, h);
-          if ((cn || ch) && live[qt] && i < n_rows) {
-            const float d2c = dist2_canon_rt(coords + (size_t)jq[qt] * n_cols, 1,
-                                             coords + (size_t)i * n_cols, 1, (int)n_cols);
-            lexi_update(cn, bd_nn[qt], bj_nn[qt], d2c, i, n_rows);
-            lexi_update(ch, bd_hd[qt], bj_hd[qt], d2c, i, n_rows);
-          }
-        }
-      }
-      m_nn[qt] = new_nn;
-      m_hd[qt] = new_hd;
+    for (int qt = 0; qt < TQ; qt += 2) {
+      constexpr int kLast = TQ - 1;
+      const int qb = (qt == 0) ? kLast : qt - 1;
+      float tmin = INFINITY, hmin = INFINITY;
+      mask_self(accB, qb, tB);
+      if (qt == 0)   // accB belongs to the previous reference tile: its FE fragment was kept
+        nn_chain<S>(a, b[qt], c0, accA, accB, fefB, q[qb].feq, tmin, hmin);
+      else
+        nn_chain<S>(a, b[qt], c0, accA, accB, fef, q[qb].feq, tmin, hmin);
+      finish(accB, (qt == 0) ? fefB : fef, qb, tmin, hmin, tB);
+      tmin = INFINITY;
+      hmin = INFINITY;
+      mask_self(accA, qt, t);
+      nn_chain<S>(a, b[qt + 1], c0, accB, accA, fef, q[qt].feq, tmin, hmin);
+      finish(accA, fef, qt, tmin, hmin, t);
+      tB = t;
     }
-#pragma unroll
-    for (int s = 0; s < S; ++s) a[s] = an[s];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      nv[g] = nvn[g];
-      fv[g] = fvn[g];
+    fefB = fef;
+  };
+
+  for (uint32_t t = 0; t < T; t += 2) {
+    const uint32_t t1 = (t + 1 < T) ? t + 1 : t;
+    load_tile<S>(img, norms, t1, lane, h, a1, n1);
+    load_frag(fe_pad, t1, h, f1);
+    tile_body(a0, n0, f0, t);
+    if (t + 1 < T) {
+      const uint32_t t2 = (t + 2 < T) ? t + 2 : t + 1;
+      load_tile<S>(img, norms, t2, lane, h, a0, n0);
+      load_frag(fe_pad, t2, h, f0);
+      tile_body(a1, n1, f1, t + 1);
     }
+  }
+  {  // drain: epilogue of the last accB
+    float tmin = INFINITY, hmin = INFINITY;
+    mask_self(accB, TQ - 1, tB);
+    nn_epi<0, 16>(accB, fefB, q[TQ - 1].feq, tmin, hmin);
+    finish(accB, fefB, TQ - 1, tmin, hmin, tB);
   }
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
+    NnQ& Q = q[qt];
     // merge the two half-waves (disjoint reference rows of the same query)
-    float od = __shfl_xor(bd_nn[qt], 32, 64);
-    uint32_t oj = (uint32_t)__shfl_xor((int)bj_nn[qt], 32, 64);
-    lexi_update(oj <= n_rows, bd_nn[qt], bj_nn[qt], od, oj, n_rows);
-    od = __shfl_xor(bd_hd[qt], 32, 64);
-    oj = (uint32_t)__shfl_xor((int)bj_hd[qt], 32, 64);
-    lexi_update(oj <= n_rows, bd_hd[qt], bj_hd[qt], od, oj, n_rows);
-    if (h == 0 && live[qt]) {
-      nn_idx[jq[qt]] = bj_nn[qt];
-      nn_d2[jq[qt]] = bd_nn[qt];
-      hd_idx[jq[qt]] = bj_hd[qt];
-      hd_d2[jq[qt]] = bd_hd[qt];
+    float od = __shfl_xor(Q.bd_nn, 32, 64);
+    uint32_t oj = (uint32_t)__shfl_xor((int)Q.bj_nn, 32, 64);
+    lexi_update(oj <= n_rows, Q.bd_nn, Q.bj_nn, od, oj, n_rows);
+    od = __shfl_xor(Q.bd_hd, 32, 64);
+    oj = (uint32_t)__shfl_xor((int)Q.bj_hd, 32, 64);
+    lexi_update(oj <= n_rows, Q.bd_hd, Q.bj_hd, od, oj, n_rows);
+    if (h == 0 && ((livemask[qt] >> lane) & 1)) {
+      nn_idx[jq[qt]] = Q.bj_nn;
+      nn_d2[jq[qt]] = Q.bd_nn;
+      hd_idx[jq[qt]] = Q.bj_hd;
+      hd_d2[jq[qt]] = Q.bd_hd;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// dispatch over the number of K-steps
+// launch helpers (one K-step count per translation unit)
 // ---------------------------------------------------------------------------------------------
 constexpr int kTQ = 4;
-
-struct Ptrs {
-  const uint32_t* maxnorm;
-  const double* sums;
-  const float* img;
-  const float* norms;
-  const float* fe;
-};
-
-inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
-  char* p = (char*)d_ws;
-  return Ptrs{(const uint32_t*)p, (const double*)(p + kHdrSums), (const float*)(p + L.off_img),
-              (const float*)(p + L.off_norm), (const float*)(p + L.off_fe)};
-}
 
 inline uint32_t grid_for(uint32_t i_from, uint32_t i_to, int tq) {
   const uint32_t tiles = (i_to + 31) / 32 - i_from / 32;
@@ -386,13 +577,13 @@ void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const P
   const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
   if (n_rad == 1)
     hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.norms, P.maxnorm, T, i_from, i_to, rad2, n_rad, pops);
+                       P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
   else if (n_rad <= 4)
     hipLaunchKernelGGL((pop_mfma_kernel<S, 4, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.norms, P.maxnorm, T, i_from, i_to, rad2, n_rad, pops);
+                       P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
   else
     hipLaunchKernelGGL((pop_mfma_kernel<S, 8, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.norms, P.maxnorm, T, i_from, i_to, rad2, n_rad, pops);
+                       P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
 }
 
 template <int S>
@@ -401,7 +592,7 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                  float* hd_d2, hipStream_t s) {
   const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
   hipLaunchKernelGGL((nn_mfma_kernel<S, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                     P.norms, P.fe, P.maxnorm, T, i_from, i_to, nn_idx, nn_d2, hd_idx, hd_d2);
+                     P.norms, P.fe, P.hdr, T, i_from, i_to, nn_idx, nn_d2, hd_idx, hd_d2);
 }
 
 }  // namespace
