@@ -562,7 +562,8 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
 // ---------------------------------------------------------------------------------------------
 // launch helpers (one K-step count per translation unit)
 // ---------------------------------------------------------------------------------------------
-constexpr int kTQ = 4;
+constexpr int kTQ = 4;     // query tiles per wave, population sweep
+constexpr int kTQnn = 4;   // query tiles per wave, neighbour sweep (more per-query state)
 
 inline uint32_t grid_for(uint32_t i_from, uint32_t i_to, int tq) {
   const uint32_t tiles = (i_to + 31) / 32 - i_from / 32;
@@ -590,8 +591,8 @@ template <int S>
 void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                  uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
                  float* hd_d2, hipStream_t s) {
-  const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
-  hipLaunchKernelGGL((nn_mfma_kernel<S, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
+  const dim3 grid(grid_for(i_from, i_to, kTQnn)), block(256);
+  hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
                      P.norms, P.fe, P.hdr, T, i_from, i_to, nn_idx, nn_d2, hd_idx, hd_d2);
 }
 

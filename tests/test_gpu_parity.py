@@ -187,6 +187,21 @@ def test_duplicates_and_offset_data(dens, oracle, variant):
     check_full(dens, oracle, shifted, [0.2], variant)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_non_finite_rows(dens, oracle, variant):
+    """rows with inf / NaN coordinates: never inside any radius, never anybody's neighbour (every
+    comparison with NaN/inf d2 is false, as in the reference); the MFMA variant hands such inputs
+    to the exact kernels through its on-device gate."""
+    need(variant, 10)
+    c = gaussian_blobs(900, 10, seed=21)
+    c[17, 3] = np.inf
+    c[400, 0] = np.nan
+    c[401, 9] = -np.inf
+    check_full(dens, oracle, c, [0.2, 0.3], variant)
+    huge = (gaussian_blobs(600, 10, seed=22) * np.float32(1e19)).astype(np.float32)   # |x|^2 overflows
+    check_full(dens, oracle, huge, [2e18], variant)
+
+
 def test_host_pointer_entry_points(oracle):
     """dc_hip_populations / dc_hip_nearest_neighbors / dc_hip_density_all with HOST pointers."""
     from clustering_amd import capi
