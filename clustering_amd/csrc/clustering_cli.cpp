@@ -1,0 +1,496 @@
+// clustering_cli.cpp -- `clustering density` on MI355X.
+//
+// Re-creates the density mode of the reference's command line (clustering.cpp:141-193 options,
+// density_clustering.cpp:559-825 control flow) on top of libdcdensity.so, with the reference's
+// file formats:
+//   coords   whitespace separated ASCII, one frame per line              (tools.hxx:39-111)
+//   -p FILE  header + one integer population per line                    (tools.cpp:50-56)
+//   -d FILE  header + one free energy per line, "%e"                     (tools.cpp:42-48)
+//   -b FILE  header + "id(nn) dsqr(nn) id(nn_hd) dsqr(nn_hd)" per line   (tools.cpp:144-174)
+//   -R r1 r2 ...  several radii in one sweep, files <base>_%f            (density_clustering.cpp:633-642)
+//   "#@   key = %.5f" header lines carry clustering_radius / lumping_radius between stages
+//   (tools.cpp:229-277) and are honoured when -D / -B re-use earlier results.
+// Boost is not available here, so the options are parsed by hand; the option names, their
+// meaning and the error texts follow the reference.  Screening / clustering output (-T, -o, -i) is
+// outside this build's scope and rejected with a clear message.
+// There is no CPU implementation behind this binary: without a HIP device it exits like the
+// reference's CUDA build does (clustering.cpp:110-113).
+#include "../../include/dc_density.h"
+#include "density_clustering_hip.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+const char* kVersion = "amd-hip 0.1 (moldyn/Clustering v1.3 file formats)";
+bool g_verbose = false;
+
+#define LOG(...)                        \
+  do {                                  \
+    if (g_verbose) {                    \
+      std::printf(__VA_ARGS__);         \
+      std::fflush(stdout);              \
+    }                                   \
+  } while (0)
+
+[[noreturn]] void die(const std::string& msg) {
+  std::cerr << msg << std::endl;
+  std::exit(EXIT_FAILURE);
+}
+
+const char* kHelp =
+    "clustering density: \n"
+    "perform clustering of MD data based on phase space densities.\n"
+    "densities are approximated by counting neighboring frames inside\n"
+    "a n-dimensional hypersphere of specified radius.\n"
+    "distances are measured with n-dim P2-norm.\n\n"
+    "options:\n"
+    "  -h [ --help ]                         show this help.\n"
+    "  -f [ --file ] arg                     input (required): phase space coordinates\n"
+    "                                        (space separated ASCII).\n"
+    "  -r [ --radius ] arg                   parameter: hypersphere radius. If not used, the\n"
+    "                                        lumping radius will be used instead.\n"
+    "  -R [ --radii ] arg                    parameter: list of radii for population/free energy\n"
+    "                                        calculations (several radii in one go).\n"
+    "  -p [ --population ] arg               output (optional): population per frame (if -R is set:\n"
+    "                                        this defines only the basename).\n"
+    "  -d [ --free-energy ] arg              output (optional): free energies per frame\n"
+    "                                        (if -R is set: this defines only the basename).\n"
+    "  -D [ --free-energy-input ] arg        input (optional): reuse free energy info.\n"
+    "  -b [ --nearest-neighbors ] arg        output (optional): nearest neighbor info.\n"
+    "  -B [ --nearest-neighbors-input ] arg  input (optional): reuse nearest neighbor info.\n"
+    "  -T, -o, -i                            screening / clustering output: not part of this build.\n"
+    "  -n [ --nthreads ] arg (=0)            accepted for compatibility (the sweeps run on the GPU).\n"
+    "  -v [ --verbose ]                      verbose mode: print runtime information to STDOUT.\n";
+
+struct Options {
+  std::string file, population, free_energy, free_energy_input, nn, nn_input;
+  bool has_radius = false;
+  float radius = 0.0f;
+  std::vector<float> radii;
+  bool screening_requested = false;
+};
+
+bool is_number(const char* s) {
+  char* end = nullptr;
+  std::strtof(s, &end);
+  return end != s && *end == '\0';
+}
+
+Options parse(int argc, char** argv) {
+  Options o;
+  std::map<std::string, std::string> longnames = {
+      {"--file", "-f"}, {"--radius", "-r"}, {"--radii", "-R"}, {"--population", "-p"},
+      {"--free-energy", "-d"}, {"--free-energy-input", "-D"}, {"--nearest-neighbors", "-b"},
+      {"--nearest-neighbors-input", "-B"}, {"--nthreads", "-n"}, {"--verbose", "-v"},
+      {"--help", "-h"}, {"--threshold-screening", "-T"}, {"--output", "-o"}, {"--input", "-i"}};
+  for (int i = 2; i < argc; ++i) {
+    std::string a = argv[i];
+    if (longnames.count(a)) a = longnames[a];
+    auto need = [&](const char* what) -> const char* {
+      if (i + 1 >= argc) die(std::string("\nerror parsing arguments:\n\nthe required argument for option '") + what + "' is missing\n");
+      return argv[++i];
+    };
+    if (a == "-h") {
+      std::cout << kHelp << std::endl;
+      std::exit(EXIT_SUCCESS);
+    } else if (a == "-f") o.file = need("--file");
+    else if (a == "-r") {
+      o.radius = std::strtof(need("--radius"), nullptr);
+      o.has_radius = true;
+    } else if (a == "-R") {
+      while (i + 1 < argc && is_number(argv[i + 1])) o.radii.push_back(std::strtof(argv[++i], nullptr));
+      if (o.radii.empty()) die("\nerror parsing arguments:\n\nthe required argument for option '--radii' is missing\n");
+    } else if (a == "-p") o.population = need("--population");
+    else if (a == "-d") o.free_energy = need("--free-energy");
+    else if (a == "-D") o.free_energy_input = need("--free-energy-input");
+    else if (a == "-b") o.nn = need("--nearest-neighbors");
+    else if (a == "-B") o.nn_input = need("--nearest-neighbors-input");
+    else if (a == "-n") (void)need("--nthreads");
+    else if (a == "-v") g_verbose = true;
+    else if (a == "-T" || a == "-o" || a == "-i") {
+      o.screening_requested = true;
+      while (i + 1 < argc && argv[i + 1][0] != '-') ++i;
+      while (i + 1 < argc && is_number(argv[i + 1])) ++i;
+    } else {
+      die("\nerror parsing arguments:\n\nunrecognised option '" + a + "'\n\n" + kHelp);
+    }
+  }
+  if (o.file.empty()) die(std::string("\nerror parsing arguments:\n\nthe option '--file' is required but missing\n\n") + kHelp);
+  return o;
+}
+
+// ---- IO -------------------------------------------------------------------------------------
+
+// whitespace separated ASCII matrix; n_cols from the first non-empty line (tools.hxx:52-76)
+void read_coords(const std::string& fname, std::vector<float>& coords, std::size_t& n_rows,
+                 std::size_t& n_cols) {
+  std::ifstream ifs(fname, std::ios::binary);
+  if (ifs.fail()) die("error: cannot open file '" + fname + "'");
+  LOG("~~~ reading coordinates\n    from file: %s\n", fname.c_str());
+  std::string text((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+  n_rows = 0;
+  n_cols = 0;
+  const char* p = text.c_str();
+  const char* end = p + text.size();
+  // first non-empty line fixes n_cols
+  {
+    const char* q = p;
+    while (q < end) {
+      const char* eol = static_cast<const char*>(std::memchr(q, '\n', end - q));
+      if (!eol) eol = end;
+      std::string line(q, eol);
+      std::istringstream ss(line);
+      std::string tok;
+      std::size_t n = 0;
+      while (ss >> tok) ++n;
+      if (n > 0) {
+        n_cols = n;
+        break;
+      }
+      q = eol + 1;
+    }
+  }
+  if (n_cols == 0) die("error: opened empty file '" + fname + "'");
+  coords.clear();
+  coords.reserve(text.size() / 8);
+  while (p < end) {
+    char* next = nullptr;
+    const float v = std::strtof(p, &next);
+    if (next == p) {
+      // not a number: skip whitespace, stop at anything else (the reference's `ifs >> buf` would
+      // fail here as well and leave the remaining values unspecified)
+      if (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\v' || *p == '\f') {
+        ++p;
+        continue;
+      }
+      break;
+    }
+    coords.push_back(v);
+    p = next;
+  }
+  n_rows = coords.size() / n_cols;
+  coords.resize(n_rows * n_cols);
+  LOG("    with dimensions: %zux%zu\n\n", n_rows, n_cols);
+}
+
+std::string provenance_header(int argc, char** argv) {
+  std::ostringstream h;
+  time_t raw;
+  time(&raw);
+  h << "# clustering " << kVersion << " - " << argv[1] << "\n#\n# Created " << asctime(localtime(&raw))
+    << "# by following command:\n#\n# ";
+  for (int i = 0; i < argc; ++i) h << argv[i] << " ";
+  h << "\n#\n# MI355X-native implementation of the density hot path of moldyn/Clustering\n"
+    << "# (method: Sittel & Stock, J. Chem. Theory Comput. 12, 2426 (2016); https://github.com/moldyn/clustering)\n";
+  return h.str();
+}
+
+typedef std::map<std::string, float> Comments;
+
+// "#@   key = %.5f" lines, only non-zero values (tools.cpp:267-277)
+std::string with_comments(std::string header, const Comments& cm) {
+  header.append("#\n# The following comments are reused for identifying\n# user-based mistakes and should not be modified.\n");
+  for (const auto& kv : cm)
+    if (kv.second != 0.) {
+      char buf[256];
+      std::snprintf(buf, sizeof(buf), "#@   %s = %.5f\n", kv.first.c_str(), kv.second);
+      header.append(buf);
+    }
+  return header;
+}
+
+void read_comments(const std::string& fname, Comments& cm) {
+  std::ifstream ifs(fname);
+  if (ifs.fail()) die("error: cannot open file '" + fname + "'");
+  std::string line;
+  while (std::getline(ifs, line)) {
+    if (line.compare(0, 2, "#@") != 0) continue;
+    std::istringstream ss(line.substr(2));
+    std::string key, eq;
+    float val;
+    if (!(ss >> key >> eq >> val) || eq != "=") continue;
+    auto it = cm.find(key);
+    if (it == cm.end()) continue;
+    if (it->second != 0 && std::abs(it->second - val) > 0.001)
+      LOG("warning: the values of %s are not in agreement\n        %g vs. %g\n", key.c_str(), val, it->second);
+    it->second = val;
+  }
+}
+
+FILE* open_out(const std::string& fname) {
+  FILE* f = std::fopen(fname.c_str(), "w");
+  if (!f) die("error: cannot open file '" + fname + "' for writing.");
+  return f;
+}
+
+void write_pops(const std::string& fname, const std::uint32_t* pops, std::size_t n,
+                const std::string& header, const Comments& cm) {
+  FILE* f = open_out(fname);
+  std::fputs((with_comments(header, cm) + "#\n# point density of each frame\n").c_str(), f);
+  for (std::size_t i = 0; i < n; ++i) std::fprintf(f, "%u\n", pops[i]);
+  std::fclose(f);
+}
+
+void write_fes(const std::string& fname, const float* fe, std::size_t n, const std::string& header,
+               const Comments& cm) {
+  FILE* f = open_out(fname);
+  std::fputs((with_comments(header, cm) + "#\n# free energy of each frame\n").c_str(), f);
+  for (std::size_t i = 0; i < n; ++i) std::fprintf(f, "%e\n", fe[i]);   // std::scientific, 6 digits
+  std::fclose(f);
+}
+
+void write_neighborhood(const std::string& fname, std::size_t n, const std::uint32_t* nn_idx,
+                        const float* nn_d2, const std::uint32_t* hd_idx, const float* hd_d2,
+                        const std::string& header, const Comments& cm) {
+  FILE* f = open_out(fname);
+  std::fputs((with_comments(header, cm) +
+              "#\n# column definitions:\n"
+              "#        nn = nearest neighbor\n"
+              "#     nn_hd = nearest neighbor with higher density\n"
+              "#     id(i) = id/line number of i\n"
+              "#   dsqr(i) = squared euclidean distance to i\n#\n"
+              "# id(nn)  dsqr(nn) id(nn_hd) dsqr(nn_hd)\n").c_str(), f);
+  for (std::size_t i = 0; i < n; ++i)   // default ostream float format == %g with 6 digits
+    std::fprintf(f, "%u %g %u %g\n", nn_idx[i], nn_d2[i], hd_idx[i], hd_d2[i]);
+  std::fclose(f);
+}
+
+// one number per line, lines that do not start with a number are comments (tools.hxx:230-252)
+template <typename T>
+std::vector<T> read_single_column(const std::string& fname) {
+  std::ifstream ifs(fname);
+  if (ifs.fail()) die("error: cannot open file '" + fname + "'");
+  std::vector<T> dat;
+  std::string line;
+  while (std::getline(ifs, line)) {
+    std::istringstream ss(line);
+    T v;
+    if (ss >> v) dat.push_back(v);
+  }
+  if (dat.empty()) die("error: opened empty file '" + fname + "'");
+  return dat;
+}
+
+void read_neighborhood(const std::string& fname, std::vector<std::uint32_t>& nn_idx,
+                       std::vector<float>& nn_d2, std::vector<std::uint32_t>& hd_idx,
+                       std::vector<float>& hd_d2) {
+  std::ifstream ifs(fname);
+  if (ifs.fail()) die("error: cannot open file '" + fname + "'");
+  std::string line;
+  while (std::getline(ifs, line)) {
+    std::istringstream ss(line);
+    std::size_t a, c;
+    float b, d;
+    if (ss >> a >> b >> c >> d) {
+      nn_idx.push_back((std::uint32_t)a);
+      nn_d2.push_back(b);
+      hd_idx.push_back((std::uint32_t)c);
+      hd_d2.push_back(d);
+    }
+  }
+}
+
+std::string sprintf_f(const std::string& base, float v) {
+  char buf[64];
+  std::snprintf(buf, sizeof(buf), "_%f", v);
+  return base + buf;
+}
+
+// ---- the density mode (density_clustering.cpp:559-825 without screening) ------------------------
+void must(int rc, const char* what) {
+  if (rc != DC_OK) die(std::string("HIP error: ") + what + "\n" + dc_hip_last_error());
+}
+
+int density_main(int argc, char** argv) {
+  Options o = parse(argc, argv);
+  // like the reference's CUDA build: fail early if there is no GPU (clustering.cpp:110-113)
+  const int n_gpus = Clustering::Density::CUDA::get_num_gpus();
+  if (o.screening_requested)
+    die("error: screening / clustering output (-T, -o, -i) is not part of this build;\n"
+        "       use -p/-d/-b here and run the screening step with the reference binary (-D/-B).");
+  const std::string header = provenance_header(argc, argv);
+  Comments cm = {{"clustering_radius", 0.f}, {"lumping_radius", 0.f}, {"screening_from", 0.f},
+                 {"screening_to", 0.f}, {"screening_step", 0.f}, {"minimal_population", 0.f},
+                 {"cmin", 0.f}, {"single_coring_time", 0.f}, {"limits", 0.f}};
+  LOG("\n%s\n~~~ using for parallization: HIP (%d GPU%s)\n", header.c_str(), n_gpus, n_gpus == 1 ? "" : "s");
+
+  std::vector<float> coords;
+  std::size_t n_rows = 0, n_cols = 0;
+  read_coords(o.file, coords, n_rows, n_cols);
+  if (n_rows == 0) die("error: no frames in '" + o.file + "'");
+
+  std::vector<float> fe;
+  std::vector<std::uint32_t> pops;   // single-radius populations
+  auto sweep = [&](const std::vector<float>& radii, std::size_t fe_index, bool want_nn,
+                   std::vector<std::uint32_t>& pops_out, std::vector<float>& fe_out,
+                   std::vector<std::uint32_t>& nn_idx, std::vector<float>& nn_d2,
+                   std::vector<std::uint32_t>& hd_idx, std::vector<float>& hd_d2) {
+    pops_out.assign(radii.size() * n_rows, 0);
+    fe_out.assign(n_rows, 0.f);
+    if (want_nn) {
+      nn_idx.assign(n_rows, 0);
+      hd_idx.assign(n_rows, 0);
+      nn_d2.assign(n_rows, 0.f);
+      hd_d2.assign(n_rows, 0.f);
+    }
+    must(dc_hip_density_all(coords.data(), n_rows, n_cols, radii.data(), radii.size(), fe_index,
+                            n_gpus, pops_out.data(), fe_out.data(),
+                            want_nn ? nn_idx.data() : nullptr, want_nn ? nn_d2.data() : nullptr,
+                            want_nn ? hd_idx.data() : nullptr, want_nn ? hd_d2.data() : nullptr),
+         "density sweep");
+  };
+  auto sigma2_of = [&](const std::vector<float>& nn_d2) {
+    double s = 0.0;   // frame order, double (density_clustering.cpp:334-343)
+    for (float v : nn_d2) s += (double)v;
+    return s / (double)nn_d2.size();
+  };
+  std::vector<std::uint32_t> nn_idx, hd_idx;
+  std::vector<float> nn_d2, hd_d2;
+  bool have_nn = false;
+
+  LOG("~~~ free energy and population\n");
+  if (!o.free_energy_input.empty()) {
+    LOG("    re-using free energy: %s\n", o.free_energy_input.c_str());
+    if (!o.radii.empty() || o.has_radius) LOG("warning: radius (-r/-R) is ignored\n");
+    if (!o.free_energy.empty() || !o.population.empty()) LOG("warning: -p/-d flags are ignored\n");
+    fe = read_single_column<float>(o.free_energy_input);
+    if (fe.size() != n_rows) die("error: free energy file does not match the number of frames");
+    read_comments(o.free_energy_input, cm);
+  } else if (!o.free_energy.empty() || !o.population.empty()) {
+    if (!o.radii.empty()) {
+      LOG("    calculating free energy and population\n    using radii: ");
+      for (float r : o.radii) LOG("%g, ", r);
+      LOG("\n    using HIP\n");
+      // all radii in one sweep; free energies per radius from the host formula
+      std::vector<std::uint32_t> all;
+      std::vector<float> fe_r;
+      for (std::size_t k = 0; k < o.radii.size(); ++k) {
+        if (k == 0) {
+          sweep(o.radii, 0, false, all, fe_r, nn_idx, nn_d2, hd_idx, hd_d2);
+        } else if (!o.free_energy.empty()) {
+          // FE of radius k: same formula on that population row (density_clustering.cpp:197-212)
+          const std::uint32_t* p = all.data() + k * n_rows;
+          std::uint32_t mx = 0;
+          for (std::size_t i = 0; i < n_rows; ++i) mx = p[i] > mx ? p[i] : mx;
+          const float rec = 1.0f / (float)mx;
+          for (std::size_t i = 0; i < n_rows; ++i) {
+            const float q = (float)p[i] * rec;
+            fe_r[i] = (float)(-std::log((double)q));
+          }
+        }
+        LOG("    storing results for radius %g\n", o.radii[k]);
+        if (!o.population.empty())
+          write_pops(sprintf_f(o.population, o.radii[k]), all.data() + k * n_rows, n_rows, header, cm);
+        if (!o.free_energy.empty())
+          write_fes(sprintf_f(o.free_energy, o.radii[k]), fe_r.data(), n_rows, header, cm);
+      }
+    } else {
+      float radius_lump = 1.0f;
+      if (!o.has_radius) {
+        // no radius given: provisional pop(r=1)+FE+NN pass to get the lumping radius sqrt(4 sigma^2)
+        // (density_clustering.cpp:649-673)
+        LOG("    computing lumping radius\n");
+        std::vector<std::uint32_t> p1;
+        std::vector<float> fe1;
+        sweep({radius_lump}, 0, true, p1, fe1, nn_idx, nn_d2, hd_idx, hd_d2);
+        radius_lump = (float)std::sqrt(4 * sigma2_of(nn_d2));
+        LOG("        d_lump=%g\n", radius_lump);
+        cm["lumping_radius"] = radius_lump;
+      }
+      const float radius = o.has_radius ? o.radius : radius_lump;
+      LOG("    calculating free energy and population\n    using radius: %g\n", radius);
+      cm["clustering_radius"] = radius;
+      const bool want_nn = !o.nn.empty() && o.nn_input.empty();
+      sweep({radius}, 0, want_nn, pops, fe, nn_idx, nn_d2, hd_idx, hd_d2);
+      have_nn = want_nn;
+      if (!o.population.empty()) {
+        LOG("    storing population in: %s\n", o.population.c_str());
+        write_pops(o.population, pops.data(), n_rows, header, cm);
+      }
+      if (!o.free_energy.empty()) {
+        LOG("    storing free energy in: %s\n", o.free_energy.c_str());
+        write_fes(o.free_energy, fe.data(), n_rows, header, cm);
+      }
+    }
+  }
+
+  LOG("\n~~~ nearest neighbors\n");
+  if (!o.nn_input.empty()) {
+    LOG("    re-using nearest neighbor: %s\n", o.nn_input.c_str());
+    read_neighborhood(o.nn_input, nn_idx, nn_d2, hd_idx, hd_d2);
+    read_comments(o.nn_input, cm);
+  } else if (!o.nn.empty()) {
+    if (!o.radii.empty())
+      die("error: nearest neighbor calculation cannot be done with\n       several radii (-R is set).");
+    if (fe.empty())
+      die("error: nearest neighbors need free energies: give -p/-d (with -r) or -D.");
+    LOG("    calculating nearest neighbors\n");
+    if (!have_nn) {
+      nn_idx.assign(n_rows, 0);
+      hd_idx.assign(n_rows, 0);
+      nn_d2.assign(n_rows, 0.f);
+      hd_d2.assign(n_rows, 0.f);
+      // rows sharded over the GPUs like density_clustering_cuda.cu:293-326
+      const std::size_t range = n_rows / n_gpus;
+      std::vector<std::uint32_t> pi(n_rows), ph(n_rows);
+      std::vector<float> pd(n_rows), pdh(n_rows);
+      for (int g = 0; g < n_gpus; ++g) {
+        const std::size_t lo = g * range, hi = (g == n_gpus - 1) ? n_rows : (g + 1) * range;
+        must(dc_hip_nearest_neighbors(coords.data(), n_rows, n_cols, fe.data(), lo, hi, g, pi.data(),
+                                      pd.data(), ph.data(), pdh.data()),
+             "nearest-neighbour sweep");
+        for (std::size_t i = lo; i < hi; ++i) {
+          nn_idx[i] = pi[i];
+          nn_d2[i] = pd[i];
+          hd_idx[i] = ph[i];
+          hd_d2[i] = pdh[i];
+        }
+      }
+    }
+    if (cm["lumping_radius"] == 0.) {
+      const float radius_lump = (float)std::sqrt(4 * sigma2_of(nn_d2));
+      LOG("    lumping radius: %g\n", radius_lump);
+      cm["lumping_radius"] = radius_lump;
+    }
+    LOG("    storing nearest neighbors in: %s\n", o.nn.c_str());
+    write_neighborhood(o.nn, n_rows, nn_idx.data(), nn_d2.data(), hd_idx.data(), hd_d2.data(), header, cm);
+  }
+  LOG("~~~ freeing memory\n");
+  return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const std::string general_help = std::string("clustering ") + kVersion +
+      "\n\nmodes:\n  density: run density clustering (pop / free energy / nearest neighbours on the GPU)\n\n"
+      "usage:\n  clustering density --option1 --option2 ...\n\nfor a list of available options:\n"
+      "  clustering density -h\n\nthis binary is parallized with HIP (MI355X)\n\n";
+  if (argc <= 2) {
+    std::cerr << general_help;
+    return EXIT_FAILURE;
+  }
+  const std::string mode(argv[1]);
+  if (mode != "density") {
+    std::cerr << "\nerror: unrecognized mode '" << mode << "'\n\n"
+              << "(this build provides the density mode only; the other modes of moldyn/Clustering\n"
+              << " -- network, mpp, coring, noise, filter, stats -- are CPU post-processing tools)\n\n"
+              << general_help;
+    return EXIT_FAILURE;
+  }
+  return density_main(argc, argv);
+}

@@ -1,0 +1,89 @@
+// density_clustering_hip.hpp -- C++ host mirror of the reference's GPU plug-in surface
+// (density_clustering_cuda.hpp:13-54) on top of the C ABI in include/dc_density.h.
+//
+// Drop-in: a maintainer replaces `#include "density_clustering_cuda.hpp"`
+// (density_clustering.cpp:31-32) by this header and links libdcdensity.so + density_clustering_hip.cpp
+// instead of density_clustering_cuda.cu / ..._cuda_kernels.cu.  Namespace,
+// names, argument order/meaning, return types and the error convention ("message on stderr, then
+// exit(EXIT_FAILURE)", density_clustering_cuda.cu:21-30) are the reference's.
+#pragma once
+
+#include <cstddef>
+#include <map>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+namespace Clustering {
+namespace Tools {
+//! matches neighbor's frame id to distance            (tools.hpp:64)
+using Neighbor = std::pair<std::size_t, float>;
+//! map frame id to neighbors                          (tools.hpp:66)
+using Neighborhood = std::map<std::size_t, Clustering::Tools::Neighbor>;
+}  // namespace Tools
+namespace Density {
+//! radius -> populations                              (density_clustering_common.hpp:39)
+typedef std::map<float, std::vector<std::size_t>> Pops;
+
+namespace CUDA {   // the reference's namespace name is kept so that call sites compile unchanged
+
+using Neighborhood = Clustering::Tools::Neighborhood;
+
+//! prints msg + the library's last error and exits if the last C-ABI call failed
+//! (density_clustering_cuda.hpp:13-14, density_clustering_cuda.cu:21-30)
+void check_error(std::string msg = "");
+
+//! number of usable GPUs; exits if there is none (density_clustering_cuda.cu:32-43)
+int get_num_gpus();
+
+//! populations of rows [i_from, i_to) on device i_gpu, all other rows 0
+//! (calculate_populations_per_gpu, density_clustering_cuda.cu:45-137; the header declares the
+//! same job as calculate_populations_partial, density_clustering_cuda.hpp:21-30)
+Pops calculate_populations_partial(const float* coords, std::size_t n_rows, std::size_t n_cols,
+                                   std::vector<float> radii, std::size_t i_from, std::size_t i_to,
+                                   int i_gpu);
+Pops calculate_populations_per_gpu(const float* coords, std::size_t n_rows, std::size_t n_cols,
+                                   std::vector<float> radii, std::size_t i_from, std::size_t i_to,
+                                   int i_gpu);
+
+//! populations for several radii in one sweep, rows sharded over all GPUs
+//! (density_clustering_cuda.hpp:32-36, density_clustering_cuda.cu:139-182)
+Pops calculate_populations(const float* coords, const std::size_t n_rows, const std::size_t n_cols,
+                           std::vector<float> radii);
+
+//! nearest neighbour / nearest neighbour with lower free energy of rows [i_from, i_to) on device
+//! i_gpu (density_clustering_cuda.cu:184-284).  Rows outside the range hold (n_rows+1, FLT_MAX).
+std::tuple<Neighborhood, Neighborhood> nearest_neighbors_per_gpu(
+    const float* coords, const std::size_t n_rows, const std::size_t n_cols,
+    const std::vector<float>& free_energy, std::size_t i_from, std::size_t i_to, int i_gpu);
+
+//! (density_clustering_cuda.hpp:38-42, density_clustering_cuda.cu:286-328)
+std::tuple<Neighborhood, Neighborhood> nearest_neighbors(const float* coords,
+                                                         const std::size_t n_rows,
+                                                         const std::size_t n_cols,
+                                                         const std::vector<float>& free_energy);
+
+// NOT provided: screening() (density_clustering_cuda.hpp:47-54).  Screening is outside this
+// library's scope; a USE_CUDA-style host links the reference's CPU
+// Clustering::Density::screening (density_clustering_common.hpp:44-56) instead, see INTEGRATION.md.
+
+}  // namespace CUDA
+
+// ---- flat-array helpers for hosts that do not want the node-based containers -------------------
+namespace HIP {
+struct DensityResult {
+  std::vector<std::vector<std::size_t>> pops;   // [radius index][frame], in the caller's radius order
+  std::vector<float> free_energy;               // from radius fe_radius_index
+  std::vector<std::size_t> nn_idx, hd_idx;      // empty if neighbours were not requested
+  std::vector<float> nn_d2, hd_d2;
+  double sigma2 = 0.0;                          // mean nn d2 (compute_sigma2, density_clustering.cpp:334-343)
+};
+//! whole path (pop -> FE -> NN) with coordinates kept resident on the devices between the phases
+DensityResult density_all(const float* coords, std::size_t n_rows, std::size_t n_cols,
+                          const std::vector<float>& radii, std::size_t fe_radius_index,
+                          bool want_neighbors, int n_gpus = 0);
+}  // namespace HIP
+
+}  // namespace Density
+}  // namespace Clustering

@@ -1,0 +1,45 @@
+// test driver for the C++ shim (density_clustering_hip.hpp): calls the reference-shaped entry
+// points Clustering::Density::CUDA::{get_num_gpus, calculate_populations, nearest_neighbors} with
+// the reference's container types and dumps the results as text for tests/test_gpu_cli.py.
+//   test_shim coords.f32 n_rows n_cols fe.f32 r1 [r2 ...]
+#include "../../clustering_amd/csrc/density_clustering_hip.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+int main(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const std::size_t n_rows = std::strtoull(argv[2], nullptr, 10), n_cols = std::strtoull(argv[3], nullptr, 10);
+  std::vector<float> coords(n_rows * n_cols), fe(n_rows);
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(coords.data(), sizeof(float), coords.size(), f) != coords.size()) return 3;
+  std::fclose(f);
+  f = std::fopen(argv[4], "rb");
+  if (!f || std::fread(fe.data(), sizeof(float), fe.size(), f) != fe.size()) return 3;
+  std::fclose(f);
+  std::vector<float> radii;
+  for (int i = 5; i < argc; ++i) radii.push_back(std::strtof(argv[i], nullptr));
+
+  namespace G = Clustering::Density::CUDA;
+  std::printf("gpus %d\n", G::get_num_gpus());
+  Clustering::Density::Pops pops = G::calculate_populations(coords.data(), n_rows, n_cols, radii);
+  for (const auto& kv : pops) {            // std::map: ascending radius
+    std::printf("pops %.9g", kv.first);
+    for (std::size_t p : kv.second) std::printf(" %zu", p);
+    std::printf("\n");
+  }
+  Clustering::Density::Pops part = G::calculate_populations_partial(coords.data(), n_rows, n_cols, radii,
+                                                                    n_rows / 3, n_rows / 2, 0);
+  for (const auto& kv : part) {
+    std::printf("part %.9g", kv.first);
+    for (std::size_t p : kv.second) std::printf(" %zu", p);
+    std::printf("\n");
+  }
+  auto nh = G::nearest_neighbors(coords.data(), n_rows, n_cols, fe);
+  const auto& nn = std::get<0>(nh);
+  const auto& hd = std::get<1>(nh);
+  for (std::size_t i = 0; i < n_rows; ++i)
+    std::printf("nn %zu %zu %.9g %zu %.9g\n", i, nn.at(i).first, nn.at(i).second, hd.at(i).first, hd.at(i).second);
+  return 0;
+}

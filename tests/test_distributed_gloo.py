@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: the row-sharding + merge logic of clustering_amd.distributed
+(all-reduce of zero-padded populations, all-gather of padded neighbour blocks) -- the compute
+backend is injected (the CPU oracle's per-row-range functions stand in for the GPU kernels, which
+cannot run here); the product's own backend (HipBackend) is what bench.py / the GPU tests use."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from clustering_amd.rows import shard_rows
+from clustering_amd.synth import gaussian_blobs
+
+
+class OracleBackend:
+    def __init__(self):
+        from oracle.oracle import Oracle
+        self.o = Oracle()
+
+    def populations_partial(self, coords, radii, lo, hi):
+        p = self.o.populations(coords.numpy(), radii, lo, hi)
+        return torch.from_numpy(p.astype(np.int32))
+
+    def free_energies(self, pops_row):
+        return torch.from_numpy(self.o.free_energies(pops_row.numpy().astype(np.uint64)))
+
+    def nearest_neighbors_partial(self, coords, fe, lo, hi):
+        a, b, c, d = self.o.nearest_neighbors(coords.numpy(), fe.numpy(), lo, hi)
+        return (torch.from_numpy(a.astype(np.int32)), torch.from_numpy(b),
+                torch.from_numpy(c.astype(np.int32)), torch.from_numpy(d))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_rows, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clustering_amd.distributed import ShardedDensity
+        coords = torch.from_numpy(gaussian_blobs(n_rows, 5, seed=99))
+        out = ShardedDensity(OracleBackend()).run(coords, [0.1, 0.2], fe_radius_index=1, want_nn=True)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rows", [(2, 1001), (2, 64), (3, 500)])
+def test_sharded_density_matches_single_process(tmp_path, oracle, world, n_rows):
+    mp.spawn(_worker, args=(world, _free_port(), n_rows, str(tmp_path)), nprocs=world, join=True)
+    c = gaussian_blobs(n_rows, 5, seed=99)
+    pops = oracle.populations(c, [0.1, 0.2])
+    fe = oracle.free_energies(pops[1])
+    nn = oracle.nearest_neighbors(c, fe)
+    for rank in range(world):
+        got = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert (got["pops"].astype(np.uint64) == pops).all()
+        assert (got["fe"].view(np.uint32) == fe.view(np.uint32)).all()
+        assert (got["nn_idx"].astype(np.uint64) == nn[0]).all()
+        assert (got["hd_idx"].astype(np.uint64) == nn[2]).all()
+        assert (got["nn_d2"].view(np.uint32) == nn[1].view(np.uint32)).all()
+        assert (got["hd_d2"].view(np.uint32) == nn[3].view(np.uint32)).all()
+
+
+def test_shard_rows_is_the_reference_partition():
+    # density_clustering_cuda.cu:149,165-169: floor(N/G) each, last takes the remainder
+    assert [shard_rows(10, 3, g) for g in range(3)] == [(0, 3), (3, 6), (6, 10)]
+    assert [shard_rows(8, 8, g) for g in range(8)] == [(g, g + 1) for g in range(8)]
+    assert shard_rows(5, 1, 0) == (0, 5)
+    assert [shard_rows(2, 4, g) for g in range(4)] == [(0, 0), (0, 0), (0, 0), (0, 2)]

@@ -1,0 +1,136 @@
+"""GPU: the `clustering density` command line and the C++ shim (reference container types) against
+the oracle -- file formats as the reference's writers produce them (tools.cpp:42-56, 144-174)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from clustering_amd.synth import gaussian_blobs
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "clustering_amd", "bin", "clustering")
+SHIM = os.path.join(ROOT, "clustering_amd", "bin", "test_shim")
+
+
+def data_lines(path):
+    return [l for l in open(path).read().splitlines() if l and not l.startswith("#")]
+
+
+def comments(path):
+    out = {}
+    for l in open(path).read().splitlines():
+        if l.startswith("#@"):
+            k, v = l[2:].split("=")
+            out[k.strip()] = v.strip()
+    return out
+
+
+def write_coords(path, c):
+    np.savetxt(path, c, fmt="%.9g")
+    # what the reference's reader (and ours) sees after the decimal round trip
+    return np.loadtxt(path, dtype=np.float64, ndmin=2).astype(np.float32)
+
+
+def fmt_e(x):
+    return "%e" % float(np.float32(x))
+
+
+def fmt_g(x):
+    return "%g" % float(np.float32(x))
+
+
+def test_cli_single_radius_full_path(tmp_path, oracle):
+    c = write_coords(tmp_path / "coords", gaussian_blobs(3000, 5, seed=42))
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "0.1", "-p", str(tmp_path / "pop"),
+                        "-d", str(tmp_path / "fe"), "-b", str(tmp_path / "nn"), "-v"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "using radius: 0.1" in r.stdout
+    pops = oracle.populations(c, [0.1])[0]
+    fe = oracle.free_energies(pops)
+    nn = oracle.nearest_neighbors(c, fe)
+    assert data_lines(tmp_path / "pop") == [str(int(p)) for p in pops]
+    assert data_lines(tmp_path / "fe") == [fmt_e(v) for v in fe]
+    want = ["%d %s %d %s" % (nn[0][i], fmt_g(nn[1][i]), nn[2][i], fmt_g(nn[3][i])) for i in range(len(c))]
+    assert data_lines(tmp_path / "nn") == want
+    cm = comments(tmp_path / "nn")
+    assert cm["clustering_radius"] == "%.5f" % np.float32(0.1)
+    assert cm["lumping_radius"] == "%.5f" % oracle.lumping_radius(oracle.sigma2(nn[1]))
+    assert "-0.000000e+00" in data_lines(tmp_path / "fe")       # the max-pop frame
+
+
+def test_cli_multi_radius_files(tmp_path, oracle):
+    c = write_coords(tmp_path / "coords", gaussian_blobs(2000, 10, seed=43))
+    radii = [0.3, 0.1, 0.2]
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-R", *[str(x) for x in radii],
+                        "-p", str(tmp_path / "pop"), "-d", str(tmp_path / "fe")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    pops = oracle.populations(c, radii)
+    for k, rad in enumerate(radii):
+        name = "_%f" % np.float32(rad)
+        assert data_lines(str(tmp_path / "pop") + name) == [str(int(p)) for p in pops[k]]
+        assert data_lines(str(tmp_path / "fe") + name) == [fmt_e(v) for v in oracle.free_energies(pops[k])]
+
+
+def test_cli_without_radius_uses_lumping_radius_and_reuse(tmp_path, oracle):
+    """no -r: provisional pop(r=1)+FE+NN pass, radius = sqrt(4 sigma^2) (density_clustering.cpp:649-673);
+    then -D/-B re-use (file-level checkpoint/resume)."""
+    c = write_coords(tmp_path / "coords", gaussian_blobs(1500, 5, seed=44))
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-p", str(tmp_path / "pop"),
+                        "-d", str(tmp_path / "fe"), "-b", str(tmp_path / "nn")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    p1 = oracle.populations(c, [1.0])[0]
+    nn1 = oracle.nearest_neighbors(c, oracle.free_energies(p1))
+    radius = oracle.lumping_radius(oracle.sigma2(nn1[1]))
+    pops = oracle.populations(c, [radius])[0]
+    assert data_lines(tmp_path / "pop") == [str(int(p)) for p in pops]
+    cm = comments(tmp_path / "pop")
+    assert cm["clustering_radius"] == "%.5f" % radius and cm["lumping_radius"] == "%.5f" % radius
+    # re-use the free energies (-D) to recompute only the neighbours (-b)
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-D", str(tmp_path / "fe"),
+                        "-b", str(tmp_path / "nn2")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    fe_file = np.array([float(x) for x in data_lines(tmp_path / "fe")], dtype=np.float32)
+    nn = oracle.nearest_neighbors(c, fe_file)     # FE as printed with 7 digits, like the reference re-reads it
+    want = ["%d %s %d %s" % (nn[0][i], fmt_g(nn[1][i]), nn[2][i], fmt_g(nn[3][i])) for i in range(len(c))]
+    assert data_lines(tmp_path / "nn2") == want
+
+
+def test_cli_rejects_screening(tmp_path):
+    (tmp_path / "coords").write_text("0 0\n1 1\n")
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "1", "-T", "0.1", "0.1", "-o", "x"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "not part of this build" in r.stderr
+
+
+def test_cpp_shim_reference_signatures(tmp_path, oracle):
+    c = gaussian_blobs(1200, 10, seed=45)
+    n, d = c.shape
+    radii = [0.2, 0.3]
+    pops = oracle.populations(c, radii)
+    fe = oracle.free_energies(pops[0])
+    c.tofile(tmp_path / "c.f32")
+    fe.tofile(tmp_path / "fe.f32")
+    r = subprocess.run([SHIM, str(tmp_path / "c.f32"), str(n), str(d), str(tmp_path / "fe.f32"), "0.3", "0.2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0].startswith("gpus ")
+    got = {l.split()[1]: [int(x) for x in l.split()[2:]] for l in lines if l.startswith("pops ")}
+    assert got["%.9g" % np.float32(0.2)] == pops[0].tolist()
+    assert got["%.9g" % np.float32(0.3)] == pops[1].tolist()
+    part = {l.split()[1]: [int(x) for x in l.split()[2:]] for l in lines if l.startswith("part ")}
+    want = oracle.populations(c, radii, n // 3, n // 2)
+    assert part["%.9g" % np.float32(0.2)] == want[0].tolist()
+    exp = oracle.nearest_neighbors(c, fe)
+    for l in lines:
+        if l.startswith("nn "):
+            _, i, a, b, cc, dd = l.split()
+            i = int(i)
+            assert int(a) == exp[0][i] and int(cc) == exp[2][i]
+            assert np.float32(float(b)) == exp[1][i] and np.float32(float(dd)) == exp[3][i]
