@@ -36,13 +36,16 @@ __global__ void colsum_kernel(const float* __restrict__ coords, uint32_t n_rows,
   if (threadIdx.x < D) atomicAdd(&sums[threadIdx.x], part[threadIdx.x]);
 }
 
+// operand image of the (centred) coordinates, rows in natural order (perm == nullptr) or gathered
+// through perm (frames ordered by free energy).  Also: squared norms, max norm, non-finite flag.
 __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                              uint32_t S, uint32_t T, const double* __restrict__ sums,
-                             float* __restrict__ img, float* __restrict__ norms,
-                             uint32_t* __restrict__ maxnorm_bits) {
+                             const uint32_t* __restrict__ perm, float* __restrict__ img,
+                             float* __restrict__ norms, uint32_t* __restrict__ hdr) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= 32 * T) return;
   const uint32_t t = row >> 5, c = row & 31;
+  const uint32_t src = (row < n_rows) ? (perm ? perm[row] : row) : 0u;
   double nrm = 0.0;
   for (uint32_t k = 0; k < 2 * S; ++k) {
     float v = 0.0f;
@@ -50,7 +53,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_rows, 
       double mu = sums[k] / (double)n_rows;
       float muf = (float)mu;
       if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
-      v = coords[(size_t)row * D + k] - muf;            // x' = fl(x - mu)
+      v = coords[(size_t)src * D + k] - muf;            // x' = fl(x - mu)
     }
     img[((size_t)t * S + (k >> 1)) * 64 + (k & 1) * 32 + c] = v;
     nrm += (double)v * (double)v;
@@ -58,18 +61,54 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_rows, 
   // (a non-finite coordinate makes nrm non-finite, which raises the flag below)
   float nf = (row < n_rows) ? (float)nrm : INFINITY;    // pad rows can never be "inside"
   norms[row] = nf;
-  if (row < n_rows) {
+  if (row < n_rows && hdr) {
     if (nf <= kNormLimit)
-      atomicMax(maxnorm_bits, __float_as_uint(nf));
+      atomicMax(hdr, __float_as_uint(nf));
     else
-      atomicOr(maxnorm_bits + 1, 1u);   // NaN / inf / overflow-prone row: MFMA kernels stand down
+      atomicOr(hdr + 1, 1u);   // NaN / inf / overflow-prone row: MFMA kernels stand down
   }
 }
 
-__global__ void fe_pad_kernel(const float* __restrict__ fe, uint32_t n_rows, uint32_t T,
-                              float* __restrict__ out) {
+// ---- free-energy ordering of the reference frames (neighbour sweep) -----------------------------
+// sortable key of a float (ascending); NaN free energies raise the flag (direct kernels take over)
+__global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
+                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                              uint32_t* __restrict__ hdr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 32 * T) out[i] = (i < n_rows) ? fe[i] : INFINITY;
+  if (i >= n_rows) return;
+  const float f = fe[i];
+  if (f != f) atomicOr(hdr + 1, 1u);
+  const uint32_t u = __float_as_uint(f);
+  keys[i] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+  vals[i] = i;
+}
+
+__global__ void fe_scatter_kernel(const uint32_t* __restrict__ perm, const float* __restrict__ fe,
+                                  uint32_t n_rows, uint32_t T, uint32_t* __restrict__ invpos,
+                                  float* __restrict__ fe_s) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= 32 * T) return;
+  if (p < n_rows) {
+    const uint32_t i = perm[p];
+    invpos[i] = p;
+    fe_s[p] = fe[i];
+  } else {
+    fe_s[p] = INFINITY;
+  }
+}
+
+// pq[i] = #{ p : fe_s[p] < fe[i] }  (float comparison, exactly the reference's "fe[j] < fe[i]")
+__global__ void fe_rank_kernel(const float* __restrict__ fe, const float* __restrict__ fe_s,
+                               uint32_t n_rows, uint32_t* __restrict__ pq) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const float f = fe[i];
+  uint32_t lo = 0, hi = n_rows;   // first position whose value is not < f
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (fe_s[mid] < f) lo = mid + 1; else hi = mid;
+  }
+  pq[i] = lo;
 }
 
 }  // namespace
@@ -84,7 +123,7 @@ bool mfma_supports(size_t n_cols) {
 }
 size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
   if (!mfma_supports(n_cols) || n_rows == 0) return 0;
-  return make_layout(n_rows, n_cols).total;
+  return make_layout(n_rows, n_cols).fixed_end + sort_temp_bytes(n_rows);
 }
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
@@ -97,7 +136,8 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
                      (double*)(p + kHdrSums));
   hipLaunchKernelGGL(image_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords,
                      n_rows, n_cols, L.S, L.T, (const double*)(p + kHdrSums),
-                     (float*)(p + L.off_img), (float*)(p + L.off_norm), (uint32_t*)p);
+                     (const uint32_t*)nullptr, (float*)(p + L.off_img), (float*)(p + L.off_norm),
+                     (uint32_t*)p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -120,9 +160,26 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream) {
+  // order the reference frames by free energy and build their operand image
   const Layout L = make_layout(n_rows, n_cols);
-  hipLaunchKernelGGL(fe_pad_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_fe,
-                     n_rows, L.T, (float*)((char*)d_ws + L.off_fe));
+  char* p = (char*)d_ws;
+  uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
+  uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
+  uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
+  uint32_t* perm = (uint32_t*)(p + L.off_perm);
+  const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256);
+  hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in,
+                     (uint32_t*)p);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm, n_rows, p + L.fixed_end,
+                     sort_temp_bytes(n_rows), stream) != 0)
+    return;
+  hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, perm, d_fe, n_rows, L.T,
+                     (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
+  hipLaunchKernelGGL(fe_rank_kernel, grid_n, blk, 0, stream, d_fe, (const float*)(p + L.off_fe_s),
+                     n_rows, (uint32_t*)(p + L.off_pq));
+  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_cols, L.S, L.T,
+                     (const double*)(p + kHdrSums), (const uint32_t*)perm,
+                     (float*)(p + L.off_img_s), (float*)(p + L.off_norm_s), (uint32_t*)nullptr);
   switch ((n_cols + 1) / 2) {
 #define X(SV)                                                                                \
   case SV:                                                                                   \

@@ -41,7 +41,8 @@
 // Operand images (built once per call by mfma_prepare in the caller's workspace):
 //   img   [T][S][64]  A fragments in lane order: img[(t*S+s)*64 + l] = y'[32t + (l&31)][2s + (l>>5)]
 //   norms [32T]       |y'|^2 (double accumulate, rounded once); +inf for the pad rows of the last tile
-//   fe    [32T]       free energies padded with +inf (nearest-neighbour sweep only)
+//   img_s / norms_s   the same for the frames ordered by free energy (neighbour sweep), with
+//                     perm / invpos / fe_s / pq (see Layout)
 // Each wave streams the images with plain coalesced global loads (256 B per K-step); all waves of
 // the chip walk the same 44 MB, which lives in L2 / Infinity Cache.
 #pragma once
@@ -61,20 +62,38 @@ constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits); word 
 constexpr size_t kHdrSums = 256;       // byte 256..: column sums (double) for the centring
 constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram form -> flagged
 
+// Workspace layout.  Regions used by the population sweep: hdr, img, norms.  The neighbour sweep
+// adds a second operand image with the reference frames ORDERED BY FREE ENERGY (img_s, norms_s),
+// the permutation (perm: sorted position -> frame id, invpos: frame id -> sorted position), the
+// sorted free energies (fe_s, +inf padded) and, per frame, the number of frames with strictly
+// lower free energy (pq) -- plus scratch for the radix sort (keys/vals double buffers; the sort's
+// own temp storage sits after `fixed_end` and is sized by dc_mfma.hip).
 struct Layout {
   uint32_t T, S;
-  size_t off_img, off_norm, off_fe, total;
+  size_t off_img, off_norm, off_img_s, off_norm_s, off_fe_s, off_perm, off_invpos, off_pq,
+      off_keys_in, off_keys_out, off_vals_in, fixed_end;
 };
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 inline Layout make_layout(size_t n_rows, size_t n_cols) {
   Layout L;
   L.T = (uint32_t)((n_rows + 31) / 32);
   L.S = (uint32_t)((n_cols + 1) / 2);
+  const size_t img_bytes = sizeof(float) * 64 * (size_t)L.T * L.S;
+  const size_t row_bytes = align256(sizeof(float) * 32 * (size_t)L.T);
   L.off_img = kHdrBytes;
-  L.off_norm = L.off_img + sizeof(float) * 64 * (size_t)L.T * L.S;
-  L.off_fe = L.off_norm + sizeof(float) * 32 * (size_t)L.T;
-  L.total = L.off_fe + sizeof(float) * 32 * (size_t)L.T;
-  L.total = (L.total + 255) & ~(size_t)255;
+  L.off_norm = align256(L.off_img + img_bytes);
+  L.off_img_s = L.off_norm + row_bytes;
+  L.off_norm_s = align256(L.off_img_s + img_bytes);
+  L.off_fe_s = L.off_norm_s + row_bytes;
+  L.off_perm = L.off_fe_s + row_bytes;
+  L.off_invpos = L.off_perm + row_bytes;
+  L.off_pq = L.off_invpos + row_bytes;
+  L.off_keys_in = L.off_pq + row_bytes;
+  L.off_keys_out = L.off_keys_in + row_bytes;
+  L.off_vals_in = L.off_keys_out + row_bytes;
+  L.fixed_end = L.off_vals_in + row_bytes;
   return L;
 }
 
@@ -83,13 +102,26 @@ struct Ptrs {
   const double* sums;
   const float* img;
   const float* norms;
-  const float* fe;
+  const float* img_s;
+  const float* norms_s;
+  const float* fe_s;
+  const uint32_t* perm;
+  const uint32_t* invpos;
+  const uint32_t* pq;
 };
 
 inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
   char* p = (char*)d_ws;
-  return Ptrs{(const uint32_t*)p, (const double*)(p + kHdrSums), (const float*)(p + L.off_img),
-              (const float*)(p + L.off_norm), (const float*)(p + L.off_fe)};
+  return Ptrs{(const uint32_t*)p,
+              (const double*)(p + kHdrSums),
+              (const float*)(p + L.off_img),
+              (const float*)(p + L.off_norm),
+              (const float*)(p + L.off_img_s),
+              (const float*)(p + L.off_norm_s),
+              (const float*)(p + L.off_fe_s),
+              (const uint32_t*)(p + L.off_perm),
+              (const uint32_t*)(p + L.off_invpos),
+              (const uint32_t*)(p + L.off_pq)};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -147,6 +179,17 @@ __device__ __attribute__((noinline)) float exact_d2(const float* __restrict__ co
                                                    uint32_t n_cols, uint32_t jq, uint32_t i) {
   return dist2_canon_rt(coords + (size_t)jq * n_cols, 1, coords + (size_t)i * n_cols, 1,
                         (int)n_cols);
+}
+
+// minimum of elements [R0, R1) of an accumulator tile (v_min3_f32: two elements per instruction)
+template <int R0, int R1>
+__device__ __forceinline__ void tile_min(const f32x16& acc, float& m) {
+  if constexpr (R1 - R0 >= 2) {
+    m = fminf(fminf(m, acc[R0]), acc[R0 + 1]);
+    tile_min<R0 + 2, R1>(acc, m);
+  } else if constexpr (R1 - R0 == 1) {
+    m = fminf(m, acc[R0]);
+  }
 }
 
 // =============================================================================================
@@ -358,11 +401,18 @@ __device__ __forceinline__ void lexi_update(bool cond, float& bd, uint32_t& bj, 
   bj = take ? j : bj;
 }
 
+// The reference frames of this sweep are ORDERED BY FREE ENERGY (ascending).  For a query with
+// pq frames of strictly lower free energy, "fe[j] < fe[i]" (:275) is simply "sorted position < pq":
+// whole tiles are below (hd minimum = nn minimum of the tile), above (contribute nothing) or -- one
+// tile per query -- straddle the boundary.  The straddling tile and the tile that holds the query
+// itself (i != j, :262) take a per-element masked epilogue; every other tile costs 8 v_min3 and a
+// handful of scalar-ish ops per 1024 pairs.
 struct NnQ {             // per query tile, per lane
-  float feq;             // free energy of this lane's query
   float m_nn, m_hd;      // running minima of the MFMA values (this lane's reference rows only)
   float bd_nn, bd_hd;    // exact incumbents
   uint32_t bj_nn, bj_hd;
+  uint32_t pq;           // number of frames with strictly lower free energy
+  uint32_t spos;         // sorted position of the query itself
 };
 
 struct NnBest {
@@ -370,31 +420,42 @@ struct NnBest {
   uint32_t bj_nn, bj_hd;
 };
 
-template <int R0, int R1>
-__device__ __forceinline__ void nn_epi(const f32x16& acc, const f32x16& fef, float feq,
-                                       float& tmin, float& hmin) {
+struct NnMin {
+  float tmin, hmin;
+};
+
+// general (per-element) minima of one accumulator tile: self excluded, hd restricted to pos < pq
+__device__ __attribute__((noinline)) NnMin nn_special(f32x16 acc, uint32_t t, int h, uint32_t spos,
+                                                      uint32_t pq) {
+  NnMin o{INFINITY, INFINITY};
 #pragma unroll
-  for (int r = R0; r < R1; ++r) {
-    tmin = fminf(tmin, acc[r]);
-    hmin = fminf(hmin, (fef[r] < feq) ? acc[r] : INFINITY);
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t pos = tile_row(t, r, h);
+    const float v = (pos != spos) ? acc[r] : INFINITY;
+    o.tmin = fminf(o.tmin, v);
+    o.hmin = fminf(o.hmin, (pos < pq) ? v : INFINITY);
   }
+  return o;
 }
 
 // rare: exact evaluation of the candidates of one accumulator tile (values within the band of the
-// running minimum), merged lexicographically on (d2, index)
+// running minimum), merged lexicographically on (d2, frame id)
 __device__ __attribute__((noinline)) NnBest nn_fix(const float* __restrict__ coords,
+                                                   const uint32_t* __restrict__ perm,
                                                    uint32_t n_rows, uint32_t n_cols, f32x16 acc,
-                                                   f32x16 fef, float feq, float bn, float bh,
-                                                   NnBest best, uint32_t jq, uint32_t t, int h) {
+                                                   float bn, float bh, NnBest best, uint32_t jq,
+                                                   uint32_t spos, uint32_t pq, uint32_t t, int h) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const bool cn = acc[r] < bn;
-    const bool ch = (fef[r] < feq) && (acc[r] < bh);
-    const uint32_t i = tile_row(t, r, h);
-    if ((cn || ch) && i < n_rows) {
-      const float d2c = exact_d2(coords, n_cols, jq, i);
-      lexi_update(cn, best.bd_nn, best.bj_nn, d2c, i, n_rows);
-      lexi_update(ch, best.bd_hd, best.bj_hd, d2c, i, n_rows);
+    const uint32_t pos = tile_row(t, r, h);
+    const bool other = (pos != spos) && (pos < n_rows);
+    const bool cn = other && (acc[r] < bn);
+    const bool ch = other && (pos < pq) && (acc[r] < bh);
+    if (cn || ch) {
+      const uint32_t j = perm[pos];
+      const float d2c = exact_d2(coords, n_cols, jq, j);
+      lexi_update(cn, best.bd_nn, best.bj_nn, d2c, j, n_rows);
+      lexi_update(ch, best.bd_hd, best.bj_hd, d2c, j, n_rows);
     }
   }
   return best;
@@ -403,25 +464,26 @@ __device__ __attribute__((noinline)) NnBest nn_fix(const float* __restrict__ coo
 template <int S, int SI = 0>
 __device__ __forceinline__ void nn_chain(const float (&a)[S], const float (&b)[S],
                                          const f32x16& c0, f32x16& acc_new, const f32x16& acc_old,
-                                         const f32x16& fef_old, float feq_old, float& tmin,
-                                         float& hmin) {
+                                         float& tmin) {
   if constexpr (SI < S) {
     if constexpr (SI == 0)
       acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
     else
       acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
-    nn_epi<(16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, fef_old, feq_old, tmin, hmin);
-    nn_chain<S, SI + 1>(a, b, c0, acc_new, acc_old, fef_old, feq_old, tmin, hmin);
+    tile_min<(16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, tmin);
+    nn_chain<S, SI + 1>(a, b, c0, acc_new, acc_old, tmin);
   }
 }
 
 template <int S, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
-    const float* __restrict__ img, const float* __restrict__ norms,
-    const float* __restrict__ fe_pad, const uint32_t* __restrict__ hdr, uint32_t T,
-    uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
-    uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+    const float* __restrict__ img, const float* __restrict__ img_s,
+    const float* __restrict__ norms_s, const uint32_t* __restrict__ perm,
+    const uint32_t* __restrict__ invpos, const uint32_t* __restrict__ pq_of,
+    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to,
+    uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
+    float* __restrict__ hd_d2) {
   static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
@@ -447,7 +509,9 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
-    q[qt].feq = fe_pad[tl * 32 + c];
+    const uint32_t jl = live ? jq[qt] : (n_rows - 1);
+    q[qt].pq = live ? pq_of[jl] : 0u;
+    q[qt].spos = live ? invpos[jl] : 0xFFFFFFFFu;
     q[qt].m_nn = INFINITY;
     q[qt].m_hd = INFINITY;
     q[qt].bd_nn = FLT_MAX;
@@ -456,29 +520,32 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     q[qt].bj_hd = n_rows + 1;
   }
 
-  f32x16 accA, accB, fefB;
+  f32x16 accA, accB;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    accB[r] = INFINITY;
-    fefB[r] = INFINITY;
-  }
+  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
   uint32_t tB = 0;
 
   float a0[S], a1[S];
-  float4 n0[4], n1[4], f0[4], f1[4];
-  load_tile<S>(img, norms, 0, lane, h, a0, n0);
-  load_frag(fe_pad, 0, h, f0);
+  float4 n0[4], n1[4];
+  load_tile<S>(img_s, norms_s, 0, lane, h, a0, n0);
 
-  // finish one accumulator tile: band test against the running minima, rare exact path, update
-  auto finish = [&](f32x16 acc, const f32x16& fef, int qi, float tmin, float hmin, uint32_t t) {
+  // finish one accumulator tile: minima, band test against the running minima, rare exact path
+  auto finish = [&](const f32x16& acc, int qi, float tmin, uint32_t t) {
     NnQ& Q = q[qi];
-    const bool trig = (tmin < Q.m_nn + eps2) || (hmin < Q.m_hd + eps2);
+    const bool live = (livemask[qi] >> lane) & 1;
+    const bool special = live && ((t == (Q.spos >> 5)) || ((t == (Q.pq >> 5)) && ((Q.pq & 31u) != 0)));
+    float hmin = (t < (Q.pq >> 5)) ? tmin : INFINITY;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
+      const NnMin g = nn_special(acc, t, h, Q.spos, Q.pq);   // valid for every lane, just slower
+      tmin = g.tmin;
+      hmin = g.hmin;
+    }
+    const bool trig = live && ((tmin < Q.m_nn + eps2) || (hmin < Q.m_hd + eps2));
     const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
-    if (__builtin_expect((__builtin_amdgcn_ballot_w64(trig) & livemask[qi]) != 0, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
       NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-      best = nn_fix(coords, n_rows, n_cols, acc, fef, Q.feq, new_nn + eps2, new_hd + eps2, best,
-                    jq[qi], t, h);
-      const bool live = (livemask[qi] >> lane) & 1;
+      best = nn_fix(coords, perm, n_rows, n_cols, acc, new_nn + eps2, new_hd + eps2, best, jq[qi],
+                    Q.spos, Q.pq, t, h);
       Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
       Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
       Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
@@ -487,57 +554,35 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     Q.m_nn = new_nn;
     Q.m_hd = new_hd;
   };
-  // the tile that contains the queries themselves: drop i == j (:262)
-  auto mask_self = [&](f32x16& acc, int qi, uint32_t t) {
-    if (t == qt0 + qi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((r & 3) + 8 * (r >> 2) + 4 * h == c) acc[r] = INFINITY;
-    }
-  };
 
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], const float4 (&fv)[4],
-                       uint32_t t) {
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);
-    const f32x16 fef = frag16(fv);
 #pragma unroll
     for (int qt = 0; qt < TQ; qt += 2) {
       constexpr int kLast = TQ - 1;
       const int qb = (qt == 0) ? kLast : qt - 1;
-      float tmin = INFINITY, hmin = INFINITY;
-      mask_self(accB, qb, tB);
-      if (qt == 0)   // accB belongs to the previous reference tile: its FE fragment was kept
-        nn_chain<S>(a, b[qt], c0, accA, accB, fefB, q[qb].feq, tmin, hmin);
-      else
-        nn_chain<S>(a, b[qt], c0, accA, accB, fef, q[qb].feq, tmin, hmin);
-      finish(accB, (qt == 0) ? fefB : fef, qb, tmin, hmin, tB);
+      float tmin = INFINITY;
+      nn_chain<S>(a, b[qt], c0, accA, accB, tmin);
+      finish(accB, qb, tmin, tB);
       tmin = INFINITY;
-      hmin = INFINITY;
-      mask_self(accA, qt, t);
-      nn_chain<S>(a, b[qt + 1], c0, accB, accA, fef, q[qt].feq, tmin, hmin);
-      finish(accA, fef, qt, tmin, hmin, t);
+      nn_chain<S>(a, b[qt + 1], c0, accB, accA, tmin);
+      finish(accA, qt, tmin, t);
       tB = t;
     }
-    fefB = fef;
   };
 
   for (uint32_t t = 0; t < T; t += 2) {
-    const uint32_t t1 = (t + 1 < T) ? t + 1 : t;
-    load_tile<S>(img, norms, t1, lane, h, a1, n1);
-    load_frag(fe_pad, t1, h, f1);
-    tile_body(a0, n0, f0, t);
+    load_tile<S>(img_s, norms_s, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
+    tile_body(a0, n0, t);
     if (t + 1 < T) {
-      const uint32_t t2 = (t + 2 < T) ? t + 2 : t + 1;
-      load_tile<S>(img, norms, t2, lane, h, a0, n0);
-      load_frag(fe_pad, t2, h, f0);
-      tile_body(a1, n1, f1, t + 1);
+      load_tile<S>(img_s, norms_s, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
+      tile_body(a1, n1, t + 1);
     }
   }
   {  // drain: epilogue of the last accB
-    float tmin = INFINITY, hmin = INFINITY;
-    mask_self(accB, TQ - 1, tB);
-    nn_epi<0, 16>(accB, fefB, q[TQ - 1].feq, tmin, hmin);
-    finish(accB, fefB, TQ - 1, tmin, hmin, tB);
+    float tmin = INFINITY;
+    tile_min<0, 16>(accB, tmin);
+    finish(accB, TQ - 1, tmin, tB);
   }
 
 #pragma unroll
@@ -593,7 +638,8 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                  float* hd_d2, hipStream_t s) {
   const dim3 grid(grid_for(i_from, i_to, kTQnn)), block(256);
   hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                     P.norms, P.fe, P.hdr, T, i_from, i_to, nn_idx, nn_d2, hd_idx, hd_d2);
+                     P.img_s, P.norms_s, P.perm, P.invpos, P.pq, P.hdr, T, i_from, i_to, nn_idx,
+                     nn_d2, hd_idx, hd_d2);
 }
 
 }  // namespace
