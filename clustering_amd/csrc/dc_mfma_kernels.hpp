@@ -413,6 +413,9 @@ struct NnQ {             // per query tile, per lane
   uint32_t bj_nn, bj_hd;
   uint32_t pq;           // number of frames with strictly lower free energy
   uint32_t spos;         // sorted position of the query itself
+  uint32_t t_self;       // reference tile that holds the query itself
+  uint32_t t_full;       // reference tiles [0, t_full) lie entirely below the query's free energy
+  uint32_t t_part;       // the tile straddling the boundary (0xFFFFFFFF if pq is a multiple of 32)
 };
 
 struct NnBest {
@@ -512,8 +515,12 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const uint32_t jl = live ? jq[qt] : (n_rows - 1);
     q[qt].pq = live ? pq_of[jl] : 0u;
     q[qt].spos = live ? invpos[jl] : 0xFFFFFFFFu;
-    q[qt].m_nn = INFINITY;
-    q[qt].m_hd = INFINITY;
+    q[qt].t_self = live ? (q[qt].spos >> 5) : 0xFFFFFFFFu;
+    q[qt].t_full = q[qt].pq >> 5;
+    q[qt].t_part = (q[qt].pq & 31u) ? (q[qt].pq >> 5) : 0xFFFFFFFFu;
+    // idle lanes start at -inf: they can never trigger the exact path and never change
+    q[qt].m_nn = live ? INFINITY : -INFINITY;
+    q[qt].m_hd = live ? INFINITY : -INFINITY;
     q[qt].bd_nn = FLT_MAX;
     q[qt].bd_hd = FLT_MAX;
     q[qt].bj_nn = n_rows + 1;
@@ -529,20 +536,21 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
   float4 n0[4], n1[4];
   load_tile<S>(img_s, norms_s, 0, lane, h, a0, n0);
 
-  // finish one accumulator tile: minima, band test against the running minima, rare exact path
+  // finish one accumulator tile: minima, band test against the running minima, rare exact path.
+  // Bitwise logic on purpose (no short-circuit control flow in the hot path).
   auto finish = [&](const f32x16& acc, int qi, float tmin, uint32_t t) {
     NnQ& Q = q[qi];
-    const bool live = (livemask[qi] >> lane) & 1;
-    const bool special = live && ((t == (Q.spos >> 5)) || ((t == (Q.pq >> 5)) && ((Q.pq & 31u) != 0)));
-    float hmin = (t < (Q.pq >> 5)) ? tmin : INFINITY;
+    const bool special = (t == Q.t_self) | (t == Q.t_part);
+    float hmin = (t < Q.t_full) ? tmin : INFINITY;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
       const NnMin g = nn_special(acc, t, h, Q.spos, Q.pq);   // valid for every lane, just slower
       tmin = g.tmin;
       hmin = g.hmin;
     }
-    const bool trig = live && ((tmin < Q.m_nn + eps2) || (hmin < Q.m_hd + eps2));
+    const bool trig = (tmin < Q.m_nn + eps2) | (hmin < Q.m_hd + eps2);
     const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
+      const bool live = (livemask[qi] >> lane) & 1;
       NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
       best = nn_fix(coords, perm, n_rows, n_cols, acc, new_nn + eps2, new_hd + eps2, best, jq[qi],
                     Q.spos, Q.pq, t, h);
