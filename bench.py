@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--n-rows", type=int, default=1_000_000)
     ap.add_argument("--n-cols", type=int, default=10)
     ap.add_argument("--radii", type=float, nargs="+", default=[0.2])
-    ap.add_argument("--variant", default="auto", choices=["auto", "direct", "mfma"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "direct", "mfma", "pruned"])
     ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="rows of the workload the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-nn", action="store_true", help="populations + free energies only (C2-style)")

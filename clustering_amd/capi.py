@@ -11,8 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcdensity.so")
 
 DC_OK = 0
-VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA = 0, 1, 2
-VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA}
+VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA, VARIANT_MFMA_PRUNED = 0, 1, 2, 3
+VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA,
+            "pruned": VARIANT_MFMA_PRUNED}
 
 # every symbol include/dc_density.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = (

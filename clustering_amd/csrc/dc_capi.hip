@@ -131,7 +131,7 @@ int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, 
   DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_radii * n_rows, s));
   if (i_from == i_to) return DC_OK;
   const bool mfma = want_mfma(variant, n_cols);
-  if (variant == DC_VARIANT_MFMA && !mfma)
+  if ((variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA_PRUNED) && !mfma)
     return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
   if (mfma) {
     if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
@@ -149,9 +149,12 @@ int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, 
     // MFMA variant: the MFMA kernel runs unless the operand-image pass flagged the data
     // (non-finite / overflow-prone rows), in which case the gated direct kernel does the work;
     // both are enqueued, the choice is made on the device (no host synchronisation).
-    if (mfma)
+    if (mfma && variant == DC_VARIANT_MFMA)
       dc::launch_pop_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                           (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
+    else if (mfma)
+      dc::launch_pop_pruned(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
+                            (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
     if (!dc::launch_pop_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                                (uint32_t)i_to, rad2, n_rad, out,
                                mfma ? (const uint32_t*)d_workspace : nullptr, s))
@@ -210,7 +213,7 @@ int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_
     dc::launch_nn_init((uint32_t)n_rows, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, s);
   if (i_from == i_to) return check_launch("nn init");
   const bool mfma = want_mfma(variant, n_cols);
-  if (variant == DC_VARIANT_MFMA && !mfma)
+  if ((variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA_PRUNED) && !mfma)
     return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
   if (mfma) {
     if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))

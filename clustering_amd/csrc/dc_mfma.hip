@@ -38,10 +38,11 @@ __global__ void colsum_kernel(const float* __restrict__ coords, uint32_t n_rows,
 
 // operand image of the (centred) coordinates, rows in natural order (perm == nullptr) or gathered
 // through perm (frames ordered by free energy).  Also: squared norms, max norm, non-finite flag.
-__global__ void image_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
-                             uint32_t S, uint32_t T, const double* __restrict__ sums,
+__global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total, uint32_t n_rows,
+                             uint32_t D, uint32_t S, uint32_t T, const double* __restrict__ sums,
                              const uint32_t* __restrict__ perm, float* __restrict__ img,
                              float* __restrict__ norms, uint32_t* __restrict__ hdr) {
+  // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= 32 * T) return;
   const uint32_t t = row >> 5, c = row & 31;
@@ -50,7 +51,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_rows, 
   for (uint32_t k = 0; k < 2 * S; ++k) {
     float v = 0.0f;
     if (row < n_rows && k < D) {
-      double mu = sums[k] / (double)n_rows;
+      double mu = sums[k] / (double)n_total;
       float muf = (float)mu;
       if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
       v = coords[(size_t)src * D + k] - muf;            // x' = fl(x - mu)
@@ -111,6 +112,93 @@ __global__ void fe_rank_kernel(const float* __restrict__ fe, const float* __rest
   pq[i] = lo;
 }
 
+
+// ---- spatial ordering of the frames (pruned population sweep) ------------------------------------
+// header words 8..11: ~key(min col0), key(max col0), ~key(min col1), key(max col1), all as atomicMax
+__device__ __forceinline__ uint32_t fkey(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+__global__ void bounds_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
+                              uint32_t* __restrict__ hdr) {
+  uint32_t a = 0, b = 0, c = 0, d = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
+    const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
+    if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
+      a = max(a, ~fkey(x));
+      b = max(b, fkey(x));
+      c = max(c, ~fkey(y));
+      d = max(d, fkey(y));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a = max(a, (uint32_t)__shfl_xor((int)a, off, 64));
+    b = max(b, (uint32_t)__shfl_xor((int)b, off, 64));
+    c = max(c, (uint32_t)__shfl_xor((int)c, off, 64));
+    d = max(d, (uint32_t)__shfl_xor((int)d, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(hdr + 8, a);
+    atomicMax(hdr + 9, b);
+    atomicMax(hdr + 10, c);
+    atomicMax(hdr + 11, d);
+  }
+}
+
+// key = row-major index of the frame's cell in a 2-D grid on columns 0/1 (like compute_box_grid,
+// density_clustering.cpp:41-89); rows outside [i_from, i_to) sort to the end (key 0xFFFFFFFF)
+__global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
+                               const uint32_t* __restrict__ hdr, float cell, uint32_t i_from,
+                               uint32_t i_to, uint32_t* __restrict__ keys,
+                               uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  vals[i] = i;
+  if (i < i_from || i >= i_to) {
+    keys[i] = 0xFFFFFFFFu;
+    return;
+  }
+  const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
+  const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
+  // cell edge: the radius, but never so small that a dimension gets more than 60000 cells
+  float c0 = fmaxf(cell, (max0 - min0) / 60000.0f), c1 = fmaxf(cell, (max1 - min1) / 60000.0f);
+  if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
+  if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
+  const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
+  uint32_t bx = 0, by = 0;
+  if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
+    bx = (uint32_t)fminf(fmaxf((x - min0) / c0, 0.0f), 60001.0f);
+    by = (uint32_t)fminf(fmaxf((y - min1) / c1, 0.0f), 60001.0f);
+  }
+  const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 60001.0f) + 1u;
+  keys[i] = bx * nby + by;   // < 60003^2 < 2^32 - 1
+}
+
+// bounding box (lo0, hi0, lo1, hi1) of the frames of each tile of an ordered frame list
+__global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
+                           const uint32_t* __restrict__ perm, uint32_t n_used, uint32_t T,
+                           float4* __restrict__ boxes) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  float lo0 = INFINITY, hi0 = -INFINITY, lo1 = INFINITY, hi1 = -INFINITY;
+  for (uint32_t r = 0; r < 32; ++r) {
+    const uint32_t pos = t * 32 + r;
+    if (pos >= n_used) break;
+    const uint32_t i = perm[pos];
+    const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
+    lo0 = fminf(lo0, x);
+    hi0 = fmaxf(hi0, x);
+    lo1 = fminf(lo1, y);
+    hi1 = fmaxf(hi1, y);
+  }
+  boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
+}
+
 }  // namespace
 
 #define DC_FOR_EACH_S(X) \
@@ -135,7 +223,7 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
   hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_coords, n_rows, n_cols,
                      (double*)(p + kHdrSums));
   hipLaunchKernelGGL(image_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords,
-                     n_rows, n_cols, L.S, L.T, (const double*)(p + kHdrSums),
+                     n_rows, n_rows, n_cols, L.S, L.T, (const double*)(p + kHdrSums),
                      (const uint32_t*)nullptr, (float*)(p + L.off_img), (float*)(p + L.off_norm),
                      (uint32_t*)p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -149,6 +237,62 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
       pop_mfma_step_##SV(d_coords, n_rows, n_cols, d_ws, i_from, i_to, rad2, n_rad, d_pops, stream); \
+    break;
+    DC_FOR_EACH_S(X)
+#undef X
+    default:
+      break;
+  }
+}
+
+void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
+                       uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
+                       hipStream_t stream) {
+  const Layout L = make_layout(n_rows, n_cols);
+  char* p = (char*)d_ws;
+  uint32_t* hdr = (uint32_t*)p;
+  uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
+  uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
+  uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
+  uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
+  uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
+  float r2max = rad2.v[0];
+  for (int r = 1; r < n_rad; ++r) r2max = std::max(r2max, rad2.v[r]);
+  const float cell = (r2max > 0.0f) ? sqrtf(r2max) : 0.0f;
+  const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
+      grid_tiles((L.T + 255) / 256);
+  const size_t tmp_bytes = sort_temp_bytes(n_rows);
+  // order all frames by their 2-D cell, build the reference image and the tile boxes
+  hipLaunchKernelGGL(bounds_kernel, dim3(std::min<uint32_t>(1024, (n_rows + 255) / 256)), blk, 0,
+                     stream, d_coords, n_rows, n_cols, hdr);
+  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
+                     (const uint32_t*)hdr, cell, 0u, n_rows, keys_in, vals_in);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
+    return;
+  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
+                     L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p,
+                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (uint32_t*)nullptr);
+  hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
+                     (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p));
+  const bool full = (i_from == 0 && i_to == n_rows);
+  const uint32_t n_q = i_to - i_from;
+  if (!full) {
+    // query rows of this call: the same ordering restricted to [i_from, i_to)
+    hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
+                       (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_rows, p + L.fixed_end, tmp_bytes, stream))
+      return;
+    hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_q, n_cols, L.S, L.T,
+                       (const double*)(p + kHdrSums), (const uint32_t*)perm_q,
+                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (uint32_t*)nullptr);
+    hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
+                       (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q));
+  }
+  switch ((n_cols + 1) / 2) {
+#define X(SV)                                                                                 \
+  case SV:                                                                                    \
+    if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
+      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, full, rad2, n_rad, d_pops, stream); \
     break;
     DC_FOR_EACH_S(X)
 #undef X
@@ -177,8 +321,8 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
                      (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
   hipLaunchKernelGGL(fe_rank_kernel, grid_n, blk, 0, stream, d_fe, (const float*)(p + L.off_fe_s),
                      n_rows, (uint32_t*)(p + L.off_pq));
-  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_cols, L.S, L.T,
-                     (const double*)(p + kHdrSums), (const uint32_t*)perm,
+  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
+                     L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm,
                      (float*)(p + L.off_img_s), (float*)(p + L.off_norm_s), (uint32_t*)nullptr);
   switch ((n_cols + 1) / 2) {
 #define X(SV)                                                                                \

@@ -71,7 +71,11 @@ constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram 
 struct Layout {
   uint32_t T, S;
   size_t off_img, off_norm, off_img_s, off_norm_s, off_fe_s, off_perm, off_invpos, off_pq,
-      off_keys_in, off_keys_out, off_vals_in, fixed_end;
+      off_keys_in, off_keys_out, off_vals_in,
+      // spatially ordered frames (2-D cell key on columns 0/1) for the pruned population sweep:
+      // reference image / norms / permutation / per-tile boxes, and the same for the query rows
+      off_img_p, off_norm_p, off_perm_p, off_box_p, off_img_q, off_norm_q, off_perm_q, off_box_q,
+      fixed_end;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -93,7 +97,15 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_keys_in = L.off_pq + row_bytes;
   L.off_keys_out = L.off_keys_in + row_bytes;
   L.off_vals_in = L.off_keys_out + row_bytes;
-  L.fixed_end = L.off_vals_in + row_bytes;
+  L.off_img_p = L.off_vals_in + row_bytes;
+  L.off_norm_p = align256(L.off_img_p + img_bytes);
+  L.off_perm_p = L.off_norm_p + row_bytes;
+  L.off_box_p = L.off_perm_p + row_bytes;
+  L.off_img_q = align256(L.off_box_p + sizeof(float) * 4 * (size_t)L.T);
+  L.off_norm_q = align256(L.off_img_q + img_bytes);
+  L.off_perm_q = L.off_norm_q + row_bytes;
+  L.off_box_q = L.off_perm_q + row_bytes;
+  L.fixed_end = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.T);
   return L;
 }
 
@@ -108,6 +120,14 @@ struct Ptrs {
   const uint32_t* perm;
   const uint32_t* invpos;
   const uint32_t* pq;
+  const float* img_p;
+  const float* norms_p;
+  const uint32_t* perm_p;
+  const float4* box_p;
+  const float* img_q;
+  const float* norms_q;
+  const uint32_t* perm_q;
+  const float4* box_q;
 };
 
 inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
@@ -121,7 +141,15 @@ inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
               (const float*)(p + L.off_fe_s),
               (const uint32_t*)(p + L.off_perm),
               (const uint32_t*)(p + L.off_invpos),
-              (const uint32_t*)(p + L.off_pq)};
+              (const uint32_t*)(p + L.off_pq),
+              (const float*)(p + L.off_img_p),
+              (const float*)(p + L.off_norm_p),
+              (const uint32_t*)(p + L.off_perm_p),
+              (const float4*)(p + L.off_box_p),
+              (const float*)(p + L.off_img_q),
+              (const float*)(p + L.off_norm_q),
+              (const uint32_t*)(p + L.off_perm_q),
+              (const float4*)(p + L.off_box_q)};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,6 +265,7 @@ struct PopDelta {
 // (an escaping reference would park them in scratch for the whole hot loop).
 template <int NR>
 __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restrict__ coords,
+                                                          const uint32_t* __restrict__ perm,
                                                           uint32_t n_rows, uint32_t n_cols,
                                                           Rad2 rad2, f32x16 acc, PopQ<NR> q,
                                                           uint32_t wbits, uint32_t jq, uint32_t t,
@@ -249,8 +278,9 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restric
     bool any = false;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) any = any || (__float_as_uint(acc[r] - q.lo[rr]) < wbits);
-    const uint32_t i = tile_row(t, r, h);
-    if (any && i < n_rows) {
+    const uint32_t pos = tile_row(t, r, h);
+    if (any && pos < n_rows) {
+      const uint32_t i = perm ? perm[pos] : pos;   // reference rows may be spatially re-ordered
       const float d2c = exact_d2(coords, n_cols, jq, i);
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
     const bool band = e.tmin < wbits;
     if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
-      const PopDelta<NR> dl = pop_fix<NR>(coords, n_rows, n_cols, rad2, acc, q[qi], wbits, jq[qi], t, h);
+      const PopDelta<NR> dl = pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, acc, q[qi], wbits, jq[qi], t, h);
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += ((livemask[qi] >> lane) & 1) ? dl.d[rr] : 0u;
     }
@@ -380,6 +410,158 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
       const uint32_t total = q[qt].cnt[rr] + (uint32_t)__shfl_xor((int)q[qt].cnt[rr], 32, 64);
       if (h == 0 && live && rr < n_rad) {
         // the sweep met the self pair and counted it iff d2(i,i) < rad2; the reference starts at 1
+        const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
+        pops[(size_t)rr * n_rows + jq[qt]] = total + 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// population count over SPATIALLY ORDERED frames with tile-pair pruning -- the GPU counterpart of the
+// reference's box grid (density_clustering.cpp:41-89,160-168: 2-D cells on columns 0/1, only the 3x3
+// neighbour cells are searched).  Frames are sorted by their cell key, so a tile of 32 consecutive
+// frames is compact in the (col 0, col 1) plane and carries a bounding box; a (query tile, reference
+// tile) pair whose boxes are at least r_max apart cannot hold a pair with d2 < r^2 (d2 in D
+// dimensions >= d2 in two of them) and is skipped without any MFMA.  Each wave scans all reference
+// boxes (64 per step) against the box of its query group, compacts the survivors into an LDS list
+// and runs the usual Gram-chain + epilogue on them; per chain one more box test against the single
+// query tile.  Counting, guard band and exact re-check are those of pop_mfma_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int kListCap = 1024;   // reference tiles scanned per round (LDS list entries per wave)
+
+__device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
+  // boxes are (lo0, hi0, lo1, hi1); squared distance between them in the (col 0, col 1) plane
+  const float dx = fmaxf(0.0f, fmaxf(a.x - b.y, b.x - a.y));
+  const float dy = fmaxf(0.0f, fmaxf(a.z - b.w, b.z - a.w));
+  return dx * dx + dy * dy;
+}
+
+template <int S>
+__device__ __forceinline__ f32x16 gram_chain(const float (&a)[S], const float (&b)[S],
+                                             const f32x16& c0) {
+  f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
+#pragma unroll
+  for (int s = 1; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  return acc;
+}
+
+template <int S, int NR, int TQ>
+__global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
+    const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
+    const float* __restrict__ img_r, const float* __restrict__ norms_r,
+    const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r, uint32_t T,
+    const float* __restrict__ img_q, const float* __restrict__ norms_q,
+    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q,
+    const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
+    int n_rad, uint32_t* __restrict__ pops) {
+  __shared__ uint32_t lists[4][kListCap];
+  if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
+  const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+  const int wib = threadIdx.x >> 6;
+  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t TQT = (n_q + 31) / 32;
+  const uint32_t qt0 = wave * TQ;
+  if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
+  uint32_t* list = lists[wib];
+
+  float r2max = rad2.v[0];
+#pragma unroll
+  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
+  const float eps = guard_eps(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
+  const uint32_t wbits = __float_as_uint(2.0f * eps) + 1u;
+  const float far2 = r2max * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
+
+  float b[TQ][S];
+  PopQ<NR> q[TQ];
+  uint32_t jq[TQ];
+  uint64_t livemask[TQ];
+  float4 qbox[TQ];
+  float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const uint32_t tile = qt0 + qt;
+    const uint32_t tl = tile < TQT ? tile : TQT - 1;
+    const uint32_t pos = tile * 32 + c;
+    const bool live = (tile < TQT) && (pos < n_q);
+    livemask[qt] = __builtin_amdgcn_ballot_w64(live);
+    jq[qt] = live ? perm_q[pos] : 0u;
+#pragma unroll
+    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img_q[((size_t)tl * S + s) * 64 + lane];
+    const float nx = norms_q[tl * 32 + c];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      q[qt].lo[rr] = live ? (rad2.v[rr] - nx) - eps : -INFINITY;
+      q[qt].cnt[rr] = 0;
+    }
+    qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    gbox.x = fminf(gbox.x, qbox[qt].x);
+    gbox.y = fmaxf(gbox.y, qbox[qt].y);
+    gbox.z = fminf(gbox.z, qbox[qt].z);
+    gbox.w = fmaxf(gbox.w, qbox[qt].w);
+  }
+
+  uint32_t chains = 0;
+  for (uint32_t base = 0; base < T; base += kListCap) {
+    // ---- scan: which reference tiles of this round can hold a pair within r_max of the group?
+    uint32_t cnt = 0;
+    const uint32_t lim = min(T - base, (uint32_t)kListCap);
+    for (uint32_t k = 0; k < lim; k += 64) {
+      const uint32_t t = base + k + lane;
+      bool ok = false;
+      if (k + lane < lim) ok = box_gap2(gbox, box_r[t]) < far2;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+      if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+      cnt += (uint32_t)__builtin_popcountll(m);
+    }
+    if (cnt == 0) continue;
+    // ---- process the survivors (reference tile data double-buffered in registers)
+    float a[S], an[S];
+    float4 nv[4], nvn[4], rb, rbn;
+    uint32_t t = __builtin_amdgcn_readfirstlane(list[0]);
+    load_tile<S>(img_r, norms_r, t, lane, h, a, nv);
+    rb = box_r[t];
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t tn = __builtin_amdgcn_readfirstlane(list[(i + 1 < cnt) ? i + 1 : i]);
+      load_tile<S>(img_r, norms_r, tn, lane, h, an, nvn);   // prefetch the next survivor
+      rbn = box_r[tn];
+      const f32x16 c0 = frag16(nv);
+#pragma unroll
+      for (int qt = 0; qt < TQ; ++qt) {
+        if (!(box_gap2(qbox[qt], rb) < far2)) continue;     // wave-uniform: boxes are per tile
+        ++chains;
+        const f32x16 acc = gram_chain<S>(a, b[qt], c0);
+        PopAcc<NR> e;
+        pop_epi_begin<NR>(e);
+        pop_epi<NR, 0, 16>(acc, q[qt], e);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+        const bool band = e.tmin < wbits;
+        if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qt]) != 0, 0)) {
+          const PopDelta<NR> dl =
+              pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, acc, q[qt], wbits, jq[qt], t, h);
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
+        }
+      }
+      t = tn;
+      rb = rbn;
+#pragma unroll
+      for (int s = 0; s < S; ++s) a[s] = an[s];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) nv[g] = nvn[g];
+    }
+  }
+  if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
+
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const bool live = (livemask[qt] >> lane) & 1;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      const uint32_t total = q[qt].cnt[rr] + (uint32_t)__shfl_xor((int)q[qt].cnt[rr], 32, 64);
+      if (h == 0 && live && rr < n_rad) {
+        // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2
         const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
         pops[(size_t)rr * n_rows + jq[qt]] = total + 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
       }
@@ -640,6 +822,28 @@ void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const P
                        P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
 }
 
+// pruned population sweep: queries = n_q spatially ordered rows (image/perm/boxes "q"), references =
+// all rows spatially ordered ("p"); full_range: the query set is every row -> the two orders coincide
+template <int S>
+void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
+                         uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
+                         uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
+  const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + kTQ - 1) / kTQ;
+  const dim3 grid((waves + 3) / 4), block(256);
+  const float* img_q = full_range ? P.img_p : P.img_q;
+  const float* norms_q = full_range ? P.norms_p : P.norms_q;
+  const uint32_t* perm_q = full_range ? P.perm_p : P.perm_q;
+  const float4* box_q = full_range ? P.box_p : P.box_q;
+#define DC_LAUNCH_PRUNED(NRV)                                                                       \
+  hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, kTQ>), grid, block, 0, s, coords, n_rows, n_cols,   \
+                     P.img_p, P.norms_p, P.perm_p, P.box_p, T, img_q, norms_q, perm_q, box_q, n_q,   \
+                     P.hdr, chain_counter, rad2, n_rad, pops)
+  if (n_rad == 1) DC_LAUNCH_PRUNED(1);
+  else if (n_rad <= 4) DC_LAUNCH_PRUNED(4);
+  else DC_LAUNCH_PRUNED(8);
+#undef DC_LAUNCH_PRUNED
+}
+
 template <int S>
 void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                  uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
@@ -658,6 +862,9 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
   void pop_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,     \
                           uint32_t i_from, uint32_t i_to, const Rad2& rad2, int n_rad,           \
                           uint32_t* pops, hipStream_t s);                                        \
+  void pop_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,   \
+                            uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,          \
+                            uint32_t* pops, hipStream_t s);                                      \
   void nn_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,      \
                          uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2,         \
                          uint32_t* hd_idx, float* hd_d2, hipStream_t s);

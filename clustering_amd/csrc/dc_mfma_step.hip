@@ -18,6 +18,15 @@ void DC_CAT(pop_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint3
                         pops, s);
 }
 
+void DC_CAT(pop_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
+                                       void* d_ws, uint32_t n_q, bool full_range, const Rad2& rad2,
+                                       int n_rad, uint32_t* pops, hipStream_t s) {
+  const Layout L = make_layout(n_rows, n_cols);
+  // evaluated-chain counter: header word 2..3 (8-byte aligned)
+  pop_pruned_dispatch<DC_STEP>(coords, n_rows, n_cols, ws_ptrs(d_ws, L), L.T, n_q, full_range, rad2,
+                               n_rad, pops, (unsigned long long*)((char*)d_ws + 8), s);
+}
+
 void DC_CAT(nn_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
                                     void* d_ws, uint32_t i_from, uint32_t i_to, uint32_t* nn_idx,
                                     float* nn_d2, uint32_t* hd_idx, float* hd_d2, hipStream_t s) {

@@ -61,9 +61,12 @@ typedef enum dc_status {
 
 /* kernel family selector for the two pairwise sweeps */
 typedef enum dc_variant {
-  DC_VARIANT_AUTO = 0,        /* MFMA when n_cols allows, else direct */
+  DC_VARIANT_AUTO = 0,        /* fastest available: pruned MFMA when n_cols allows, else direct */
   DC_VARIANT_DIRECT = 1,      /* VALU, direct differences in the canonical order: exact by construction */
-  DC_VARIANT_MFMA = 2         /* fp32 MFMA Gram form + guard band + canonical re-check: same results */
+  DC_VARIANT_MFMA = 2,        /* fp32 MFMA Gram form + guard band + canonical re-check, every pair evaluated */
+  DC_VARIANT_MFMA_PRUNED = 3  /* the same on spatially ordered frames, skipping tile pairs farther apart than
+                                 the radius (the GPU counterpart of the reference's box grid,
+                                 density_clustering.cpp:41-89); identical results */
 } dc_variant;
 
 /* message of the last failing call on this thread ("" if none). */

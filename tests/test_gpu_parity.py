@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 KATS = json.load(open(os.path.join(HERE, "golden", "kat_cases.json")))["cases"]
 FLT_MAX = np.finfo(np.float32).max
-VARIANTS = ["direct", "mfma"]
+VARIANTS = ["direct", "mfma", "pruned"]
 
 
 def bits(a):
