@@ -115,14 +115,6 @@ __global__ void fe_rank_kernel(const float* __restrict__ fe, const float* __rest
 
 // ---- spatial ordering of the frames (pruned population sweep) ------------------------------------
 // header words 8..11: ~key(min col0), key(max col0), ~key(min col1), key(max col1), all as atomicMax
-__device__ __forceinline__ uint32_t fkey(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(uint32_t k) {
-  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-}
-
 __global__ void bounds_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                               uint32_t* __restrict__ hdr) {
   uint32_t a = 0, b = 0, c = 0, d = 0;
@@ -165,6 +157,7 @@ __global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t n_rows
   }
   const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
   const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
+  if (cell < 0.0f) cell = auto_cell(hdr, n_rows);
   // cell edge: the radius, but never so small that a dimension gets more than 60000 cells
   float c0 = fmaxf(cell, (max0 - min0) / 60000.0f), c1 = fmaxf(cell, (max1 - min1) / 60000.0f);
   if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
@@ -182,10 +175,12 @@ __global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t n_rows
 // bounding box (lo0, hi0, lo1, hi1) of the frames of each tile of an ordered frame list
 __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
                            const uint32_t* __restrict__ perm, uint32_t n_used, uint32_t T,
-                           float4* __restrict__ boxes) {
+                           float4* __restrict__ boxes, const float* __restrict__ fe,
+                           float2* __restrict__ ferange) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   float lo0 = INFINITY, hi0 = -INFINITY, lo1 = INFINITY, hi1 = -INFINITY;
+  float flo = INFINITY, fhi = -INFINITY;
   for (uint32_t r = 0; r < 32; ++r) {
     const uint32_t pos = t * 32 + r;
     if (pos >= n_used) break;
@@ -195,8 +190,21 @@ __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
     hi0 = fmaxf(hi0, x);
     lo1 = fminf(lo1, y);
     hi1 = fmaxf(hi1, y);
+    if (fe) {
+      flo = fminf(flo, fe[i]);
+      fhi = fmaxf(fhi, fe[i]);
+    }
   }
   boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
+  if (ferange) ferange[t] = make_float2(flo, fhi);
+}
+
+// stable second sort pass: key of the frame that currently sits at position p
+__global__ void gather_key_kernel(const uint32_t* __restrict__ keys_by_frame,
+                                  const uint32_t* __restrict__ perm, uint32_t n,
+                                  uint32_t* __restrict__ keys_out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) keys_out[p] = keys_by_frame[perm[p]];
 }
 
 }  // namespace
@@ -273,7 +281,8 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
                      L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p,
                      (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (uint32_t*)nullptr);
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                     (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p));
+                     (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
+                     (const float*)nullptr, (float2*)nullptr);
   const bool full = (i_from == 0 && i_to == n_rows);
   const uint32_t n_q = i_to - i_from;
   if (!full) {
@@ -286,13 +295,80 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
                        (const double*)(p + kHdrSums), (const uint32_t*)perm_q,
                        (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (uint32_t*)nullptr);
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q));
+                       (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
+                       (const float*)nullptr, (float2*)nullptr);
   }
   switch ((n_cols + 1) / 2) {
 #define X(SV)                                                                                 \
   case SV:                                                                                    \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
       pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, full, rad2, n_rad, d_pops, stream); \
+    break;
+    DC_FOR_EACH_S(X)
+#undef X
+    default:
+      break;
+  }
+}
+
+void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
+                      uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
+                      uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream) {
+  const Layout L = make_layout(n_rows, n_cols);
+  char* p = (char*)d_ws;
+  uint32_t* hdr = (uint32_t*)p;
+  uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
+  uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
+  uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
+  uint32_t* perm_fe = (uint32_t*)(p + L.off_perm);       // scratch: FE order
+  uint32_t* cellkeys = (uint32_t*)(p + L.off_pq);        // scratch: cell key per frame
+  uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
+  uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
+  const float cell = -1.0f;   // "auto": the kernels derive the cell edge from the bounding box
+  const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
+      grid_tiles((L.T + 255) / 256);
+  const size_t tmp_bytes = sort_temp_bytes(n_rows);
+  hipLaunchKernelGGL(bounds_kernel, dim3(std::min<uint32_t>(1024, (n_rows + 255) / 256)), blk, 0,
+                     stream, d_coords, n_rows, n_cols, hdr);
+  // 1. frames by ascending free energy (stable), 2. stable sort of that order by cell key
+  hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in, hdr);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_fe, n_rows, p + L.fixed_end, tmp_bytes, stream))
+    return;
+  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
+                     (const uint32_t*)hdr, cell, 0u, n_rows, cellkeys, vals_in);
+  hipLaunchKernelGGL(gather_key_kernel, grid_n, blk, 0, stream, (const uint32_t*)cellkeys,
+                     (const uint32_t*)perm_fe, n_rows, keys_in);
+  if (sort_pairs_u32(keys_in, keys_out, perm_fe, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
+    return;
+  hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
+                     L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
+  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
+                     L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p,
+                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (uint32_t*)nullptr);
+  hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
+                     (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
+                     (float2*)(p + L.off_ferange_p));
+  const bool full = (i_from == 0 && i_to == n_rows);
+  const uint32_t n_q = i_to - i_from;
+  if (!full) {
+    // query rows of this call: the cell ordering restricted to [i_from, i_to)
+    hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
+                       (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_rows, p + L.fixed_end, tmp_bytes, stream))
+      return;
+    hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_q, n_cols, L.S, L.T,
+                       (const double*)(p + kHdrSums), (const uint32_t*)perm_q,
+                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (uint32_t*)nullptr);
+    hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
+                       (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
+                       (const float*)nullptr, (float2*)nullptr);
+  }
+  switch ((n_cols + 1) / 2) {
+#define X(SV)                                                                                   \
+  case SV:                                                                                      \
+    if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
+      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, n_q, full ? 1 : 0, -1.0f,         \
+                          d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, stream);                        \
     break;
     DC_FOR_EACH_S(X)
 #undef X

@@ -18,6 +18,10 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
                        void* d_ws, hipStream_t stream);
+// neighbour sweep over (cell, free energy)-ordered frames with ring-wise pruning
+void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
+                      uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
+                      uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);

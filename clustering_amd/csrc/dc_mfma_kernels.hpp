@@ -75,6 +75,7 @@ struct Layout {
       // spatially ordered frames (2-D cell key on columns 0/1) for the pruned population sweep:
       // reference image / norms / permutation / per-tile boxes, and the same for the query rows
       off_img_p, off_norm_p, off_perm_p, off_box_p, off_img_q, off_norm_q, off_perm_q, off_box_q,
+      off_ferange_p,   // per reference tile (fe_lo, fe_hi) -- pruned neighbour sweep
       fixed_end;
 };
 
@@ -105,7 +106,8 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_norm_q = align256(L.off_img_q + img_bytes);
   L.off_perm_q = L.off_norm_q + row_bytes;
   L.off_box_q = L.off_perm_q + row_bytes;
-  L.fixed_end = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.T);
+  L.off_ferange_p = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.T);
+  L.fixed_end = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.T);
   return L;
 }
 
@@ -150,6 +152,25 @@ inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
               (const float*)(p + L.off_norm_q),
               (const uint32_t*)(p + L.off_perm_q),
               (const float4*)(p + L.off_box_q)};
+}
+
+// ordered-integer image of a float (ascending) and back; header words 8..11 hold the bounding box of
+// columns 0/1 as ~key(min0), key(max0), ~key(min1), key(max1) (all maintained with atomicMax)
+__device__ __forceinline__ uint32_t fkey(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// cell edge of the neighbour sweep's ordering: about 4096 frames per cell of the bounding box
+__device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uint32_t n_rows) {
+  const float e0 = fkey_inv(hdr[9]) - fkey_inv(~hdr[8]), e1 = fkey_inv(hdr[11]) - fkey_inv(~hdr[10]);
+  const double a0 = (e0 > 0.0f && e0 <= FLT_MAX) ? (double)e0 : 0.0;
+  const double a1 = (e1 > 0.0f && e1 <= FLT_MAX) ? (double)e1 : 0.0;
+  const double c = (a0 > 0.0 && a1 > 0.0) ? sqrt(a0 * a1 * 4096.0 / (double)n_rows)
+                                           : (a0 + a1) * 4096.0 / (double)n_rows;
+  return (float)c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -795,6 +816,258 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// neighbour sweep over frames ordered by (2-D cell, free energy) with ring-wise tile pruning.
+//
+// Order: cells of a coarse 2-D grid on columns 0/1 (row-major), frames of a cell by ascending free
+// energy.  A tile therefore is (a) compact in the (col 0, col 1) plane -> bounding box, and (b) has
+// a narrow free-energy range [fe_lo, fe_hi] -> for a query with free energy feq the tile is
+// entirely lower (fe_hi < feq: hd minimum = nn minimum), entirely not lower (fe_lo >= feq) or mixed
+// (masked per-element epilogue, like the tile that holds the query itself).
+//
+// Pruning: a wave processes reference tiles in rings of growing box distance from its query group.
+// After a ring with outer radius R every unvisited frame is at least R away (d2 in D dimensions >=
+// box gap in two of them), so a query whose EXACT incumbent d2 is < R^2 is settled.  The next radius
+// is the largest incumbent still to be confirmed (or 4x, while some query has no candidate yet).
+// Typical: one local ring, one confirming ring, done -- far clusters are never touched.
+// ---------------------------------------------------------------------------------------------
+struct NnPQ {            // per query tile, per lane
+  float feq;             // free energy of the query
+  float m_nn, m_hd;      // running minima of the MFMA values over the visited reference rows
+  float bd_nn, bd_hd;    // exact incumbents (canonical d2)
+  uint32_t bj_nn, bj_hd;
+  uint32_t spos;         // position of the query itself in the reference order
+};
+
+__device__ __attribute__((noinline)) NnMin nn_special_fe(f32x16 acc, const float* __restrict__ fe_c,
+                                                         uint32_t t, int h, uint32_t spos,
+                                                         float feq) {
+  NnMin o{INFINITY, INFINITY};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t pos = tile_row(t, r, h);
+    const float v = (pos != spos) ? acc[r] : INFINITY;
+    o.tmin = fminf(o.tmin, v);
+    o.hmin = fminf(o.hmin, (fe_c[pos] < feq) ? v : INFINITY);   // fe_c is +inf padded
+  }
+  return o;
+}
+
+__device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ coords,
+                                                      const uint32_t* __restrict__ perm,
+                                                      const float* __restrict__ fe_c,
+                                                      uint32_t n_rows, uint32_t n_cols, f32x16 acc,
+                                                      float bn, float bh, NnBest best, uint32_t jq,
+                                                      uint32_t spos, float feq, uint32_t t, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t pos = tile_row(t, r, h);
+    const bool other = (pos != spos) && (pos < n_rows);
+    const bool cn = other && (acc[r] < bn);
+    const bool ch = other && (acc[r] < bh) && (fe_c[pos] < feq);
+    if (cn || ch) {
+      const uint32_t j = perm[pos];
+      const float d2c = exact_d2(coords, n_cols, jq, j);
+      lexi_update(cn, best.bd_nn, best.bj_nn, d2c, j, n_rows);
+      lexi_update(ch, best.bd_hd, best.bj_hd, d2c, j, n_rows);
+    }
+  }
+  return best;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <int S, int TQ>
+__global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
+    const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
+    const float* __restrict__ fe, const float* __restrict__ img_r,
+    const float* __restrict__ norms_r, const uint32_t* __restrict__ perm_r,
+    const float4* __restrict__ box_r, const float2* __restrict__ ferange_r,
+    const float* __restrict__ fe_c, const uint32_t* __restrict__ invpos_r, uint32_t T,
+    const float* __restrict__ img_q, const uint32_t* __restrict__ perm_q,
+    const float4* __restrict__ box_q, uint32_t n_q, int full_range, float cell2,
+    const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
+    uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
+    float* __restrict__ hd_d2) {
+  __shared__ uint32_t lists[4][kListCap];
+  if (hdr[1] != 0) return;
+  const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+  const int wib = threadIdx.x >> 6;
+  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t TQT = (n_q + 31) / 32;
+  const uint32_t qt0 = wave * TQ;
+  if (qt0 >= TQT) return;
+  uint32_t* list = lists[wib];
+
+  const float M = __uint_as_float(hdr[0]);
+  const float eps = guard_eps(M, 4.0f * M, 2 * S, (int)n_cols);
+  const float eps2 = 2.5f * eps;
+  if (cell2 < 0.0f) {
+    const float cl = auto_cell(hdr, n_rows);
+    cell2 = cl * cl;
+  }
+
+  float b[TQ][S];
+  NnPQ q[TQ];
+  uint32_t jq[TQ];
+  uint64_t livemask[TQ];
+  float4 qbox[TQ];
+  float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const uint32_t tile = qt0 + qt;
+    const uint32_t tl = tile < TQT ? tile : TQT - 1;
+    const uint32_t pos = tile * 32 + c;
+    const bool live = (tile < TQT) && (pos < n_q);
+    livemask[qt] = __builtin_amdgcn_ballot_w64(live);
+    jq[qt] = live ? perm_q[pos] : 0u;
+#pragma unroll
+    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img_q[((size_t)tl * S + s) * 64 + lane];
+    q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
+    q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
+    q[qt].m_nn = live ? INFINITY : -INFINITY;   // idle lanes can never trigger the exact path
+    q[qt].m_hd = live ? INFINITY : -INFINITY;
+    q[qt].bd_nn = FLT_MAX;
+    q[qt].bd_hd = FLT_MAX;
+    q[qt].bj_nn = n_rows + 1;
+    q[qt].bj_hd = n_rows + 1;
+    qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    gbox.x = fminf(gbox.x, qbox[qt].x);
+    gbox.y = fmaxf(gbox.y, qbox[qt].y);
+    gbox.z = fminf(gbox.z, qbox[qt].z);
+    gbox.w = fmaxf(gbox.w, qbox[qt].w);
+  }
+  // lowest free energy of the whole data set: a query at that level has no lower-FE neighbour
+  float fe_floor = INFINITY;
+  for (uint32_t k = lane; k < T; k += 64) fe_floor = fminf(fe_floor, ferange_r[k].x);
+  fe_floor = wave_min(fe_floor);
+
+  uint32_t chains = 0, visited = 0;
+  const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
+  float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
+  float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
+  if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
+  for (;;) {
+    for (uint32_t base = 0; base < T; base += kListCap) {
+      uint32_t cnt = 0;
+      const uint32_t lim = min(T - base, (uint32_t)kListCap);
+      for (uint32_t k = 0; k < lim; k += 64) {
+        const uint32_t t = base + k + lane;
+        bool ok = false;
+        if (k + lane < lim) {
+          const float g2 = box_gap2(gbox, box_r[t]);
+          ok = (g2 < r2_hi) & (g2 >= r2_lo);
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+        if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+        cnt += (uint32_t)__builtin_popcountll(m);
+      }
+      if (cnt == 0) continue;
+      visited += cnt;
+      float a[S], an[S];
+      float4 nv[4], nvn[4];
+      uint32_t t = __builtin_amdgcn_readfirstlane(list[0]);
+      load_tile<S>(img_r, norms_r, t, lane, h, a, nv);
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t tn = __builtin_amdgcn_readfirstlane(list[(i + 1 < cnt) ? i + 1 : i]);
+        load_tile<S>(img_r, norms_r, tn, lane, h, an, nvn);   // prefetch the next survivor
+        const f32x16 c0 = frag16(nv);
+        const float2 fr = ferange_r[t];
+#pragma unroll
+        for (int qt = 0; qt < TQ; ++qt) {
+          NnPQ& Q = q[qt];
+          ++chains;
+          const f32x16 acc = gram_chain<S>(a, b[qt], c0);
+          float tmin = INFINITY;
+          tile_min<0, 16>(acc, tmin);
+          const bool all_lower = fr.y < Q.feq;
+          const bool mixed = (fr.x < Q.feq) & !all_lower;
+          const bool special = mixed | (t == (Q.spos >> 5));
+          float hmin = all_lower ? tmin : INFINITY;
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
+            const NnMin g = nn_special_fe(acc, fe_c, t, h, Q.spos, Q.feq);
+            tmin = g.tmin;
+            hmin = g.hmin;
+          }
+          const bool trig = (tmin < Q.m_nn + eps2) | (hmin < Q.m_hd + eps2);
+          const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
+            const bool live = (livemask[qt] >> lane) & 1;
+            NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
+            best = nn_fix_fe(coords, perm_r, fe_c, n_rows, n_cols, acc, new_nn + eps2, new_hd + eps2,
+                             best, jq[qt], Q.spos, Q.feq, t, h);
+            Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
+            Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
+            Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
+            Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
+          }
+          Q.m_nn = new_nn;
+          Q.m_hd = new_hd;
+        }
+        t = tn;
+#pragma unroll
+        for (int s = 0; s < S; ++s) a[s] = an[s];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nv[g] = nvn[g];
+      }
+    }
+    if (!(r2_hi <= FLT_MAX) || visited >= T) break;   // every reference tile has been visited
+    // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
+    const float sure = r2_hi * 0.9999f;
+    float need = 0.0f;      // largest incumbent that still has to be confirmed
+    bool blind = false;     // some query has no candidate at all yet
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt) {
+      const bool live = (livemask[qt] >> lane) & 1;
+      const bool hd_possible = fe_floor < q[qt].feq;
+      // a query's incumbent is the better one of its two half-wave lanes
+      const float inc_nn = fminf(q[qt].bd_nn, __shfl_xor(q[qt].bd_nn, 32, 64));
+      const float inc_hd = fminf(q[qt].bd_hd, __shfl_xor(q[qt].bd_hd, 32, 64));
+      const float want = fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f);
+      const bool open = live & !(want < sure);
+      blind = blind | (open & !(want < FLT_MAX));
+      need = fmaxf(need, open ? want : 0.0f);
+    }
+    const bool any_open = __builtin_amdgcn_ballot_w64(need > 0.0f) != 0;
+    if (!any_open) break;
+    const bool any_blind = __builtin_amdgcn_ballot_w64(blind) != 0;
+    r2_lo = r2_hi;
+    if (any_blind) {
+      r2_hi = r2_hi * 4.0f;
+    } else {
+      r2_hi = fmaxf(wave_max(need) * 1.001f, r2_hi * 1.001f);
+    }
+    if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
+  }
+  if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
+
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    NnPQ& Q = q[qt];
+    float od = __shfl_xor(Q.bd_nn, 32, 64);
+    uint32_t oj = (uint32_t)__shfl_xor((int)Q.bj_nn, 32, 64);
+    lexi_update(oj <= n_rows, Q.bd_nn, Q.bj_nn, od, oj, n_rows);
+    od = __shfl_xor(Q.bd_hd, 32, 64);
+    oj = (uint32_t)__shfl_xor((int)Q.bj_hd, 32, 64);
+    lexi_update(oj <= n_rows, Q.bd_hd, Q.bj_hd, od, oj, n_rows);
+    if (h == 0 && ((livemask[qt] >> lane) & 1)) {
+      nn_idx[jq[qt]] = Q.bj_nn;
+      nn_d2[jq[qt]] = Q.bd_nn;
+      hd_idx[jq[qt]] = Q.bj_hd;
+      hd_d2[jq[qt]] = Q.bd_hd;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch helpers (one K-step count per translation unit)
 // ---------------------------------------------------------------------------------------------
 constexpr int kTQ = 4;     // query tiles per wave, population sweep
@@ -820,6 +1093,34 @@ void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const P
   else
     hipLaunchKernelGGL((pop_mfma_kernel<S, 8, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
                        P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
+}
+
+struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy) ordering
+  const float* img_r;
+  const float* norms_r;
+  const uint32_t* perm_r;
+  const float4* box_r;
+  const float2* ferange_r;
+  const float* fe_c;
+  const uint32_t* invpos_r;
+  const float* img_q;
+  const uint32_t* perm_q;
+  const float4* box_q;
+  uint32_t n_q;
+  int full_range;
+  float cell2;
+};
+
+template <int S>
+void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe,
+                        const NnPrunedArgs& A, uint32_t T, const uint32_t* hdr,
+                        unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
+                        uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
+  const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + kTQnn - 1) / kTQnn;
+  hipLaunchKernelGGL((nn_pruned_kernel<S, kTQnn>), dim3((waves + 3) / 4), dim3(256), 0, s, coords,
+                     n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r, A.fe_c,
+                     A.invpos_r, T, A.img_q, A.perm_q, A.box_q, A.n_q, A.full_range, A.cell2, hdr,
+                     chain_counter, nn_idx, nn_d2, hd_idx, hd_d2);
 }
 
 // pruned population sweep: queries = n_q spatially ordered rows (image/perm/boxes "q"), references =
@@ -865,6 +1166,10 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
   void pop_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,   \
                             uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,          \
                             uint32_t* pops, hipStream_t s);                                      \
+  void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
+                           void* d_ws, uint32_t n_q, int full_range, float cell2,                \
+                           uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,       \
+                           hipStream_t s);                                                       \
   void nn_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,      \
                          uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2,         \
                          uint32_t* hd_idx, float* hd_d2, hipStream_t s);

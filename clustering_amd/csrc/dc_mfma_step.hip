@@ -27,6 +27,30 @@ void DC_CAT(pop_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uin
                                n_rad, pops, (unsigned long long*)((char*)d_ws + 8), s);
 }
 
+void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
+                                      const float* fe, void* d_ws, uint32_t n_q, int full_range,
+                                      float cell2, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
+                                      float* hd_d2, hipStream_t s) {
+  const Layout L = make_layout(n_rows, n_cols);
+  char* p = (char*)d_ws;
+  NnPrunedArgs A;
+  A.img_r = (const float*)(p + L.off_img_p);
+  A.norms_r = (const float*)(p + L.off_norm_p);
+  A.perm_r = (const uint32_t*)(p + L.off_perm_p);
+  A.box_r = (const float4*)(p + L.off_box_p);
+  A.ferange_r = (const float2*)(p + L.off_ferange_p);
+  A.fe_c = (const float*)(p + L.off_fe_s);
+  A.invpos_r = (const uint32_t*)(p + L.off_invpos);
+  A.img_q = full_range ? A.img_r : (const float*)(p + L.off_img_q);
+  A.perm_q = full_range ? A.perm_r : (const uint32_t*)(p + L.off_perm_q);
+  A.box_q = full_range ? A.box_r : (const float4*)(p + L.off_box_q);
+  A.n_q = n_q;
+  A.full_range = full_range;
+  A.cell2 = cell2;
+  nn_pruned_dispatch<DC_STEP>(coords, n_rows, n_cols, fe, A, L.T, (const uint32_t*)p,
+                              (unsigned long long*)(p + 16), nn_idx, nn_d2, hd_idx, hd_d2, s);
+}
+
 void DC_CAT(nn_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
                                     void* d_ws, uint32_t i_from, uint32_t i_to, uint32_t* nn_idx,
                                     float* nn_d2, uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
