@@ -19,7 +19,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA
 SYMBOLS = (
     "dc_hip_last_error", "dc_hip_abi_version", "dc_hip_device_count", "dc_hip_workspace_bytes",
     "dc_hip_populations_dev", "dc_hip_free_energies_dev", "dc_hip_nearest_neighbors_dev",
-    "dc_hip_sigma2_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
+    "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
 )
 
 
@@ -50,6 +50,8 @@ def _load():
                                                  i32, vp]
     lib.dc_hip_sigma2_dev.restype = i32
     lib.dc_hip_sigma2_dev.argtypes = [vp, sz, C.POINTER(C.c_double), vp]
+    lib.dc_hip_workspace_counters_dev.restype = i32
+    lib.dc_hip_workspace_counters_dev.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
     lib.dc_hip_populations.restype = i32
     lib.dc_hip_populations.argtypes = [vp, sz, sz, vp, sz, sz, sz, i32, vp]
     lib.dc_hip_nearest_neighbors.restype = i32

@@ -121,6 +121,18 @@ size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radii) {
   return dc::mfma_workspace_bytes(n_rows, n_cols);
 }
 
+int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles, uint64_t* nn_tiles,
+                                  void* stream) {
+  if (!d_workspace) return fail(DC_ERR_INVALID_ARGUMENT, "null workspace");
+  uint64_t c[2] = {0, 0};   // header bytes 8..23 (see dc_mfma_step.hip)
+  hipStream_t s = (hipStream_t)stream;
+  DC_HIP_TRY(hipMemcpyAsync(c, (const char*)d_workspace + 8, sizeof(c), hipMemcpyDeviceToHost, s));
+  DC_HIP_TRY(hipStreamSynchronize(s));
+  if (pop_tiles) *pop_tiles = c[0];
+  if (nn_tiles) *nn_tiles = c[1];
+  return DC_OK;
+}
+
 int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, const float* radii,
                            size_t n_radii, size_t i_from, size_t i_to, uint32_t* d_pops,
                            void* d_workspace, size_t workspace_bytes, int variant, void* stream) {

@@ -163,13 +163,13 @@ __device__ __forceinline__ uint32_t fkey(float f) {
 __device__ __forceinline__ float fkey_inv(uint32_t k) {
   return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
-// cell edge of the neighbour sweep's ordering: about 4096 frames per cell of the bounding box
+// cell edge of the neighbour sweep's ordering: about 8192 frames per cell of the bounding box
 __device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uint32_t n_rows) {
   const float e0 = fkey_inv(hdr[9]) - fkey_inv(~hdr[8]), e1 = fkey_inv(hdr[11]) - fkey_inv(~hdr[10]);
   const double a0 = (e0 > 0.0f && e0 <= FLT_MAX) ? (double)e0 : 0.0;
   const double a1 = (e1 > 0.0f && e1 <= FLT_MAX) ? (double)e1 : 0.0;
-  const double c = (a0 > 0.0 && a1 > 0.0) ? sqrt(a0 * a1 * 4096.0 / (double)n_rows)
-                                           : (a0 + a1) * 4096.0 / (double)n_rows;
+  const double c = (a0 > 0.0 && a1 > 0.0) ? sqrt(a0 * a1 * 8192.0 / (double)n_rows)
+                                           : (a0 + a1) * 8192.0 / (double)n_rows;
   return (float)c;
 }
 
@@ -529,27 +529,32 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const uint32_t lim = min(T - base, (uint32_t)kListCap);
     for (uint32_t k = 0; k < lim; k += 64) {
       const uint32_t t = base + k + lane;
-      bool ok = false;
-      if (k + lane < lim) ok = box_gap2(gbox, box_r[t]) < far2;
-      const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
-      if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+      uint32_t qmask = 0;   // bit qt: reference tile t can hold a pair within r_max of query tile qt
+      if (k + lane < lim) {
+        const float4 rb = box_r[t];
+        if (box_gap2(gbox, rb) < far2) {
+#pragma unroll
+          for (int qt = 0; qt < TQ; ++qt) qmask |= (box_gap2(qbox[qt], rb) < far2) ? (1u << qt) : 0u;
+        }
+      }
+      const uint64_t m = __builtin_amdgcn_ballot_w64(qmask != 0);
+      if (qmask) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t | (qmask << 28);
       cnt += (uint32_t)__builtin_popcountll(m);
     }
     if (cnt == 0) continue;
     // ---- process the survivors (reference tile data double-buffered in registers)
     float a[S], an[S];
-    float4 nv[4], nvn[4], rb, rbn;
-    uint32_t t = __builtin_amdgcn_readfirstlane(list[0]);
-    load_tile<S>(img_r, norms_r, t, lane, h, a, nv);
-    rb = box_r[t];
+    float4 nv[4], nvn[4];
+    uint32_t ent = __builtin_amdgcn_readfirstlane(list[0]);
+    load_tile<S>(img_r, norms_r, ent & 0x0FFFFFFFu, lane, h, a, nv);
     for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t tn = __builtin_amdgcn_readfirstlane(list[(i + 1 < cnt) ? i + 1 : i]);
-      load_tile<S>(img_r, norms_r, tn, lane, h, an, nvn);   // prefetch the next survivor
-      rbn = box_r[tn];
+      const uint32_t entn = __builtin_amdgcn_readfirstlane(list[(i + 1 < cnt) ? i + 1 : i]);
+      load_tile<S>(img_r, norms_r, entn & 0x0FFFFFFFu, lane, h, an, nvn);   // prefetch the next survivor
+      const uint32_t t = ent & 0x0FFFFFFFu, qmask = ent >> 28;
       const f32x16 c0 = frag16(nv);
 #pragma unroll
       for (int qt = 0; qt < TQ; ++qt) {
-        if (!(box_gap2(qbox[qt], rb) < far2)) continue;     // wave-uniform: boxes are per tile
+        if (!(qmask & (1u << qt))) continue;                // scalar test: boxes are per tile
         ++chains;
         const f32x16 acc = gram_chain<S>(a, b[qt], c0);
         PopAcc<NR> e;
@@ -565,8 +570,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
           for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
         }
       }
-      t = tn;
-      rb = rbn;
+      ent = entn;
 #pragma unroll
       for (int s = 0; s < S; ++s) a[s] = an[s];
 #pragma unroll
@@ -973,12 +977,14 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       if (cnt == 0) continue;
       visited += cnt;
       float a[S], an[S];
-      float4 nv[4], nvn[4];
+      float4 nv[4], nvn[4], fv[4], fvn[4];
       uint32_t t = __builtin_amdgcn_readfirstlane(list[0]);
       load_tile<S>(img_r, norms_r, t, lane, h, a, nv);
+      load_frag(fe_c, t, h, fv);
       for (uint32_t i = 0; i < cnt; ++i) {
         const uint32_t tn = __builtin_amdgcn_readfirstlane(list[(i + 1 < cnt) ? i + 1 : i]);
         load_tile<S>(img_r, norms_r, tn, lane, h, an, nvn);   // prefetch the next survivor
+        load_frag(fe_c, tn, h, fvn);
         const f32x16 c0 = frag16(nv);
         const float2 fr = ferange_r[t];
 #pragma unroll
@@ -993,9 +999,16 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           const bool special = mixed | (t == (Q.spos >> 5));
           float hmin = all_lower ? tmin : INFINITY;
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
-            const NnMin g = nn_special_fe(acc, fe_c, t, h, Q.spos, Q.feq);
-            tmin = g.tmin;
-            hmin = g.hmin;
+            // masked per-element minima (the tile holds the query itself and/or straddles feq)
+            const f32x16 fef = frag16(fv);
+            tmin = INFINITY;
+            hmin = INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = (tile_row(t, r, h) != Q.spos) ? acc[r] : INFINITY;
+              tmin = fminf(tmin, v);
+              hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
+            }
           }
           const bool trig = (tmin < Q.m_nn + eps2) | (hmin < Q.m_hd + eps2);
           const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
@@ -1016,7 +1029,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 #pragma unroll
         for (int s = 0; s < S; ++s) a[s] = an[s];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nv[g] = nvn[g];
+        for (int g = 0; g < 4; ++g) {
+          nv[g] = nvn[g];
+          fv[g] = fvn[g];
+        }
       }
     }
     if (!(r2_hi <= FLT_MAX) || visited >= T) break;   // every reference tile has been visited

@@ -122,6 +122,20 @@ def nearest_neighbors_partial(coords, fe, i_from=0, i_to=None, variant="auto"):
     return nn_idx, nn_d2, hd_idx, hd_d2
 
 
+def evaluated_tiles(device):
+    """(pop_tiles, nn_tiles): 32x32 frame-pair tiles evaluated by the last pruned sweeps on this device's
+    workspace.  The header is rebuilt by every sweep, so read it right after the sweep of interest
+    (the other counter is then 0)."""
+    ws = _workspace(device)
+    if ws.buf is None:
+        return 0, 0
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    with torch.cuda.device(device):
+        rc = capi.lib.dc_hip_workspace_counters_dev(_dev(ws.buf), C.byref(a), C.byref(b), _stream_ptr())
+    capi.check(rc, "dc_hip_workspace_counters_dev")
+    return int(a.value), int(b.value)
+
+
 def compute_sigma2(nn_d2):
     """compute_sigma2 (density_clustering.cpp:334-343)."""
     out = C.c_double(0.0)

@@ -88,6 +88,13 @@ DC_API int dc_hip_device_count(void);
  * norms; 0-filled by the callee as needed).  Pass a buffer at least this large. */
 DC_API size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radii);
 
+/* statistics of the sweeps that last ran in this workspace (asynchronous pruned variants leave them
+ * in the workspace header): number of 32x32 frame-pair tiles actually evaluated by the population
+ * and by the neighbour sweep (every pair = n_rows^2/1024 per full sweep; the direct kernels and
+ * DC_VARIANT_MFMA do not count and report 0).  Synchronises the stream. */
+DC_API int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles,
+                                         uint64_t* nn_tiles, void* stream);
+
 /* replaces the kernel loop of calculate_populations_per_gpu (density_clustering_cuda.cu:45-137;
  * kernel population_count, density_clustering_cuda_kernels.cu:9-56): ONE launch sweeps all
  * n_rows reference frames for the query rows [i_from, i_to).
