@@ -199,6 +199,17 @@ __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
   if (ferange) ferange[t] = make_float2(flo, fhi);
 }
 
+// original coordinates gathered into an ordered frame list (the exact path then needs no
+// permutation look-up before it can fetch a row)
+__global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
+                                   const uint32_t* __restrict__ perm, uint32_t n,
+                                   float* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n * D) return;
+  const uint32_t pos = (uint32_t)(e / D), k = (uint32_t)(e - (size_t)pos * D);
+  out[e] = coords[(size_t)perm[pos] * D + k];
+}
+
 // stable second sort pass: key of the frame that currently sits at position p
 __global__ void gather_key_kernel(const uint32_t* __restrict__ keys_by_frame,
                                   const uint32_t* __restrict__ perm, uint32_t n,
@@ -348,6 +359,9 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
                      (float2*)(p + L.off_ferange_p));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
+                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
+                     (float*)(p + L.off_coords_p));
   const bool full = (i_from == 0 && i_to == n_rows);
   const uint32_t n_q = i_to - i_from;
   if (!full) {

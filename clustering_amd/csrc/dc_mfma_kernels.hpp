@@ -76,6 +76,7 @@ struct Layout {
       // reference image / norms / permutation / per-tile boxes, and the same for the query rows
       off_img_p, off_norm_p, off_perm_p, off_box_p, off_img_q, off_norm_q, off_perm_q, off_box_q,
       off_ferange_p,   // per reference tile (fe_lo, fe_hi) -- pruned neighbour sweep
+      off_coords_p,    // ORIGINAL coordinates gathered into the reference order (exact path reads)
       fixed_end;
 };
 
@@ -107,7 +108,8 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_perm_q = L.off_norm_q + row_bytes;
   L.off_box_q = L.off_perm_q + row_bytes;
   L.off_ferange_p = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.T);
-  L.fixed_end = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.T);
+  L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.T);
+  L.fixed_end = align256(L.off_coords_p + sizeof(float) * n_rows * n_cols);
   return L;
 }
 
@@ -542,14 +544,14 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       cnt += (uint32_t)__builtin_popcountll(m);
     }
     if (cnt == 0) continue;
-    // ---- process the survivors (reference tile data double-buffered in registers)
-    float a[S], an[S];
-    float4 nv[4], nvn[4];
-    uint32_t ent = __builtin_amdgcn_readfirstlane(list[0]);
-    load_tile<S>(img_r, norms_r, ent & 0x0FFFFFFFu, lane, h, a, nv);
-    for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t entn = __builtin_amdgcn_readfirstlane(list[(i + 1 < cnt) ? i + 1 : i]);
-      load_tile<S>(img_r, norms_r, entn & 0x0FFFFFFFu, lane, h, an, nvn);   // prefetch the next survivor
+    // ---- process the survivors: reference tile data in three rotating register buffers, i.e. the
+    //      loads of survivor i+2 are in flight while survivor i is being computed
+    float a0[S], a1[S], a2[S];
+    float4 n0[4], n1[4], n2[4];
+    auto entry = [&](uint32_t i) {
+      return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
+    };
+    auto compute = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t ent) {
       const uint32_t t = ent & 0x0FFFFFFFu, qmask = ent >> 28;
       const f32x16 c0 = frag16(nv);
 #pragma unroll
@@ -570,11 +572,24 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
           for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
         }
       }
-      ent = entn;
-#pragma unroll
-      for (int s = 0; s < S; ++s) a[s] = an[s];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) nv[g] = nvn[g];
+    };
+    uint32_t e0 = entry(0), e1 = entry(1), e2;
+    load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+    load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
+    for (uint32_t i = 0; i < cnt; i += 3) {
+      e2 = entry(i + 2);
+      load_tile<S>(img_r, norms_r, e2 & 0x0FFFFFFFu, lane, h, a2, n2);
+      compute(a0, n0, e0);
+      if (i + 1 < cnt) {
+        e0 = entry(i + 3);
+        load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+        compute(a1, n1, e1);
+      }
+      if (i + 2 < cnt) {
+        e1 = entry(i + 4);
+        load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
+        compute(a2, n2, e2);
+      }
     }
   }
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
@@ -856,12 +871,16 @@ __device__ __attribute__((noinline)) NnMin nn_special_fe(f32x16 acc, const float
   return o;
 }
 
-__device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ coords,
+// The exact path reads the query row from LDS (staged once per wave) and the reference row from a
+// copy of the ORIGINAL coordinates gathered into the reference order: one global-load latency per
+// call instead of two dependent ones (permutation, then row).
+__device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ coords_c,
                                                       const uint32_t* __restrict__ perm,
                                                       const float* __restrict__ fe_c,
-                                                      uint32_t n_rows, uint32_t n_cols, f32x16 acc,
-                                                      float bn, float bh, NnBest best, uint32_t jq,
-                                                      uint32_t spos, float feq, uint32_t t, int h) {
+                                                      const float* qrow, uint32_t n_rows,
+                                                      uint32_t n_cols, f32x16 acc, float bn,
+                                                      float bh, NnBest best, uint32_t spos,
+                                                      float feq, uint32_t t, int h) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const uint32_t pos = tile_row(t, r, h);
@@ -870,7 +889,7 @@ __device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ 
     const bool ch = other && (acc[r] < bh) && (fe_c[pos] < feq);
     if (cn || ch) {
       const uint32_t j = perm[pos];
-      const float d2c = exact_d2(coords, n_cols, jq, j);
+      const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)pos * n_cols, 1, (int)n_cols);
       lexi_update(cn, best.bd_nn, best.bj_nn, d2c, j, n_rows);
       lexi_update(ch, best.bd_hd, best.bj_hd, d2c, j, n_rows);
     }
@@ -895,13 +914,15 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ fe, const float* __restrict__ img_r,
     const float* __restrict__ norms_r, const uint32_t* __restrict__ perm_r,
     const float4* __restrict__ box_r, const float2* __restrict__ ferange_r,
-    const float* __restrict__ fe_c, const uint32_t* __restrict__ invpos_r, uint32_t T,
+    const float* __restrict__ fe_c, const float* __restrict__ coords_c,
+    const uint32_t* __restrict__ invpos_r, uint32_t T,
     const float* __restrict__ img_q, const uint32_t* __restrict__ perm_q,
     const float4* __restrict__ box_q, uint32_t n_q, int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
     uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
     float* __restrict__ hd_d2) {
   __shared__ uint32_t lists[4][kListCap];
+  extern __shared__ __attribute__((aligned(16))) float qrows_all[];   // [4 waves][TQ*32][n_cols]
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
@@ -910,6 +931,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;
   uint32_t* list = lists[wib];
+  float* qrows = qrows_all + (size_t)wib * (TQ * 32) * n_cols;
 
   const float M = __uint_as_float(hdr[0]);
   const float eps = guard_eps(M, 4.0f * M, 2 * S, (int)n_cols);
@@ -937,6 +959,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img_q[((size_t)tl * S + s) * 64 + lane];
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
+    if (h == 0)   // original coordinates of this lane's query, for the exact path
+      for (uint32_t k = 0; k < n_cols; ++k)
+        qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
     q[qt].m_nn = live ? INFINITY : -INFINITY;   // idle lanes can never trigger the exact path
     q[qt].m_hd = live ? INFINITY : -INFINITY;
     q[qt].bd_nn = FLT_MAX;
@@ -976,15 +1001,18 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       }
       if (cnt == 0) continue;
       visited += cnt;
-      float a[S], an[S];
-      float4 nv[4], nvn[4], fv[4], fvn[4];
-      uint32_t t = __builtin_amdgcn_readfirstlane(list[0]);
-      load_tile<S>(img_r, norms_r, t, lane, h, a, nv);
-      load_frag(fe_c, t, h, fv);
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const uint32_t tn = __builtin_amdgcn_readfirstlane(list[(i + 1 < cnt) ? i + 1 : i]);
-        load_tile<S>(img_r, norms_r, tn, lane, h, an, nvn);   // prefetch the next survivor
-        load_frag(fe_c, tn, h, fvn);
+      // reference tile data in three rotating register buffers (loads run two survivors ahead)
+      float a0[S], a1[S], a2[S];
+      float4 n0[4], n1[4], n2[4], f0[4], f1[4], f2[4];
+      auto entry = [&](uint32_t i) {
+        return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
+      };
+      auto issue = [&](uint32_t t, float (&a)[S], float4 (&nv)[4], float4 (&fv)[4]) {
+        load_tile<S>(img_r, norms_r, t, lane, h, a, nv);
+        load_frag(fe_c, t, h, fv);
+      };
+      auto compute = [&](const float (&a)[S], const float4 (&nv)[4], const float4 (&fv)[4],
+                         uint32_t t) {
         const f32x16 c0 = frag16(nv);
         const float2 fr = ferange_r[t];
 #pragma unroll
@@ -1015,8 +1043,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
             const bool live = (livemask[qt] >> lane) & 1;
             NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-            best = nn_fix_fe(coords, perm_r, fe_c, n_rows, n_cols, acc, new_nn + eps2, new_hd + eps2,
-                             best, jq[qt], Q.spos, Q.feq, t, h);
+            best = nn_fix_fe(coords_c, perm_r, fe_c, qrows + (qt * 32 + c) * n_cols, n_rows, n_cols,
+                             acc, new_nn + eps2, new_hd + eps2, best, Q.spos, Q.feq, t, h);
             Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
             Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
             Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
@@ -1025,13 +1053,23 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           Q.m_nn = new_nn;
           Q.m_hd = new_hd;
         }
-        t = tn;
-#pragma unroll
-        for (int s = 0; s < S; ++s) a[s] = an[s];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          nv[g] = nvn[g];
-          fv[g] = fvn[g];
+      };
+      uint32_t t0 = entry(0), t1 = entry(1), t2;
+      issue(t0, a0, n0, f0);
+      issue(t1, a1, n1, f1);
+      for (uint32_t i = 0; i < cnt; i += 3) {
+        t2 = entry(i + 2);
+        issue(t2, a2, n2, f2);
+        compute(a0, n0, f0, t0);
+        if (i + 1 < cnt) {
+          t0 = entry(i + 3);
+          issue(t0, a0, n0, f0);
+          compute(a1, n1, f1, t1);
+        }
+        if (i + 2 < cnt) {
+          t1 = entry(i + 4);
+          issue(t1, a1, n1, f1);
+          compute(a2, n2, f2, t2);
         }
       }
     }
@@ -1118,6 +1156,7 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   const float4* box_r;
   const float2* ferange_r;
   const float* fe_c;
+  const float* coords_c;
   const uint32_t* invpos_r;
   const float* img_q;
   const uint32_t* perm_q;
@@ -1133,9 +1172,10 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
                         unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                         uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + kTQnn - 1) / kTQnn;
-  hipLaunchKernelGGL((nn_pruned_kernel<S, kTQnn>), dim3((waves + 3) / 4), dim3(256), 0, s, coords,
+  const size_t smem = sizeof(float) * 4 * kTQnn * 32 * (size_t)n_cols;   // query rows, per wave
+  hipLaunchKernelGGL((nn_pruned_kernel<S, kTQnn>), dim3((waves + 3) / 4), dim3(256), smem, s, coords,
                      n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r, A.fe_c,
-                     A.invpos_r, T, A.img_q, A.perm_q, A.box_q, A.n_q, A.full_range, A.cell2, hdr,
+                     A.coords_c, A.invpos_r, T, A.img_q, A.perm_q, A.box_q, A.n_q, A.full_range, A.cell2, hdr,
                      chain_counter, nn_idx, nn_d2, hd_idx, hd_d2);
 }
 

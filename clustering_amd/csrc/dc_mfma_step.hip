@@ -40,6 +40,7 @@ void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint
   A.box_r = (const float4*)(p + L.off_box_p);
   A.ferange_r = (const float2*)(p + L.off_ferange_p);
   A.fe_c = (const float*)(p + L.off_fe_s);
+  A.coords_c = (const float*)(p + L.off_coords_p);
   A.invpos_r = (const uint32_t*)(p + L.off_invpos);
   A.img_q = full_range ? A.img_r : (const float*)(p + L.off_img_q);
   A.perm_q = full_range ? A.perm_r : (const uint32_t*)(p + L.off_perm_q);
