@@ -248,9 +248,9 @@ __device__ __forceinline__ void tile_min(const f32x16& acc, float& m) {
 // =============================================================================================
 template <int NR>
 struct PopQ {            // per query tile, per lane
-  float lo[NR];          // r^2 - |x'|^2 - eps ; -inf for lanes that own no live query
-  uint32_t cnt[NR];
-};
+  float nx;              // |x'|^2 of this lane's query; +inf for lanes that own no live query
+  uint32_t cnt[NR];      // (the threshold of radius r is lo_r = (r^2 - eps) - nx: one op per use,
+};                       //  instead of NR more registers per query tile)
 
 template <int NR>
 struct PopAcc {          // per chain scratch
@@ -259,12 +259,14 @@ struct PopAcc {          // per chain scratch
 };
 
 template <int NR, int R0, int R1>
-__device__ __forceinline__ void pop_epi(const f32x16& acc, const PopQ<NR>& q, PopAcc<NR>& e) {
+__device__ __forceinline__ void pop_epi(const f32x16& acc, const PopQ<NR>& q, const Rad2& rad2e,
+                                        PopAcc<NR>& e) {
 #pragma unroll
-  for (int r = R0; r < R1; ++r) {
+  for (int rr = 0; rr < NR; ++rr) {
+    const float lo = rad2e.v[rr] - q.nx;   // rad2e = r^2 - eps (wave-uniform)
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-      const uint32_t tb = __float_as_uint(acc[r] - q.lo[rr]);
+    for (int r = R0; r < R1; ++r) {
+      const uint32_t tb = __float_as_uint(acc[r] - lo);
       e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], tb, 31);   // (bits << 1) | sign(t)
       e.tmin = min(e.tmin, tb);                                     // negative t: huge unsigned
     }
@@ -290,24 +292,28 @@ template <int NR>
 __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restrict__ coords,
                                                           const uint32_t* __restrict__ perm,
                                                           uint32_t n_rows, uint32_t n_cols,
-                                                          Rad2 rad2, f32x16 acc, PopQ<NR> q,
-                                                          uint32_t wbits, uint32_t jq, uint32_t t,
-                                                          int h) {
+                                                          Rad2 rad2, Rad2 rad2e, f32x16 acc,
+                                                          PopQ<NR> q, uint32_t wbits, uint32_t jq,
+                                                          uint32_t t, int h) {
   PopDelta<NR> out;
+  float lo[NR];
 #pragma unroll
-  for (int rr = 0; rr < NR; ++rr) out.d[rr] = 0;
+  for (int rr = 0; rr < NR; ++rr) {
+    out.d[rr] = 0;
+    lo[rr] = rad2e.v[rr] - q.nx;   // the same arithmetic as pop_epi
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     bool any = false;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) any = any || (__float_as_uint(acc[r] - q.lo[rr]) < wbits);
+    for (int rr = 0; rr < NR; ++rr) any = any || (__float_as_uint(acc[r] - lo[rr]) < wbits);
     const uint32_t pos = tile_row(t, r, h);
     if (any && pos < n_rows) {
       const uint32_t i = perm ? perm[pos] : pos;   // reference rows may be spatially re-ordered
       const float d2c = exact_d2(coords, n_cols, jq, i);
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
-        if (__float_as_uint(acc[r] - q.lo[rr]) < wbits) out.d[rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
+        if (__float_as_uint(acc[r] - lo[rr]) < wbits) out.d[rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
     }
   }
   return out;
@@ -318,14 +324,14 @@ template <int S, int NR, int SI = 0>
 __device__ __forceinline__ void pop_chain(const float (&a)[S], const float (&b)[S],
                                           const f32x16& c0, f32x16& acc_new,
                                           const f32x16& acc_old, const PopQ<NR>& q_old,
-                                          PopAcc<NR>& e) {
+                                          const Rad2& rad2e, PopAcc<NR>& e) {
   if constexpr (SI < S) {
     if constexpr (SI == 0)
       acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
     else
       acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
-    pop_epi<NR, (16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, q_old, e);
-    pop_chain<S, NR, SI + 1>(a, b, c0, acc_new, acc_old, q_old, e);
+    pop_epi<NR, (16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, q_old, rad2e, e);
+    pop_chain<S, NR, SI + 1>(a, b, c0, acc_new, acc_old, q_old, rad2e, e);
   }
 }
 
@@ -348,6 +354,9 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
   const float eps = guard_eps(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
   // band width 2*eps as an unsigned key; +1 ulp. eps = +inf (never for flagged-free data) -> all
   const uint32_t wbits = __float_as_uint(2.0f * eps) + 1u;
+  Rad2 rad2e;   // r^2 - eps
+#pragma unroll
+  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) rad2e.v[rr] = rad2.v[rr] - eps;
 
   float b[TQ][S];
   PopQ<NR> q[TQ];
@@ -362,12 +371,9 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
-    const float nx = norms[tl * 32 + c];
+    q[qt].nx = live ? norms[tl * 32 + c] : INFINITY;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-      q[qt].lo[rr] = live ? (rad2.v[rr] - nx) - eps : -INFINITY;
-      q[qt].cnt[rr] = 0;
-    }
+    for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] = 0;
   }
 
   // accumulator ping-pong: B starts as "+inf everywhere" = contributes nothing
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
     const bool band = e.tmin < wbits;
     if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
-      const PopDelta<NR> dl = pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, acc, q[qi], wbits, jq[qi], t, h);
+      const PopDelta<NR> dl = pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, rad2e, acc, q[qi], wbits, jq[qi], t, h);
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += ((livemask[qi] >> lane) & 1) ? dl.d[rr] : 0u;
     }
@@ -401,10 +407,10 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
       const int qb = (qt == 0) ? kLast : qt - 1;
       PopAcc<NR> e;
       pop_epi_begin<NR>(e);
-      pop_chain<S, NR>(a, b[qt], c0, accA, accB, q[qb], e);
+      pop_chain<S, NR>(a, b[qt], c0, accA, accB, q[qb], rad2e, e);
       finish(accB, qb, e, tB);
       pop_epi_begin<NR>(e);
-      pop_chain<S, NR>(a, b[qt + 1], c0, accB, accA, q[qt], e);
+      pop_chain<S, NR>(a, b[qt + 1], c0, accB, accA, q[qt], rad2e, e);
       finish(accA, qt, e, t);
       tB = t;
     }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
   {  // drain: epilogue of the last accB
     PopAcc<NR> e;
     pop_epi_begin<NR>(e);
-    pop_epi<NR, 0, 16>(accB, q[TQ - 1], e);
+    pop_epi<NR, 0, 16>(accB, q[TQ - 1], rad2e, e);
     finish(accB, TQ - 1, e, tB);
   }
 
@@ -494,6 +500,9 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const float eps = guard_eps(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
   const uint32_t wbits = __float_as_uint(2.0f * eps) + 1u;
   const float far2 = r2max * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
+  Rad2 rad2e;   // r^2 - eps
+#pragma unroll
+  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) rad2e.v[rr] = rad2.v[rr] - eps;
 
   float b[TQ][S];
   PopQ<NR> q[TQ];
@@ -511,12 +520,9 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     jq[qt] = live ? perm_q[pos] : 0u;
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img_q[((size_t)tl * S + s) * 64 + lane];
-    const float nx = norms_q[tl * 32 + c];
+    q[qt].nx = live ? norms_q[tl * 32 + c] : INFINITY;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-      q[qt].lo[rr] = live ? (rad2.v[rr] - nx) - eps : -INFINITY;
-      q[qt].cnt[rr] = 0;
-    }
+    for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] = 0;
     qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
     gbox.x = fminf(gbox.x, qbox[qt].x);
     gbox.y = fmaxf(gbox.y, qbox[qt].y);
@@ -561,34 +567,49 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
         const f32x16 acc = gram_chain<S>(a, b[qt], c0);
         PopAcc<NR> e;
         pop_epi_begin<NR>(e);
-        pop_epi<NR, 0, 16>(acc, q[qt], e);
+        pop_epi<NR, 0, 16>(acc, q[qt], rad2e, e);
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
         const bool band = e.tmin < wbits;
         if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qt]) != 0, 0)) {
           const PopDelta<NR> dl =
-              pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, acc, q[qt], wbits, jq[qt], t, h);
+              pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, rad2e, acc, q[qt], wbits, jq[qt], t, h);
 #pragma unroll
           for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
         }
       }
     };
-    uint32_t e0 = entry(0), e1 = entry(1), e2;
-    load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
-    load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
-    for (uint32_t i = 0; i < cnt; i += 3) {
-      e2 = entry(i + 2);
-      load_tile<S>(img_r, norms_r, e2 & 0x0FFFFFFFu, lane, h, a2, n2);
-      compute(a0, n0, e0);
-      if (i + 1 < cnt) {
-        e0 = entry(i + 3);
-        load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
-        compute(a1, n1, e1);
+    if constexpr (S <= 8) {
+      uint32_t e0 = entry(0), e1 = entry(1), e2;
+      load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+      load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
+      for (uint32_t i = 0; i < cnt; i += 3) {
+        e2 = entry(i + 2);
+        load_tile<S>(img_r, norms_r, e2 & 0x0FFFFFFFu, lane, h, a2, n2);
+        compute(a0, n0, e0);
+        if (i + 1 < cnt) {
+          e0 = entry(i + 3);
+          load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+          compute(a1, n1, e1);
+        }
+        if (i + 2 < cnt) {
+          e1 = entry(i + 4);
+          load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
+          compute(a2, n2, e2);
+        }
       }
-      if (i + 2 < cnt) {
-        e1 = entry(i + 4);
+    } else {   // many K-steps: the operand registers are scarce, one survivor of look-ahead
+      uint32_t e0 = entry(0), e1;
+      load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+      for (uint32_t i = 0; i < cnt; i += 2) {
+        e1 = entry(i + 1);
         load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
-        compute(a2, n2, e2);
+        compute(a0, n0, e0);
+        if (i + 1 < cnt) {
+          e0 = entry(i + 2);
+          load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+          compute(a1, n1, e1);
+        }
       }
     }
   }
@@ -1054,22 +1075,37 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           Q.m_hd = new_hd;
         }
       };
-      uint32_t t0 = entry(0), t1 = entry(1), t2;
-      issue(t0, a0, n0, f0);
-      issue(t1, a1, n1, f1);
-      for (uint32_t i = 0; i < cnt; i += 3) {
-        t2 = entry(i + 2);
-        issue(t2, a2, n2, f2);
-        compute(a0, n0, f0, t0);
-        if (i + 1 < cnt) {
-          t0 = entry(i + 3);
-          issue(t0, a0, n0, f0);
-          compute(a1, n1, f1, t1);
+      if constexpr (S <= 8) {
+        uint32_t t0 = entry(0), t1 = entry(1), t2;
+        issue(t0, a0, n0, f0);
+        issue(t1, a1, n1, f1);
+        for (uint32_t i = 0; i < cnt; i += 3) {
+          t2 = entry(i + 2);
+          issue(t2, a2, n2, f2);
+          compute(a0, n0, f0, t0);
+          if (i + 1 < cnt) {
+            t0 = entry(i + 3);
+            issue(t0, a0, n0, f0);
+            compute(a1, n1, f1, t1);
+          }
+          if (i + 2 < cnt) {
+            t1 = entry(i + 4);
+            issue(t1, a1, n1, f1);
+            compute(a2, n2, f2, t2);
+          }
         }
-        if (i + 2 < cnt) {
-          t1 = entry(i + 4);
+      } else {   // many K-steps: one survivor of look-ahead
+        uint32_t t0 = entry(0), t1;
+        issue(t0, a0, n0, f0);
+        for (uint32_t i = 0; i < cnt; i += 2) {
+          t1 = entry(i + 1);
           issue(t1, a1, n1, f1);
-          compute(a2, n2, f2, t2);
+          compute(a0, n0, f0, t0);
+          if (i + 1 < cnt) {
+            t0 = entry(i + 2);
+            issue(t0, a0, n0, f0);
+            compute(a1, n1, f1, t1);
+          }
         }
       }
     }
@@ -1124,8 +1160,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 // ---------------------------------------------------------------------------------------------
 // launch helpers (one K-step count per translation unit)
 // ---------------------------------------------------------------------------------------------
-constexpr int kTQ = 4;     // query tiles per wave, population sweep
-constexpr int kTQnn = 4;   // query tiles per wave, neighbour sweep (more per-query state)
+// query tiles per wave: 4 while the resident B fragments (TQ*S registers) are cheap, 2 beyond
+template <int S>
+constexpr int tq_for = (S <= 8) ? 4 : 2;
 
 inline uint32_t grid_for(uint32_t i_from, uint32_t i_to, int tq) {
   const uint32_t tiles = (i_to + 31) / 32 - i_from / 32;
@@ -1137,6 +1174,7 @@ template <int S>
 void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                   uint32_t i_from, uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* pops,
                   hipStream_t s) {
+  constexpr int kTQ = tq_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
   if (n_rad == 1)
     hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
@@ -1171,6 +1209,7 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
                         const NnPrunedArgs& A, uint32_t T, const uint32_t* hdr,
                         unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                         uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
+  constexpr int kTQnn = tq_for<S>;
   const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + kTQnn - 1) / kTQnn;
   const size_t smem = sizeof(float) * 4 * kTQnn * 32 * (size_t)n_cols;   // query rows, per wave
   hipLaunchKernelGGL((nn_pruned_kernel<S, kTQnn>), dim3((waves + 3) / 4), dim3(256), smem, s, coords,
@@ -1185,6 +1224,7 @@ template <int S>
 void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
                          uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
                          uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
+  constexpr int kTQ = tq_for<S>;
   const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + kTQ - 1) / kTQ;
   const dim3 grid((waves + 3) / 4), block(256);
   const float* img_q = full_range ? P.img_p : P.img_q;
@@ -1205,6 +1245,7 @@ template <int S>
 void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                  uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
                  float* hd_d2, hipStream_t s) {
+  constexpr int kTQnn = tq_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQnn)), block(256);
   hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
                      P.img_s, P.norms_s, P.perm, P.invpos, P.pq, P.hdr, T, i_from, i_to, nn_idx,
