@@ -258,15 +258,20 @@ struct PopAcc {          // per chain scratch
   uint32_t tmin;         // unsigned min over elements and radii of bits(acc - lo)
 };
 
+// thresholds of one query for all radii of the launch: lo_r = (r^2 - eps) - |x'|^2
+template <int NR>
+__device__ __forceinline__ void pop_lo(const PopQ<NR>& q, const Rad2& rad2e, float (&lo)[NR]) {
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) lo[rr] = rad2e.v[rr] - q.nx;
+}
+
 template <int NR, int R0, int R1>
-__device__ __forceinline__ void pop_epi(const f32x16& acc, const PopQ<NR>& q, const Rad2& rad2e,
-                                        PopAcc<NR>& e) {
+__device__ __forceinline__ void pop_epi(const f32x16& acc, const float (&lo)[NR], PopAcc<NR>& e) {
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
-    const float lo = rad2e.v[rr] - q.nx;   // rad2e = r^2 - eps (wave-uniform)
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-      const uint32_t tb = __float_as_uint(acc[r] - lo);
+      const uint32_t tb = __float_as_uint(acc[r] - lo[rr]);
       e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], tb, 31);   // (bits << 1) | sign(t)
       e.tmin = min(e.tmin, tb);                                     // negative t: huge unsigned
     }
@@ -302,18 +307,28 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restric
     out.d[rr] = 0;
     lo[rr] = rad2e.v[rr] - q.nx;   // the same arithmetic as pop_epi
   }
+  uint32_t m = 0;   // elements of this lane that sit in some radius' band
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     bool any = false;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) any = any || (__float_as_uint(acc[r] - lo[rr]) < wbits);
-    const uint32_t pos = tile_row(t, r, h);
-    if (any && pos < n_rows) {
+    for (int rr = 0; rr < NR; ++rr) any = any | (__float_as_uint(acc[r] - lo[rr]) < wbits);
+    m |= (any & (tile_row(t, r, h) < n_rows)) ? (1u << r) : 0u;
+  }
+  // lane-parallel exact evaluation: one band pair per lane per iteration (row fetches overlap)
+  while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+    if (m != 0) {
+      const int r = __builtin_ctz(m);
+      const uint32_t pos = tile_row(t, r, h);
       const uint32_t i = perm ? perm[pos] : pos;   // reference rows may be spatially re-ordered
       const float d2c = exact_d2(coords, n_cols, jq, i);
+      float av = acc[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) av = (r == k) ? acc[k] : av;   // acc[r], r per lane
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
-        if (__float_as_uint(acc[r] - lo[rr]) < wbits) out.d[rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
+        if (__float_as_uint(av - lo[rr]) < wbits) out.d[rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
+      m &= m - 1;
     }
   }
   return out;
@@ -323,15 +338,15 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restric
 template <int S, int NR, int SI = 0>
 __device__ __forceinline__ void pop_chain(const float (&a)[S], const float (&b)[S],
                                           const f32x16& c0, f32x16& acc_new,
-                                          const f32x16& acc_old, const PopQ<NR>& q_old,
-                                          const Rad2& rad2e, PopAcc<NR>& e) {
+                                          const f32x16& acc_old, const float (&lo_old)[NR],
+                                          PopAcc<NR>& e) {
   if constexpr (SI < S) {
     if constexpr (SI == 0)
       acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
     else
       acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
-    pop_epi<NR, (16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, q_old, rad2e, e);
-    pop_chain<S, NR, SI + 1>(a, b, c0, acc_new, acc_old, q_old, rad2e, e);
+    pop_epi<NR, (16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, lo_old, e);
+    pop_chain<S, NR, SI + 1>(a, b, c0, acc_new, acc_old, lo_old, e);
   }
 }
 
@@ -406,11 +421,14 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
       constexpr int kLast = TQ - 1;
       const int qb = (qt == 0) ? kLast : qt - 1;
       PopAcc<NR> e;
+      float lo[NR];
       pop_epi_begin<NR>(e);
-      pop_chain<S, NR>(a, b[qt], c0, accA, accB, q[qb], rad2e, e);
+      pop_lo<NR>(q[qb], rad2e, lo);
+      pop_chain<S, NR>(a, b[qt], c0, accA, accB, lo, e);
       finish(accB, qb, e, tB);
       pop_epi_begin<NR>(e);
-      pop_chain<S, NR>(a, b[qt + 1], c0, accB, accA, q[qt], rad2e, e);
+      pop_lo<NR>(q[qt], rad2e, lo);
+      pop_chain<S, NR>(a, b[qt + 1], c0, accB, accA, lo, e);
       finish(accA, qt, e, t);
       tB = t;
     }
@@ -426,8 +444,10 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
   }
   {  // drain: epilogue of the last accB
     PopAcc<NR> e;
+    float lo[NR];
     pop_epi_begin<NR>(e);
-    pop_epi<NR, 0, 16>(accB, q[TQ - 1], rad2e, e);
+    pop_lo<NR>(q[TQ - 1], rad2e, lo);
+    pop_epi<NR, 0, 16>(accB, lo, e);
     finish(accB, TQ - 1, e, tB);
   }
 
@@ -566,8 +586,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
         ++chains;
         const f32x16 acc = gram_chain<S>(a, b[qt], c0);
         PopAcc<NR> e;
+        float lo[NR];
         pop_epi_begin<NR>(e);
-        pop_epi<NR, 0, 16>(acc, q[qt], rad2e, e);
+        pop_lo<NR>(q[qt], rad2e, lo);
+        pop_epi<NR, 0, 16>(acc, lo, e);
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
         const bool band = e.tmin < wbits;
@@ -691,17 +713,23 @@ __device__ __attribute__((noinline)) NnBest nn_fix(const float* __restrict__ coo
                                                    uint32_t n_rows, uint32_t n_cols, f32x16 acc,
                                                    float bn, float bh, NnBest best, uint32_t jq,
                                                    uint32_t spos, uint32_t pq, uint32_t t, int h) {
+  uint32_t mn = 0, mh = 0;   // candidate elements of this lane
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const uint32_t pos = tile_row(t, r, h);
-    const bool other = (pos != spos) && (pos < n_rows);
-    const bool cn = other && (acc[r] < bn);
-    const bool ch = other && (pos < pq) && (acc[r] < bh);
-    if (cn || ch) {
-      const uint32_t j = perm[pos];
+    const bool other = (pos != spos) & (pos < n_rows);
+    mn |= (other & (acc[r] < bn)) ? (1u << r) : 0u;
+    mh |= (other & (pos < pq) & (acc[r] < bh)) ? (1u << r) : 0u;
+  }
+  uint32_t m = mn | mh;      // lane-parallel exact evaluation, one candidate per lane per iteration
+  while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+    if (m != 0) {
+      const int r = __builtin_ctz(m);
+      const uint32_t j = perm[tile_row(t, r, h)];
       const float d2c = exact_d2(coords, n_cols, jq, j);
-      lexi_update(cn, best.bd_nn, best.bj_nn, d2c, j, n_rows);
-      lexi_update(ch, best.bd_hd, best.bj_hd, d2c, j, n_rows);
+      lexi_update((mn >> r) & 1u, best.bd_nn, best.bj_nn, d2c, j, n_rows);
+      lexi_update((mh >> r) & 1u, best.bd_hd, best.bj_hd, d2c, j, n_rows);
+      m &= m - 1;
     }
   }
   return best;
@@ -897,22 +925,31 @@ __device__ __attribute__((noinline)) NnMin nn_special_fe(f32x16 acc, const float
 // call instead of two dependent ones (permutation, then row).
 __device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ coords_c,
                                                       const uint32_t* __restrict__ perm,
-                                                      const float* __restrict__ fe_c,
                                                       const float* qrow, uint32_t n_rows,
-                                                      uint32_t n_cols, f32x16 acc, float bn,
-                                                      float bh, NnBest best, uint32_t spos,
-                                                      float feq, uint32_t t, int h) {
+                                                      uint32_t n_cols, f32x16 acc, f32x16 fef,
+                                                      float bn, float bh, NnBest best,
+                                                      uint32_t spos, float feq, uint32_t t, int h) {
+  // 1. which of this lane's 16 elements are candidates (no memory traffic)
+  uint32_t mn = 0, mh = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const uint32_t pos = tile_row(t, r, h);
-    const bool other = (pos != spos) && (pos < n_rows);
-    const bool cn = other && (acc[r] < bn);
-    const bool ch = other && (acc[r] < bh) && (fe_c[pos] < feq);
-    if (cn || ch) {
+    const bool other = (pos != spos) & (pos < n_rows);
+    mn |= (other & (acc[r] < bn)) ? (1u << r) : 0u;
+    mh |= (other & (acc[r] < bh) & (fef[r] < feq)) ? (1u << r) : 0u;
+  }
+  // 2. every lane evaluates ITS next candidate in the same iteration: the row fetches of all lanes
+  //    overlap, the loop runs max-candidates-per-lane times (usually once)
+  uint32_t m = mn | mh;
+  while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+    if (m != 0) {
+      const int r = __builtin_ctz(m);
+      const uint32_t pos = tile_row(t, r, h);
       const uint32_t j = perm[pos];
       const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)pos * n_cols, 1, (int)n_cols);
-      lexi_update(cn, best.bd_nn, best.bj_nn, d2c, j, n_rows);
-      lexi_update(ch, best.bd_hd, best.bj_hd, d2c, j, n_rows);
+      lexi_update((mn >> r) & 1u, best.bd_nn, best.bj_nn, d2c, j, n_rows);
+      lexi_update((mh >> r) & 1u, best.bd_hd, best.bj_hd, d2c, j, n_rows);
+      m &= m - 1;
     }
   }
   return best;
@@ -1064,8 +1101,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
             const bool live = (livemask[qt] >> lane) & 1;
             NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-            best = nn_fix_fe(coords_c, perm_r, fe_c, qrows + (qt * 32 + c) * n_cols, n_rows, n_cols,
-                             acc, new_nn + eps2, new_hd + eps2, best, Q.spos, Q.feq, t, h);
+            best = nn_fix_fe(coords_c, perm_r, qrows + (qt * 32 + c) * n_cols, n_rows, n_cols, acc,
+                             frag16(fv), new_nn + eps2, new_hd + eps2, best, Q.spos, Q.feq, t, h);
             Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
             Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
             Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
