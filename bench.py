@@ -163,6 +163,25 @@ def main():
         fe_c = backend.free_energies(pops_c[0].contiguous())
         backend.nearest_neighbors_partial(coords, fe_c, lo, hi)
         nn_tiles = density.evaluated_tiles(dev)[1]
+    # reference point for the roofline: the same sweeps with EVERY pair evaluated (DC_VARIANT_MFMA)
+    full_ms = None
+    if args.variant in ("auto", "pruned") and rank == 0:
+        fb = HipBackend("mfma")
+        e0, e1, e2, e3 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        fb.populations_partial(coords, args.radii, lo, hi)          # warm-up (workspace, code)
+        e0.record()
+        pf = fb.populations_partial(coords, args.radii, lo, hi)
+        e1.record()
+        full_ms = {"pop_kernel": None, "nn_kernel": None}
+        if want_nn:
+            ff = fb.free_energies(pf[0].contiguous())
+            e2.record()
+            fb.nearest_neighbors_partial(coords, ff, lo, hi)
+            e3.record()
+        torch.cuda.synchronize()
+        full_ms["pop_kernel"] = e0.elapsed_time(e1)
+        if want_nn:
+            full_ms["nn_kernel"] = e2.elapsed_time(e3)
 
     sweeps = 2 if want_nn else 1
     pairs_per_step = sweeps * float(n) * float(n)
@@ -206,7 +225,7 @@ def main():
                 "parallelism": f"rows sharded over {world} GPU(s), coords replicated; all-reduce(pops) + all-gather(nn)",
             },
             "phases_ms": {"pop_kernel": 1e3 * pop_t, "nn_kernel": 1e3 * nn_t,
-                          "other (fe, collectives, host)": ms_per_step - 1e3 * (pop_t + nn_t)},
+                          "other (fe, collectives, host)": max(0.0, ms_per_step - 1e3 * (pop_t + nn_t))},
             "check": {"mean_pop_r0": pop_sum / n, "max_pop_r0": int(out["pops"][0].max().item())},
             "roofline": {
                 "bound": "mfma",
@@ -223,6 +242,17 @@ def main():
                 "evaluated_fraction": {"pop": pop_pairs / full_pairs, "nn": nn_pairs / full_pairs},
             },
         }
+        if full_ms is not None:
+            # the unpruned fp32-MFMA sweeps (every ordered pair evaluated) for comparison
+            fl = float(local_rows) * n * 2.0 * d
+            line["roofline_full_sweep"] = {
+                "variant": "mfma (no pruning)", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "pop": {"launch_ms": full_ms["pop_kernel"],
+                        "frac": fl / (full_ms["pop_kernel"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+                "nn": None if full_ms["nn_kernel"] is None else {
+                    "launch_ms": full_ms["nn_kernel"],
+                    "frac": fl / (full_ms["nn_kernel"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+            }
         if args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(coords_np, args.radii, min(args.cpu_sample, n), want_nn)
         else:
