@@ -955,6 +955,36 @@ __device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ 
   return best;
 }
 
+// ---- deferred exact evaluation -------------------------------------------------------------------
+// The neighbour sweep does not evaluate a candidate the moment it appears (one or two lanes busy, a
+// full memory latency each time); it parks (position, kind) in a small per-lane LDS queue and
+// evaluates whole queue slots at once: every lane of the wave then fetches and evaluates ITS entry
+// in parallel.  The approximate running minima that select candidates never depend on exact
+// values, so deferring changes nothing but the order of the lexicographic merges.
+constexpr int kQueueCap = 4;                 // entries per lane and query tile
+constexpr uint32_t kQueuePosMask = 0x3FFFFFFFu;   // entry = position | nn-flag << 30 | hd-flag << 31
+
+__device__ __attribute__((noinline)) NnBest nn_flush(const uint32_t* queue /* [kQueueCap][64] */,
+                                                     uint32_t count, const float* qrow,
+                                                     const float* __restrict__ coords_c,
+                                                     const uint32_t* __restrict__ perm,
+                                                     uint32_t n_rows, uint32_t n_cols, NnBest best,
+                                                     int lane) {
+#pragma unroll
+  for (int k = 0; k < kQueueCap; ++k) {
+    if (__builtin_amdgcn_ballot_w64((uint32_t)k < count) == 0) break;
+    if ((uint32_t)k < count) {
+      const uint32_t ent = queue[k * 64 + lane];
+      const uint32_t pos = ent & kQueuePosMask;
+      const uint32_t j = perm[pos];
+      const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)pos * n_cols, 1, (int)n_cols);
+      lexi_update((ent >> 30) & 1u, best.bd_nn, best.bj_nn, d2c, j, n_rows);
+      lexi_update((ent >> 31) & 1u, best.bd_hd, best.bj_hd, d2c, j, n_rows);
+    }
+  }
+  return best;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -980,7 +1010,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
     float* __restrict__ hd_d2) {
   __shared__ uint32_t lists[4][kListCap];
-  extern __shared__ __attribute__((aligned(16))) float qrows_all[];   // [4 waves][TQ*32][n_cols]
+  // dynamic LDS: [4 waves][TQ*32][n_cols] query rows (original coordinates), then the candidate
+  // queues [4 waves][TQ][kQueueCap][64]
+  extern __shared__ __attribute__((aligned(16))) float qrows_all[];
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
@@ -990,6 +1022,11 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   if (qt0 >= TQT) return;
   uint32_t* list = lists[wib];
   float* qrows = qrows_all + (size_t)wib * (TQ * 32) * n_cols;
+  uint32_t* queues = reinterpret_cast<uint32_t*>(qrows_all + (size_t)4 * (TQ * 32) * n_cols) +
+                     (size_t)wib * TQ * kQueueCap * 64;
+  uint32_t qcount[TQ];
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) qcount[qt] = 0;
 
   const float M = __uint_as_float(hdr[0]);
   const float eps = guard_eps(M, 4.0f * M, 2 * S, (int)n_cols);
@@ -1036,6 +1073,20 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   float fe_floor = INFINITY;
   for (uint32_t k = lane; k < T; k += 64) fe_floor = fminf(fe_floor, ferange_r[k].x);
   fe_floor = wave_min(fe_floor);
+
+  // evaluate and empty the candidate queue of query tile qi (all lanes in parallel per slot)
+  auto flush = [&](int qi) {
+    if (__builtin_amdgcn_ballot_w64(qcount[qi] != 0) == 0) return;
+    NnPQ& Q = q[qi];
+    NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
+    best = nn_flush(queues + qi * (kQueueCap * 64), qcount[qi], qrows + (qi * 32 + c) * n_cols,
+                    coords_c, perm_r, n_rows, n_cols, best, lane);
+    Q.bd_nn = best.bd_nn;
+    Q.bj_nn = best.bj_nn;
+    Q.bd_hd = best.bd_hd;
+    Q.bj_hd = best.bj_hd;
+    qcount[qi] = 0;
+  };
 
   uint32_t chains = 0, visited = 0;
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
@@ -1099,14 +1150,31 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           const bool trig = (tmin < Q.m_nn + eps2) | (hmin < Q.m_hd + eps2);
           const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
+            // park this tile's candidates (values within the band of the running minima)
+            const f32x16 fef = frag16(fv);
+            const float bn = new_nn + eps2, bh = new_hd + eps2;
             const bool live = (livemask[qt] >> lane) & 1;
-            NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-            best = nn_fix_fe(coords_c, perm_r, qrows + (qt * 32 + c) * n_cols, n_rows, n_cols, acc,
-                             frag16(fv), new_nn + eps2, new_hd + eps2, best, Q.spos, Q.feq, t, h);
-            Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
-            Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
-            Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
-            Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
+            uint32_t mn = 0, mh = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t pos = tile_row(t, r, h);
+              const bool other = live & (pos != Q.spos) & (pos < n_rows);
+              mn |= (other & (acc[r] < bn)) ? (1u << r) : 0u;
+              mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (1u << r) : 0u;
+            }
+            uint32_t m = mn | mh;
+            uint32_t* qu = queues + qt * (kQueueCap * 64);
+            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+              if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qt] == (uint32_t)kQueueCap)) != 0)
+                flush(qt);
+              if (m != 0) {
+                const int r = __builtin_ctz(m);
+                qu[qcount[qt] * 64 + lane] =
+                    tile_row(t, r, h) | (((mn >> r) & 1u) << 30) | (((mh >> r) & 1u) << 31);
+                ++qcount[qt];
+                m &= m - 1;
+              }
+            }
           }
           Q.m_nn = new_nn;
           Q.m_hd = new_hd;
@@ -1146,6 +1214,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         }
       }
     }
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt) flush(qt);        // the settle test needs the exact incumbents
     if (!(r2_hi <= FLT_MAX) || visited >= T) break;   // every reference tile has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
     const float sure = r2_hi * 0.9999f;
@@ -1248,7 +1318,9 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
                         uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   constexpr int kTQnn = tq_for<S>;
   const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + kTQnn - 1) / kTQnn;
-  const size_t smem = sizeof(float) * 4 * kTQnn * 32 * (size_t)n_cols;   // query rows, per wave
+  // query rows (original coordinates) + candidate queues, per wave
+  const size_t smem = sizeof(float) * 4 * kTQnn * 32 * (size_t)n_cols +
+                      sizeof(uint32_t) * 4 * kTQnn * kQueueCap * 64;
   hipLaunchKernelGGL((nn_pruned_kernel<S, kTQnn>), dim3((waves + 3) / 4), dim3(256), smem, s, coords,
                      n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r, A.fe_c,
                      A.coords_c, A.invpos_r, T, A.img_q, A.perm_q, A.box_q, A.n_q, A.full_range, A.cell2, hdr,
