@@ -1311,43 +1311,103 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   float cell2;
 };
 
+// Query tiles per wave for the pruned sweeps: as many as the K-steps allow (operand reuse), but few
+// enough that the launch has >= 2 waves per SIMD -- a rank that owns only N/8 of the rows (8-GPU
+// run) would otherwise leave most of the chip idle.
+inline int pick_tq(uint32_t tiles, int tq_max) {
+  int tq = tq_max;
+  while (tq > 1 && (tiles + tq - 1) / tq < 2048u) tq >>= 1;
+  return tq;
+}
+
+template <int S, int TQV>
+void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe,
+                      const NnPrunedArgs& A, uint32_t T, const uint32_t* hdr,
+                      unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
+                      uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
+  const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
+  // query rows (original coordinates) + candidate queues, per wave
+  const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
+                      sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
+  hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + 3) / 4), dim3(256), smem, s, coords,
+                     n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r, A.fe_c,
+                     A.coords_c, A.invpos_r, T, A.img_q, A.perm_q, A.box_q, A.n_q, A.full_range,
+                     A.cell2, hdr, chain_counter, nn_idx, nn_d2, hd_idx, hd_d2);
+}
+
 template <int S>
 void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe,
                         const NnPrunedArgs& A, uint32_t T, const uint32_t* hdr,
                         unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                         uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
-  constexpr int kTQnn = tq_for<S>;
-  const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + kTQnn - 1) / kTQnn;
-  // query rows (original coordinates) + candidate queues, per wave
-  const size_t smem = sizeof(float) * 4 * kTQnn * 32 * (size_t)n_cols +
-                      sizeof(uint32_t) * 4 * kTQnn * kQueueCap * 64;
-  hipLaunchKernelGGL((nn_pruned_kernel<S, kTQnn>), dim3((waves + 3) / 4), dim3(256), smem, s, coords,
-                     n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r, A.fe_c,
-                     A.coords_c, A.invpos_r, T, A.img_q, A.perm_q, A.box_q, A.n_q, A.full_range, A.cell2, hdr,
-                     chain_counter, nn_idx, nn_d2, hd_idx, hd_d2);
+  switch (pick_tq((A.n_q + 31) / 32, tq_for<S>)) {
+    case 4:
+      if constexpr (tq_for<S> >= 4)
+        nn_pruned_launch<S, 4>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
+                               hd_idx, hd_d2, s);
+      break;
+    case 2:
+      nn_pruned_launch<S, 2>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
+                             hd_idx, hd_d2, s);
+      break;
+    default:
+      nn_pruned_launch<S, 1>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
+                             hd_idx, hd_d2, s);
+      break;
+  }
 }
 
 // pruned population sweep: queries = n_q spatially ordered rows (image/perm/boxes "q"), references =
 // all rows spatially ordered ("p"); full_range: the query set is every row -> the two orders coincide
-template <int S>
-void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
-                         uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
-                         uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
-  constexpr int kTQ = tq_for<S>;
-  const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + kTQ - 1) / kTQ;
+template <int S, int NRV, int TQV>
+void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
+                       uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
+                       uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
+  const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
   const dim3 grid((waves + 3) / 4), block(256);
   const float* img_q = full_range ? P.img_p : P.img_q;
   const float* norms_q = full_range ? P.norms_p : P.norms_q;
   const uint32_t* perm_q = full_range ? P.perm_p : P.perm_q;
   const float4* box_q = full_range ? P.box_p : P.box_q;
-#define DC_LAUNCH_PRUNED(NRV)                                                                       \
-  hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, kTQ>), grid, block, 0, s, coords, n_rows, n_cols,   \
-                     P.img_p, P.norms_p, P.perm_p, P.box_p, T, img_q, norms_q, perm_q, box_q, n_q,   \
-                     P.hdr, chain_counter, rad2, n_rad, pops)
-  if (n_rad == 1) DC_LAUNCH_PRUNED(1);
-  else if (n_rad <= 4) DC_LAUNCH_PRUNED(4);
-  else DC_LAUNCH_PRUNED(8);
-#undef DC_LAUNCH_PRUNED
+  hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV>), grid, block, 0, s, coords, n_rows, n_cols,
+                     P.img_p, P.norms_p, P.perm_p, P.box_p, T, img_q, norms_q, perm_q, box_q, n_q,
+                     P.hdr, chain_counter, rad2, n_rad, pops);
+}
+
+template <int S, int NRV>
+void pop_pruned_tq(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
+                   uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad, uint32_t* pops,
+                   unsigned long long* chain_counter, hipStream_t s) {
+  switch (pick_tq((n_q + 31) / 32, tq_for<S>)) {
+    case 4:
+      if constexpr (tq_for<S> >= 4)
+        pop_pruned_launch<S, NRV, 4>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+                                     chain_counter, s);
+      break;
+    case 2:
+      pop_pruned_launch<S, NRV, 2>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+                                   chain_counter, s);
+      break;
+    default:
+      pop_pruned_launch<S, NRV, 1>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+                                   chain_counter, s);
+      break;
+  }
+}
+
+template <int S>
+void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
+                         uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
+                         uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
+  if (n_rad == 1)
+    pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+                        chain_counter, s);
+  else if (n_rad <= 4)
+    pop_pruned_tq<S, 4>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+                        chain_counter, s);
+  else
+    pop_pruned_tq<S, 8>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+                        chain_counter, s);
 }
 
 template <int S>
