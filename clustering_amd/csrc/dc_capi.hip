@@ -149,7 +149,8 @@ int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, 
     if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
       return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                   dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
-    if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, s))
+    if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
+                                  variant == DC_VARIANT_MFMA, s))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
   }
   for (size_t r0 = 0; r0 < n_radii; r0 += dc::kMaxRadiiPerLaunch) {
@@ -231,10 +232,12 @@ int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_
     if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
       return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                   dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
-    if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, s))
-      return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
     // (the pruned sweep packs reference positions into 30 bits of its candidate queue entries)
-    if (variant == DC_VARIANT_MFMA || n_rows >= ((size_t)1 << 30))
+    const bool full_sweep = variant == DC_VARIANT_MFMA || n_rows >= ((size_t)1 << 30);
+    if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
+                                  full_sweep, s))
+      return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
+    if (full_sweep)
       dc::launch_nn_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
                          (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
     else

@@ -36,12 +36,57 @@ __global__ void colsum_kernel(const float* __restrict__ coords, uint32_t n_rows,
   if (threadIdx.x < D) atomicAdd(&sums[threadIdx.x], part[threadIdx.x]);
 }
 
+// wave-wide maximum -> one global atomicMax, and only when it would change the word (a plain read
+// of a hot word is an L2 hit; a million same-address atomics are not)
+__device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+  if ((threadIdx.x & 63) == 0 && v > __atomic_load_n(addr, __ATOMIC_RELAXED)) atomicMax(addr, v);
+}
+
+// Header pass over the frames in natural order: max |x'|^2 (word 0), non-finite / overflow flag
+// (word 1) and the extent of columns 0/1 (words 8..11: ~key(min col0), key(max col0), ~key(min col1),
+// key(max col1), all maintained with atomicMax).  |x'|^2 is formed exactly as image_kernel forms it,
+// so word 0 bounds every norm of every operand image built from these coordinates.
+// 256 rows per block staged through LDS (coalesced reads; odd row stride against bank conflicts).
+__global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
+                                const double* __restrict__ sums, uint32_t* __restrict__ hdr) {
+  extern __shared__ float rs_tile[];
+  const uint32_t Dp = D | 1u;
+  const size_t base = (size_t)blockIdx.x * 256 * D, total = (size_t)n_rows * D;
+  for (uint32_t e = threadIdx.x; e < 256 * D; e += 256) {
+    const uint32_t r = e / D, k = e - r * D;
+    rs_tile[r * Dp + k] = (base + e < total) ? coords[base + e] : 0.0f;
+  }
+  __syncthreads();
+  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  const bool live = row < n_rows;
+  const float* x = rs_tile + threadIdx.x * Dp;
+  double nrm = 0.0;
+  for (uint32_t k = 0; k < D; ++k) {
+    float muf = (float)(sums[k] / (double)n_rows);
+    if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
+    const float v = x[k] - muf;
+    nrm += (double)v * (double)v;
+  }
+  const float nf = (float)nrm;
+  const bool ok = live && (nf <= kNormLimit);
+  if (live && !ok) atomicOr(hdr + 1, 1u);   // NaN / inf / overflow-prone row: MFMA kernels stand down
+  publish_max(hdr, ok ? __float_as_uint(nf) : 0u);
+  const float c0 = x[0], c1 = (D > 1) ? x[1] : 0.0f;
+  const bool fin = live && (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
+  publish_max(hdr + 8, fin ? ~fkey(c0) : 0u);
+  publish_max(hdr + 9, fin ? fkey(c0) : 0u);
+  publish_max(hdr + 10, fin ? ~fkey(c1) : 0u);
+  publish_max(hdr + 11, fin ? fkey(c1) : 0u);
+}
+
 // operand image of the (centred) coordinates, rows in natural order (perm == nullptr) or gathered
-// through perm (frames ordered by free energy).  Also: squared norms, max norm, non-finite flag.
+// through perm (an ordered frame list).  Also: squared norms.
 __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total, uint32_t n_rows,
                              uint32_t D, uint32_t S, uint32_t T, const double* __restrict__ sums,
                              const uint32_t* __restrict__ perm, float* __restrict__ img,
-                             float* __restrict__ norms, uint32_t* __restrict__ hdr) {
+                             float* __restrict__ norms) {
   // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= 32 * T) return;
@@ -59,15 +104,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
     img[((size_t)t * S + (k >> 1)) * 64 + (k & 1) * 32 + c] = v;
     nrm += (double)v * (double)v;
   }
-  // (a non-finite coordinate makes nrm non-finite, which raises the flag below)
-  float nf = (row < n_rows) ? (float)nrm : INFINITY;    // pad rows can never be "inside"
-  norms[row] = nf;
-  if (row < n_rows && hdr) {
-    if (nf <= kNormLimit)
-      atomicMax(hdr, __float_as_uint(nf));
-    else
-      atomicOr(hdr + 1, 1u);   // NaN / inf / overflow-prone row: MFMA kernels stand down
-  }
+  norms[row] = (row < n_rows) ? (float)nrm : INFINITY;   // pad rows can never be "inside"
 }
 
 // ---- free-energy ordering of the reference frames (neighbour sweep) -----------------------------
@@ -76,12 +113,19 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                               uint32_t* __restrict__ hdr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  const float f = fe[i];
-  if (f != f) atomicOr(hdr + 1, 1u);
-  const uint32_t u = __float_as_uint(f);
-  keys[i] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-  vals[i] = i;
+  uint32_t inv = 0;
+  if (i < n_rows) {
+    const float f = fe[i];
+    if (f != f) atomicOr(hdr + 1, 1u);
+    const uint32_t u = __float_as_uint(f);
+    const uint32_t key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+    keys[i] = key;
+    vals[i] = i;
+    inv = ~key;
+  }
+  // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax); one atomic
+  // per wave
+  publish_max(hdr + 12, inv);
 }
 
 __global__ void fe_scatter_kernel(const uint32_t* __restrict__ perm, const float* __restrict__ fe,
@@ -113,48 +157,17 @@ __global__ void fe_rank_kernel(const float* __restrict__ fe, const float* __rest
 }
 
 
-// ---- spatial ordering of the frames (pruned population sweep) ------------------------------------
-// header words 8..11: ~key(min col0), key(max col0), ~key(min col1), key(max col1), all as atomicMax
-__global__ void bounds_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
-                              uint32_t* __restrict__ hdr) {
-  uint32_t a = 0, b = 0, c = 0, d = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
-    const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-    if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
-      a = max(a, ~fkey(x));
-      b = max(b, fkey(x));
-      c = max(c, ~fkey(y));
-      d = max(d, fkey(y));
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a = max(a, (uint32_t)__shfl_xor((int)a, off, 64));
-    b = max(b, (uint32_t)__shfl_xor((int)b, off, 64));
-    c = max(c, (uint32_t)__shfl_xor((int)c, off, 64));
-    d = max(d, (uint32_t)__shfl_xor((int)d, off, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(hdr + 8, a);
-    atomicMax(hdr + 9, b);
-    atomicMax(hdr + 10, c);
-    atomicMax(hdr + 11, d);
-  }
-}
-
+// ---- spatial ordering of the frames (pruned sweeps) ----------------------------------------------
 // key = row-major index of the frame's cell in a 2-D grid on columns 0/1 (like compute_box_grid,
-// density_clustering.cpp:41-89); rows outside [i_from, i_to) sort to the end (key 0xFFFFFFFF)
+// density_clustering.cpp:41-89) for the rows [i_from, i_to): keys[j], vals[j] = key, id of row i_from+j
 __global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                                const uint32_t* __restrict__ hdr, float cell, uint32_t i_from,
                                uint32_t i_to, uint32_t* __restrict__ keys,
                                uint32_t* __restrict__ vals) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  vals[i] = i;
-  if (i < i_from || i >= i_to) {
-    keys[i] = 0xFFFFFFFFu;
-    return;
-  }
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = i_from + j;
+  if (i >= i_to) return;
+  vals[j] = i;
   const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
   const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
   if (cell < 0.0f) cell = auto_cell(hdr, n_rows);
@@ -169,7 +182,7 @@ __global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t n_rows
     by = (uint32_t)fminf(fmaxf((y - min1) / c1, 0.0f), 60001.0f);
   }
   const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 60001.0f) + 1u;
-  keys[i] = bx * nby + by;   // < 60003^2 < 2^32 - 1
+  keys[j] = bx * nby + by;   // < 60003^2 < 2^32 - 1
 }
 
 // bounding box (lo0, hi0, lo1, hi1) of the frames of each tile of an ordered frame list
@@ -234,17 +247,21 @@ size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
 }
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
-                 hipStream_t stream) {
+                 bool natural_image, hipStream_t stream) {
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
   if (hipMemsetAsync(p, 0, kHdrBytes, stream) != hipSuccess) return -1;
   const uint32_t blocks = (uint32_t)std::min<size_t>(512, ((size_t)n_rows * n_cols + 255) / 256);
   hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_coords, n_rows, n_cols,
                      (double*)(p + kHdrSums));
-  hipLaunchKernelGGL(image_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords,
-                     n_rows, n_rows, n_cols, L.S, L.T, (const double*)(p + kHdrSums),
-                     (const uint32_t*)nullptr, (float*)(p + L.off_img), (float*)(p + L.off_norm),
-                     (uint32_t*)p);
+  hipLaunchKernelGGL(rowstats_kernel, dim3((n_rows + 255) / 256), dim3(256),
+                     sizeof(float) * 256 * (n_cols | 1u), stream, d_coords, n_rows, n_cols,
+                     (const double*)(p + kHdrSums), (uint32_t*)p);
+  // frames in natural order: only the full-sweep kernels read this image
+  if (natural_image)
+    hipLaunchKernelGGL(image_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords,
+                       n_rows, n_rows, n_cols, L.S, L.T, (const double*)(p + kHdrSums),
+                       (const uint32_t*)nullptr, (float*)(p + L.off_img), (float*)(p + L.off_norm));
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -282,15 +299,13 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
       grid_tiles((L.T + 255) / 256);
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
   // order all frames by their 2-D cell, build the reference image and the tile boxes
-  hipLaunchKernelGGL(bounds_kernel, dim3(std::min<uint32_t>(1024, (n_rows + 255) / 256)), blk, 0,
-                     stream, d_coords, n_rows, n_cols, hdr);
   hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
                      (const uint32_t*)hdr, cell, 0u, n_rows, keys_in, vals_in);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
     return;
   hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
                      L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p,
-                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (uint32_t*)nullptr);
+                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
                      (const float*)nullptr, (float2*)nullptr);
@@ -298,13 +313,13 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
   const uint32_t n_q = i_to - i_from;
   if (!full) {
     // query rows of this call: the same ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
-                       (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_rows, p + L.fixed_end, tmp_bytes, stream))
+    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_rows,
+                       n_cols, (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
     hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_q, n_cols, L.S, L.T,
                        (const double*)(p + kHdrSums), (const uint32_t*)perm_q,
-                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (uint32_t*)nullptr);
+                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
                        (const float*)nullptr, (float2*)nullptr);
@@ -339,8 +354,6 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
       grid_tiles((L.T + 255) / 256);
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
-  hipLaunchKernelGGL(bounds_kernel, dim3(std::min<uint32_t>(1024, (n_rows + 255) / 256)), blk, 0,
-                     stream, d_coords, n_rows, n_cols, hdr);
   // 1. frames by ascending free energy (stable), 2. stable sort of that order by cell key
   hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in, hdr);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_fe, n_rows, p + L.fixed_end, tmp_bytes, stream))
@@ -355,7 +368,7 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
   hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
                      L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p,
-                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (uint32_t*)nullptr);
+                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
                      (float2*)(p + L.off_ferange_p));
@@ -366,13 +379,13 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   const uint32_t n_q = i_to - i_from;
   if (!full) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
-                       (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_rows, p + L.fixed_end, tmp_bytes, stream))
+    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_rows,
+                       n_cols, (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
     hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_q, n_cols, L.S, L.T,
                        (const double*)(p + kHdrSums), (const uint32_t*)perm_q,
-                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (uint32_t*)nullptr);
+                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
                        (const float*)nullptr, (float2*)nullptr);
@@ -413,7 +426,7 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
                      n_rows, (uint32_t*)(p + L.off_pq));
   hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
                      L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm,
-                     (float*)(p + L.off_img_s), (float*)(p + L.off_norm_s), (uint32_t*)nullptr);
+                     (float*)(p + L.off_img_s), (float*)(p + L.off_norm_s));
   switch ((n_cols + 1) / 2) {
 #define X(SV)                                                                                \
   case SV:                                                                                   \

@@ -10,6 +10,7 @@ bool mfma_supports(size_t n_cols);
 size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols);
 // builds the operand images of d_coords in the workspace; returns 0 on success
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
+                 bool natural_image,
                  hipStream_t stream);
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,

@@ -59,6 +59,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxSteps = 16;          // K-steps of two columns -> n_cols <= 32
 constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits); word 1: non-finite flag;
+                                       // words 8..11: extent of columns 0/1; word 12: ~key of min FE
 constexpr size_t kHdrSums = 256;       // byte 256..: column sums (double) for the centring
 constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram form -> flagged
 
@@ -77,6 +78,7 @@ struct Layout {
       off_img_p, off_norm_p, off_perm_p, off_box_p, off_img_q, off_norm_q, off_perm_q, off_box_q,
       off_ferange_p,   // per reference tile (fe_lo, fe_hi) -- pruned neighbour sweep
       off_coords_p,    // ORIGINAL coordinates gathered into the reference order (exact path reads)
+      off_merge64,     // [2][n_rows] packed (d2, id) for merging reference chunks (neighbour sweep)
       fixed_end;
 };
 
@@ -109,7 +111,8 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_box_q = L.off_perm_q + row_bytes;
   L.off_ferange_p = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.T);
   L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.T);
-  L.fixed_end = align256(L.off_coords_p + sizeof(float) * n_rows * n_cols);
+  L.off_merge64 = align256(L.off_coords_p + sizeof(float) * n_rows * n_cols);
+  L.fixed_end = align256(L.off_merge64 + sizeof(unsigned long long) * 2 * n_rows);
   return L;
 }
 
@@ -509,6 +512,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
   const uint32_t wave = blockIdx.x * 4 + wib;
+  // gridDim.y > 1: the reference tiles are dealt round-robin to gridDim.y waves per query group and
+  // the partial counts are merged with atomics (keeps small launches, e.g. one rank of an 8-GPU
+  // run, at >= 2 waves per SIMD without giving up the operand reuse of TQ query tiles per wave)
+  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
@@ -555,11 +562,14 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     // ---- scan: which reference tiles of this round can hold a pair within r_max of the group?
     uint32_t cnt = 0;
     const uint32_t lim = min(T - base, (uint32_t)kListCap);
+    // (the box of step k+1 is fetched while step k is tested: the scan is latency-, not work-bound)
+    float4 rb_next = ((uint32_t)lane < lim) ? box_r[base + lane] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
     for (uint32_t k = 0; k < lim; k += 64) {
       const uint32_t t = base + k + lane;
+      const float4 rb = rb_next;
+      if (k + 64 + lane < lim) rb_next = box_r[t + 64];
       uint32_t qmask = 0;   // bit qt: reference tile t can hold a pair within r_max of query tile qt
-      if (k + lane < lim) {
-        const float4 rb = box_r[t];
+      if ((k + lane < lim) && (t % n_chunks == chunk)) {   // this wave's share of the references
         if (box_gap2(gbox, rb) < far2) {
 #pragma unroll
           for (int qt = 0; qt < TQ; ++qt) qmask |= (box_gap2(qbox[qt], rb) < far2) ? (1u << qt) : 0u;
@@ -644,9 +654,17 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     for (int rr = 0; rr < NR; ++rr) {
       const uint32_t total = q[qt].cnt[rr] + (uint32_t)__shfl_xor((int)q[qt].cnt[rr], 32, 64);
       if (h == 0 && live && rr < n_rad) {
-        // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2
-        const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
-        pops[(size_t)rr * n_rows + jq[qt]] = total + 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
+        // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2;
+        // the reference starts every population at 1 (:132-134): corrected once, by chunk 0
+        uint32_t v = total;
+        if (chunk == 0) {
+          const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
+          v += 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
+        }
+        if (n_chunks == 1)
+          pops[(size_t)rr * n_rows + jq[qt]] = v;
+        else
+          atomicAdd(&pops[(size_t)rr * n_rows + jq[qt]], v);   // pops was zero-filled by the caller
       }
     }
   }
@@ -1004,11 +1022,12 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float4* __restrict__ box_r, const float2* __restrict__ ferange_r,
     const float* __restrict__ fe_c, const float* __restrict__ coords_c,
     const uint32_t* __restrict__ invpos_r, uint32_t T,
-    const float* __restrict__ img_q, const uint32_t* __restrict__ perm_q,
-    const float4* __restrict__ box_q, uint32_t n_q, int full_range, float cell2,
+    const float* __restrict__ img_q, const float* __restrict__ norms_q,
+    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q,
+    int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
-    uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
-    float* __restrict__ hd_d2) {
+    unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx,
+    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
   __shared__ uint32_t lists[4][kListCap];
   // dynamic LDS: [4 waves][TQ*32][n_cols] query rows (original coordinates), then the candidate
   // queues [4 waves][TQ][kQueueCap][64]
@@ -1017,6 +1036,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
   const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;
@@ -1041,6 +1061,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
   float4 qbox[TQ];
+  float g_nn[TQ], g_hd[TQ];   // exact incumbents published by other reference chunks (FLT_MAX: none)
   float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
@@ -1059,6 +1080,18 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
     q[qt].m_nn = live ? INFINITY : -INFINITY;   // idle lanes can never trigger the exact path
     q[qt].m_hd = live ? INFINITY : -INFINITY;
+    g_nn[qt] = FLT_MAX;
+    g_hd[qt] = FLT_MAX;
+    if (n_chunks > 1 && live) {
+      // what the waves of other reference chunks have already published for this query: an exact
+      // upper bound.  Only candidates that can still beat (or tie) it need to be looked at, i.e.
+      // MFMA values below (d2 - |x'|^2) + eps; the band test adds its usual 2.5 eps on top.
+      g_nn[qt] = __uint_as_float((uint32_t)(merge64[jq[qt]] >> 32));
+      g_hd[qt] = __uint_as_float((uint32_t)(merge64[(size_t)n_rows + jq[qt]] >> 32));
+      const float nx = norms_q[tl * 32 + c];
+      if (g_nn[qt] < FLT_MAX) q[qt].m_nn = (g_nn[qt] - nx) + eps;
+      if (g_hd[qt] < FLT_MAX) q[qt].m_hd = (g_hd[qt] - nx) + eps;
+    }
     q[qt].bd_nn = FLT_MAX;
     q[qt].bd_hd = FLT_MAX;
     q[qt].bj_nn = n_rows + 1;
@@ -1069,10 +1102,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
-  // lowest free energy of the whole data set: a query at that level has no lower-FE neighbour
-  float fe_floor = INFINITY;
-  for (uint32_t k = lane; k < T; k += 64) fe_floor = fminf(fe_floor, ferange_r[k].x);
-  fe_floor = wave_min(fe_floor);
+  // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
+  // ordering pass): a query at that level has no lower-FE neighbour
+  const float fe_floor = fkey_inv(~hdr[12]);
 
   // evaluate and empty the candidate queue of query tile qi (all lanes in parallel per slot)
   auto flush = [&](int qi) {
@@ -1097,13 +1129,18 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     for (uint32_t base = 0; base < T; base += kListCap) {
       uint32_t cnt = 0;
       const uint32_t lim = min(T - base, (uint32_t)kListCap);
+      float4 rb_next = ((uint32_t)lane < lim) ? box_r[base + lane] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
       for (uint32_t k = 0; k < lim; k += 64) {
         const uint32_t t = base + k + lane;
+        const float4 rb = rb_next;   // fetched one step ahead: the scan is latency-bound otherwise
+        if (k + 64 + lane < lim) rb_next = box_r[t + 64];
         bool ok = false;
-        if (k + lane < lim) {
-          const float g2 = box_gap2(gbox, box_r[t]);
+        if ((k + lane < lim) && (t % n_chunks == chunk)) {   // this wave's share of the references
+          const float g2 = box_gap2(gbox, rb);
           ok = (g2 < r2_hi) & (g2 >= r2_lo);
         }
+        // (the ring logic below only ever sees this share: its incumbents are upper bounds of the
+        //  true ones, so the rings are at worst a little wider than necessary)
         const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
         if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
         cnt += (uint32_t)__builtin_popcountll(m);
@@ -1216,7 +1253,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     }
 #pragma unroll
     for (int qt = 0; qt < TQ; ++qt) flush(qt);        // the settle test needs the exact incumbents
-    if (!(r2_hi <= FLT_MAX) || visited >= T) break;   // every reference tile has been visited
+    if (!(r2_hi <= FLT_MAX) || visited >= (T - chunk + n_chunks - 1) / n_chunks)
+      break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
     const float sure = r2_hi * 0.9999f;
     float need = 0.0f;      // largest incumbent that still has to be confirmed
@@ -1226,8 +1264,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       const bool live = (livemask[qt] >> lane) & 1;
       const bool hd_possible = fe_floor < q[qt].feq;
       // a query's incumbent is the better one of its two half-wave lanes
-      const float inc_nn = fminf(q[qt].bd_nn, __shfl_xor(q[qt].bd_nn, 32, 64));
-      const float inc_hd = fminf(q[qt].bd_hd, __shfl_xor(q[qt].bd_hd, 32, 64));
+      const float inc_nn = fminf(g_nn[qt], fminf(q[qt].bd_nn, __shfl_xor(q[qt].bd_nn, 32, 64)));
+      const float inc_hd = fminf(g_hd[qt], fminf(q[qt].bd_hd, __shfl_xor(q[qt].bd_hd, 32, 64)));
       const float want = fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f);
       const bool open = live & !(want < sure);
       blind = blind | (open & !(want < FLT_MAX));
@@ -1256,12 +1294,41 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     oj = (uint32_t)__shfl_xor((int)Q.bj_hd, 32, 64);
     lexi_update(oj <= n_rows, Q.bd_hd, Q.bj_hd, od, oj, n_rows);
     if (h == 0 && ((livemask[qt] >> lane) & 1)) {
-      nn_idx[jq[qt]] = Q.bj_nn;
-      nn_d2[jq[qt]] = Q.bd_nn;
-      hd_idx[jq[qt]] = Q.bj_hd;
-      hd_d2[jq[qt]] = Q.bd_hd;
+      if (n_chunks == 1) {
+        nn_idx[jq[qt]] = Q.bj_nn;
+        nn_d2[jq[qt]] = Q.bd_nn;
+        hd_idx[jq[qt]] = Q.bj_hd;
+        hd_d2[jq[qt]] = Q.bd_hd;
+      } else {
+        // d2 >= 0, so (d2 bits << 32 | frame id) orders like the lexicographic (d2, id): the merge
+        // over the chunks is a 64-bit atomic min (merge64 was filled with (FLT_MAX, n_rows+1))
+        atomicMin(&merge64[jq[qt]],
+                  ((unsigned long long)__float_as_uint(Q.bd_nn) << 32) | Q.bj_nn);
+        atomicMin(&merge64[(size_t)n_rows + jq[qt]],
+                  ((unsigned long long)__float_as_uint(Q.bd_hd) << 32) | Q.bj_hd);
+      }
     }
   }
+}
+
+__global__ void nn_merge_fill_kernel(unsigned long long* __restrict__ merge64, uint32_t n_rows) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * n_rows) merge64[i] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | (n_rows + 1);
+}
+
+__global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ merge64,
+                                       const uint32_t* __restrict__ perm_q, uint32_t n_q,
+                                       uint32_t n_rows, uint32_t* __restrict__ nn_idx,
+                                       float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
+                                       float* __restrict__ hd_d2) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_q) return;
+  const uint32_t i = perm_q[p];   // the query rows of this call
+  const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
+  nn_idx[i] = (uint32_t)a;
+  nn_d2[i] = __uint_as_float((uint32_t)(a >> 32));
+  hd_idx[i] = (uint32_t)b;
+  hd_d2[i] = __uint_as_float((uint32_t)(b >> 32));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1304,8 +1371,10 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   const float* coords_c;
   const uint32_t* invpos_r;
   const float* img_q;
+  const float* norms_q;
   const uint32_t* perm_q;
   const float4* box_q;
+  unsigned long long* merge64;
   uint32_t n_q;
   int full_range;
   float cell2;
@@ -1315,9 +1384,25 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // enough that the launch has >= 2 waves per SIMD -- a rank that owns only N/8 of the rows (8-GPU
 // run) would otherwise leave most of the chip idle.
 inline int pick_tq(uint32_t tiles, int tq_max) {
-  int tq = tq_max;
-  while (tq > 1 && (tiles + tq - 1) / tq < 2048u) tq >>= 1;
-  return tq;
+  (void)tiles;
+  return tq_max;
+}
+// Reference chunks per query group (gridDim.y).  The cost of a query group follows the local density
+// of the data (dense regions keep many more reference tiles), and with two resident waves per SIMD a
+// launch of a few thousand waves ends in a long, mostly idle tail behind its heaviest groups.  The
+// launch is therefore split along the reference axis into at least `target` waves (measured on C3:
+// 8 to 16 waves per wave slot; the full 1M-frame sweep gains 5..15 %, one rank of an 8-GPU run
+// 35 %); the operand reuse of TQ query tiles per wave is kept, partial results merge with atomics.
+constexpr uint32_t kPopWaveTarget = 16384, kNnWaveTarget = 32768;
+// A share never drops below about 128 reference tiles (the per-wave set-up and box scan must stay
+// small next to the chains).
+inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles) {
+  const uint32_t waves = (tiles + tq - 1) / tq;
+  if (waves >= target) return 1u;
+  uint32_t r = (target + waves - 1) / waves;
+  const uint32_t cap = ref_tiles / 128u < 64u ? ref_tiles / 128u : 64u;
+  r = r > cap ? cap : r;
+  return r < 1u ? 1u : r;
 }
 
 template <int S, int TQV>
@@ -1326,13 +1411,22 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                       unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
+  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T);
   // query rows (original coordinates) + candidate queues, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
-  hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + 3) / 4), dim3(256), smem, s, coords,
-                     n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r, A.fe_c,
-                     A.coords_c, A.invpos_r, T, A.img_q, A.perm_q, A.box_q, A.n_q, A.full_range,
-                     A.cell2, hdr, chain_counter, nn_idx, nn_d2, hd_idx, hd_d2);
+  if (n_chunks > 1)
+    hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s,
+                       A.merge64, n_rows);
+  hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + 3) / 4, n_chunks), dim3(256), smem, s,
+                     coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r,
+                     A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q,
+                     A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
+                     hd_d2);
+  if (n_chunks > 1)
+    hipLaunchKernelGGL(nn_merge_unpack_kernel, dim3((A.n_q + 255) / 256), dim3(256), 0, s,
+                       (const unsigned long long*)A.merge64, A.perm_q, A.n_q, n_rows, nn_idx, nn_d2,
+                       hd_idx, hd_d2);
 }
 
 template <int S>
@@ -1364,7 +1458,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
                        uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
                        uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
   const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
-  const dim3 grid((waves + 3) / 4), block(256);
+  const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T)), block(256);
   const float* img_q = full_range ? P.img_p : P.img_q;
   const float* norms_q = full_range ? P.norms_p : P.norms_q;
   const uint32_t* perm_q = full_range ? P.perm_p : P.perm_q;

@@ -43,8 +43,10 @@ void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint
   A.coords_c = (const float*)(p + L.off_coords_p);
   A.invpos_r = (const uint32_t*)(p + L.off_invpos);
   A.img_q = full_range ? A.img_r : (const float*)(p + L.off_img_q);
+  A.norms_q = full_range ? A.norms_r : (const float*)(p + L.off_norm_q);
   A.perm_q = full_range ? A.perm_r : (const uint32_t*)(p + L.off_perm_q);
   A.box_q = full_range ? A.box_r : (const float4*)(p + L.off_box_q);
+  A.merge64 = (unsigned long long*)(p + L.off_merge64);
   A.n_q = n_q;
   A.full_range = full_range;
   A.cell2 = cell2;
