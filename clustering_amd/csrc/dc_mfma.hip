@@ -81,30 +81,44 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   publish_max(hdr + 11, fin ? fkey(c1) : 0u);
 }
 
-// operand image of the (centred) coordinates, rows in natural order (perm == nullptr) or gathered
-// through perm (an ordered frame list).  Also: squared norms.
+// operand image of the (centred) coordinates in the bf16x3 slot layout (dc_mfma_kernels.hpp), rows
+// in natural order (perm == nullptr) or gathered through perm (an ordered frame list).  One thread
+// writes the 16-byte fragment of one lane of one MFMA of one tile; the threads of MFMA 0, half 0
+// also write the squared norm of their row (norms != nullptr).  b_form: query-side pieces (-2x').
 __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total, uint32_t n_rows,
-                             uint32_t D, uint32_t S, uint32_t T, const double* __restrict__ sums,
-                             const uint32_t* __restrict__ perm, float* __restrict__ img,
+                             uint32_t D, uint32_t NM, uint32_t T, const double* __restrict__ sums,
+                             const uint32_t* __restrict__ perm, int b_form, uint4* __restrict__ img,
                              float* __restrict__ norms) {
   // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= 32 * T) return;
-  const uint32_t t = row >> 5, c = row & 31;
-  const uint32_t src = (row < n_rows) ? (perm ? perm[row] : row) : 0u;
-  double nrm = 0.0;
-  for (uint32_t k = 0; k < 2 * S; ++k) {
-    float v = 0.0f;
-    if (row < n_rows && k < D) {
-      double mu = sums[k] / (double)n_total;
-      float muf = (float)mu;
-      if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
-      v = coords[(size_t)src * D + k] - muf;            // x' = fl(x - mu)
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (size_t)T * NM * 64) return;
+  const uint32_t lane = (uint32_t)(id & 63), m = (uint32_t)((id >> 6) % NM), t = (uint32_t)((id >> 6) / NM);
+  const uint32_t row = 32 * t + (lane & 31), h = lane >> 5;
+  const bool live = row < n_rows;
+  const uint32_t src = live ? (perm ? perm[row] : row) : 0u;
+  const float* x = coords + (size_t)src * D;
+  auto col = [&](uint32_t k) -> float {
+    float muf = (float)(sums[k] / (double)n_total);
+    if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
+    return x[k] - muf;                                   // x' = fl(x - mu)
+  };
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  if (live) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+      const uint32_t v = slot_value(16 * m + 8 * h + j, D, b_form != 0, col) & 0xFFFFu;
+      w[j >> 1] |= v << (16 * (j & 1));
     }
-    img[((size_t)t * S + (k >> 1)) * 64 + (k & 1) * 32 + c] = v;
-    nrm += (double)v * (double)v;
   }
-  norms[row] = (row < n_rows) ? (float)nrm : INFINITY;   // pad rows can never be "inside"
+  img[id] = make_uint4(w[0], w[1], w[2], w[3]);          // pad rows: all zero
+  if (norms && m == 0 && h == 0) {
+    double nrm = 0.0;
+    for (uint32_t k = 0; k < D; ++k) {
+      const float v = live ? col(k) : 0.0f;
+      nrm += (double)v * (double)v;
+    }
+    norms[row] = live ? (float)nrm : INFINITY;           // pad rows can never be "inside"
+  }
 }
 
 // ---- free-energy ordering of the reference frames (neighbour sweep) -----------------------------
@@ -233,13 +247,12 @@ __global__ void gather_key_kernel(const uint32_t* __restrict__ keys_by_frame,
 
 }  // namespace
 
-#define DC_FOR_EACH_S(X) \
-  X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define DC_FOR_EACH_S(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 DC_FOR_EACH_S(DC_DECLARE_STEP)
 
 bool mfma_supports(size_t n_cols) {
-  if (n_cols < 1 || n_cols > 2 * (size_t)kMaxSteps) return false;
-  return ((DC_STEP_MASK >> ((n_cols + 1) / 2 - 1)) & 1u) != 0;
+  if (n_cols < 1 || n_cols > (size_t)kMaxCols) return false;
+  return ((DC_STEP_MASK >> (nm_for((int)n_cols) - 1)) & 1u) != 0;
 }
 size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
   if (!mfma_supports(n_cols) || n_rows == 0) return 0;
@@ -258,17 +271,22 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
                      sizeof(float) * 256 * (n_cols | 1u), stream, d_coords, n_rows, n_cols,
                      (const double*)(p + kHdrSums), (uint32_t*)p);
   // frames in natural order: only the full-sweep kernels read this image
-  if (natural_image)
-    hipLaunchKernelGGL(image_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords,
-                       n_rows, n_rows, n_cols, L.S, L.T, (const double*)(p + kHdrSums),
-                       (const uint32_t*)nullptr, (float*)(p + L.off_img), (float*)(p + L.off_norm));
+  if (natural_image) {
+    const dim3 grid_img((uint32_t)(((size_t)L.T * L.NM * 64 + 255) / 256));
+    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
+                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)nullptr, 0,
+                       (uint4*)(p + L.off_img), (float*)(p + L.off_norm));
+    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
+                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)nullptr, 1,
+                       (uint4*)(p + L.off_img_b), (float*)nullptr);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                      hipStream_t stream) {
-  switch ((n_cols + 1) / 2) {
+  switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
@@ -297,34 +315,44 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
   const float cell = (r2max > 0.0f) ? sqrtf(r2max) : 0.0f;
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
       grid_tiles((L.T + 255) / 256);
+  auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
   // order all frames by their 2-D cell, build the reference image and the tile boxes
   hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
                      (const uint32_t*)hdr, cell, 0u, n_rows, keys_in, vals_in);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
     return;
-  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
-                     L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p,
-                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
+  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
+                     L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 0,
+                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
                      (const float*)nullptr, (float2*)nullptr);
+  // original rows in the reference order: the deferred exact path reads them without a
+  // permutation look-up
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
+                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
+                     (float*)(p + L.off_coords_p));
   const bool full = (i_from == 0 && i_to == n_rows);
-  const uint32_t n_q = i_to - i_from;
+  const uint32_t n_q = i_to - i_from, T_q = (n_q + 31) / 32;
+  if (full)   // the queries are all rows in the reference order: only their B form is missing
+    hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
+                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 1,
+                       (uint4*)(p + L.off_img_q), (float*)nullptr);
   if (!full) {
     // query rows of this call: the same ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_rows,
                        n_cols, (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
-    hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_q, n_cols, L.S, L.T,
-                       (const double*)(p + kHdrSums), (const uint32_t*)perm_q,
-                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
+    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
+                       L.NM, T_q, (const double*)(p + kHdrSums), (const uint32_t*)perm_q, 1,
+                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
                        (const float*)nullptr, (float2*)nullptr);
   }
-  switch ((n_cols + 1) / 2) {
+  switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                 \
   case SV:                                                                                    \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
@@ -353,6 +381,7 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   const float cell = -1.0f;   // "auto": the kernels derive the cell edge from the bounding box
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
       grid_tiles((L.T + 255) / 256);
+  auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
   // 1. frames by ascending free energy (stable), 2. stable sort of that order by cell key
   hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in, hdr);
@@ -366,9 +395,9 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
     return;
   hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
-  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
-                     L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p,
-                     (float*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
+  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
+                     L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 0,
+                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
                      (float2*)(p + L.off_ferange_p));
@@ -376,21 +405,25 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
                      0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
                      (float*)(p + L.off_coords_p));
   const bool full = (i_from == 0 && i_to == n_rows);
-  const uint32_t n_q = i_to - i_from;
+  const uint32_t n_q = i_to - i_from, T_q = (n_q + 31) / 32;
+  if (full)   // the queries are all rows in the reference order: only their B form is missing
+    hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
+                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 1,
+                       (uint4*)(p + L.off_img_q), (float*)nullptr);
   if (!full) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_rows,
                        n_cols, (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
-    hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_q, n_cols, L.S, L.T,
-                       (const double*)(p + kHdrSums), (const uint32_t*)perm_q,
-                       (float*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
+    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
+                       L.NM, T_q, (const double*)(p + kHdrSums), (const uint32_t*)perm_q, 1,
+                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
                        (const float*)nullptr, (float2*)nullptr);
   }
-  switch ((n_cols + 1) / 2) {
+  switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
@@ -415,6 +448,7 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
   uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
   uint32_t* perm = (uint32_t*)(p + L.off_perm);
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256);
+  auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in,
                      (uint32_t*)p);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm, n_rows, p + L.fixed_end,
@@ -424,10 +458,10 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
                      (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
   hipLaunchKernelGGL(fe_rank_kernel, grid_n, blk, 0, stream, d_fe, (const float*)(p + L.off_fe_s),
                      n_rows, (uint32_t*)(p + L.off_pq));
-  hipLaunchKernelGGL(image_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_rows, n_cols, L.S,
-                     L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm,
-                     (float*)(p + L.off_img_s), (float*)(p + L.off_norm_s));
-  switch ((n_cols + 1) / 2) {
+  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
+                     L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm, 0,
+                     (uint4*)(p + L.off_img_s), (float*)(p + L.off_norm_s));
+  switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                \
   case SV:                                                                                   \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                     \

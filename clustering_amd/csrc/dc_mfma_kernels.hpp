@@ -1,10 +1,10 @@
-// dc_mfma_kernels.hpp -- fp32-MFMA variants of the two pairwise sweeps (gfx950,
-// v_mfma_f32_32x32x2_f32).  Included by dc_mfma.hip (host side) and dc_mfma_step.hip (one
-// translation unit per K-step count).
+// dc_mfma_kernels.hpp -- matrix-core variants of the two pairwise sweeps (gfx950,
+// v_mfma_f32_32x32x16_bf16 on fp32 coordinates split into three bf16 pieces).  Included by
+// dc_mfma.hip (host side) and dc_mfma_step.hip (one translation unit per MFMA count).
 //
 // Idea.  The N x D . D x N distance block is a dense contraction:
 //     d2(x, y) = |x|^2 + |y|^2 - 2 x.y
-// so a 32(reference) x 32(query) tile costs ceil(D/2) MFMAs instead of 32*32*(3D-1) VALU ops.
+// so a 32(reference) x 32(query) tile is a few MFMAs instead of 32*32*(3D-1) VALU ops.
 // But the Gram form does not round like the reference's direct-difference sum, and the outputs
 // (integer populations, neighbour indices) must equal the reference's bit for bit.  So the MFMA
 // result is used only as a CLASSIFIER with a rigorous guard band eps (derivation in DESIGN.md):
@@ -17,34 +17,46 @@
 // whose MFMA distance is within 2.5 eps of the running minimum is evaluated exactly and merged
 // lexicographically on (d2, index), which reproduces "lowest index wins ties" (:270) exactly.
 //
-// Mapping (one wave = TQ query tiles of 32 frames, swept against all reference tiles of 32 frames):
-//   v_mfma_f32_32x32x2_f32:  D[i][j] = C[i][j] + sum_k A[i][k] B[k][j],  lane l holds A[l&31][l>>5],
-//   B[l>>5][l&31]; D[i][j] sits in lane (j + 32*h), register r with i = (r&3) + 8*(r>>2) + 4*h.
-//     A = centred reference coordinates   y'[i][k]            (streamed, one dword per K-step)
-//     B = -2 * centred query coordinates  x'[j][k]            (resident in VGPRs for the whole sweep)
-//     C = |y'_i|^2 broadcast along the row                     (initial accumulator, 4 x dwordx4)
-//   => acc = |y'|^2 - 2 x'.y' ; the query norm moves into the per-lane threshold r^2 - |x'|^2 - eps.
+// Why bf16 pieces.  On gfx950 the fp32-input MFMA runs at the vector rate and shares the vector
+// pipe (its 64 cycles per K=2 step do not overlap the VALU epilogue: measured); the bf16
+// MFMA is 16x faster per flop and runs beside the VALU.  An fp32 value is EXACTLY the sum of three
+// bf16 values (8 + 8 + 8 significant bits, round-to-nearest residuals): v = hi + mid + lo.  Of the
+// nine piece products of x_k * y_k the three smallest (mid*lo, lo*mid, lo*lo <= 2^-24 |x_k y_k|) are
+// dropped into the guard band, the other six are exact in fp32 and summed by the MFMA:
+//     -2 x.y  ~  sum_k  yh*xh + ym*xh + yh*xm + ym*xm + yl*xh + yh*xl       (x pieces of -2x')
+// i.e. 6 D "slots" of the K axis, plus three slots (1 * pieces of a per-query constant c_q) that fold
+// the query norm and the threshold into the accumulator:
+//     acc = |y'|^2 + c_q - 2 x'.y'   with  c_q = |x'|^2 - (r^2 - eps)   (populations: inside <=> acc < 0)
+//                                          c_q = |x'|^2                 (neighbours:  acc ~ d2)
+// NM = ceil((6 D + 3) / 16) MFMAs per tile (4 for D = 10, against 5 fp32 MFMAs of 4x the cycles).
+// Slot order: the constant and the hi*hi products come FIRST, so after the first MFMA(s) the
+// accumulator of a pair near the threshold is already small and the remaining (small) terms are
+// added at a small magnitude -- that is what keeps the accumulation error, and with it eps, at the
+// level of the fp32 chain (the hardware truncates every addend to 2^-24 of the largest one and
+// rounds once per MFMA: measured by scratch/mfma_probe.hip, asserted by tests/cpp/test_mfma_model).
+//
+// Mapping (one wave = TQ query tiles of 32 frames, swept against reference tiles of 32 frames):
+//   v_mfma_f32_32x32x16_bf16:  D[i][j] = C[i][j] + sum_k A[i][k] B[k][j];  lane l = (r = l&31, h = l>>5)
+//   holds A[r][8h..8h+7] and B[8h..8h+7][r] (8 bf16 = 4 VGPRs each); D[i][j] sits in lane (j + 32*h),
+//   register g with i = (g&3) + 8*(g>>2) + 4*h.
+//     A = reference pieces (streamed: NM x 16 B per lane and tile)
+//     B = query pieces of -2x' and of c_q (resident in VGPRs for the whole sweep)
+//     C = |y'_i|^2 broadcast along the row (initial accumulator, 4 x dwordx4; +inf for pad rows)
 // Queries sit on the lane axis, so populations / running minima are per-lane registers; the two
 // half-waves (h = 0/1) see disjoint reference rows of the same 32 queries and are merged by one
 // __shfl_xor(.., 32) at the very end.
 //
-// Schedule.  The S MFMAs of chain k are interleaved in program order with the VALU epilogue of
-// chain k-1 (two accumulator tiles ping-pong), so a single wave keeps the matrix pipe busy and the
-// second wave of the SIMD fills the gaps.  The epilogues use no compare masks at all (no SGPR
-// hand-offs between VALU and SALU): with t = acc - lo,
-//     inside  <=>  sign bit of t               -> shifted into a bit string (v_alignbit), v_bcnt
-//     in band <=>  bits(t) <u bits(2 eps)      -> unsigned min (v_min3_u32), one test per chain
-// which is valid because the MFMA kernels only run on finite data (the operand-image pass raises
-// a flag for non-finite or overflow-prone rows; the flagged case runs the direct kernels instead,
-// both launches are gated on the device so no host synchronisation is needed).
+// The epilogues use no compare masks at all (no SGPR hand-offs between VALU and SALU):
+//     inside  <=>  sign bit of acc             -> shifted into a bit string (v_alignbit), v_bcnt
+//     in band <=>  bits(acc) <u bits(2 eps)    -> unsigned min (v_min3_u32), one test per chain
+// which is valid because the MFMA kernels only run on finite data (the header pass raises a flag
+// for non-finite or overflow-prone rows; the flagged case runs the direct kernels instead, both
+// launches are gated on the device so no host synchronisation is needed).
 //
-// Operand images (built once per call by mfma_prepare in the caller's workspace):
-//   img   [T][S][64]  A fragments in lane order: img[(t*S+s)*64 + l] = y'[32t + (l&31)][2s + (l>>5)]
-//   norms [32T]       |y'|^2 (double accumulate, rounded once); +inf for the pad rows of the last tile
-//   img_s / norms_s   the same for the frames ordered by free energy (neighbour sweep), with
-//                     perm / invpos / fe_s / pq (see Layout)
-// Each wave streams the images with plain coalesced global loads (256 B per K-step); all waves of
-// the chip walk the same 44 MB, which lives in L2 / Infinity Cache.
+// Operand images (built per call in the caller's workspace, dc_mfma.hip):
+//   A form [T][NM][64] x 16 B: fragment of lane l of MFMA m of tile t = slots 16m + 8(l>>5) + 0..7 of
+//                              row 32t + (l&31); B form: the same with the query-side pieces
+//   norms  [32T]               |y'|^2 (double accumulate, rounded once); +inf for the pad rows
 #pragma once
 #include "dc_mfma.hpp"
 
@@ -56,8 +68,13 @@ namespace dc {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kMaxSteps = 16;          // K-steps of two columns -> n_cols <= 32
+constexpr int kMaxCols = 32;           // n_cols handled by the matrix-core kernels
+constexpr int kConstSlots = 3;         // K slots 0..2: 1 (A side) x pieces of the query constant (B side)
+// MFMAs per tile pair: 6 piece products per column + the constant slots, 16 slots per MFMA
+constexpr int nm_for(int n_cols) { return (6 * n_cols + kConstSlots + 15) / 16; }
+constexpr int kMaxMfma = nm_for(kMaxCols);   // 13
 constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits); word 1: non-finite flag;
                                        // words 8..11: extent of columns 0/1; word 12: ~key of min FE
 constexpr size_t kHdrSums = 256;       // byte 256..: column sums (double) for the centring
@@ -70,11 +87,14 @@ constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram 
 // lower free energy (pq) -- plus scratch for the radix sort (keys/vals double buffers; the sort's
 // own temp storage sits after `fixed_end` and is sized by dc_mfma.hip).
 struct Layout {
-  uint32_t T, S;
-  size_t off_img, off_norm, off_img_s, off_norm_s, off_fe_s, off_perm, off_invpos, off_pq,
+  uint32_t T, NM;
+  // img: A form, natural order; img_b: B form, natural order (queries of the full sweeps);
+  // img_s: A form, frames ordered by free energy (full neighbour sweep)
+  size_t off_img, off_img_b, off_norm, off_img_s, off_norm_s, off_fe_s, off_perm, off_invpos, off_pq,
       off_keys_in, off_keys_out, off_vals_in,
       // spatially ordered frames (2-D cell key on columns 0/1) for the pruned population sweep:
-      // reference image / norms / permutation / per-tile boxes, and the same for the query rows
+      // reference image (A form) / norms / permutation / per-tile boxes, and the same for the query
+      // rows (B form)
       off_img_p, off_norm_p, off_perm_p, off_box_p, off_img_q, off_norm_q, off_perm_q, off_box_q,
       off_ferange_p,   // per reference tile (fe_lo, fe_hi) -- pruned neighbour sweep
       off_coords_p,    // ORIGINAL coordinates gathered into the reference order (exact path reads)
@@ -87,11 +107,12 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline Layout make_layout(size_t n_rows, size_t n_cols) {
   Layout L;
   L.T = (uint32_t)((n_rows + 31) / 32);
-  L.S = (uint32_t)((n_cols + 1) / 2);
-  const size_t img_bytes = sizeof(float) * 64 * (size_t)L.T * L.S;
+  L.NM = (uint32_t)nm_for((int)n_cols);
+  const size_t img_bytes = (size_t)16 * 64 * (size_t)L.T * L.NM;
   const size_t row_bytes = align256(sizeof(float) * 32 * (size_t)L.T);
   L.off_img = kHdrBytes;
-  L.off_norm = align256(L.off_img + img_bytes);
+  L.off_img_b = align256(L.off_img + img_bytes);
+  L.off_norm = align256(L.off_img_b + img_bytes);
   L.off_img_s = L.off_norm + row_bytes;
   L.off_norm_s = align256(L.off_img_s + img_bytes);
   L.off_fe_s = L.off_norm_s + row_bytes;
@@ -119,44 +140,48 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
 struct Ptrs {
   const uint32_t* hdr;   // [0] max norm bits, [1] non-finite flag
   const double* sums;
-  const float* img;
+  const uint4* img;
+  const uint4* img_b;
   const float* norms;
-  const float* img_s;
+  const uint4* img_s;
   const float* norms_s;
   const float* fe_s;
   const uint32_t* perm;
   const uint32_t* invpos;
   const uint32_t* pq;
-  const float* img_p;
+  const uint4* img_p;
   const float* norms_p;
   const uint32_t* perm_p;
   const float4* box_p;
-  const float* img_q;
+  const uint4* img_q;
   const float* norms_q;
   const uint32_t* perm_q;
   const float4* box_q;
+  const float* coords_p;   // original coordinates gathered into the reference order
 };
 
 inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
   char* p = (char*)d_ws;
   return Ptrs{(const uint32_t*)p,
               (const double*)(p + kHdrSums),
-              (const float*)(p + L.off_img),
+              (const uint4*)(p + L.off_img),
+              (const uint4*)(p + L.off_img_b),
               (const float*)(p + L.off_norm),
-              (const float*)(p + L.off_img_s),
+              (const uint4*)(p + L.off_img_s),
               (const float*)(p + L.off_norm_s),
               (const float*)(p + L.off_fe_s),
               (const uint32_t*)(p + L.off_perm),
               (const uint32_t*)(p + L.off_invpos),
               (const uint32_t*)(p + L.off_pq),
-              (const float*)(p + L.off_img_p),
+              (const uint4*)(p + L.off_img_p),
               (const float*)(p + L.off_norm_p),
               (const uint32_t*)(p + L.off_perm_p),
               (const float4*)(p + L.off_box_p),
-              (const float*)(p + L.off_img_q),
+              (const uint4*)(p + L.off_img_q),
               (const float*)(p + L.off_norm_q),
               (const uint32_t*)(p + L.off_perm_q),
-              (const float4*)(p + L.off_box_q)};
+              (const float4*)(p + L.off_box_q),
+              (const float*)(p + L.off_coords_p)};
 }
 
 // ordered-integer image of a float (ascending) and back; header words 8..11 hold the bounding box of
@@ -179,29 +204,118 @@ __device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// guard band (DESIGN.md "guard band"): |acc + |x'|^2 - d2_canonical| <= eps for every pair whose
-// canonical d2 is <= d2cap, given M = max |x'|^2, K = 2S fused multiply-adds in the MFMA chain.
-//   eps = 1.25 * u * [ (4K + 10) * M + (D/4 + 12) * d2cap ],  u = 2^-24, rounded up.
+// guard band (DESIGN.md "guard band").  For every pair, with d2 its canonical squared distance,
+// u = 2^-24, M = max |x'|^2 and c_q the folded query constant (see the file header):
+//     | acc - (d2 + c_q - |x'|^2) |  <=  e0 + kappa * (d2 + |thr|)
+// where thr = r^2 for the population sweep (c_q = |x'|^2 - (r^2 - eps)) and 0 for the neighbour sweep.
+//   u * [ 3 M + thr                                   norms rounded once, c_q = fl(|x'|^2 - thr)
+//       + 4.1 M                                       dropped piece products (mid*lo, lo*mid, lo*lo)
+//       + 17 (2 M + thr) + (nb-1) 18 (4.02 M + thr)   the nb MFMAs that hold c_q and the hi*hi products:
+//                                                     17 addends, each truncated to 2^-24 of the largest
+//       + ns 18 (d2 + thr + 0.0165 M) + (d2 + thr)    the ns MFMAs of small products, accumulator ~ d2 - thr
+//       + (D/4 + 9) d2 + 2 M ]                        canonical summation order + centring (as for fp32)
+// with a further factor 1.25 on everything.  nb = ceil((D + 3) / 16), ns = NM - nb.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float guard_eps(float M, float d2cap, int K, int D) {
-  const double u = 5.9604644775390625e-8;
-  const double cap = (d2cap > 0.0f) ? (double)d2cap : 0.0;
-  const double e = 1.25 * u * ((4.0 * K + 10.0) * (double)M + (0.25 * D + 12.0) * cap);
-  const float f = (float)e;
-  if (!(f <= FLT_MAX)) return INFINITY;                 // inf or NaN
-  return __uint_as_float(__float_as_uint(f) + 1u);      // next float up (f >= 0)
+struct GuardBand {
+  float e0;      // absolute part (M and thr terms)
+  float kappa;   // relative part, per unit of d2
+};
+
+__device__ __forceinline__ float next_up(float f) {   // f >= 0 finite; inf / NaN -> inf
+  if (!(f <= FLT_MAX)) return INFINITY;
+  return __uint_as_float(__float_as_uint(f) + 1u);
 }
 
-template <int S>
-__device__ __forceinline__ void load_tile(const float* __restrict__ img,
+__device__ __forceinline__ GuardBand guard_band(float M, float thr, int D) {
+  const double u = 5.9604644775390625e-8;
+  const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
+  const double t = (thr > 0.0f) ? (double)thr : 0.0;
+  const double cM = 3.0 + 4.1 + 34.0 + 72.4 * (nb - 1) + 0.3 * ns + 2.0;
+  const double cT = 1.0 + 17.0 + 18.0 * (nb - 1) + 18.0 * ns + 1.0;
+  const double cD = 18.0 * ns + 1.0 + 0.25 * D + 9.0;
+  GuardBand g;
+  g.e0 = next_up((float)(1.25 * u * (cM * (double)M + cT * t)));
+  g.kappa = next_up((float)(1.25 * u * cD));
+  return g;
+}
+
+// population sweep: one band for all pairs with d2 up to the largest radius of the launch
+__device__ __forceinline__ float guard_eps_pop(float M, float r2max, int D) {
+  const GuardBand g = guard_band(M, r2max, D);
+  const float cap = (r2max > 0.0f) ? r2max : 0.0f;
+  return next_up(g.e0 + g.kappa * cap);
+}
+
+// ---- fp32 -> three bf16 pieces (exact: v = hi + mid + lo for finite v away from underflow) -------
+__device__ __forceinline__ uint32_t bf16_rne(float f) {   // finite f
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_val(uint32_t b) { return __uint_as_float(b << 16); }
+struct Pieces {
+  uint32_t hi, mid, lo;   // bf16 bit patterns
+};
+__device__ __forceinline__ Pieces split3(float v) {
+  Pieces p;
+  p.hi = bf16_rne(v);
+  const float r1 = v - bf16_val(p.hi);     // exact
+  p.mid = bf16_rne(r1);
+  const float r2 = r1 - bf16_val(p.mid);   // exact
+  p.lo = bf16_rne(r2);
+  return p;
+}
+
+// K-slot s of a frame: which piece of which column (or the constant) sits there.
+//   slots 0..2            constant: A side 1.0, B side the pieces (hi, mid, lo) of c_q
+//   slots 3 + g*D + k     column k, piece pair g (A piece x B piece), large products first:
+//                         0 hi*hi, 1 mid*hi, 2 hi*mid, 3 mid*mid, 4 lo*hi, 5 hi*lo
+//   beyond 3 + 6 D        zero padding
+// Returns the bf16 pattern for the A form (reference side) or the B form (query side, column values
+// are those of -2x') of a row whose centred columns are fetched through `col(k)`.
+template <class ColFn>
+__device__ __forceinline__ uint32_t slot_value(uint32_t s, uint32_t D, bool b_form, ColFn col) {
+  if (s < (uint32_t)kConstSlots) return b_form ? 0u : 0x3F80u;   // (the kernels patch c_q in)
+  const uint32_t sp = s - kConstSlots, g = sp / D, k = sp - g * D;
+  if (g >= 6u) return 0u;
+  const float v = b_form ? -2.0f * col(k) : col(k);
+  const Pieces p = split3(v);
+  // piece index (0 hi, 1 mid, 2 lo) per group: A side 0,1,0,1,2,0 ; B side 0,0,1,1,0,2
+  const uint32_t sel = b_form ? ((0x201100u >> (4 * g)) & 3u) : ((0x021010u >> (4 * g)) & 3u);
+  return sel == 0u ? p.hi : (sel == 1u ? p.mid : p.lo);
+}
+
+template <int NM>
+__device__ __forceinline__ void load_tile(const uint4* __restrict__ img,
                                           const float* __restrict__ norms, uint32_t t, int lane,
-                                          int h, float (&a)[S], float4 (&nv)[4]) {
-  const float* ip = img + (size_t)t * (S * 64) + lane;
+                                          int h, s16x8 (&a)[NM], float4 (&nv)[4]) {
+  const uint4* ip = img + (size_t)t * (NM * 64) + lane;
 #pragma unroll
-  for (int s = 0; s < S; ++s) a[s] = ip[s * 64];
+  for (int m = 0; m < NM; ++m) {
+    const uint4 v = ip[m * 64];
+    a[m] = __builtin_bit_cast(s16x8, v);
+  }
   const float4* np = reinterpret_cast<const float4*>(norms + (size_t)t * 32 + 4 * h);
 #pragma unroll
   for (int g = 0; g < 4; ++g) nv[g] = np[2 * g];        // rows 8g + 4h .. +3  <->  registers 4g .. 4g+3
+}
+
+// resident query-side operand of one query tile: B form fragments with the pieces of the per-lane
+// constant c_q patched into slots 0..2 (held by the h = 0 half of the wave)
+template <int NM>
+__device__ __forceinline__ void load_query(const uint4* __restrict__ img_b, uint32_t tile, int lane,
+                                           int h, float cq, s16x8 (&b)[NM]) {
+  const uint4* ip = img_b + (size_t)tile * (NM * 64) + lane;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const uint4 v = ip[m * 64];
+    b[m] = __builtin_bit_cast(s16x8, v);
+  }
+  const Pieces p = split3(cq);
+  if (h == 0) {
+    b[0][0] = (short)p.hi;
+    b[0][1] = (short)p.mid;
+    b[0][2] = (short)p.lo;
+  }
 }
 
 __device__ __forceinline__ void load_frag(const float* __restrict__ rowvals, uint32_t t, int h,
@@ -222,6 +336,18 @@ __device__ __forceinline__ f32x16 frag16(const float4 (&v)[4]) {
   }
   return o;
 }
+
+template <int NM>
+__device__ __forceinline__ f32x16 gram_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM],
+                                             const f32x16& c0) {
+  f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+#pragma unroll
+  for (int m = 1; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[m], acc, 0, 0, 0);
+  return acc;
+}
+
+// a query lane that owns no live row: the constant keeps its accumulators hugely positive
+constexpr float kDeadConst = 1.0e30f;
 
 // row of reference tile t held by register r of a lane in half h
 __device__ __forceinline__ uint32_t tile_row(uint32_t t, int r, int h) {
@@ -249,43 +375,44 @@ __device__ __forceinline__ void tile_min(const f32x16& acc, float& m) {
 // =============================================================================================
 // population count
 // =============================================================================================
+// The accumulator of radius 0 is t_0 = acc (threshold folded into c_q); radius r uses
+// t_r = acc - delta_r with delta_r = (r_r^2 - eps) - (r_0^2 - eps), the same for every query.
 template <int NR>
 struct PopQ {            // per query tile, per lane
-  float nx;              // |x'|^2 of this lane's query; +inf for lanes that own no live query
-  uint32_t cnt[NR];      // (the threshold of radius r is lo_r = (r^2 - eps) - nx: one op per use,
-};                       //  instead of NR more registers per query tile)
+  uint32_t cnt[NR];
+};
 
 template <int NR>
 struct PopAcc {          // per chain scratch
-  uint32_t bits[NR];     // sign bits of (acc - lo), one per element, shifted in from the right
-  uint32_t tmin;         // unsigned min over elements and radii of bits(acc - lo)
+  uint32_t bits[NR];     // sign bits of t_r, one per element, shifted in from the right
+  uint32_t tmin;         // unsigned min over elements and radii of bits(t_r)
 };
 
-// thresholds of one query for all radii of the launch: lo_r = (r^2 - eps) - |x'|^2
 template <int NR>
-__device__ __forceinline__ void pop_lo(const PopQ<NR>& q, const Rad2& rad2e, float (&lo)[NR]) {
+struct PopDeltas {
+  float d[NR];           // d[0] is 0 and never used
+};
+
+template <int NR>
+__device__ __forceinline__ PopDeltas<NR> pop_deltas(const Rad2& rad2e) {
+  PopDeltas<NR> o;
 #pragma unroll
-  for (int rr = 0; rr < NR; ++rr) lo[rr] = rad2e.v[rr] - q.nx;
+  for (int rr = 0; rr < NR; ++rr) o.d[rr] = rad2e.v[rr] - rad2e.v[0];
+  return o;
 }
 
-template <int NR, int R0, int R1>
-__device__ __forceinline__ void pop_epi(const f32x16& acc, const float (&lo)[NR], PopAcc<NR>& e) {
+template <int NR>
+__device__ __forceinline__ void pop_epi(const f32x16& acc, const PopDeltas<NR>& dl, PopAcc<NR>& e) {
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
+    e.bits[rr] = 0;
 #pragma unroll
-    for (int r = R0; r < R1; ++r) {
-      const uint32_t tb = __float_as_uint(acc[r] - lo[rr]);
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t tb = __float_as_uint(rr == 0 ? acc[r] : acc[r] - dl.d[rr]);
       e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], tb, 31);   // (bits << 1) | sign(t)
       e.tmin = min(e.tmin, tb);                                     // negative t: huge unsigned
     }
   }
-}
-
-template <int NR>
-__device__ __forceinline__ void pop_epi_begin(PopAcc<NR>& e) {
-#pragma unroll
-  for (int rr = 0; rr < NR; ++rr) e.bits[rr] = 0;
-  e.tmin = 0xFFFFFFFFu;
 }
 
 template <int NR>
@@ -300,22 +427,19 @@ template <int NR>
 __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restrict__ coords,
                                                           const uint32_t* __restrict__ perm,
                                                           uint32_t n_rows, uint32_t n_cols,
-                                                          Rad2 rad2, Rad2 rad2e, f32x16 acc,
-                                                          PopQ<NR> q, uint32_t wbits, uint32_t jq,
-                                                          uint32_t t, int h) {
+                                                          Rad2 rad2, PopDeltas<NR> dl, f32x16 acc,
+                                                          uint32_t wbits, uint32_t jq, uint32_t t,
+                                                          int h) {
   PopDelta<NR> out;
-  float lo[NR];
 #pragma unroll
-  for (int rr = 0; rr < NR; ++rr) {
-    out.d[rr] = 0;
-    lo[rr] = rad2e.v[rr] - q.nx;   // the same arithmetic as pop_epi
-  }
+  for (int rr = 0; rr < NR; ++rr) out.d[rr] = 0;
   uint32_t m = 0;   // elements of this lane that sit in some radius' band
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     bool any = false;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) any = any | (__float_as_uint(acc[r] - lo[rr]) < wbits);
+    for (int rr = 0; rr < NR; ++rr)   // the same arithmetic as pop_epi
+      any = any | (__float_as_uint(rr == 0 ? acc[r] : acc[r] - dl.d[rr]) < wbits);
     m |= (any & (tile_row(t, r, h) < n_rows)) ? (1u << r) : 0u;
   }
   // lane-parallel exact evaluation: one band pair per lane per iteration (row fetches overlap)
@@ -330,53 +454,54 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restric
       for (int k = 1; k < 16; ++k) av = (r == k) ? acc[k] : av;   // acc[r], r per lane
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
-        if (__float_as_uint(av - lo[rr]) < wbits) out.d[rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
+        if (__float_as_uint(rr == 0 ? av : av - dl.d[rr]) < wbits)
+          out.d[rr] += (d2c < rad2.v[rr]) ? 1u : 0u;
       m &= m - 1;
     }
   }
   return out;
 }
 
-// MFMA chain into acc_new, interleaved with the epilogue of acc_old (query state q_old)
-template <int S, int NR, int SI = 0>
-__device__ __forceinline__ void pop_chain(const float (&a)[S], const float (&b)[S],
-                                          const f32x16& c0, f32x16& acc_new,
-                                          const f32x16& acc_old, const float (&lo_old)[NR],
-                                          PopAcc<NR>& e) {
-  if constexpr (SI < S) {
-    if constexpr (SI == 0)
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
-    else
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
-    pop_epi<NR, (16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, lo_old, e);
-    pop_chain<S, NR, SI + 1>(a, b, c0, acc_new, acc_old, lo_old, e);
-  }
+// thresholds of a population launch, shared by the full and the pruned sweep
+template <int NR>
+struct PopSetup {
+  float eps;
+  uint32_t wbits;        // band width 2*eps as an unsigned key, +1 ulp
+  Rad2 rad2e;            // r^2 - eps
+  PopDeltas<NR> dl;
+};
+
+template <int NR>
+__device__ __forceinline__ PopSetup<NR> pop_setup(const uint32_t* __restrict__ hdr, const Rad2& rad2,
+                                                  uint32_t n_cols) {
+  PopSetup<NR> P;
+  float r2max = rad2.v[0];
+#pragma unroll
+  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
+  P.eps = guard_eps_pop(__uint_as_float(hdr[0]), r2max, (int)n_cols);
+  // (delta_r = fl(rad2e_r - rad2e_0) adds at most u * r2max to the band: inside the 1.25 factor)
+  P.wbits = __float_as_uint(2.0f * P.eps) + 1u;
+#pragma unroll
+  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) P.rad2e.v[rr] = rad2.v[rr] - P.eps;
+  P.dl = pop_deltas<NR>(P.rad2e);
+  return P;
 }
 
-template <int S, int NR, int TQ>
+template <int NM, int NR, int TQ>
 __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
-    const float* __restrict__ img, const float* __restrict__ norms,
-    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to, Rad2 rad2,
-    int n_rad, uint32_t* __restrict__ pops) {
-  static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+    const uint4* __restrict__ img, const uint4* __restrict__ img_b,
+    const float* __restrict__ norms, const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from,
+    uint32_t i_to, Rad2 rad2, int n_rad, uint32_t* __restrict__ pops) {
   if (hdr[1] != 0) return;   // non-finite / overflow-prone data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t qt0 = i_from / 32 + wave * TQ;
   if (qt0 * 32 >= i_to) return;   // whole wave leaves; no barriers in this kernel
 
-  float r2max = rad2.v[0];
-#pragma unroll
-  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
-  const float eps = guard_eps(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
-  // band width 2*eps as an unsigned key; +1 ulp. eps = +inf (never for flagged-free data) -> all
-  const uint32_t wbits = __float_as_uint(2.0f * eps) + 1u;
-  Rad2 rad2e;   // r^2 - eps
-#pragma unroll
-  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) rad2e.v[rr] = rad2.v[rr] - eps;
+  const PopSetup<NR> P = pop_setup<NR>(hdr, rad2, n_cols);
 
-  float b[TQ][S];
+  s16x8 b[TQ][NM];
   PopQ<NR> q[TQ];
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
@@ -387,71 +512,43 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     const bool live = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
-#pragma unroll
-    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
-    q[qt].nx = live ? norms[tl * 32 + c] : INFINITY;
+    const float cq = live ? norms[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
+    load_query<NM>(img_b, tl, lane, h, cq, b[qt]);
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] = 0;
   }
 
-  // accumulator ping-pong: B starts as "+inf everywhere" = contributes nothing
-  f32x16 accA, accB;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
-  uint32_t tB = 0;   // reference tile accB belongs to
-
-  float a0[S], a1[S];
+  s16x8 a0[NM], a1[NM];
   float4 n0[4], n1[4];
-  load_tile<S>(img, norms, 0, lane, h, a0, n0);
+  load_tile<NM>(img, norms, 0, lane, h, a0, n0);
 
-  auto finish = [&](const f32x16& acc, int qi, PopAcc<NR>& e, uint32_t t) {
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
-    const bool band = e.tmin < wbits;
-    if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
-      const PopDelta<NR> dl = pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, rad2e, acc, q[qi], wbits, jq[qi], t, h);
-#pragma unroll
-      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += ((livemask[qi] >> lane) & 1) ? dl.d[rr] : 0u;
-    }
-  };
-
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
+  auto tile_body = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);
 #pragma unroll
-    for (int qt = 0; qt < TQ; qt += 2) {
-      // chain qt -> accA while finishing accB (= query tile TQ-1 of the previous reference tile
-      // when qt == 0, else qt-1 of this one)
-      constexpr int kLast = TQ - 1;
-      const int qb = (qt == 0) ? kLast : qt - 1;
+    for (int qt = 0; qt < TQ; ++qt) {
+      const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
       PopAcc<NR> e;
-      float lo[NR];
-      pop_epi_begin<NR>(e);
-      pop_lo<NR>(q[qb], rad2e, lo);
-      pop_chain<S, NR>(a, b[qt], c0, accA, accB, lo, e);
-      finish(accB, qb, e, tB);
-      pop_epi_begin<NR>(e);
-      pop_lo<NR>(q[qt], rad2e, lo);
-      pop_chain<S, NR>(a, b[qt + 1], c0, accB, accA, lo, e);
-      finish(accA, qt, e, t);
-      tB = t;
+      e.tmin = 0xFFFFFFFFu;
+      pop_epi<NR>(acc, P.dl, e);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+      const bool band = e.tmin < P.wbits;
+      if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qt]) != 0, 0)) {
+        const PopDelta<NR> dl =
+            pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qt], t, h);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
+      }
     }
   };
 
   for (uint32_t t = 0; t < T; t += 2) {
-    load_tile<S>(img, norms, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
+    load_tile<NM>(img, norms, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
     tile_body(a0, n0, t);
     if (t + 1 < T) {
-      load_tile<S>(img, norms, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
+      load_tile<NM>(img, norms, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
       tile_body(a1, n1, t + 1);
     }
-  }
-  {  // drain: epilogue of the last accB
-    PopAcc<NR> e;
-    float lo[NR];
-    pop_epi_begin<NR>(e);
-    pop_lo<NR>(q[TQ - 1], rad2e, lo);
-    pop_epi<NR, 0, 16>(accB, lo, e);
-    finish(accB, TQ - 1, e, tB);
   }
 
 #pragma unroll
@@ -481,6 +578,39 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
 // query tile.  Counting, guard band and exact re-check are those of pop_mfma_kernel.
 // ---------------------------------------------------------------------------------------------
 constexpr int kListCap = 1024;   // reference tiles scanned per round (LDS list entries per wave)
+constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane and query tile
+
+// ---- deferred exact re-check (pruned sweep) --------------------------------------------------------
+// A band pair is not evaluated the moment it appears (one or two lanes busy for a full, dependent
+// memory latency each time -- measured: a third of the sweep); it is parked as (reference position,
+// radii whose band it sits in) in a small per-lane LDS queue.  When a lane's queue is full, and at
+// the end, all lanes evaluate their entries in parallel: query row from LDS (staged once per wave),
+// reference row from a copy of the ORIGINAL coordinates gathered into the reference order.
+constexpr uint32_t kPopQueuePosBits = 24;    // entry = position | radius flags << 24
+constexpr uint32_t kPopQueueMaxRows = 1u << kPopQueuePosBits;
+
+template <int NR>
+__device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queue /* [kQueueCap][64] */,
+                                                            uint32_t count, const float* qrow,
+                                                            const float* __restrict__ coords_r,
+                                                            uint32_t n_cols, Rad2 rad2, int lane) {
+  PopDelta<NR> out;
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) out.d[rr] = 0;
+#pragma unroll
+  for (int k = 0; k < kQueueCap; ++k) {
+    if (__builtin_amdgcn_ballot_w64((uint32_t)k < count) == 0) break;
+    if ((uint32_t)k < count) {
+      const uint32_t ent = queue[k * 64 + lane];
+      const uint32_t pos = ent & (kPopQueueMaxRows - 1u), flags = ent >> kPopQueuePosBits;
+      const float d2c = dist2_canon_rt(qrow, 1, coords_r + (size_t)pos * n_cols, 1, (int)n_cols);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr)
+        out.d[rr] += ((((flags >> rr) & 1u) != 0u) & (d2c < rad2.v[rr])) ? 1u : 0u;
+    }
+  }
+  return out;
+}
 
 __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
   // boxes are (lo0, hi0, lo1, hi1); squared distance between them in the (col 0, col 1) plane
@@ -489,25 +619,20 @@ __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
   return dx * dx + dy * dy;
 }
 
-template <int S>
-__device__ __forceinline__ f32x16 gram_chain(const float (&a)[S], const float (&b)[S],
-                                             const f32x16& c0) {
-  f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
-#pragma unroll
-  for (int s = 1; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-  return acc;
-}
-
-template <int S, int NR, int TQ>
+template <int NM, int NR, int TQ>
 __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
-    const float* __restrict__ img_r, const float* __restrict__ norms_r,
-    const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r, uint32_t T,
-    const float* __restrict__ img_q, const float* __restrict__ norms_q,
+    const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
+    const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r,
+    const float* __restrict__ coords_r, uint32_t T,
+    const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
     int n_rad, uint32_t* __restrict__ pops) {
   __shared__ uint32_t lists[4][kListCap];
+  // dynamic LDS: [4 waves][TQ*32][n_cols] query rows (original coordinates), then the queues of
+  // deferred exact evaluations [4 waves][TQ][kQueueCap][64]
+  extern __shared__ __attribute__((aligned(16))) float pop_qrows_all[];
   if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
@@ -520,18 +645,21 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
   uint32_t* list = lists[wib];
+  float* qrows = pop_qrows_all + (size_t)wib * (TQ * 32) * n_cols;
+  uint32_t* queues = reinterpret_cast<uint32_t*>(pop_qrows_all + (size_t)4 * (TQ * 32) * n_cols) +
+                     (size_t)wib * TQ * kQueueCap * 64;
+  const bool use_queue = n_rows <= kPopQueueMaxRows;   // positions fit the queue entries
+  uint32_t qcount[TQ];
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) qcount[qt] = 0;
 
+  const PopSetup<NR> P = pop_setup<NR>(hdr, rad2, n_cols);
   float r2max = rad2.v[0];
 #pragma unroll
   for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
-  const float eps = guard_eps(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
-  const uint32_t wbits = __float_as_uint(2.0f * eps) + 1u;
   const float far2 = r2max * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
-  Rad2 rad2e;   // r^2 - eps
-#pragma unroll
-  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) rad2e.v[rr] = rad2.v[rr] - eps;
 
-  float b[TQ][S];
+  s16x8 b[TQ][NM];
   PopQ<NR> q[TQ];
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
@@ -545,9 +673,11 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const bool live = (tile < TQT) && (pos < n_q);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? perm_q[pos] : 0u;
-#pragma unroll
-    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img_q[((size_t)tl * S + s) * 64 + lane];
-    q[qt].nx = live ? norms_q[tl * 32 + c] : INFINITY;
+    const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
+    load_query<NM>(img_q, tl, lane, h, cq, b[qt]);
+    if (h == 0)   // original coordinates of this lane's query, for the exact path
+      for (uint32_t k = 0; k < n_cols; ++k)
+        qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] = 0;
     qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
@@ -556,6 +686,16 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
+
+  // evaluate and empty the queue of query tile qi (all lanes in parallel per slot)
+  auto flush = [&](int qi) {
+    if (__builtin_amdgcn_ballot_w64(qcount[qi] != 0) == 0) return;
+    const PopDelta<NR> dl = pop_flush<NR>(queues + qi * (kQueueCap * 64), qcount[qi],
+                                          qrows + (qi * 32 + c) * n_cols, coords_r, n_cols, rad2, lane);
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += dl.d[rr];
+    qcount[qi] = 0;
+  };
 
   uint32_t chains = 0;
   for (uint32_t base = 0; base < T; base += kListCap) {
@@ -580,72 +720,87 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       cnt += (uint32_t)__builtin_popcountll(m);
     }
     if (cnt == 0) continue;
-    // ---- process the survivors: reference tile data in three rotating register buffers, i.e. the
-    //      loads of survivor i+2 are in flight while survivor i is being computed
-    float a0[S], a1[S], a2[S];
-    float4 n0[4], n1[4], n2[4];
+    // ---- process the survivors: the operands of survivor i+1 are in flight while survivor i is
+    //      being computed
+    s16x8 a0[NM], a1[NM];
+    float4 n0[4], n1[4];
     auto entry = [&](uint32_t i) {
       return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
     };
-    auto compute = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t ent) {
+    auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t ent) {
       const uint32_t t = ent & 0x0FFFFFFFu, qmask = ent >> 28;
       const f32x16 c0 = frag16(nv);
 #pragma unroll
       for (int qt = 0; qt < TQ; ++qt) {
         if (!(qmask & (1u << qt))) continue;                // scalar test: boxes are per tile
         ++chains;
-        const f32x16 acc = gram_chain<S>(a, b[qt], c0);
+        const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
         PopAcc<NR> e;
-        float lo[NR];
-        pop_epi_begin<NR>(e);
-        pop_lo<NR>(q[qt], rad2e, lo);
-        pop_epi<NR, 0, 16>(acc, lo, e);
+        e.tmin = 0xFFFFFFFFu;
+        pop_epi<NR>(acc, P.dl, e);
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
-        const bool band = e.tmin < wbits;
+        const bool band = e.tmin < P.wbits;
         if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qt]) != 0, 0)) {
-          const PopDelta<NR> dl =
-              pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, rad2e, acc, q[qt], wbits, jq[qt], t, h);
+          if (use_queue) {
+            // park the band elements of this lane: (position, radii whose band holds the element).
+            // Band <=> 0 <= t < w: the sign string of (t - w) minus the sign string of t, both in the
+            // order of the epilogue (element r at bit 15 - r).  Pad rows (acc = +inf) and idle lanes
+            // (acc ~ 1e30) are never in a band, so no further masking is needed.
+            const float w = __uint_as_float(P.wbits);
+            uint32_t fl[NR];   // per radius: bit (15 - r) set <=> element r sits in that radius' band
 #pragma unroll
-          for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
+            for (int rr = 0; rr < NR; ++rr) {
+              uint32_t below = 0;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float tv = rr == 0 ? acc[r] : acc[r] - P.dl.d[rr];
+                below = __builtin_amdgcn_alignbit(below, __float_as_uint(tv - w), 31);
+              }
+              fl[rr] = below & ~e.bits[rr] & 0xFFFFu;
+            }
+            uint32_t m = 0;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) m |= fl[rr];
+            uint32_t* qu = queues + qt * (kQueueCap * 64);
+            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+              if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qt] == (uint32_t)kQueueCap)) != 0)
+                flush(qt);
+              if (m != 0) {
+                const int p = __builtin_ctz(m);
+                uint32_t flags = 0;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) flags |= ((fl[rr] >> p) & 1u) << rr;
+                qu[qcount[qt] * 64 + lane] = tile_row(t, 15 - p, h) | (flags << kPopQueuePosBits);
+                ++qcount[qt];
+                m &= m - 1;
+              }
+            }
+          } else {
+            const PopDelta<NR> dl =
+                pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qt], t, h);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
+          }
         }
       }
     };
-    if constexpr (S <= 8) {
-      uint32_t e0 = entry(0), e1 = entry(1), e2;
-      load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
-      load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
-      for (uint32_t i = 0; i < cnt; i += 3) {
-        e2 = entry(i + 2);
-        load_tile<S>(img_r, norms_r, e2 & 0x0FFFFFFFu, lane, h, a2, n2);
-        compute(a0, n0, e0);
-        if (i + 1 < cnt) {
-          e0 = entry(i + 3);
-          load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
-          compute(a1, n1, e1);
-        }
-        if (i + 2 < cnt) {
-          e1 = entry(i + 4);
-          load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
-          compute(a2, n2, e2);
-        }
-      }
-    } else {   // many K-steps: the operand registers are scarce, one survivor of look-ahead
-      uint32_t e0 = entry(0), e1;
-      load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
-      for (uint32_t i = 0; i < cnt; i += 2) {
-        e1 = entry(i + 1);
-        load_tile<S>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
-        compute(a0, n0, e0);
-        if (i + 1 < cnt) {
-          e0 = entry(i + 2);
-          load_tile<S>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
-          compute(a1, n1, e1);
-        }
+    uint32_t e0 = entry(0), e1;
+    load_tile<NM>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+    for (uint32_t i = 0; i < cnt; i += 2) {
+      e1 = entry(i + 1);
+      load_tile<NM>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
+      compute(a0, n0, e0);
+      if (i + 1 < cnt) {
+        e0 = entry(i + 2);
+        load_tile<NM>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+        compute(a1, n1, e1);
       }
     }
   }
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) flush(qt);
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
@@ -753,42 +908,31 @@ __device__ __attribute__((noinline)) NnBest nn_fix(const float* __restrict__ coo
   return best;
 }
 
-template <int S, int SI = 0>
-__device__ __forceinline__ void nn_chain(const float (&a)[S], const float (&b)[S],
-                                         const f32x16& c0, f32x16& acc_new, const f32x16& acc_old,
-                                         float& tmin) {
-  if constexpr (SI < S) {
-    if constexpr (SI == 0)
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
-    else
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
-    tile_min<(16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, tmin);
-    nn_chain<S, SI + 1>(a, b, c0, acc_new, acc_old, tmin);
-  }
+// band of the neighbour sweep: candidates are the frames whose MFMA value is below
+// m + 2.5 (e0 + kappa m), m the running minimum (the relative part makes the band follow the
+// distance scale of the query; 2.5 > 2 covers the error of the minimum AND of the candidate)
+__device__ __forceinline__ float nn_band(const GuardBand& g, float m) {
+  return m + 2.5f * (g.e0 + g.kappa * fmaxf(m, 0.0f));
 }
 
-template <int S, int TQ>
+template <int NM, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
-    const float* __restrict__ img, const float* __restrict__ img_s,
-    const float* __restrict__ norms_s, const uint32_t* __restrict__ perm,
-    const uint32_t* __restrict__ invpos, const uint32_t* __restrict__ pq_of,
-    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to,
-    uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
-    float* __restrict__ hd_d2) {
-  static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+    const uint4* __restrict__ img_b, const float* __restrict__ norms,
+    const uint4* __restrict__ img_s, const float* __restrict__ norms_s,
+    const uint32_t* __restrict__ perm, const uint32_t* __restrict__ invpos,
+    const uint32_t* __restrict__ pq_of, const uint32_t* __restrict__ hdr, uint32_t T,
+    uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
+    uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t qt0 = i_from / 32 + wave * TQ;
   if (qt0 * 32 >= i_to) return;
 
-  const float M = __uint_as_float(hdr[0]);
-  // candidates can be as far apart as 2*sqrt(M): d2cap = 4M
-  const float eps = guard_eps(M, 4.0f * M, 2 * S, (int)n_cols);
-  const float eps2 = 2.5f * eps;
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]), 0.0f, (int)n_cols);
 
-  float b[TQ][S];
+  s16x8 b[TQ][NM];
   NnQ q[TQ];
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
@@ -799,8 +943,7 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const bool live = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
-#pragma unroll
-    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
+    load_query<NM>(img_b, tl, lane, h, live ? norms[tl * 32 + c] : kDeadConst, b[qt]);
     const uint32_t jl = live ? jq[qt] : (n_rows - 1);
     q[qt].pq = live ? pq_of[jl] : 0u;
     q[qt].spos = live ? invpos[jl] : 0xFFFFFFFFu;
@@ -816,70 +959,51 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     q[qt].bj_hd = n_rows + 1;
   }
 
-  f32x16 accA, accB;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
-  uint32_t tB = 0;
-
-  float a0[S], a1[S];
+  s16x8 a0[NM], a1[NM];
   float4 n0[4], n1[4];
-  load_tile<S>(img_s, norms_s, 0, lane, h, a0, n0);
+  load_tile<NM>(img_s, norms_s, 0, lane, h, a0, n0);
 
-  // finish one accumulator tile: minima, band test against the running minima, rare exact path.
+  // one accumulator tile: minima, band test against the running minima, rare exact path.
   // Bitwise logic on purpose (no short-circuit control flow in the hot path).
-  auto finish = [&](const f32x16& acc, int qi, float tmin, uint32_t t) {
-    NnQ& Q = q[qi];
-    const bool special = (t == Q.t_self) | (t == Q.t_part);
-    float hmin = (t < Q.t_full) ? tmin : INFINITY;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
-      const NnMin g = nn_special(acc, t, h, Q.spos, Q.pq);   // valid for every lane, just slower
-      tmin = g.tmin;
-      hmin = g.hmin;
-    }
-    const bool trig = (tmin < Q.m_nn + eps2) | (hmin < Q.m_hd + eps2);
-    const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
-      const bool live = (livemask[qi] >> lane) & 1;
-      NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-      best = nn_fix(coords, perm, n_rows, n_cols, acc, new_nn + eps2, new_hd + eps2, best, jq[qi],
-                    Q.spos, Q.pq, t, h);
-      Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
-      Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
-      Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
-      Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
-    }
-    Q.m_nn = new_nn;
-    Q.m_hd = new_hd;
-  };
-
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
+  auto tile_body = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);
 #pragma unroll
-    for (int qt = 0; qt < TQ; qt += 2) {
-      constexpr int kLast = TQ - 1;
-      const int qb = (qt == 0) ? kLast : qt - 1;
+    for (int qt = 0; qt < TQ; ++qt) {
+      NnQ& Q = q[qt];
+      const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
       float tmin = INFINITY;
-      nn_chain<S>(a, b[qt], c0, accA, accB, tmin);
-      finish(accB, qb, tmin, tB);
-      tmin = INFINITY;
-      nn_chain<S>(a, b[qt + 1], c0, accB, accA, tmin);
-      finish(accA, qt, tmin, t);
-      tB = t;
+      tile_min<0, 16>(acc, tmin);
+      const bool special = (t == Q.t_self) | (t == Q.t_part);
+      float hmin = (t < Q.t_full) ? tmin : INFINITY;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
+        const NnMin g = nn_special(acc, t, h, Q.spos, Q.pq);   // valid for every lane, just slower
+        tmin = g.tmin;
+        hmin = g.hmin;
+      }
+      const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+      const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
+      const bool trig = (tmin < bn) | (hmin < bh);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
+        const bool live = (livemask[qt] >> lane) & 1;
+        NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
+        best = nn_fix(coords, perm, n_rows, n_cols, acc, bn, bh, best, jq[qt], Q.spos, Q.pq, t, h);
+        Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
+        Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
+        Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
+        Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
+      }
+      Q.m_nn = new_nn;
+      Q.m_hd = new_hd;
     }
   };
 
   for (uint32_t t = 0; t < T; t += 2) {
-    load_tile<S>(img_s, norms_s, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
+    load_tile<NM>(img_s, norms_s, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
     tile_body(a0, n0, t);
     if (t + 1 < T) {
-      load_tile<S>(img_s, norms_s, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
+      load_tile<NM>(img_s, norms_s, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
       tile_body(a1, n1, t + 1);
     }
-  }
-  {  // drain: epilogue of the last accB
-    float tmin = INFINITY;
-    tile_min<0, 16>(accB, tmin);
-    finish(accB, TQ - 1, tmin, tB);
   }
 
 #pragma unroll
@@ -979,7 +1103,6 @@ __device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ 
 // evaluates whole queue slots at once: every lane of the wave then fetches and evaluates ITS entry
 // in parallel.  The approximate running minima that select candidates never depend on exact
 // values, so deferring changes nothing but the order of the lexicographic merges.
-constexpr int kQueueCap = 4;                 // entries per lane and query tile
 constexpr uint32_t kQueuePosMask = 0x3FFFFFFFu;   // entry = position | nn-flag << 30 | hd-flag << 31
 
 __device__ __attribute__((noinline)) NnBest nn_flush(const uint32_t* queue /* [kQueueCap][64] */,
@@ -1014,15 +1137,15 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-template <int S, int TQ>
+template <int NM, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
-    const float* __restrict__ fe, const float* __restrict__ img_r,
+    const float* __restrict__ fe, const uint4* __restrict__ img_r,
     const float* __restrict__ norms_r, const uint32_t* __restrict__ perm_r,
     const float4* __restrict__ box_r, const float2* __restrict__ ferange_r,
     const float* __restrict__ fe_c, const float* __restrict__ coords_c,
     const uint32_t* __restrict__ invpos_r, uint32_t T,
-    const float* __restrict__ img_q, const float* __restrict__ norms_q,
+    const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q,
     int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
@@ -1048,15 +1171,13 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) qcount[qt] = 0;
 
-  const float M = __uint_as_float(hdr[0]);
-  const float eps = guard_eps(M, 4.0f * M, 2 * S, (int)n_cols);
-  const float eps2 = 2.5f * eps;
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]), 0.0f, (int)n_cols);
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows);
     cell2 = cl * cl;
   }
 
-  float b[TQ][S];
+  s16x8 b[TQ][NM];
   NnPQ q[TQ];
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
@@ -1071,8 +1192,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const bool live = (tile < TQT) && (pos < n_q);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? perm_q[pos] : 0u;
-#pragma unroll
-    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img_q[((size_t)tl * S + s) * 64 + lane];
+    load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : kDeadConst, b[qt]);
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
     if (h == 0)   // original coordinates of this lane's query, for the exact path
@@ -1085,12 +1205,11 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     if (n_chunks > 1 && live) {
       // what the waves of other reference chunks have already published for this query: an exact
       // upper bound.  Only candidates that can still beat (or tie) it need to be looked at, i.e.
-      // MFMA values below (d2 - |x'|^2) + eps; the band test adds its usual 2.5 eps on top.
+      // MFMA values below d2 + eps(d2); the band test adds its usual margin on top.
       g_nn[qt] = __uint_as_float((uint32_t)(merge64[jq[qt]] >> 32));
       g_hd[qt] = __uint_as_float((uint32_t)(merge64[(size_t)n_rows + jq[qt]] >> 32));
-      const float nx = norms_q[tl * 32 + c];
-      if (g_nn[qt] < FLT_MAX) q[qt].m_nn = (g_nn[qt] - nx) + eps;
-      if (g_hd[qt] < FLT_MAX) q[qt].m_hd = (g_hd[qt] - nx) + eps;
+      if (g_nn[qt] < FLT_MAX) q[qt].m_nn = g_nn[qt] + (gb.e0 + gb.kappa * g_nn[qt]);
+      if (g_hd[qt] < FLT_MAX) q[qt].m_hd = g_hd[qt] + (gb.e0 + gb.kappa * g_hd[qt]);
     }
     q[qt].bd_nn = FLT_MAX;
     q[qt].bd_hd = FLT_MAX;
@@ -1147,17 +1266,17 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       }
       if (cnt == 0) continue;
       visited += cnt;
-      // reference tile data in three rotating register buffers (loads run two survivors ahead)
-      float a0[S], a1[S], a2[S];
-      float4 n0[4], n1[4], n2[4], f0[4], f1[4], f2[4];
+      // reference tile data in two register buffers (the loads run one survivor ahead)
+      s16x8 a0[NM], a1[NM];
+      float4 n0[4], n1[4], f0[4], f1[4];
       auto entry = [&](uint32_t i) {
         return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
       };
-      auto issue = [&](uint32_t t, float (&a)[S], float4 (&nv)[4], float4 (&fv)[4]) {
-        load_tile<S>(img_r, norms_r, t, lane, h, a, nv);
+      auto issue = [&](uint32_t t, s16x8 (&a)[NM], float4 (&nv)[4], float4 (&fv)[4]) {
+        load_tile<NM>(img_r, norms_r, t, lane, h, a, nv);
         load_frag(fe_c, t, h, fv);
       };
-      auto compute = [&](const float (&a)[S], const float4 (&nv)[4], const float4 (&fv)[4],
+      auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], const float4 (&fv)[4],
                          uint32_t t) {
         const f32x16 c0 = frag16(nv);
         const float2 fr = ferange_r[t];
@@ -1165,14 +1284,15 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         for (int qt = 0; qt < TQ; ++qt) {
           NnPQ& Q = q[qt];
           ++chains;
-          const f32x16 acc = gram_chain<S>(a, b[qt], c0);
+          const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
           float tmin = INFINITY;
           tile_min<0, 16>(acc, tmin);
           const bool all_lower = fr.y < Q.feq;
           const bool mixed = (fr.x < Q.feq) & !all_lower;
           const bool special = mixed | (t == (Q.spos >> 5));
           float hmin = all_lower ? tmin : INFINITY;
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
+          const bool any_special = __builtin_amdgcn_ballot_w64(special) != 0;
+          if (__builtin_expect(any_special, 0)) {
             // masked per-element minima (the tile holds the query itself and/or straddles feq)
             const f32x16 fef = frag16(fv);
             tmin = INFINITY;
@@ -1184,20 +1304,34 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
             }
           }
-          const bool trig = (tmin < Q.m_nn + eps2) | (hmin < Q.m_hd + eps2);
           const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+          const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
+          const bool trig = (tmin < bn) | (hmin < bh);
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
-            // park this tile's candidates (values within the band of the running minima)
-            const f32x16 fef = frag16(fv);
-            const float bn = new_nn + eps2, bh = new_hd + eps2;
-            const bool live = (livemask[qt] >> lane) & 1;
+            // park this tile's candidates (values within the band of the running minima); element r
+            // of the accumulator is bit (15 - r) of the masks
             uint32_t mn = 0, mh = 0;
+            if (!any_special && t + 1 != T) {
+              // plain tile: below-threshold sign strings (idle lanes have thresholds of -inf, pad rows
+              // only exist in the last tile)
+              uint32_t sn = 0, sh = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const uint32_t pos = tile_row(t, r, h);
-              const bool other = live & (pos != Q.spos) & (pos < n_rows);
-              mn |= (other & (acc[r] < bn)) ? (1u << r) : 0u;
-              mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (1u << r) : 0u;
+              for (int r = 0; r < 16; ++r) {
+                sn = __builtin_amdgcn_alignbit(sn, __float_as_uint(acc[r] - bn), 31);
+                sh = __builtin_amdgcn_alignbit(sh, __float_as_uint(acc[r] - bh), 31);
+              }
+              mn = sn & 0xFFFFu;
+              mh = all_lower ? (sh & 0xFFFFu) : 0u;
+            } else {
+              const f32x16 fef = frag16(fv);
+              const bool live = (livemask[qt] >> lane) & 1;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const uint32_t pos = tile_row(t, r, h);
+                const bool other = live & (pos != Q.spos) & (pos < n_rows);
+                mn |= (other & (acc[r] < bn)) ? (0x8000u >> r) : 0u;
+                mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (0x8000u >> r) : 0u;
+              }
             }
             uint32_t m = mn | mh;
             uint32_t* qu = queues + qt * (kQueueCap * 64);
@@ -1205,9 +1339,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qt] == (uint32_t)kQueueCap)) != 0)
                 flush(qt);
               if (m != 0) {
-                const int r = __builtin_ctz(m);
+                const int p = __builtin_ctz(m);
                 qu[qcount[qt] * 64 + lane] =
-                    tile_row(t, r, h) | (((mn >> r) & 1u) << 30) | (((mh >> r) & 1u) << 31);
+                    tile_row(t, 15 - p, h) | (((mn >> p) & 1u) << 30) | (((mh >> p) & 1u) << 31);
                 ++qcount[qt];
                 m &= m - 1;
               }
@@ -1217,37 +1351,16 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           Q.m_hd = new_hd;
         }
       };
-      if constexpr (S <= 8) {
-        uint32_t t0 = entry(0), t1 = entry(1), t2;
-        issue(t0, a0, n0, f0);
+      uint32_t t0 = entry(0), t1;
+      issue(t0, a0, n0, f0);
+      for (uint32_t i = 0; i < cnt; i += 2) {
+        t1 = entry(i + 1);
         issue(t1, a1, n1, f1);
-        for (uint32_t i = 0; i < cnt; i += 3) {
-          t2 = entry(i + 2);
-          issue(t2, a2, n2, f2);
-          compute(a0, n0, f0, t0);
-          if (i + 1 < cnt) {
-            t0 = entry(i + 3);
-            issue(t0, a0, n0, f0);
-            compute(a1, n1, f1, t1);
-          }
-          if (i + 2 < cnt) {
-            t1 = entry(i + 4);
-            issue(t1, a1, n1, f1);
-            compute(a2, n2, f2, t2);
-          }
-        }
-      } else {   // many K-steps: one survivor of look-ahead
-        uint32_t t0 = entry(0), t1;
-        issue(t0, a0, n0, f0);
-        for (uint32_t i = 0; i < cnt; i += 2) {
-          t1 = entry(i + 1);
-          issue(t1, a1, n1, f1);
-          compute(a0, n0, f0, t0);
-          if (i + 1 < cnt) {
-            t0 = entry(i + 2);
-            issue(t0, a0, n0, f0);
-            compute(a1, n1, f1, t1);
-          }
+        compute(a0, n0, f0, t0);
+        if (i + 1 < cnt) {
+          t0 = entry(i + 2);
+          issue(t0, a0, n0, f0);
+          compute(a1, n1, f1, t1);
         }
       }
     }
@@ -1332,11 +1445,12 @@ __global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ me
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch helpers (one K-step count per translation unit)
+// launch helpers (one MFMA count per translation unit; the template parameter S below is NM)
 // ---------------------------------------------------------------------------------------------
-// query tiles per wave: 4 while the resident B fragments (TQ*S registers) are cheap, 2 beyond
-template <int S>
-constexpr int tq_for = (S <= 8) ? 4 : 2;
+// query tiles per wave: as many as the resident B fragments (4 * TQ * NM registers) and the two A
+// buffers (8 * NM) leave room for at two waves per SIMD
+template <int NM>
+constexpr int tq_for = (NM <= 4) ? 4 : (NM <= 8) ? 2 : 1;
 
 inline uint32_t grid_for(uint32_t i_from, uint32_t i_to, int tq) {
   const uint32_t tiles = (i_to + 31) / 32 - i_from / 32;
@@ -1352,17 +1466,17 @@ void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const P
   const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
   if (n_rad == 1)
     hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
+                       P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
   else if (n_rad <= 4)
     hipLaunchKernelGGL((pop_mfma_kernel<S, 4, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
+                       P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
   else
     hipLaunchKernelGGL((pop_mfma_kernel<S, 8, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
+                       P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
 }
 
 struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy) ordering
-  const float* img_r;
+  const uint4* img_r;
   const float* norms_r;
   const uint32_t* perm_r;
   const float4* box_r;
@@ -1370,7 +1484,7 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   const float* fe_c;
   const float* coords_c;
   const uint32_t* invpos_r;
-  const float* img_q;
+  const uint4* img_q;
   const float* norms_q;
   const uint32_t* perm_q;
   const float4* box_q;
@@ -1459,13 +1573,16 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
                        uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
   const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
   const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T)), block(256);
-  const float* img_q = full_range ? P.img_p : P.img_q;
+  const uint4* img_q = P.img_q;   // B form of the query rows (all rows, same order, if full_range)
   const float* norms_q = full_range ? P.norms_p : P.norms_q;
   const uint32_t* perm_q = full_range ? P.perm_p : P.perm_q;
   const float4* box_q = full_range ? P.box_p : P.box_q;
-  hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV>), grid, block, 0, s, coords, n_rows, n_cols,
-                     P.img_p, P.norms_p, P.perm_p, P.box_p, T, img_q, norms_q, perm_q, box_q, n_q,
-                     P.hdr, chain_counter, rad2, n_rad, pops);
+  // query rows (original coordinates) + queues of deferred exact evaluations, per wave
+  const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
+                      sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
+  hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV>), grid, block, smem, s, coords, n_rows, n_cols,
+                     P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q,
+                     box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops);
 }
 
 template <int S, int NRV>
@@ -1510,15 +1627,15 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                  float* hd_d2, hipStream_t s) {
   constexpr int kTQnn = tq_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQnn)), block(256);
-  hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                     P.img_s, P.norms_s, P.perm, P.invpos, P.pq, P.hdr, T, i_from, i_to, nn_idx,
+  hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img_b,
+                     P.norms, P.img_s, P.norms_s, P.perm, P.invpos, P.pq, P.hdr, T, i_from, i_to, nn_idx,
                      nn_d2, hd_idx, hd_d2);
 }
 
 }  // namespace
 
-// one translation unit per K-step count (dc_mfma_step.hip, -DDC_STEP=n) so the instances build
-// in parallel; dc_mfma.hip switches over them.
+// one translation unit per MFMA count NM = nm_for(n_cols) (dc_mfma_step.hip, -DDC_STEP=n) so the
+// instances build in parallel; dc_mfma.hip switches over them.
 #define DC_DECLARE_STEP(SV)                                                                      \
   void pop_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,     \
                           uint32_t i_from, uint32_t i_to, const Rad2& rad2, int n_rad,           \

@@ -1,9 +1,9 @@
-// dc_mfma_step.hip -- instantiates the MFMA sweeps for ONE K-step count (compile with -DDC_STEP=n,
-// n = ceil(n_cols/2)); see dc_mfma_kernels.hpp.
+// dc_mfma_step.hip -- instantiates the MFMA sweeps for ONE MFMA count per tile pair (compile with
+// -DDC_STEP=n, n = nm_for(n_cols) = ceil((6 n_cols + 3) / 16)); see dc_mfma_kernels.hpp.
 #include "dc_mfma_kernels.hpp"
 
 #ifndef DC_STEP
-#error "compile with -DDC_STEP=<number of K-steps>"
+#error "compile with -DDC_STEP=<MFMAs per tile pair>"
 #endif
 #define DC_CAT2(a, b) a##b
 #define DC_CAT(a, b) DC_CAT2(a, b)
@@ -34,7 +34,7 @@ void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
   NnPrunedArgs A;
-  A.img_r = (const float*)(p + L.off_img_p);
+  A.img_r = (const uint4*)(p + L.off_img_p);
   A.norms_r = (const float*)(p + L.off_norm_p);
   A.perm_r = (const uint32_t*)(p + L.off_perm_p);
   A.box_r = (const float4*)(p + L.off_box_p);
@@ -42,7 +42,7 @@ void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint
   A.fe_c = (const float*)(p + L.off_fe_s);
   A.coords_c = (const float*)(p + L.off_coords_p);
   A.invpos_r = (const uint32_t*)(p + L.off_invpos);
-  A.img_q = full_range ? A.img_r : (const float*)(p + L.off_img_q);
+  A.img_q = (const uint4*)(p + L.off_img_q);   // B form of the query rows
   A.norms_q = full_range ? A.norms_r : (const float*)(p + L.off_norm_q);
   A.perm_q = full_range ? A.perm_r : (const uint32_t*)(p + L.off_perm_q);
   A.box_q = full_range ? A.box_r : (const float4*)(p + L.off_box_q);
