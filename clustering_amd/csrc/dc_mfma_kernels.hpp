@@ -63,6 +63,8 @@
 #include <float.h>
 #include <math.h>
 
+#include <type_traits>
+
 namespace dc {
 
 namespace {
@@ -346,6 +348,16 @@ __device__ __forceinline__ f32x16 gram_chain(const s16x8 (&a)[NM], const s16x8 (
   return acc;
 }
 
+// f(integral_constant<0>), f(integral_constant<2>), ... for the even indices below N (compile-time
+// indices for register arrays inside the pipelined tile bodies)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void constexpr_for_pairs(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    constexpr_for_pairs<N, I + 2>(f);
+  }
+}
+
 // a query lane that owns no live row: the constant keeps its accumulators hugely positive
 constexpr float kDeadConst = 1.0e30f;
 
@@ -402,16 +414,40 @@ __device__ __forceinline__ PopDeltas<NR> pop_deltas(const Rad2& rad2e) {
 }
 
 template <int NR>
+__device__ __forceinline__ void pop_epi_begin(PopAcc<NR>& e) {
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) e.bits[rr] = 0;
+  e.tmin = 0xFFFFFFFFu;
+}
+
+// elements [R0, R1) of one accumulator tile (element r ends up at bit 15 - r of the sign strings)
+template <int NR, int R0, int R1>
 __device__ __forceinline__ void pop_epi(const f32x16& acc, const PopDeltas<NR>& dl, PopAcc<NR>& e) {
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
-    e.bits[rr] = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = R0; r < R1; ++r) {
       const uint32_t tb = __float_as_uint(rr == 0 ? acc[r] : acc[r] - dl.d[rr]);
       e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], tb, 31);   // (bits << 1) | sign(t)
       e.tmin = min(e.tmin, tb);                                     // negative t: huge unsigned
     }
+  }
+}
+
+// MFMA chain into acc_new with the epilogue of acc_old spread between the MFMAs: a wave issues in
+// order, so the VALU work has to sit in the shadow of the matrix pipe in PROGRAM order
+template <int NM, int NR, int MI = 0>
+__device__ __forceinline__ void pop_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM],
+                                          const f32x16& c0, f32x16& acc_new,
+                                          const f32x16& acc_old, const PopDeltas<NR>& dl,
+                                          PopAcc<NR>& e) {
+  if constexpr (MI < NM) {
+    if constexpr (MI == 0)
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+    else
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[MI], b[MI], acc_new, 0, 0, 0);
+    pop_epi<NR, (16 * MI) / NM, (16 * (MI + 1)) / NM>(acc_old, dl, e);
+    pop_chain<NM, NR, MI + 1>(a, b, c0, acc_new, acc_old, dl, e);
   }
 }
 
@@ -528,8 +564,8 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     for (int qt = 0; qt < TQ; ++qt) {
       const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
       PopAcc<NR> e;
-      e.tmin = 0xFFFFFFFFu;
-      pop_epi<NR>(acc, P.dl, e);
+      pop_epi_begin<NR>(e);
+      pop_epi<NR, 0, 16>(acc, P.dl, e);
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
       const bool band = e.tmin < P.wbits;
@@ -708,94 +744,121 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       const uint32_t t = base + k + lane;
       const float4 rb = rb_next;
       if (k + 64 + lane < lim) rb_next = box_r[t + 64];
-      uint32_t qmask = 0;   // bit qt: reference tile t can hold a pair within r_max of query tile qt
-      if ((k + lane < lim) && (t % n_chunks == chunk)) {   // this wave's share of the references
-        if (box_gap2(gbox, rb) < far2) {
-#pragma unroll
-          for (int qt = 0; qt < TQ; ++qt) qmask |= (box_gap2(qbox[qt], rb) < far2) ? (1u << qt) : 0u;
-        }
-      }
-      const uint64_t m = __builtin_amdgcn_ballot_w64(qmask != 0);
-      if (qmask) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t | (qmask << 28);
+      // (one test against the box of the whole query group: per-query-tile masks were measured to
+      //  save < 0.5 % of the chains and they keep the chains from being pipelined)
+      const bool ok = (k + lane < lim) && (t % n_chunks == chunk) &&   // this wave's share
+                      (box_gap2(gbox, rb) < far2);
+      const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+      if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
       cnt += (uint32_t)__builtin_popcountll(m);
     }
     if (cnt == 0) continue;
-    // ---- process the survivors: the operands of survivor i+1 are in flight while survivor i is
-    //      being computed
+    // ---- process the survivors.  The operands of survivor i+1 are in flight while survivor i is
+    //      computed, and the chains are software-pipelined over two accumulator tiles: while the
+    //      MFMAs of one chain run, the epilogue of the previous chain issues in their shadow.
     s16x8 a0[NM], a1[NM];
     float4 n0[4], n1[4];
     auto entry = [&](uint32_t i) {
       return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
     };
-    auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t ent) {
-      const uint32_t t = ent & 0x0FFFFFFFu, qmask = ent >> 28;
-      const f32x16 c0 = frag16(nv);
+    // the rest of an epilogue: counts, band test, parking of the band pairs
+    auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<NR>& e, uint32_t t) {
+      constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
-      for (int qt = 0; qt < TQ; ++qt) {
-        if (!(qmask & (1u << qt))) continue;                // scalar test: boxes are per tile
-        ++chains;
-        const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
-        PopAcc<NR> e;
-        e.tmin = 0xFFFFFFFFu;
-        pop_epi<NR>(acc, P.dl, e);
+      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+      const bool band = e.tmin < P.wbits;
+      if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
+        if (use_queue) {
+          // park the band elements of this lane: (position, radii whose band holds the element).
+          // Band <=> 0 <= t < w: the sign string of (t - w) minus the sign string of t, both in the
+          // order of the epilogue (element r at bit 15 - r).  Pad rows (acc = +inf) and idle lanes
+          // (acc ~ 1e30) are never in a band, so no further masking is needed.
+          const float w = __uint_as_float(P.wbits);
+          uint32_t fl[NR];   // per radius: bit (15 - r) set <=> element r sits in that radius' band
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
-        const bool band = e.tmin < P.wbits;
-        if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qt]) != 0, 0)) {
-          if (use_queue) {
-            // park the band elements of this lane: (position, radii whose band holds the element).
-            // Band <=> 0 <= t < w: the sign string of (t - w) minus the sign string of t, both in the
-            // order of the epilogue (element r at bit 15 - r).  Pad rows (acc = +inf) and idle lanes
-            // (acc ~ 1e30) are never in a band, so no further masking is needed.
-            const float w = __uint_as_float(P.wbits);
-            uint32_t fl[NR];   // per radius: bit (15 - r) set <=> element r sits in that radius' band
+          for (int rr = 0; rr < NR; ++rr) {
+            uint32_t below = 0;
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-              uint32_t below = 0;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const float tv = rr == 0 ? acc[r] : acc[r] - P.dl.d[rr];
-                below = __builtin_amdgcn_alignbit(below, __float_as_uint(tv - w), 31);
-              }
-              fl[rr] = below & ~e.bits[rr] & 0xFFFFu;
+            for (int r = 0; r < 16; ++r) {
+              const float tv = rr == 0 ? acc[r] : acc[r] - P.dl.d[rr];
+              below = __builtin_amdgcn_alignbit(below, __float_as_uint(tv - w), 31);
             }
-            uint32_t m = 0;
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) m |= fl[rr];
-            uint32_t* qu = queues + qt * (kQueueCap * 64);
-            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
-              if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qt] == (uint32_t)kQueueCap)) != 0)
-                flush(qt);
-              if (m != 0) {
-                const int p = __builtin_ctz(m);
-                uint32_t flags = 0;
-#pragma unroll
-                for (int rr = 0; rr < NR; ++rr) flags |= ((fl[rr] >> p) & 1u) << rr;
-                qu[qcount[qt] * 64 + lane] = tile_row(t, 15 - p, h) | (flags << kPopQueuePosBits);
-                ++qcount[qt];
-                m &= m - 1;
-              }
-            }
-          } else {
-            const PopDelta<NR> dl =
-                pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qt], t, h);
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
+            fl[rr] = below & ~e.bits[rr] & 0xFFFFu;
           }
+          uint32_t m = 0;
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) m |= fl[rr];
+          uint32_t* qu = queues + qi * (kQueueCap * 64);
+          while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+            if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qi] == (uint32_t)kQueueCap)) != 0)
+              flush(qi);
+            if (m != 0) {
+              const int p = __builtin_ctz(m);
+              uint32_t flags = 0;
+#pragma unroll
+              for (int rr = 0; rr < NR; ++rr) flags |= ((fl[rr] >> p) & 1u) << rr;
+              qu[qcount[qi] * 64 + lane] = tile_row(t, 15 - p, h) | (flags << kPopQueuePosBits);
+              ++qcount[qi];
+              m &= m - 1;
+            }
+          }
+        } else {
+          const PopDelta<NR> dl =
+              pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qi], t, h);
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += ((livemask[qi] >> lane) & 1) ? dl.d[rr] : 0u;
         }
       }
     };
+    // accB always holds the chain whose epilogue is still pending: query tile TQ-1 of reference
+    // tile tB (or +inf everywhere = contributes nothing)
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
+    uint32_t tB = 0;
+    auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
+      const f32x16 c0 = frag16(nv);
+      chains += TQ;
+      if constexpr (TQ == 1) {
+        // one chain per tile: run it into accA, finish accB, then move A -> B
+        PopAcc<NR> e;
+        pop_epi_begin<NR>(e);
+        pop_chain<NM, NR>(a, b[0], c0, accA, accB, P.dl, e);
+        finish(accB, std::integral_constant<int, 0>{}, e, tB);
+        accB = accA;
+      } else {
+        static_assert(TQ == 1 || TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+        constexpr_for_pairs<TQ>([&](auto qt_c) {
+          constexpr int qt = decltype(qt_c)::value;
+          constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
+          PopAcc<NR> e;
+          pop_epi_begin<NR>(e);
+          pop_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
+          finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
+          pop_epi_begin<NR>(e);
+          pop_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e);
+          finish(accA, std::integral_constant<int, qt>{}, e, t);
+        });
+      }
+      tB = t;
+    };
     uint32_t e0 = entry(0), e1;
-    load_tile<NM>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+    load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
     for (uint32_t i = 0; i < cnt; i += 2) {
       e1 = entry(i + 1);
-      load_tile<NM>(img_r, norms_r, e1 & 0x0FFFFFFFu, lane, h, a1, n1);
+      load_tile<NM>(img_r, norms_r, e1, lane, h, a1, n1);
       compute(a0, n0, e0);
       if (i + 1 < cnt) {
         e0 = entry(i + 2);
-        load_tile<NM>(img_r, norms_r, e0 & 0x0FFFFFFFu, lane, h, a0, n0);
+        load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
         compute(a1, n1, e1);
       }
+    }
+    {  // drain: epilogue of the last pending chain of this round
+      PopAcc<NR> e;
+      pop_epi_begin<NR>(e);
+      pop_epi<NR, 0, 16>(accB, P.dl, e);
+      finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
     }
   }
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
@@ -913,6 +976,21 @@ __device__ __attribute__((noinline)) NnBest nn_fix(const float* __restrict__ coo
 // distance scale of the query; 2.5 > 2 covers the error of the minimum AND of the candidate)
 __device__ __forceinline__ float nn_band(const GuardBand& g, float m) {
   return m + 2.5f * (g.e0 + g.kappa * fmaxf(m, 0.0f));
+}
+
+// MFMA chain into acc_new with the tile minimum of acc_old spread between the MFMAs (see pop_chain)
+template <int NM, int MI = 0>
+__device__ __forceinline__ void nn_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM],
+                                         const f32x16& c0, f32x16& acc_new, const f32x16& acc_old,
+                                         float& tmin) {
+  if constexpr (MI < NM) {
+    if constexpr (MI == 0)
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+    else
+      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[MI], b[MI], acc_new, 0, 0, 0);
+    tile_min<(16 * MI) / NM, (16 * (MI + 1)) / NM>(acc_old, tmin);
+    nn_chain<NM, MI + 1>(a, b, c0, acc_new, acc_old, tmin);
+  }
 }
 
 template <int NM, int TQ>
@@ -1266,102 +1344,136 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       }
       if (cnt == 0) continue;
       visited += cnt;
-      // reference tile data in two register buffers (the loads run one survivor ahead)
+      // Reference tile data in two register buffers (the loads run one survivor ahead); the chains
+      // are software-pipelined over two accumulator tiles: while the MFMAs of one chain run, the
+      // tile minimum of the previous chain issues in their shadow (a wave issues in order).
       s16x8 a0[NM], a1[NM];
-      float4 n0[4], n1[4], f0[4], f1[4];
+      float4 n0[4], n1[4];
       auto entry = [&](uint32_t i) {
         return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
       };
-      auto issue = [&](uint32_t t, s16x8 (&a)[NM], float4 (&nv)[4], float4 (&fv)[4]) {
-        load_tile<NM>(img_r, norms_r, t, lane, h, a, nv);
-        load_frag(fe_c, t, h, fv);
-      };
-      auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], const float4 (&fv)[4],
-                         uint32_t t) {
-        const f32x16 c0 = frag16(nv);
-        const float2 fr = ferange_r[t];
+      // the rest of an epilogue: free-energy classes, band test, parking of the candidates.
+      // (t, fr) describe the reference tile the accumulator belongs to.
+      auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t, float2 fr) {
+        constexpr int qi = decltype(qi_c)::value;
+        NnPQ& Q = q[qi];
+        const bool all_lower = fr.y < Q.feq;
+        const bool mixed = (fr.x < Q.feq) & !all_lower;
+        const bool special = mixed | (t == (Q.spos >> 5));
+        float hmin = all_lower ? tmin : INFINITY;
+        const bool any_special = __builtin_amdgcn_ballot_w64(special) != 0;
+        if (__builtin_expect(any_special, 0)) {
+          // masked per-element minima (the tile holds the query itself and/or straddles feq); the
+          // free energies of the tile's frames are fetched only here
+          float4 fv[4];
+          load_frag(fe_c, t, h, fv);
+          const f32x16 fef = frag16(fv);
+          tmin = INFINITY;
+          hmin = INFINITY;
 #pragma unroll
-        for (int qt = 0; qt < TQ; ++qt) {
-          NnPQ& Q = q[qt];
-          ++chains;
-          const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
-          float tmin = INFINITY;
-          tile_min<0, 16>(acc, tmin);
-          const bool all_lower = fr.y < Q.feq;
-          const bool mixed = (fr.x < Q.feq) & !all_lower;
-          const bool special = mixed | (t == (Q.spos >> 5));
-          float hmin = all_lower ? tmin : INFINITY;
-          const bool any_special = __builtin_amdgcn_ballot_w64(special) != 0;
-          if (__builtin_expect(any_special, 0)) {
-            // masked per-element minima (the tile holds the query itself and/or straddles feq)
-            const f32x16 fef = frag16(fv);
-            tmin = INFINITY;
-            hmin = INFINITY;
+          for (int r = 0; r < 16; ++r) {
+            const float v = (tile_row(t, r, h) != Q.spos) ? acc[r] : INFINITY;
+            tmin = fminf(tmin, v);
+            hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
+          }
+        }
+        const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+        const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
+        const bool trig = (tmin < bn) | (hmin < bh);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
+          // park this tile's candidates (values within the band of the running minima); element r
+          // of the accumulator is bit (15 - r) of the masks
+          uint32_t mn = 0, mh = 0;
+          if (!any_special && t + 1 != T) {
+            // plain tile: below-threshold sign strings (idle lanes have thresholds of -inf, pad rows
+            // only exist in the last tile)
+            uint32_t sn = 0, sh = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = (tile_row(t, r, h) != Q.spos) ? acc[r] : INFINITY;
-              tmin = fminf(tmin, v);
-              hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
+              sn = __builtin_amdgcn_alignbit(sn, __float_as_uint(acc[r] - bn), 31);
+              sh = __builtin_amdgcn_alignbit(sh, __float_as_uint(acc[r] - bh), 31);
+            }
+            mn = sn & 0xFFFFu;
+            mh = all_lower ? (sh & 0xFFFFu) : 0u;
+          } else {
+            float4 fv[4];
+            load_frag(fe_c, t, h, fv);
+            const f32x16 fef = frag16(fv);
+            const bool live = (livemask[qi] >> lane) & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t pos = tile_row(t, r, h);
+              const bool other = live & (pos != Q.spos) & (pos < n_rows);
+              mn |= (other & (acc[r] < bn)) ? (0x8000u >> r) : 0u;
+              mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (0x8000u >> r) : 0u;
             }
           }
-          const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
-          const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
-          const bool trig = (tmin < bn) | (hmin < bh);
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
-            // park this tile's candidates (values within the band of the running minima); element r
-            // of the accumulator is bit (15 - r) of the masks
-            uint32_t mn = 0, mh = 0;
-            if (!any_special && t + 1 != T) {
-              // plain tile: below-threshold sign strings (idle lanes have thresholds of -inf, pad rows
-              // only exist in the last tile)
-              uint32_t sn = 0, sh = 0;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                sn = __builtin_amdgcn_alignbit(sn, __float_as_uint(acc[r] - bn), 31);
-                sh = __builtin_amdgcn_alignbit(sh, __float_as_uint(acc[r] - bh), 31);
-              }
-              mn = sn & 0xFFFFu;
-              mh = all_lower ? (sh & 0xFFFFu) : 0u;
-            } else {
-              const f32x16 fef = frag16(fv);
-              const bool live = (livemask[qt] >> lane) & 1;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const uint32_t pos = tile_row(t, r, h);
-                const bool other = live & (pos != Q.spos) & (pos < n_rows);
-                mn |= (other & (acc[r] < bn)) ? (0x8000u >> r) : 0u;
-                mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (0x8000u >> r) : 0u;
-              }
-            }
-            uint32_t m = mn | mh;
-            uint32_t* qu = queues + qt * (kQueueCap * 64);
-            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
-              if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qt] == (uint32_t)kQueueCap)) != 0)
-                flush(qt);
-              if (m != 0) {
-                const int p = __builtin_ctz(m);
-                qu[qcount[qt] * 64 + lane] =
-                    tile_row(t, 15 - p, h) | (((mn >> p) & 1u) << 30) | (((mh >> p) & 1u) << 31);
-                ++qcount[qt];
-                m &= m - 1;
-              }
+          uint32_t m = mn | mh;
+          uint32_t* qu = queues + qi * (kQueueCap * 64);
+          while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+            if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qi] == (uint32_t)kQueueCap)) != 0)
+              flush(qi);
+            if (m != 0) {
+              const int p = __builtin_ctz(m);
+              qu[qcount[qi] * 64 + lane] =
+                  tile_row(t, 15 - p, h) | (((mn >> p) & 1u) << 30) | (((mh >> p) & 1u) << 31);
+              ++qcount[qi];
+              m &= m - 1;
             }
           }
-          Q.m_nn = new_nn;
-          Q.m_hd = new_hd;
         }
+        Q.m_nn = new_nn;
+        Q.m_hd = new_hd;
+      };
+      // accB always holds the chain whose epilogue is still pending: query tile TQ-1 of reference
+      // tile tB (or +inf everywhere: no minimum, no candidates)
+      f32x16 accA, accB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
+      uint32_t tB = 0;
+      float2 frB = make_float2(INFINITY, INFINITY);
+      auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
+        const f32x16 c0 = frag16(nv);
+        const float2 fr = ferange_r[t];
+        chains += TQ;
+        if constexpr (TQ == 1) {
+          float tmin = INFINITY;
+          nn_chain<NM>(a, b[0], c0, accA, accB, tmin);
+          finish(accB, std::integral_constant<int, 0>{}, tmin, tB, frB);
+          accB = accA;
+        } else {
+          static_assert(TQ == 1 || TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+          constexpr_for_pairs<TQ>([&](auto qt_c) {
+            constexpr int qt = decltype(qt_c)::value;
+            constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
+            float tmin = INFINITY;
+            nn_chain<NM>(a, b[qt], c0, accA, accB, tmin);
+            finish(accB, std::integral_constant<int, qb>{}, tmin, (qt == 0) ? tB : t,
+                   (qt == 0) ? frB : fr);
+            tmin = INFINITY;
+            nn_chain<NM>(a, b[qt + 1], c0, accB, accA, tmin);
+            finish(accA, std::integral_constant<int, qt>{}, tmin, t, fr);
+          });
+        }
+        tB = t;
+        frB = fr;
       };
       uint32_t t0 = entry(0), t1;
-      issue(t0, a0, n0, f0);
+      load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
       for (uint32_t i = 0; i < cnt; i += 2) {
         t1 = entry(i + 1);
-        issue(t1, a1, n1, f1);
-        compute(a0, n0, f0, t0);
+        load_tile<NM>(img_r, norms_r, t1, lane, h, a1, n1);
+        compute(a0, n0, t0);
         if (i + 1 < cnt) {
           t0 = entry(i + 2);
-          issue(t0, a0, n0, f0);
-          compute(a1, n1, f1, t1);
+          load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+          compute(a1, n1, t1);
         }
+      }
+      {  // drain: epilogue of the last pending chain of this round
+        float tmin = INFINITY;
+        tile_min<0, 16>(accB, tmin);
+        finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
       }
     }
 #pragma unroll
