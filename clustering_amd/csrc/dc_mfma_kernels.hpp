@@ -301,6 +301,22 @@ __device__ __forceinline__ void load_tile(const uint4* __restrict__ img,
   for (int g = 0; g < 4; ++g) nv[g] = np[2 * g];        // rows 8g + 4h .. +3  <->  registers 4g .. 4g+3
 }
 
+// single-buffered operands (many MFMAs per chain: no room for two buffers): fragment m of the NEXT
+// reference tile replaces fragment m of the current one right after the last MFMA that reads it
+// (the last chain of the tile); the row norms go with fragment 0
+template <int NM, int MI>
+__device__ __forceinline__ void refill_frag(const uint4* __restrict__ img,
+                                            const float* __restrict__ norms, uint32_t t_next,
+                                            int lane, int h, s16x8 (&a)[NM], float4 (&nv)[4]) {
+  const uint4 v = img[(size_t)t_next * (NM * 64) + MI * 64 + lane];
+  a[MI] = __builtin_bit_cast(s16x8, v);
+  if constexpr (MI == 0) {
+    const float4* np = reinterpret_cast<const float4*>(norms + (size_t)t_next * 32 + 4 * h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) nv[g] = np[2 * g];
+  }
+}
+
 // resident query-side operand of one query tile: B form fragments with the pieces of the per-lane
 // constant c_q patched into slots 0..2 (held by the h = 0 half of the wave)
 template <int NM>
@@ -357,6 +373,11 @@ __device__ __forceinline__ void constexpr_for_pairs(F&& f) {
     constexpr_for_pairs<N, I + 2>(f);
   }
 }
+
+// reference operands of the pruned sweeps: two register buffers while they are small (<= 4 MFMAs per
+// chain), one buffer refilled during the last chain of a tile beyond that
+template <int NM>
+constexpr bool kSingleBuffer = NM > 4;
 
 // a query lane that owns no live row: the constant keeps its accumulators hugely positive
 constexpr float kDeadConst = 1.0e30f;
@@ -436,18 +457,24 @@ __device__ __forceinline__ void pop_epi(const f32x16& acc, const PopDeltas<NR>& 
 
 // MFMA chain into acc_new with the epilogue of acc_old spread between the MFMAs: a wave issues in
 // order, so the VALU work has to sit in the shadow of the matrix pipe in PROGRAM order
-template <int NM, int NR, int MI = 0>
+struct NoRefill {
+  template <int MI>
+  __device__ __forceinline__ void operator()(std::integral_constant<int, MI>) const {}
+};
+
+template <int NM, int NR, int MI = 0, class Refill = NoRefill>
 __device__ __forceinline__ void pop_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM],
                                           const f32x16& c0, f32x16& acc_new,
                                           const f32x16& acc_old, const PopDeltas<NR>& dl,
-                                          PopAcc<NR>& e) {
+                                          PopAcc<NR>& e, const Refill& refill = Refill{}) {
   if constexpr (MI < NM) {
     if constexpr (MI == 0)
       acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
     else
       acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[MI], b[MI], acc_new, 0, 0, 0);
+    refill(std::integral_constant<int, MI>{});   // fragment MI of the next tile (last chain only)
     pop_epi<NR, (16 * MI) / NM, (16 * (MI + 1)) / NM>(acc_old, dl, e);
-    pop_chain<NM, NR, MI + 1>(a, b, c0, acc_new, acc_old, dl, e);
+    pop_chain<NM, NR, MI + 1, Refill>(a, b, c0, acc_new, acc_old, dl, e, refill);
   }
 }
 
@@ -756,8 +783,8 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     // ---- process the survivors.  The operands of survivor i+1 are in flight while survivor i is
     //      computed, and the chains are software-pipelined over two accumulator tiles: while the
     //      MFMAs of one chain run, the epilogue of the previous chain issues in their shadow.
-    s16x8 a0[NM], a1[NM];
-    float4 n0[4], n1[4];
+    s16x8 a0[NM];
+    float4 n0[4];
     auto entry = [&](uint32_t i) {
       return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
     };
@@ -816,42 +843,53 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
     uint32_t tB = 0;
-    auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
+    // t_next: the survivor after t (single-buffered operands are refilled during the last chain)
+    auto compute = [&](s16x8 (&a)[NM], float4 (&nv)[4], uint32_t t, uint32_t t_next) {
       const f32x16 c0 = frag16(nv);
       chains += TQ;
-      if constexpr (TQ == 1) {
-        // one chain per tile: run it into accA, finish accB, then move A -> B
+      static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+      auto refill = [&](auto mi_c) {
+        if constexpr (kSingleBuffer<NM>)
+          refill_frag<NM, decltype(mi_c)::value>(img_r, norms_r, t_next, lane, h, a, nv);
+      };
+      constexpr_for_pairs<TQ>([&](auto qt_c) {
+        constexpr int qt = decltype(qt_c)::value;
+        constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
         PopAcc<NR> e;
         pop_epi_begin<NR>(e);
-        pop_chain<NM, NR>(a, b[0], c0, accA, accB, P.dl, e);
-        finish(accB, std::integral_constant<int, 0>{}, e, tB);
-        accB = accA;
-      } else {
-        static_assert(TQ == 1 || TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
-        constexpr_for_pairs<TQ>([&](auto qt_c) {
-          constexpr int qt = decltype(qt_c)::value;
-          constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
-          PopAcc<NR> e;
-          pop_epi_begin<NR>(e);
-          pop_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
-          finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
-          pop_epi_begin<NR>(e);
+        pop_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
+        finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
+        pop_epi_begin<NR>(e);
+        if constexpr (qt + 2 == TQ)   // last chain of the tile
+          pop_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e, refill);
+        else
           pop_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e);
-          finish(accA, std::integral_constant<int, qt>{}, e, t);
-        });
-      }
+        finish(accA, std::integral_constant<int, qt>{}, e, t);
+      });
       tB = t;
     };
-    uint32_t e0 = entry(0), e1;
-    load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
-    for (uint32_t i = 0; i < cnt; i += 2) {
-      e1 = entry(i + 1);
-      load_tile<NM>(img_r, norms_r, e1, lane, h, a1, n1);
-      compute(a0, n0, e0);
-      if (i + 1 < cnt) {
-        e0 = entry(i + 2);
-        load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
-        compute(a1, n1, e1);
+    if constexpr (kSingleBuffer<NM>) {
+      uint32_t e0 = entry(0);
+      load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t e1 = entry(i + 1);
+        compute(a0, n0, e0, e1);
+        e0 = e1;
+      }
+    } else {
+      s16x8 a1[NM];
+      float4 n1[4];
+      uint32_t e0 = entry(0), e1;
+      load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
+      for (uint32_t i = 0; i < cnt; i += 2) {
+        e1 = entry(i + 1);
+        load_tile<NM>(img_r, norms_r, e1, lane, h, a1, n1);
+        compute(a0, n0, e0, e1);
+        if (i + 1 < cnt) {
+          e0 = entry(i + 2);
+          load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
+          compute(a1, n1, e1, e0);
+        }
       }
     }
     {  // drain: epilogue of the last pending chain of this round
@@ -979,17 +1017,18 @@ __device__ __forceinline__ float nn_band(const GuardBand& g, float m) {
 }
 
 // MFMA chain into acc_new with the tile minimum of acc_old spread between the MFMAs (see pop_chain)
-template <int NM, int MI = 0>
+template <int NM, int MI = 0, class Refill = NoRefill>
 __device__ __forceinline__ void nn_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM],
                                          const f32x16& c0, f32x16& acc_new, const f32x16& acc_old,
-                                         float& tmin) {
+                                         float& tmin, const Refill& refill = Refill{}) {
   if constexpr (MI < NM) {
     if constexpr (MI == 0)
       acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
     else
       acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[MI], b[MI], acc_new, 0, 0, 0);
+    refill(std::integral_constant<int, MI>{});   // fragment MI of the next tile (last chain only)
     tile_min<(16 * MI) / NM, (16 * (MI + 1)) / NM>(acc_old, tmin);
-    nn_chain<NM, MI + 1>(a, b, c0, acc_new, acc_old, tmin);
+    nn_chain<NM, MI + 1, Refill>(a, b, c0, acc_new, acc_old, tmin, refill);
   }
 }
 
@@ -1347,8 +1386,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       // Reference tile data in two register buffers (the loads run one survivor ahead); the chains
       // are software-pipelined over two accumulator tiles: while the MFMAs of one chain run, the
       // tile minimum of the previous chain issues in their shadow (a wave issues in order).
-      s16x8 a0[NM], a1[NM];
-      float4 n0[4], n1[4];
+      s16x8 a0[NM];
+      float4 n0[4];
       auto entry = [&](uint32_t i) {
         return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
       };
@@ -1432,42 +1471,54 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
       uint32_t tB = 0;
       float2 frB = make_float2(INFINITY, INFINITY);
-      auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
+      auto compute = [&](s16x8 (&a)[NM], float4 (&nv)[4], uint32_t t, uint32_t t_next) {
         const f32x16 c0 = frag16(nv);
         const float2 fr = ferange_r[t];
         chains += TQ;
-        if constexpr (TQ == 1) {
+        static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+        auto refill = [&](auto mi_c) {
+          if constexpr (kSingleBuffer<NM>)
+            refill_frag<NM, decltype(mi_c)::value>(img_r, norms_r, t_next, lane, h, a, nv);
+        };
+        constexpr_for_pairs<TQ>([&](auto qt_c) {
+          constexpr int qt = decltype(qt_c)::value;
+          constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
           float tmin = INFINITY;
-          nn_chain<NM>(a, b[0], c0, accA, accB, tmin);
-          finish(accB, std::integral_constant<int, 0>{}, tmin, tB, frB);
-          accB = accA;
-        } else {
-          static_assert(TQ == 1 || TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
-          constexpr_for_pairs<TQ>([&](auto qt_c) {
-            constexpr int qt = decltype(qt_c)::value;
-            constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
-            float tmin = INFINITY;
-            nn_chain<NM>(a, b[qt], c0, accA, accB, tmin);
-            finish(accB, std::integral_constant<int, qb>{}, tmin, (qt == 0) ? tB : t,
-                   (qt == 0) ? frB : fr);
-            tmin = INFINITY;
+          nn_chain<NM>(a, b[qt], c0, accA, accB, tmin);
+          finish(accB, std::integral_constant<int, qb>{}, tmin, (qt == 0) ? tB : t,
+                 (qt == 0) ? frB : fr);
+          tmin = INFINITY;
+          if constexpr (qt + 2 == TQ)   // last chain of the tile
+            nn_chain<NM>(a, b[qt + 1], c0, accB, accA, tmin, refill);
+          else
             nn_chain<NM>(a, b[qt + 1], c0, accB, accA, tmin);
-            finish(accA, std::integral_constant<int, qt>{}, tmin, t, fr);
-          });
-        }
+          finish(accA, std::integral_constant<int, qt>{}, tmin, t, fr);
+        });
         tB = t;
         frB = fr;
       };
-      uint32_t t0 = entry(0), t1;
-      load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
-      for (uint32_t i = 0; i < cnt; i += 2) {
-        t1 = entry(i + 1);
-        load_tile<NM>(img_r, norms_r, t1, lane, h, a1, n1);
-        compute(a0, n0, t0);
-        if (i + 1 < cnt) {
-          t0 = entry(i + 2);
-          load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
-          compute(a1, n1, t1);
+      if constexpr (kSingleBuffer<NM>) {
+        uint32_t t0 = entry(0);
+        load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+        for (uint32_t i = 0; i < cnt; ++i) {
+          const uint32_t t1 = entry(i + 1);
+          compute(a0, n0, t0, t1);
+          t0 = t1;
+        }
+      } else {
+        s16x8 a1[NM];
+        float4 n1[4];
+        uint32_t t0 = entry(0), t1;
+        load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+        for (uint32_t i = 0; i < cnt; i += 2) {
+          t1 = entry(i + 1);
+          load_tile<NM>(img_r, norms_r, t1, lane, h, a1, n1);
+          compute(a0, n0, t0, t1);
+          if (i + 1 < cnt) {
+            t0 = entry(i + 2);
+            load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+            compute(a1, n1, t1, t0);
+          }
         }
       }
       {  // drain: epilogue of the last pending chain of this round
@@ -1559,10 +1610,13 @@ __global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ me
 // ---------------------------------------------------------------------------------------------
 // launch helpers (one MFMA count per translation unit; the template parameter S below is NM)
 // ---------------------------------------------------------------------------------------------
-// query tiles per wave: as many as the resident B fragments (4 * TQ * NM registers) and the two A
-// buffers (8 * NM) leave room for at two waves per SIMD
+// query tiles per wave (pruned sweeps): as many as the resident B fragments (4 * TQ * NM registers)
+// leave room for at two waves per SIMD; each reference fragment is fetched once per TQ chains
 template <int NM>
-constexpr int tq_for = (NM <= 4) ? 4 : (NM <= 8) ? 2 : 1;
+constexpr int tq_for = (NM <= 8) ? 4 : 2;
+// query tiles per wave of the full sweeps (double-buffered reference operands)
+template <int NM>
+constexpr int tq_full_for = (NM <= 4) ? 4 : (NM <= 8) ? 2 : 1;
 
 inline uint32_t grid_for(uint32_t i_from, uint32_t i_to, int tq) {
   const uint32_t tiles = (i_to + 31) / 32 - i_from / 32;
@@ -1574,7 +1628,7 @@ template <int S>
 void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                   uint32_t i_from, uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* pops,
                   hipStream_t s) {
-  constexpr int kTQ = tq_for<S>;
+  constexpr int kTQ = tq_full_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
   if (n_rad == 1)
     hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
@@ -1606,13 +1660,6 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   float cell2;
 };
 
-// Query tiles per wave for the pruned sweeps: as many as the K-steps allow (operand reuse), but few
-// enough that the launch has >= 2 waves per SIMD -- a rank that owns only N/8 of the rows (8-GPU
-// run) would otherwise leave most of the chip idle.
-inline int pick_tq(uint32_t tiles, int tq_max) {
-  (void)tiles;
-  return tq_max;
-}
 // Reference chunks per query group (gridDim.y).  The cost of a query group follows the local density
 // of the data (dense regions keep many more reference tiles), and with two resident waves per SIMD a
 // launch of a few thousand waves ends in a long, mostly idle tail behind its heaviest groups.  The
@@ -1660,21 +1707,8 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
                         const NnPrunedArgs& A, uint32_t T, const uint32_t* hdr,
                         unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                         uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
-  switch (pick_tq((A.n_q + 31) / 32, tq_for<S>)) {
-    case 4:
-      if constexpr (tq_for<S> >= 4)
-        nn_pruned_launch<S, 4>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
-                               hd_idx, hd_d2, s);
-      break;
-    case 2:
-      nn_pruned_launch<S, 2>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
-                             hd_idx, hd_d2, s);
-      break;
-    default:
-      nn_pruned_launch<S, 1>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
-                             hd_idx, hd_d2, s);
-      break;
-  }
+  nn_pruned_launch<S, tq_for<S>>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
+                                 hd_idx, hd_d2, s);
 }
 
 // pruned population sweep: queries = n_q spatially ordered rows (image/perm/boxes "q"), references =
@@ -1701,21 +1735,8 @@ template <int S, int NRV>
 void pop_pruned_tq(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                    uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad, uint32_t* pops,
                    unsigned long long* chain_counter, hipStream_t s) {
-  switch (pick_tq((n_q + 31) / 32, tq_for<S>)) {
-    case 4:
-      if constexpr (tq_for<S> >= 4)
-        pop_pruned_launch<S, NRV, 4>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
-                                     chain_counter, s);
-      break;
-    case 2:
-      pop_pruned_launch<S, NRV, 2>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
-                                   chain_counter, s);
-      break;
-    default:
-      pop_pruned_launch<S, NRV, 1>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
-                                   chain_counter, s);
-      break;
-  }
+  pop_pruned_launch<S, NRV, tq_for<S>>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad,
+                                       pops, chain_counter, s);
 }
 
 template <int S>
@@ -1737,7 +1758,7 @@ template <int S>
 void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                  uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
                  float* hd_d2, hipStream_t s) {
-  constexpr int kTQnn = tq_for<S>;
+  constexpr int kTQnn = tq_full_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQnn)), block(256);
   hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img_b,
                      P.norms, P.img_s, P.norms_s, P.perm, P.invpos, P.pq, P.hdr, T, i_from, i_to, nn_idx,
