@@ -283,25 +283,53 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The matrix-core population kernels take ONE radius per sweep: with the threshold folded into the
+// accumulator a radius costs 16 v_alignbit + 8 v_min3 per 1024 pairs, less than the subtract /
+// sign / min triple per radius of a multi-radius epilogue -- and the MFMAs of a repeated sweep hide
+// behind that epilogue.  Radii are therefore swept one after the other (the pruned sweep then also
+// prunes every radius with its own cell size).
+static Rad2 single_radius(const Rad2& rad2, int r) {
+  Rad2 one;
+  for (int k = 0; k < kMaxRadiiPerLaunch; ++k) one.v[k] = -1.0f;
+  one.v[0] = rad2.v[r];
+  return one;
+}
+
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                      hipStream_t stream) {
-  switch (nm_for((int)n_cols)) {
+  for (int r = 0; r < n_rad; ++r) {
+    const Rad2 one = single_radius(rad2, r);
+    uint32_t* out = d_pops + (size_t)r * n_rows;
+    switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
-      pop_mfma_step_##SV(d_coords, n_rows, n_cols, d_ws, i_from, i_to, rad2, n_rad, d_pops, stream); \
+      pop_mfma_step_##SV(d_coords, n_rows, n_cols, d_ws, i_from, i_to, one, 1, out, stream);     \
     break;
-    DC_FOR_EACH_S(X)
+      DC_FOR_EACH_S(X)
 #undef X
-    default:
-      break;
+      default:
+        break;
+    }
   }
 }
+
+static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
+                           uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
+                           hipStream_t stream);
 
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                        hipStream_t stream) {
+  for (int r = 0; r < n_rad; ++r)
+    pop_pruned_one(d_coords, n_rows, n_cols, i_from, i_to, single_radius(rad2, r), 1,
+                   d_pops + (size_t)r * n_rows, d_ws, stream);
+}
+
+static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
+                           uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
+                           hipStream_t stream) {
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
   uint32_t* hdr = (uint32_t*)p;

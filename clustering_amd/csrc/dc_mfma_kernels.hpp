@@ -1630,15 +1630,9 @@ void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const P
                   hipStream_t s) {
   constexpr int kTQ = tq_full_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
-  if (n_rad == 1)
-    hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
-  else if (n_rad <= 4)
-    hipLaunchKernelGGL((pop_mfma_kernel<S, 4, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
-  else
-    hipLaunchKernelGGL((pop_mfma_kernel<S, 8, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                       P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
+  // one radius per sweep (dc_mfma.hip loops over the radii of a call)
+  hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
+                     P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
 }
 
 struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy) ordering
@@ -1743,15 +1737,9 @@ template <int S>
 void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
                          uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
                          uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
-  if (n_rad == 1)
-    pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
-                        chain_counter, s);
-  else if (n_rad <= 4)
-    pop_pruned_tq<S, 4>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
-                        chain_counter, s);
-  else
-    pop_pruned_tq<S, 8>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
-                        chain_counter, s);
+  // one radius per sweep (dc_mfma.hip loops over the radii of a call)
+  pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+                      chain_counter, s);
 }
 
 template <int S>
