@@ -1,0 +1,239 @@
+// test_mfma_model.hip -- GPU self-test of the two hardware facts the guard band of the matrix-core
+// sweeps rests on (dc_mfma_kernels.hpp, DESIGN.md "guard band"):
+//
+//  (1) accumulation model of v_mfma_f32_32x32x16_bf16:  D = C + sum_k a_k b_k with every addend
+//      truncated to a multiple of q = 2^(e_max - 24) (e_max: exponent of the largest |addend|,
+//      C included), an exact sum and one final rounding, i.e.
+//          | D_hw - D_exact |  <=  17 q + ulp(D_exact) / 2
+//      checked on crafted worst cases and on random products over wide exponent ranges;
+//  (2) end to end: the accumulator of the bf16x3 Gram chain (operand images built by the product's
+//      own slot_value / split3 / gram_chain) stays within the MFMA + dropped-products part of the
+//      band of its exact value |y'|^2 + c_q - 2 x'.y', for several dimensions and data scales.
+//
+// Prints a summary and exits 0 when both hold, 1 otherwise.  Built by clustering_amd/csrc/Makefile,
+// run by tests/test_gpu_parity.py (pytest -m gpu).
+#include "../../clustering_amd/csrc/dc_mfma_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+using namespace dc;
+
+#define CHECK(x)                                                                  \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));              \
+      return 2;                                                                   \
+    }                                                                             \
+  } while (0)
+
+// ---- (1) one MFMA on host-supplied operands ----------------------------------------------------
+__global__ void one_mfma(const unsigned short* A, const unsigned short* B, const float* C, float* D) {
+  // A [32][16], B [16][32] (k-major), C/D [32][32]
+  const int l = threadIdx.x, r = l & 31, h = l >> 5;
+  s16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    a[j] = (short)A[r * 16 + 8 * h + j];
+    b[j] = (short)B[(8 * h + j) * 32 + r];
+  }
+  f32x16 c;
+  for (int g = 0; g < 16; ++g) c[g] = C[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r];
+  const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  for (int g = 0; g < 16; ++g) D[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r] = d[g];
+}
+
+// ---- (2) the product's Gram chain on 32 reference x 32 query rows ---------------------------------
+template <int NM>
+__global__ void gram_tile(const float* ref, const float* qry, uint32_t D, const float* ny,
+                          const float* cq, float* out) {
+  // ref/qry: [32][D] centred coordinates; out [32 ref][32 qry]
+  const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+  s16x8 a[NM], b[NM];
+  for (int m = 0; m < NM; ++m)
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t s = 16 * m + 8 * h + j;
+      a[m][j] = (short)slot_value(s, D, false, [&](uint32_t k) { return ref[c * D + k]; });
+      b[m][j] = (short)slot_value(s, D, true, [&](uint32_t k) { return qry[c * D + k]; });
+    }
+  const Pieces p = split3(cq[c]);
+  if (h == 0) {
+    b[0][0] = (short)p.hi;
+    b[0][1] = (short)p.mid;
+    b[0][2] = (short)p.lo;
+  }
+  f32x16 c0;
+  for (int g = 0; g < 16; ++g) c0[g] = ny[(g & 3) + 8 * (g >> 2) + 4 * h];
+  const f32x16 acc = gram_chain<NM>(a, b, c0);
+  for (int g = 0; g < 16; ++g) out[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + c] = acc[g];
+}
+
+static unsigned short f2bf(float f) {  // values with <= 8 significant bits: exact
+  unsigned u;
+  memcpy(&u, &f, 4);
+  return (unsigned short)(u >> 16);
+}
+static float bf2f(unsigned short b) {
+  unsigned u = (unsigned)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static double ulp_of(long double v) {   // spacing of floats at |v|
+  int e;
+  frexpl(fabsl(v) > 0 ? v : 1e-300L, &e);   // |v| in [2^(e-1), 2^e)
+  return ldexp(1.0, e - 24);
+}
+static double q_of(long double maxmag) {   // 2^(e_max - 24), 2^e_max <= maxmag
+  int e;
+  frexpl(maxmag > 0 ? maxmag : 1e-300L, &e);
+  return ldexp(1.0, e - 1 - 24);
+}
+
+template <int NM>
+static int run_gram(uint32_t D, float scale, float offset, float thr, double* worst_ratio, int trials) {
+  float *d_ref, *d_qry, *d_ny, *d_cq, *d_out;
+  CHECK(hipMalloc((void**)&d_ref, 32 * D * 4));
+  CHECK(hipMalloc((void**)&d_qry, 32 * D * 4));
+  CHECK(hipMalloc((void**)&d_ny, 128));
+  CHECK(hipMalloc((void**)&d_cq, 128));
+  CHECK(hipMalloc((void**)&d_out, 4096));
+  std::vector<float> ref(32 * D), qry(32 * D), ny(32), cq(32), out(1024);
+  const double u = ldexp(1.0, -24);
+  const int nb = ((int)D + kConstSlots + 15) / 16, ns = nm_for((int)D) - nb;
+  int bad = 0;
+  for (int t = 0; t < trials; ++t) {
+    // two nearby "frames clouds" displaced from the origin (like clusters far from the mean)
+    double M = 0;
+    for (int i = 0; i < 32; ++i) {
+      double n1 = 0, n2 = 0;
+      for (uint32_t k = 0; k < D; ++k) {
+        const float base = offset * ((k % 3) - 1.0f);
+        ref[i * D + k] = base + scale * (float)((rand() % 20001) - 10000) * 1e-4f;
+        qry[i * D + k] = base + scale * (float)((rand() % 20001) - 10000) * 1e-4f;
+        n1 += (double)ref[i * D + k] * ref[i * D + k];
+        n2 += (double)qry[i * D + k] * qry[i * D + k];
+      }
+      ny[i] = (float)n1;
+      cq[i] = (float)n2 - thr;
+      M = fmax(M, fmax(n1, n2));
+    }
+    CHECK(hipMemcpy(d_ref, ref.data(), 32 * D * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_qry, qry.data(), 32 * D * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_ny, ny.data(), 128, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_cq, cq.data(), 128, hipMemcpyHostToDevice));
+    gram_tile<NM><<<1, 64>>>(d_ref, d_qry, D, d_ny, d_cq, d_out);
+    CHECK(hipMemcpy(out.data(), d_out, 4096, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32; ++i)
+      for (int j = 0; j < 32; ++j) {
+        long double dot = 0;
+        for (uint32_t k = 0; k < D; ++k) dot += (long double)ref[i * D + k] * (long double)qry[j * D + k];
+        const long double E = (long double)ny[i] + (long double)cq[j] - 2.0L * dot;
+        const double absE = (double)fabsl(E);
+        // MFMA + dropped-products part of the band (no 1.25 factor, no centring / canonical terms)
+        const double bound = u * (4.1 * M + 17.0 * (2.0 * M + thr) + (nb - 1) * 18.0 * (4.02 * M + thr) +
+                                  ns * 18.0 * (absE + 0.0165 * M) + absE);
+        const double err = (double)fabsl((long double)out[i * 32 + j] - E);
+        if (err / bound > *worst_ratio) *worst_ratio = err / bound;
+        if (err > bound) ++bad;
+      }
+  }
+  hipFree(d_ref); hipFree(d_qry); hipFree(d_ny); hipFree(d_cq); hipFree(d_out);
+  return bad;
+}
+
+int main() {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+    fprintf(stderr, "no HIP device\n");
+    return 2;
+  }
+  unsigned short *dA, *dB;
+  float *dC, *dD;
+  CHECK(hipMalloc((void**)&dA, 1024));
+  CHECK(hipMalloc((void**)&dB, 1024));
+  CHECK(hipMalloc((void**)&dC, 4096));
+  CHECK(hipMalloc((void**)&dD, 4096));
+  std::vector<unsigned short> A(512), B(512);
+  std::vector<float> C(1024), D(1024);
+  int failures = 0;
+  double worst_q = 0;   // worst (error - ulp/2) in units of q
+  srand(20240);
+  for (int E : {0, 4, 12, 24, 40}) {
+    for (int trial = 0; trial < 300; ++trial) {
+      const bool crafted = (E == 0);
+      for (int r = 0; r < 32; ++r)
+        for (int k = 0; k < 16; ++k) {
+          float v;
+          if (crafted) {
+            // every product just below one truncation unit of C = +-1 (or a few units): 255/128 * 2^-25
+            // and friends; row-dependent sign patterns
+            const float m = 1.0f + (float)(128 + (rand() & 127)) / 256.0f;   // [1.5, 2)
+            v = ((r + (trial & 1) * k) & 1 ? -m : m) * ldexpf(1.0f, -25 - (rand() % 3));
+          } else {
+            const float m = 1.0f + (rand() & 127) / 128.0f;
+            v = ((rand() & 1) ? -m : m) * ldexpf(1.0f, -(rand() % (E + 1)));
+          }
+          A[r * 16 + k] = f2bf(v);
+        }
+      for (int k = 0; k < 16; ++k)
+        for (int j = 0; j < 32; ++j) {
+          float v;
+          if (crafted) {
+            v = 1.0f;
+          } else {
+            const float m = 1.0f + (rand() & 127) / 128.0f;
+            v = ((rand() & 1) ? -m : m) * ldexpf(1.0f, -(rand() % (E + 1)));
+          }
+          B[k * 32 + j] = f2bf(v);
+        }
+      for (auto& v : C)
+        v = crafted ? ((rand() & 1) ? -1.0f : 1.0f)
+                    : ((rand() & 1) ? -1.0f : 1.0f) * (1.0f + (rand() & 0xffff) / 65536.0f) *
+                          ldexpf(1.0f, -(rand() % (E + 1)));
+      CHECK(hipMemcpy(dA, A.data(), 1024, hipMemcpyHostToDevice));
+      CHECK(hipMemcpy(dB, B.data(), 1024, hipMemcpyHostToDevice));
+      CHECK(hipMemcpy(dC, C.data(), 4096, hipMemcpyHostToDevice));
+      one_mfma<<<1, 64>>>(dA, dB, dC, dD);
+      CHECK(hipMemcpy(D.data(), dD, 4096, hipMemcpyDeviceToHost));
+      for (int r = 0; r < 32; ++r)
+        for (int j = 0; j < 32; ++j) {
+          long double ex = C[r * 32 + j], mx = fabsl(ex);
+          for (int k = 0; k < 16; ++k) {
+            const long double p = (long double)bf2f(A[r * 16 + k]) * (long double)bf2f(B[k * 32 + j]);
+            ex += p;
+            if (fabsl(p) > mx) mx = fabsl(p);
+          }
+          const double err = (double)fabsl((long double)D[r * 32 + j] - ex);
+          const double q = q_of(mx), half_ulp = 0.5 * ulp_of(ex);
+          const double in_q = (err - half_ulp) / q;
+          if (in_q > worst_q) worst_q = in_q;
+          if (err > 17.0 * q + half_ulp * 1.0000001) ++failures;
+        }
+    }
+  }
+  printf("mfma accumulate model: worst (error - ulp/2) = %.3f q  (bound 17 q), violations %d\n", worst_q,
+         failures);
+
+  double worst_ratio = 0;
+  int bad = 0;
+  bad += run_gram<nm_for(2)>(2, 1.0f, 0.0f, 0.01f, &worst_ratio, 40);
+  bad += run_gram<nm_for(3)>(3, 0.3f, 1.0f, 0.04f, &worst_ratio, 40);
+  bad += run_gram<nm_for(10)>(10, 0.1f, 0.5f, 0.04f, &worst_ratio, 60);
+  bad += run_gram<nm_for(10)>(10, 0.01f, 3.0f, 0.0004f, &worst_ratio, 60);
+  bad += run_gram<nm_for(10)>(10, 100.0f, 1000.0f, 2500.0f, &worst_ratio, 40);
+  bad += run_gram<nm_for(13)>(13, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
+  bad += run_gram<nm_for(14)>(14, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
+  bad += run_gram<nm_for(30)>(30, 0.1f, 0.5f, 0.09f, &worst_ratio, 40);
+  bad += run_gram<nm_for(32)>(32, 1e-3f, 1e-2f, 1e-5f, &worst_ratio, 40);
+  printf("bf16x3 gram chain: worst error / (MFMA + dropped-product part of the band) = %.3f, violations %d\n",
+         worst_ratio, bad);
+  const bool ok = failures == 0 && bad == 0;
+  printf("%s\n", ok ? "OK" : "FAILED");
+  return ok ? 0 : 1;
+}

@@ -243,3 +243,18 @@ def test_errors_are_codes_not_exits():
     assert rc == -1
     rc = capi.lib.dc_hip_populations(vp(c), 4, 0, vp(r), 1, 0, 4, 0, vp(pops))   # n_cols == 0
     assert rc == -1
+
+
+@pytest.mark.gpu
+def test_mfma_accumulate_model_and_gram_band():
+    """The guard band of the matrix-core sweeps assumes (1) how v_mfma_f32_32x32x16_bf16 rounds its
+    17-term sums and (2) that the bf16x3 Gram chain stays inside the MFMA part of the band; both are
+    checked on the device by a small HIP program built with the library (tests/cpp/test_mfma_model.hip)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "clustering_amd", "bin",
+                       "test_mfma_model")
+    assert os.path.exists(exe), "build the library first (make -C clustering_amd/csrc)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout
