@@ -761,20 +761,24 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   };
 
   uint32_t chains = 0;
-  for (uint32_t base = 0; base < T; base += kListCap) {
+  // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
+  // every share sees every region; the scan only touches its own boxes)
+  const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
+  for (uint32_t base = 0; base < U; base += kListCap) {
     // ---- scan: which reference tiles of this round can hold a pair within r_max of the group?
     uint32_t cnt = 0;
-    const uint32_t lim = min(T - base, (uint32_t)kListCap);
+    const uint32_t lim = min(U - base, (uint32_t)kListCap);
+    auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
     // (the box of step k+1 is fetched while step k is tested: the scan is latency-, not work-bound)
-    float4 rb_next = ((uint32_t)lane < lim) ? box_r[base + lane] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    float4 rb_next = ((uint32_t)lane < lim) ? box_r[tile_of(base + lane)]
+                                            : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
     for (uint32_t k = 0; k < lim; k += 64) {
-      const uint32_t t = base + k + lane;
+      const uint32_t t = tile_of(base + k + lane);
       const float4 rb = rb_next;
-      if (k + 64 + lane < lim) rb_next = box_r[t + 64];
+      if (k + 64 + lane < lim) rb_next = box_r[tile_of(base + k + 64 + lane)];
       // (one test against the box of the whole query group: per-query-tile masks were measured to
       //  save < 0.5 % of the chains and they keep the chains from being pipelined)
-      const bool ok = (k + lane < lim) && (t % n_chunks == chunk) &&   // this wave's share
-                      (box_gap2(gbox, rb) < far2);
+      const bool ok = (k + lane < lim) && (box_gap2(gbox, rb) < far2);
       const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
       if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
       cnt += (uint32_t)__builtin_popcountll(m);
@@ -1357,26 +1361,31 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   };
 
   uint32_t chains = 0, visited = 0;
+  // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
+  // every share sees every region; the scans only touch their own boxes)
+  const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
   if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
   for (;;) {
-    for (uint32_t base = 0; base < T; base += kListCap) {
+    for (uint32_t base = 0; base < U; base += kListCap) {
       uint32_t cnt = 0;
-      const uint32_t lim = min(T - base, (uint32_t)kListCap);
-      float4 rb_next = ((uint32_t)lane < lim) ? box_r[base + lane] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+      const uint32_t lim = min(U - base, (uint32_t)kListCap);
+      auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
+      float4 rb_next = ((uint32_t)lane < lim) ? box_r[tile_of(base + lane)]
+                                              : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
       for (uint32_t k = 0; k < lim; k += 64) {
-        const uint32_t t = base + k + lane;
+        const uint32_t t = tile_of(base + k + lane);
         const float4 rb = rb_next;   // fetched one step ahead: the scan is latency-bound otherwise
-        if (k + 64 + lane < lim) rb_next = box_r[t + 64];
+        if (k + 64 + lane < lim) rb_next = box_r[tile_of(base + k + 64 + lane)];
         bool ok = false;
-        if ((k + lane < lim) && (t % n_chunks == chunk)) {   // this wave's share of the references
+        if (k + lane < lim) {
           const float g2 = box_gap2(gbox, rb);
           ok = (g2 < r2_hi) & (g2 >= r2_lo);
         }
-        // (the ring logic below only ever sees this share: its incumbents are upper bounds of the
-        //  true ones, so the rings are at worst a little wider than necessary)
+        // (the ring logic below only ever sees this wave's share of the references: its incumbents
+        //  are upper bounds of the true ones, so the rings are at worst a little wider than necessary)
         const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
         if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
         cnt += (uint32_t)__builtin_popcountll(m);
@@ -1529,7 +1538,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     }
 #pragma unroll
     for (int qt = 0; qt < TQ; ++qt) flush(qt);        // the settle test needs the exact incumbents
-    if (!(r2_hi <= FLT_MAX) || visited >= (T - chunk + n_chunks - 1) / n_chunks)
+    if (!(r2_hi <= FLT_MAX) || visited >= U)
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
     const float sure = r2_hi * 0.9999f;

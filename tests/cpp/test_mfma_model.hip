@@ -143,7 +143,7 @@ static int run_gram(uint32_t D, float scale, float offset, float thr, double* wo
         if (err > bound) ++bad;
       }
   }
-  hipFree(d_ref); hipFree(d_qry); hipFree(d_ny); hipFree(d_cq); hipFree(d_out);
+  (void)hipFree(d_ref); (void)hipFree(d_qry); (void)hipFree(d_ny); (void)hipFree(d_cq); (void)hipFree(d_out);
   return bad;
 }
 
