@@ -640,6 +640,15 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
 // and runs the usual Gram-chain + epilogue on them; per chain one more box test against the single
 // query tile.  Counting, guard band and exact re-check are those of pop_mfma_kernel.
 // ---------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.
+// Query groups are numbered along the spatial ordering, and neighbouring groups walk nearly the same
+// reference tiles: this remap gives every XCD a CONTIGUOUS range of groups, so that the tiles its
+// waves stream are shared through its L2 instead of being fetched by all eight.
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n_blocks) {
+  const uint32_t xcd = b & 7u, idx = b >> 3, n_full = n_blocks >> 3, rem = n_blocks & 7u;
+  return xcd * n_full + (xcd < rem ? xcd : rem) + idx;
+}
+
 constexpr int kListCap = 1024;   // reference tiles scanned per round (LDS list entries per wave)
 constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane and query tile
 
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
-  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t wave = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib;
   // gridDim.y > 1: the reference tiles are dealt round-robin to gridDim.y waves per query group and
   // the partial counts are merged with atomics (keeps small launches, e.g. one rank of an 8-GPU
   // run, at >= 2 waves per SIMD without giving up the operand reuse of TQ query tiles per wave)
@@ -1279,7 +1288,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
-  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t wave = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib;
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t qt0 = wave * TQ;
