@@ -1417,65 +1417,75 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         const bool all_lower = fr.y < Q.feq;
         const bool mixed = (fr.x < Q.feq) & !all_lower;
         const bool special = mixed | (t == (Q.spos >> 5));
+        // plain tile: the minimum over the whole tile serves both searches.  ONE wave-level test
+        // covers "some lane needs the masked minima" and "some lane has candidates": the scalar
+        // hand-off (v_cmp -> s_cbranch) is a pipeline bubble at two waves per SIMD.
         float hmin = all_lower ? tmin : INFINITY;
-        const bool any_special = __builtin_amdgcn_ballot_w64(special) != 0;
-        if (__builtin_expect(any_special, 0)) {
-          // masked per-element minima (the tile holds the query itself and/or straddles feq); the
-          // free energies of the tile's frames are fetched only here
-          float4 fv[4];
-          load_frag(fe_c, t, h, fv);
-          const f32x16 fef = frag16(fv);
-          tmin = INFINITY;
-          hmin = INFINITY;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = (tile_row(t, r, h) != Q.spos) ? acc[r] : INFINITY;
-            tmin = fminf(tmin, v);
-            hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
-          }
-        }
-        const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
-        const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
-        const bool trig = (tmin < bn) | (hmin < bh);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
-          // park this tile's candidates (values within the band of the running minima); element r
-          // of the accumulator is bit (15 - r) of the masks
-          uint32_t mn = 0, mh = 0;
-          if (!any_special && t + 1 != T) {
-            // plain tile: below-threshold sign strings (idle lanes have thresholds of -inf, pad rows
-            // only exist in the last tile)
-            uint32_t sn = 0, sh = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              sn = __builtin_amdgcn_alignbit(sn, __float_as_uint(acc[r] - bn), 31);
-              sh = __builtin_amdgcn_alignbit(sh, __float_as_uint(acc[r] - bh), 31);
-            }
-            mn = sn & 0xFFFFu;
-            mh = all_lower ? (sh & 0xFFFFu) : 0u;
-          } else {
+        float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+        float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
+        const bool rare = special | (tmin < bn) | (hmin < bh);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+          const bool any_special = __builtin_amdgcn_ballot_w64(special) != 0;
+          if (any_special) {
+            // masked per-element minima (the tile holds the query itself and/or straddles feq); the
+            // free energies of the tile's frames are fetched only here
             float4 fv[4];
             load_frag(fe_c, t, h, fv);
             const f32x16 fef = frag16(fv);
-            const bool live = (livemask[qi] >> lane) & 1;
+            tmin = INFINITY;
+            hmin = INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const uint32_t pos = tile_row(t, r, h);
-              const bool other = live & (pos != Q.spos) & (pos < n_rows);
-              mn |= (other & (acc[r] < bn)) ? (0x8000u >> r) : 0u;
-              mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (0x8000u >> r) : 0u;
+              const float v = (tile_row(t, r, h) != Q.spos) ? acc[r] : INFINITY;
+              tmin = fminf(tmin, v);
+              hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
             }
+            new_nn = fminf(Q.m_nn, tmin);
+            new_hd = fminf(Q.m_hd, hmin);
+            bn = nn_band(gb, new_nn);
+            bh = nn_band(gb, new_hd);
           }
-          uint32_t m = mn | mh;
-          uint32_t* qu = queues + qi * (kQueueCap * 64);
-          while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
-            if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qi] == (uint32_t)kQueueCap)) != 0)
-              flush(qi);
-            if (m != 0) {
-              const int p = __builtin_ctz(m);
-              qu[qcount[qi] * 64 + lane] =
-                  tile_row(t, 15 - p, h) | (((mn >> p) & 1u) << 30) | (((mh >> p) & 1u) << 31);
-              ++qcount[qi];
-              m &= m - 1;
+          const bool trig = (tmin < bn) | (hmin < bh);
+          if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+            // park this tile's candidates (values within the band of the running minima); element r
+            // of the accumulator is bit (15 - r) of the masks
+            uint32_t mn = 0, mh = 0;
+            if (!any_special && t + 1 != T) {
+              // plain tile: below-threshold sign strings (idle lanes have thresholds of -inf, pad
+              // rows only exist in the last tile)
+              uint32_t sn = 0, sh = 0;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                sn = __builtin_amdgcn_alignbit(sn, __float_as_uint(acc[r] - bn), 31);
+                sh = __builtin_amdgcn_alignbit(sh, __float_as_uint(acc[r] - bh), 31);
+              }
+              mn = sn & 0xFFFFu;
+              mh = all_lower ? (sh & 0xFFFFu) : 0u;
+            } else {
+              float4 fv[4];
+              load_frag(fe_c, t, h, fv);
+              const f32x16 fef = frag16(fv);
+              const bool live = (livemask[qi] >> lane) & 1;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const uint32_t pos = tile_row(t, r, h);
+                const bool other = live & (pos != Q.spos) & (pos < n_rows);
+                mn |= (other & (acc[r] < bn)) ? (0x8000u >> r) : 0u;
+                mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (0x8000u >> r) : 0u;
+              }
+            }
+            uint32_t m = mn | mh;
+            uint32_t* qu = queues + qi * (kQueueCap * 64);
+            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+              if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qi] == (uint32_t)kQueueCap)) != 0)
+                flush(qi);
+              if (m != 0) {
+                const int p = __builtin_ctz(m);
+                qu[qcount[qi] * 64 + lane] =
+                    tile_row(t, 15 - p, h) | (((mn >> p) & 1u) << 30) | (((mh >> p) & 1u) << 31);
+                ++qcount[qi];
+                m &= m - 1;
+              }
             }
           }
         }
