@@ -1173,6 +1173,7 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
 struct NnPQ {            // per query tile, per lane
   float feq;             // free energy of the query
   float m_nn, m_hd;      // running minima of the MFMA values over the visited reference rows
+  float bn, bh;          // nn_band(m_nn), nn_band(m_hd): candidates are the values below these
   float bd_nn, bd_hd;    // exact incumbents (canonical d2)
   uint32_t bj_nn, bj_hd;
   uint32_t spos;         // position of the query itself in the reference order
@@ -1341,6 +1342,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       if (g_nn[qt] < FLT_MAX) q[qt].m_nn = g_nn[qt] + (gb.e0 + gb.kappa * g_nn[qt]);
       if (g_hd[qt] < FLT_MAX) q[qt].m_hd = g_hd[qt] + (gb.e0 + gb.kappa * g_hd[qt]);
     }
+    q[qt].bn = nn_band(gb, q[qt].m_nn);
+    q[qt].bh = nn_band(gb, q[qt].m_hd);
     q[qt].bd_nn = FLT_MAX;
     q[qt].bd_hd = FLT_MAX;
     q[qt].bj_nn = n_rows + 1;
@@ -1414,17 +1417,19 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t, float2 fr) {
         constexpr int qi = decltype(qi_c)::value;
         NnPQ& Q = q[qi];
-        const bool all_lower = fr.y < Q.feq;
-        const bool mixed = (fr.x < Q.feq) & !all_lower;
-        const bool special = mixed | (t == (Q.spos >> 5));
-        // plain tile: the minimum over the whole tile serves both searches.  ONE wave-level test
-        // covers "some lane needs the masked minima" and "some lane has candidates": the scalar
+        // Common path: two compares against the cached candidate thresholds.  "Lower free energy" is
+        // taken conservatively here (the tile has SOME lower frame => its minimum might be one), and
+        // the tile holding the query itself always passes (its own d2 ~ 0): whatever needs the
+        // per-element treatment ends up in the rare path.  The running minima can only change there
+        // too (a value below the minimum is below its band).  ONE wave-level test: the scalar
         // hand-off (v_cmp -> s_cbranch) is a pipeline bubble at two waves per SIMD.
-        float hmin = all_lower ? tmin : INFINITY;
-        float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
-        float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
-        const bool rare = special | (tmin < bn) | (hmin < bh);
+        const float hcons = (fr.x < Q.feq) ? tmin : INFINITY;
+        const bool rare = (tmin < Q.bn) | (hcons < Q.bh);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+          const bool all_lower = fr.y < Q.feq;
+          const bool mixed = (fr.x < Q.feq) & !all_lower;
+          const bool special = mixed | (t == (Q.spos >> 5));
+          float hmin = all_lower ? tmin : INFINITY;
           const bool any_special = __builtin_amdgcn_ballot_w64(special) != 0;
           if (any_special) {
             // masked per-element minima (the tile holds the query itself and/or straddles feq); the
@@ -1440,11 +1445,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               tmin = fminf(tmin, v);
               hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
             }
-            new_nn = fminf(Q.m_nn, tmin);
-            new_hd = fminf(Q.m_hd, hmin);
-            bn = nn_band(gb, new_nn);
-            bh = nn_band(gb, new_hd);
           }
+          const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+          const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
           const bool trig = (tmin < bn) | (hmin < bh);
           if (__builtin_amdgcn_ballot_w64(trig) != 0) {
             // park this tile's candidates (values within the band of the running minima); element r
@@ -1488,9 +1491,11 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               }
             }
           }
+          Q.m_nn = new_nn;
+          Q.m_hd = new_hd;
+          Q.bn = bn;
+          Q.bh = bh;
         }
-        Q.m_nn = new_nn;
-        Q.m_hd = new_hd;
       };
       // accB always holds the chain whose epilogue is still pending: query tile TQ-1 of reference
       // tile tB (or +inf everywhere: no minimum, no candidates)
