@@ -38,6 +38,26 @@ def split_flop_per_pair(d):
     return 2 * (6 * d + 3)
 
 
+def measured_traffic(kernel, n, d, radii, variant):
+    """HBM-side bytes per launch of the dominant kernel: not measurable from inside the timed run (PMC
+    counters need their own rocprofv3 passes), so the figure comes from the committed counter summary
+    of the SAME workload (profiles/r1_pruned_pmc.json, produced with scratch/pmc_summary.py); None for
+    any other workload or variant."""
+    path = os.path.join(ROOT, "profiles", "r1_pruned_pmc.json")
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = prof.get("workload", {})
+    if (w.get("n_rows"), w.get("n_cols"), w.get("radii")) != (n, d, list(radii)) or variant not in ("auto", "pruned"):
+        return None
+    tag = "pop_pruned_kernel" if kernel == "population_count" else "nn_pruned_kernel"
+    for name, e in prof.get("kernels", {}).items():
+        if tag in name:
+            return e.get("traffic_bytes")
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,7 +265,10 @@ def main():
                 "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_TFLOPS,
-                "traffic": None,
+                "traffic": measured_traffic(dom, n, d, args.radii, args.variant) if world == 1 else None,
+                "traffic_note": "bytes per launch at the L2's memory side from profiles/r1_pruned_pmc.json (separate "
+                                "rocprofv3 --pmc pass, gfx950 correction applied; includes Infinity-Cache hits); the "
+                                "kernel is matrix-bound, its operand image (128 MB) is re-streamed by every wave through L2",
                 "flop_per_pair": split_flop_per_pair(d),
                 "fp32_equivalent": {"flop_per_pair": 2 * d, "achieved": achieved_fp32,
                                     "peak": PEAK_FP32_TFLOPS, "frac": achieved_fp32 / PEAK_FP32_TFLOPS},

@@ -1690,17 +1690,21 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // Reference chunks per query group (gridDim.y).  The cost of a query group follows the local density
 // of the data (dense regions keep many more reference tiles), and with two resident waves per SIMD a
 // launch of a few thousand waves ends in a long, mostly idle tail behind its heaviest groups.  The
-// launch is therefore split along the reference axis into at least `target` waves (measured on C3:
-// 8 to 16 waves per wave slot; the full 1M-frame sweep gains 5..15 %, one rank of an 8-GPU run
-// 35 %); the operand reuse of TQ query tiles per wave is kept, partial results merge with atomics.
-constexpr uint32_t kPopWaveTarget = 16384, kNnWaveTarget = 32768;
-// A share never drops below about 128 reference tiles (the per-wave set-up and box scan must stay
-// small next to the chains).
-inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles) {
+// launch is therefore split along the reference axis into about `target` waves; the operand reuse of
+// TQ query tiles per wave is kept, partial results merge with atomics.  A share never drops below
+// `share_floor` reference tiles: the per-wave set-up, the ring logic of the neighbour sweep and the
+// box scans must stay small next to the chains.  Measured on C3 (1M x 10): the full sweeps are
+// fastest at 12 chunks (pop 38.3 -> 35.6 ms, nn 50.2 -> 38.8 ms against one chunk), one eighth of the
+// rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
+constexpr uint32_t kPopWaveTarget = 98304, kNnWaveTarget = 98304;
+constexpr uint32_t kPopShareFloor = 512, kNnShareFloor = 900;
+inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles,
+                            uint32_t share_floor) {
   const uint32_t waves = (tiles + tq - 1) / tq;
   if (waves >= target) return 1u;
   uint32_t r = (target + waves - 1) / waves;
-  const uint32_t cap = ref_tiles / 128u < 64u ? ref_tiles / 128u : 64u;
+  const uint32_t by_share = ref_tiles / share_floor;
+  const uint32_t cap = by_share < 64u ? by_share : 64u;
   r = r > cap ? cap : r;
   return r < 1u ? 1u : r;
 }
@@ -1711,7 +1715,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                       unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
-  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T);
+  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor);
   // query rows (original coordinates) + candidate queues, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
@@ -1745,7 +1749,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
                        uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
                        uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
   const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
-  const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T)), block(256);
+  const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor)), block(256);
   const uint4* img_q = P.img_q;   // B form of the query rows (all rows, same order, if full_range)
   const float* norms_q = full_range ? P.norms_p : P.norms_q;
   const uint32_t* perm_q = full_range ? P.perm_p : P.perm_q;
