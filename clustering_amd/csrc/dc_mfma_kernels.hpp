@@ -585,24 +585,48 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
   float4 n0[4], n1[4];
   load_tile<NM>(img, norms, 0, lane, h, a0, n0);
 
+  // the rest of an epilogue: counts, band test, rare exact path
+  auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<NR>& e, uint32_t t) {
+    constexpr int qi = decltype(qi_c)::value;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+    const bool band = e.tmin < P.wbits;
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
+      const PopDelta<NR> dl =
+          pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qi], t, h);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += ((livemask[qi] >> lane) & 1) ? dl.d[rr] : 0u;
+    }
+  };
+
+  // chains software-pipelined over two accumulator tiles (see pop_pruned_kernel); accB holds the chain
+  // whose epilogue is pending (+inf everywhere = contributes nothing)
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
+  uint32_t tB = 0;
   auto tile_body = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);
-#pragma unroll
-    for (int qt = 0; qt < TQ; ++qt) {
-      const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
+    if constexpr (TQ == 1) {
       PopAcc<NR> e;
       pop_epi_begin<NR>(e);
-      pop_epi<NR, 0, 16>(acc, P.dl, e);
-#pragma unroll
-      for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
-      const bool band = e.tmin < P.wbits;
-      if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qt]) != 0, 0)) {
-        const PopDelta<NR> dl =
-            pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qt], t, h);
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] += ((livemask[qt] >> lane) & 1) ? dl.d[rr] : 0u;
-      }
+      pop_chain<NM, NR>(a, b[0], c0, accA, accB, P.dl, e);
+      finish(accB, std::integral_constant<int, 0>{}, e, tB);
+      accB = accA;   // (16 moves against >= 9 MFMAs per chain)
+    } else {
+      constexpr_for_pairs<TQ>([&](auto qt_c) {
+        constexpr int qt = decltype(qt_c)::value;
+        constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
+        PopAcc<NR> e;
+        pop_epi_begin<NR>(e);
+        pop_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
+        finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
+        pop_epi_begin<NR>(e);
+        pop_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e);
+        finish(accA, std::integral_constant<int, qt>{}, e, t);
+      });
     }
+    tB = t;
   };
 
   for (uint32_t t = 0; t < T; t += 2) {
@@ -612,6 +636,12 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
       load_tile<NM>(img, norms, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
       tile_body(a1, n1, t + 1);
     }
+  }
+  {  // drain: epilogue of the last pending chain
+    PopAcc<NR> e;
+    pop_epi_begin<NR>(e);
+    pop_epi<NR, 0, 16>(accB, P.dl, e);
+    finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
   }
 
 #pragma unroll
@@ -1093,38 +1123,59 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
   float4 n0[4], n1[4];
   load_tile<NM>(img_s, norms_s, 0, lane, h, a0, n0);
 
-  // one accumulator tile: minima, band test against the running minima, rare exact path.
-  // Bitwise logic on purpose (no short-circuit control flow in the hot path).
+  // the rest of an epilogue: minima of the special tiles, band test against the running minima, rare
+  // exact path.  Bitwise logic on purpose (no short-circuit control flow in the hot path).
+  auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t) {
+    constexpr int qi = decltype(qi_c)::value;
+    NnQ& Q = q[qi];
+    const bool special = (t == Q.t_self) | (t == Q.t_part);
+    float hmin = (t < Q.t_full) ? tmin : INFINITY;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
+      const NnMin g = nn_special(acc, t, h, Q.spos, Q.pq);   // valid for every lane, just slower
+      tmin = g.tmin;
+      hmin = g.hmin;
+    }
+    const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+    const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
+    const bool trig = (tmin < bn) | (hmin < bh);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
+      const bool live = (livemask[qi] >> lane) & 1;
+      NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
+      best = nn_fix(coords, perm, n_rows, n_cols, acc, bn, bh, best, jq[qi], Q.spos, Q.pq, t, h);
+      Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
+      Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
+      Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
+      Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
+    }
+    Q.m_nn = new_nn;
+    Q.m_hd = new_hd;
+  };
+
+  // chains software-pipelined over two accumulator tiles (see nn_pruned_kernel)
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
+  uint32_t tB = 0;
   auto tile_body = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);
-#pragma unroll
-    for (int qt = 0; qt < TQ; ++qt) {
-      NnQ& Q = q[qt];
-      const f32x16 acc = gram_chain<NM>(a, b[qt], c0);
+    if constexpr (TQ == 1) {
       float tmin = INFINITY;
-      tile_min<0, 16>(acc, tmin);
-      const bool special = (t == Q.t_self) | (t == Q.t_part);
-      float hmin = (t < Q.t_full) ? tmin : INFINITY;
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
-        const NnMin g = nn_special(acc, t, h, Q.spos, Q.pq);   // valid for every lane, just slower
-        tmin = g.tmin;
-        hmin = g.hmin;
-      }
-      const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
-      const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
-      const bool trig = (tmin < bn) | (hmin < bh);
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
-        const bool live = (livemask[qt] >> lane) & 1;
-        NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-        best = nn_fix(coords, perm, n_rows, n_cols, acc, bn, bh, best, jq[qt], Q.spos, Q.pq, t, h);
-        Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
-        Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
-        Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
-        Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
-      }
-      Q.m_nn = new_nn;
-      Q.m_hd = new_hd;
+      nn_chain<NM>(a, b[0], c0, accA, accB, tmin);
+      finish(accB, std::integral_constant<int, 0>{}, tmin, tB);
+      accB = accA;
+    } else {
+      constexpr_for_pairs<TQ>([&](auto qt_c) {
+        constexpr int qt = decltype(qt_c)::value;
+        constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
+        float tmin = INFINITY;
+        nn_chain<NM>(a, b[qt], c0, accA, accB, tmin);
+        finish(accB, std::integral_constant<int, qb>{}, tmin, (qt == 0) ? tB : t);
+        tmin = INFINITY;
+        nn_chain<NM>(a, b[qt + 1], c0, accB, accA, tmin);
+        finish(accA, std::integral_constant<int, qt>{}, tmin, t);
+      });
     }
+    tB = t;
   };
 
   for (uint32_t t = 0; t < T; t += 2) {
@@ -1134,6 +1185,11 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
       load_tile<NM>(img_s, norms_s, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
       tile_body(a1, n1, t + 1);
     }
+  }
+  {  // drain: epilogue of the last pending chain
+    float tmin = INFINITY;
+    tile_min<0, 16>(accB, tmin);
+    finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB);
   }
 
 #pragma unroll
