@@ -11,11 +11,11 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one
     1 000 000 frames x 10 dims, 3-Gaussian-blob generator of SURVEY.md 8(d) (seed 20240), r = 0.2.
 Metric: frame-pairs/s (density pop+nn) = 2*N^2 / t_step  (ordered pairs of both sweeps per second).
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-    "roofline":     dominant kernel vs the dense bf16 MFMA peak (2.5 PFLOP/s): the sweeps split every fp32
-                    coordinate into three bf16 pieces and sum 6 piece products per column plus 3
-                    constant slots on the matrix cores = 2*(6*D+3) flop per evaluated pair; the
-                    same time against the fp32 peak (157.3 TFLOP/s, 2*D flop per pair) is reported
-                    next to it as "fp32_equivalent"
+    "roofline":     dominant kernel, SURVEY.md 8(d): algorithmic 2*D flop per EVALUATED frame pair against
+                    the fp32 MFMA peak (157.3 TFLOP/s).  The sweeps run that contraction as an exact
+                    three-piece bf16 split on the bf16 matrix pipe (2*(6*D+3) flop per pair executed,
+                    dense peak 2.5 PFLOP/s), so the fp32 fraction can exceed 1; the executed figure is
+                    reported next to it as "matrix_pipe"
     "cpu_baseline": the CPU restatement (oracle, fast build, all host threads) on a bounded sample.
 """
 import argparse
@@ -233,8 +233,8 @@ def main():
             dom, dom_t, dom_pairs = "nearest_neighbor_search", nn_t, nn_pairs
         else:
             dom, dom_t, dom_pairs = "population_count", pop_t, pop_pairs
-        achieved = dom_pairs * split_flop_per_pair(d) / dom_t / 1e12
-        achieved_fp32 = dom_pairs * 2.0 * d / dom_t / 1e12
+        achieved = dom_pairs * 2.0 * d / dom_t / 1e12                        # algorithmic, SURVEY 8(d)
+        executed = dom_pairs * split_flop_per_pair(d) / dom_t / 1e12         # what the bf16 pipe does
         pop_sum = int(out["pops"][0].sum(dtype=torch.int64).item())
         line = {
             "metric": "frame-pairs/s (density pop+nn)" if want_nn else "frame-pairs/s (density pop)",
@@ -247,7 +247,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16x3 (exact 3-piece split of the f32 coordinates), f32 accumulate; exact f32 re-check",
+            "dtype": "f32 (Gram form evaluated as an exact bf16x3 split on the bf16 MFMA pipe, f32 accumulate; "
+                     "undecided pairs re-checked in canonical f32)",
             "data": "synthetic",
             "config": {
                 "workload": f"{n} frames x {d} dims, 3-Gaussian-blob (sigma 0.08, seed 20240), radii {args.radii}, "
@@ -262,16 +263,18 @@ def main():
                 "bound": "mfma",
                 "kernel": dom,
                 "achieved": achieved,
-                "peak": PEAK_BF16_TFLOPS,
+                "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_BF16_TFLOPS,
+                "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": measured_traffic(dom, n, d, args.radii, args.variant) if world == 1 else None,
                 "traffic_note": "bytes per launch at the L2's memory side from profiles/r1_pruned_pmc.json (separate "
                                 "rocprofv3 --pmc pass, gfx950 correction applied; includes Infinity-Cache hits); the "
                                 "kernel is matrix-bound, its operand image (128 MB) is re-streamed by every wave through L2",
-                "flop_per_pair": split_flop_per_pair(d),
-                "fp32_equivalent": {"flop_per_pair": 2 * d, "achieved": achieved_fp32,
-                                    "peak": PEAK_FP32_TFLOPS, "frac": achieved_fp32 / PEAK_FP32_TFLOPS},
+                "flop_per_pair": 2 * d,
+                "matrix_pipe": {"what": "flops the bf16 MFMA pipe executes for the split (6 piece products per "
+                                        "column + 3 constant slots), against its dense peak",
+                                "flop_per_pair": split_flop_per_pair(d), "achieved": executed,
+                                "peak": PEAK_BF16_TFLOPS, "frac": executed / PEAK_BF16_TFLOPS},
                 "pairs_per_launch": dom_pairs,
                 "pairs_per_launch_unpruned": full_pairs,
                 "launch_ms": 1e3 * dom_t,
@@ -284,10 +287,10 @@ def main():
             fl32 = float(local_rows) * n * 2.0 * d
 
             def full(ms):
-                return {"launch_ms": ms, "frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                        "frac_fp32_equivalent": fl32 / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+                return {"launch_ms": ms, "frac": fl32 / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                        "frac_matrix_pipe": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
             line["roofline_full_sweep"] = {
-                "variant": "mfma (no pruning)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "variant": "mfma (no pruning)", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "pop": full(full_ms["pop_kernel"]),
                 "nn": None if full_ms["nn_kernel"] is None else full(full_ms["nn_kernel"]),
             }
