@@ -267,6 +267,31 @@ int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2_out, v
   return DC_OK;
 }
 
+int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
+                            uint32_t* d_pops, uint32_t* d_pairs, size_t capacity,
+                            unsigned long long* d_count, void* d_workspace, size_t workspace_bytes,
+                            void* stream) {
+  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
+  if (!d_count) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_rows == 0) {
+    DC_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+    return DC_OK;
+  }
+  if (!d_coords || !d_pops) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  if (!dc::mfma_supports(n_cols))
+    return fail(DC_ERR_INVALID_ARGUMENT, "radius pairs need n_cols <= 32 (got %zu)", n_cols);
+  if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
+    return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
+                dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
+  DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_rows, s));
+  if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, false, s))
+    return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
+  dc::launch_radius_pairs(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, r2, d_pops, (uint2*)d_pairs,
+                          (unsigned long long)capacity, d_count, d_workspace, s);
+  return check_launch("radius pair sweep launch");
+}
+
 // ------------------------------------------------------------------------------------------
 // host-pointer wrappers
 // ------------------------------------------------------------------------------------------
@@ -334,6 +359,44 @@ int dc_hip_populations(const float* coords, size_t n_rows, size_t n_cols, const 
     if (e == hipSuccess) e = hipStreamSynchronize(j.stream);
     if (e != hipSuccess) rc = fail(DC_ERR_HIP, "population sweep: %s", hipGetErrorString(e));
   }
+  j.release();
+  return rc;
+}
+
+int dc_hip_radius_pairs(const float* coords, size_t n_rows, size_t n_cols, float r2, int device,
+                        uint32_t* pairs, size_t capacity, unsigned long long* count) {
+  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
+  if (!count) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  *count = 0;
+  if (n_rows == 0) return DC_OK;
+  if (!coords || (capacity && !pairs)) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  DeviceJob j;
+  int rc = job_open(j, device, coords, n_rows, n_cols);
+  uint32_t* d_pairs = nullptr;
+  unsigned long long* d_count = nullptr;
+  hipError_t e = hipSuccess;
+  if (rc == DC_OK) {
+    e = hipMalloc((void**)&j.d_pops, sizeof(uint32_t) * n_rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_count, sizeof(unsigned long long));
+    if (e == hipSuccess && capacity) e = hipMalloc((void**)&d_pairs, sizeof(uint32_t) * 2 * capacity);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "radius pairs setup: %s", hipGetErrorString(e));
+  }
+  if (rc == DC_OK)
+    rc = dc_hip_radius_pairs_dev(j.d_coords, n_rows, n_cols, r2, j.d_pops, d_pairs, capacity, d_count,
+                                 j.d_ws, j.ws_bytes, j.stream);
+  if (rc == DC_OK) {
+    e = hipMemcpyAsync(count, d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, j.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(j.stream);
+    if (e == hipSuccess && *count == ~0ull) {
+      rc = fail(DC_ERR_INVALID_ARGUMENT, "radius pairs need finite coordinates");
+    } else if (e == hipSuccess && capacity) {
+      const size_t n = (size_t)std::min<unsigned long long>(*count, capacity);
+      if (n) e = hipMemcpy(pairs, d_pairs, sizeof(uint32_t) * 2 * n, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "radius pair sweep: %s", hipGetErrorString(e));
+  }
+  if (d_pairs) (void)hipFree(d_pairs);
+  if (d_count) (void)hipFree(d_count);
   j.release();
   return rc;
 }

@@ -317,19 +317,51 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                            uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           hipStream_t stream);
+                           const EdgeSink* sink, hipStream_t stream);
 
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                        hipStream_t stream) {
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, i_from, i_to, single_radius(rad2, r), 1,
-                   d_pops + (size_t)r * n_rows, d_ws, stream);
+                   d_pops + (size_t)r * n_rows, d_ws, nullptr, stream);
+}
+
+// positions of the sweep's spatial order -> frame ids, for the pairs actually written; a flagged
+// data set (the matrix-core kernel stood down) reports count = ~0
+__global__ void edges_to_frames_kernel(uint2* __restrict__ edges, const unsigned long long* __restrict__ count,
+                                       unsigned long long capacity, const uint32_t* __restrict__ perm) {
+  const unsigned long long n = *count < capacity ? *count : capacity;
+  for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint2 e = edges[k];
+    edges[k] = make_uint2(perm[e.x], perm[e.y]);
+  }
+}
+__global__ void edges_flag_kernel(const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ count) {
+  if (hdr[1] != 0) *count = ~0ull;
+}
+
+void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
+                         uint32_t* d_pops, uint2* d_pairs, unsigned long long capacity,
+                         unsigned long long* d_count, void* d_ws, hipStream_t stream) {
+  const Layout L = make_layout(n_rows, n_cols);
+  Rad2 one;
+  for (int k = 0; k < kMaxRadiiPerLaunch; ++k) one.v[k] = -1.0f;
+  one.v[0] = r2;
+  (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
+  const EdgeSink sink{d_pairs, d_count, d_pairs ? capacity : 0ull};
+  pop_pruned_one(d_coords, n_rows, n_cols, 0u, n_rows, one, 1, d_pops, d_ws, &sink, stream);
+  if (d_pairs && capacity)
+    hipLaunchKernelGGL(edges_to_frames_kernel, dim3(1024), dim3(256), 0, stream, d_pairs,
+                       (const unsigned long long*)d_count, capacity,
+                       (const uint32_t*)((char*)d_ws + L.off_perm_p));
+  hipLaunchKernelGGL(edges_flag_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)d_ws, d_count);
 }
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                            uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           hipStream_t stream) {
+                           const EdgeSink* sink, hipStream_t stream) {
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
   uint32_t* hdr = (uint32_t*)p;
@@ -384,7 +416,8 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
 #define X(SV)                                                                                 \
   case SV:                                                                                    \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
-      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, full, rad2, n_rad, d_pops, stream); \
+      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, full, rad2, n_rad, d_pops, sink,  \
+                           stream);                                                           \
     break;
     DC_FOR_EACH_S(X)
 #undef X

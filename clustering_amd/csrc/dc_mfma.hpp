@@ -4,6 +4,16 @@
 
 namespace dc {
 
+// Optional second product of the pruned population sweep: the list of all unordered frame pairs
+// within the radius (the radius graph that the reference's screening walks frame by frame,
+// density_clustering.cpp:292-332).  Pairs are emitted as positions in the sweep's spatial order,
+// (query position, reference position) with reference < query, i.e. every pair exactly once.
+struct EdgeSink {
+  uint2* edges;                    // nullptr: counting only
+  unsigned long long* count;       // total number of pairs found (may exceed capacity)
+  unsigned long long capacity;
+};
+
 // true if the MFMA kernels handle this n_cols
 bool mfma_supports(size_t n_cols);
 // bytes of device scratch (operand images, norms) for a problem size; 0 if unsupported
@@ -19,6 +29,12 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
                        void* d_ws, hipStream_t stream);
+// pruned population sweep at squared radius r2 that also lists every unordered frame pair with
+// canonical d2 < r2 (frame ids; d_pairs may be nullptr to count only); needs mfma_prepare first.
+// *d_count: number of pairs found (> capacity: buffer too small), ~0 if the data was flagged.
+void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
+                         uint32_t* d_pops, uint2* d_pairs, unsigned long long capacity,
+                         unsigned long long* d_count, void* d_ws, hipStream_t stream);
 // neighbour sweep over (cell, free energy)-ordered frames with ring-wise pruning
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,

@@ -691,11 +691,25 @@ constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane
 constexpr uint32_t kPopQueuePosBits = 24;    // entry = position | radius flags << 24
 constexpr uint32_t kPopQueueMaxRows = 1u << kPopQueuePosBits;
 
-template <int NR>
+// wave-aggregated append: lanes with `have` add one pair each
+__device__ __forceinline__ void emit_edge(const EdgeSink& sink, bool have, uint32_t pos_q, uint32_t pos_r) {
+  const uint64_t m = __builtin_amdgcn_ballot_w64(have);
+  if (m == 0) return;
+  unsigned long long base = 0;
+  const int leader = __builtin_ctzll(m);
+  if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(sink.count, (unsigned long long)__builtin_popcountll(m));
+  base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+  if (have && sink.edges && base + rank < sink.capacity) sink.edges[base + rank] = make_uint2(pos_q, pos_r);
+}
+
+template <int NR, bool EMIT>
 __device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queue /* [kQueueCap][64] */,
                                                             uint32_t count, const float* qrow,
                                                             const float* __restrict__ coords_r,
-                                                            uint32_t n_cols, Rad2 rad2, int lane) {
+                                                            uint32_t n_cols, Rad2 rad2, int lane,
+                                                            EdgeSink sink, uint32_t pos_q) {
   PopDelta<NR> out;
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) out.d[rr] = 0;
@@ -709,6 +723,7 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queu
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
         out.d[rr] += ((((flags >> rr) & 1u) != 0u) & (d2c < rad2.v[rr])) ? 1u : 0u;
+      if constexpr (EMIT) emit_edge(sink, (d2c < rad2.v[0]) & (pos < pos_q), pos_q, pos);
     }
   }
   return out;
@@ -721,7 +736,7 @@ __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
   return dx * dx + dy * dy;
 }
 
-template <int NM, int NR, int TQ>
+template <int NM, int NR, int TQ, bool EMIT = false>
 __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
@@ -730,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
-    int n_rad, uint32_t* __restrict__ pops) {
+    int n_rad, uint32_t* __restrict__ pops, EdgeSink sink) {
   __shared__ uint32_t lists[4][kListCap];
   // dynamic LDS: [4 waves][TQ*32][n_cols] query rows (original coordinates), then the queues of
   // deferred exact evaluations [4 waves][TQ][kQueueCap][64]
@@ -792,8 +807,9 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   // evaluate and empty the queue of query tile qi (all lanes in parallel per slot)
   auto flush = [&](int qi) {
     if (__builtin_amdgcn_ballot_w64(qcount[qi] != 0) == 0) return;
-    const PopDelta<NR> dl = pop_flush<NR>(queues + qi * (kQueueCap * 64), qcount[qi],
-                                          qrows + (qi * 32 + c) * n_cols, coords_r, n_cols, rad2, lane);
+    const PopDelta<NR> dl =
+        pop_flush<NR, EMIT>(queues + qi * (kQueueCap * 64), qcount[qi], qrows + (qi * 32 + c) * n_cols,
+                            coords_r, n_cols, rad2, lane, sink, (qt0 + (uint32_t)qi) * 32u + (uint32_t)c);
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += dl.d[rr];
     qcount[qi] = 0;
@@ -836,6 +852,18 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+      if constexpr (EMIT) {
+        // pairs decided "inside" by the accumulator alone: element r = bit 15 - r of the sign string
+        uint32_t inside = e.bits[0] & 0xFFFFu;
+        if (__builtin_amdgcn_ballot_w64(inside != 0) != 0) {
+          const uint32_t pos_q = (qt0 + (uint32_t)qi) * 32u + (uint32_t)c;
+          while (__builtin_amdgcn_ballot_w64(inside != 0) != 0) {
+            const uint32_t pos_r = tile_row(t, 15 - (inside ? __builtin_ctz(inside) : 0), h);
+            emit_edge(sink, (inside != 0) & (pos_r < pos_q), pos_q, pos_r);
+            inside &= inside - 1u;
+          }
+        }
+      }
       const bool band = e.tmin < P.wbits;
       if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
         if (use_queue) {
@@ -1803,7 +1831,8 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
 template <int S, int NRV, int TQV>
 void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
                        uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
-                       uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
+                       uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
+                       hipStream_t s) {
   const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
   const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor)), block(256);
   const uint4* img_q = P.img_q;   // B form of the query rows (all rows, same order, if full_range)
@@ -1813,26 +1842,32 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // query rows (original coordinates) + queues of deferred exact evaluations, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
-  hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV>), grid, block, smem, s, coords, n_rows, n_cols,
-                     P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q,
-                     box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops);
+  if (sink)   // radius-graph variant: full range only (query positions = reference positions)
+    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, true>), grid, block, smem, s, coords, n_rows,
+                       n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
+                       perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
+  else
+    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, false>), grid, block, smem, s, coords, n_rows,
+                       n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
+                       perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, EdgeSink{nullptr, nullptr, 0});
 }
 
 template <int S, int NRV>
 void pop_pruned_tq(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                    uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad, uint32_t* pops,
-                   unsigned long long* chain_counter, hipStream_t s) {
+                   unsigned long long* chain_counter, const EdgeSink* sink, hipStream_t s) {
   pop_pruned_launch<S, NRV, tq_for<S>>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad,
-                                       pops, chain_counter, s);
+                                       pops, chain_counter, sink, s);
 }
 
 template <int S>
 void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
                          uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
-                         uint32_t* pops, unsigned long long* chain_counter, hipStream_t s) {
+                         uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
+                         hipStream_t s) {
   // one radius per sweep (dc_mfma.hip loops over the radii of a call)
   pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
-                      chain_counter, s);
+                      chain_counter, sink, s);
 }
 
 template <int S>
@@ -1856,7 +1891,7 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                           uint32_t* pops, hipStream_t s);                                        \
   void pop_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,   \
                             uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,          \
-                            uint32_t* pops, hipStream_t s);                                      \
+                            uint32_t* pops, const EdgeSink* sink, hipStream_t s);                \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
                            void* d_ws, uint32_t n_q, int full_range, float cell2,                \
                            uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,       \

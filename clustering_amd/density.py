@@ -136,6 +136,37 @@ def evaluated_tiles(device):
     return int(a.value), int(b.value)
 
 
+def radius_pairs(coords, r2, capacity=None):
+    """All unordered frame pairs with canonical d2 < r2 (the radius graph of the reference's screening,
+    density_clustering.cpp:292-332) -> (pairs int64 [n_pairs, 2] on the device, pops int32 [n_rows]).
+    One counting sweep sizes the buffer unless a capacity is given."""
+    n_rows, n_cols = _check_coords(coords)
+    dev = coords.device
+    pops = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def sweep(pairs, cap):
+        with torch.cuda.device(dev):
+            ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
+            rc = capi.lib.dc_hip_radius_pairs_dev(_dev(coords), n_rows, n_cols, float(r2), _dev(pops),
+                                                  _dev(pairs) if pairs is not None else None, cap,
+                                                  _dev(count), ws, ws_bytes, _stream_ptr())
+        capi.check(rc, "dc_hip_radius_pairs_dev")
+        return int(count.item())
+
+    if capacity is None:
+        capacity = sweep(None, 0)
+    if capacity < 0:
+        raise capi.DensityLibraryError("radius pairs need finite coordinates")
+    pairs = torch.empty((max(capacity, 1), 2), dtype=torch.int32, device=dev)
+    n = sweep(pairs, capacity)
+    if n < 0:
+        raise capi.DensityLibraryError("radius pairs need finite coordinates")
+    if n > capacity:
+        return radius_pairs(coords, r2, n)
+    return pairs[:n].to(torch.int64), pops
+
+
 def compute_sigma2(nn_d2):
     """compute_sigma2 (density_clustering.cpp:334-343)."""
     out = C.c_double(0.0)

@@ -132,6 +132,22 @@ DC_API int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, si
  * Synchronises the stream. */
 DC_API int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2_out, void* stream);
 
+/* the radius graph that the reference's screening walks one frame at a time: replaces the O(n^2) scans
+ * of high_density_neighborhood (density_clustering.cpp:292-332, called per frame from
+ * density_clustering_common.cpp:97-121; CUDA: density_clustering_cuda.cu:396-594) by ONE pruned sweep
+ * that lists every unordered frame pair {i, j}, i != j, whose canonical d2 is < r2 (strict, :319).
+ *   r2       the squared distance itself (the reference passes max_dist = 4*sigma2, a float)
+ *   d_pops   [n_rows] uint32 device, out: populations at that radius (1 + number of partners)
+ *   d_pairs  [capacity][2] uint32 device, out: frame ids of the pairs, in no particular order, each
+ *            pair once; may be NULL with capacity 0 to count only
+ *   d_count  device uint64, out: number of pairs found -- if it exceeds capacity only the first
+ *            `capacity` were written (call again with a larger buffer); ~0 if the coordinates are not
+ *            finite (no pairs are produced then).  Needs n_cols <= 32 and a workspace as above. */
+DC_API int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
+                                   uint32_t* d_pops, uint32_t* d_pairs, size_t capacity,
+                                   unsigned long long* d_count, void* d_workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * host-pointer entry points (mirror the reference's per-GPU host functions)
  * ------------------------------------------------------------------------------------- */
@@ -147,6 +163,11 @@ DC_API int dc_hip_populations(const float* coords, size_t n_rows, size_t n_cols,
 DC_API int dc_hip_nearest_neighbors(const float* coords, size_t n_rows, size_t n_cols, const float* fe,
                                     size_t i_from, size_t i_to, int device, uint32_t* nn_idx,
                                     float* nn_d2, uint32_t* hd_idx, float* hd_d2);
+
+/* host-pointer form of dc_hip_radius_pairs_dev.  pairs: HOST [capacity][2]; *count: pairs found (if
+ * larger than capacity, call again with a buffer of that size). */
+DC_API int dc_hip_radius_pairs(const float* coords, size_t n_rows, size_t n_cols, float r2, int device,
+                               uint32_t* pairs, size_t capacity, unsigned long long* count);
 
 /* whole path on n_devices GPUs of this process (devices 0..n_devices-1), coords uploaded once per
  * device and kept resident across pop -> FE -> NN.  Row blocks as

@@ -258,3 +258,32 @@ def test_mfma_accumulate_model_and_gram_band():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def _brute_pairs(c, r2):
+    """All unordered pairs with canonical d2 < r2 (numpy emulation of the canonical order)."""
+    from refmath import d2_matrix
+    d2 = d2_matrix(c)
+    ii, jj = np.nonzero(np.tril(d2 < np.float32(r2), k=-1))   # j < i
+    return {(int(j), int(i)) for i, j in zip(ii, jj)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,n_cols,r2", [(700, 3, 0.02), (3000, 10, 0.045), (1500, 30, 0.25), (257, 2, 1e-4)])
+def test_radius_pairs_match_brute_force(dens, n_rows, n_cols, r2):
+    """dc_hip_radius_pairs_dev lists exactly the pairs the reference's high_density_neighborhood would
+    find frame by frame (strict <, canonical d2), each pair once; pops agree with the population sweep."""
+    import torch
+    from clustering_amd.synth import gaussian_blobs
+    c = gaussian_blobs(n_rows, n_cols, seed=7 + n_cols)
+    ct = torch.from_numpy(c).cuda()
+    pairs, pops = dens.radius_pairs(ct, r2)
+    got = [(int(min(a, b)), int(max(a, b))) for a, b in pairs.cpu().numpy()]
+    assert len(got) == len(set(got)), "a pair was listed twice"
+    want = _brute_pairs(c, r2)
+    assert set(got) == want
+    deg = np.ones(n_rows, dtype=np.int64)
+    for a, b in want:
+        deg[a] += 1
+        deg[b] += 1
+    assert (pops.cpu().numpy().astype(np.int64) == deg).all()
