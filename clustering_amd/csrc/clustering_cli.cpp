@@ -17,8 +17,10 @@
 // reference's CUDA build does (clustering.cpp:110-113).
 #include "../../include/dc_density.h"
 #include "density_clustering_hip.hpp"
+#include "screening_host.hpp"
 
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -72,7 +74,11 @@ const char* kHelp =
     "  -D [ --free-energy-input ] arg        input (optional): reuse free energy info.\n"
     "  -b [ --nearest-neighbors ] arg        output (optional): nearest neighbor info.\n"
     "  -B [ --nearest-neighbors-input ] arg  input (optional): reuse nearest neighbor info.\n"
-    "  -T, -o, -i                            screening / clustering output: not part of this build.\n"
+    "  -T [ --threshold-screening ] arg      parameters: screening of free energy landscape. format:\n"
+    "                                        FROM STEP TO; e.g.: \'-T 0.1 0.1 11.1\'. for defaults:\n"
+    "                                        \'-T -1\'. FROM: 0.1, STEP: 0.1, TO: MAX_FE.\n"
+    "  -o [ --output ] arg                   output (optional): clustering information.\n"
+    "  -i [ --input ] arg                    input (optional): initial state definition.\n"
     "  -n [ --nthreads ] arg (=0)            accepted for compatibility (the sweeps run on the GPU).\n"
     "  -v [ --verbose ]                      verbose mode: print runtime information to STDOUT.\n";
 
@@ -81,7 +87,9 @@ struct Options {
   bool has_radius = false;
   float radius = 0.0f;
   std::vector<float> radii;
-  bool screening_requested = false;
+  std::string output, input;
+  bool has_threshold = false;
+  std::vector<float> threshold;
 };
 
 bool is_number(const char* s) {
@@ -121,11 +129,13 @@ Options parse(int argc, char** argv) {
     else if (a == "-B") o.nn_input = need("--nearest-neighbors-input");
     else if (a == "-n") (void)need("--nthreads");
     else if (a == "-v") g_verbose = true;
-    else if (a == "-T" || a == "-o" || a == "-i") {
-      o.screening_requested = true;
-      while (i + 1 < argc && argv[i + 1][0] != '-') ++i;
-      while (i + 1 < argc && is_number(argv[i + 1])) ++i;
-    } else {
+    else if (a == "-T") {
+      o.has_threshold = true;
+      while (i + 1 < argc && is_number(argv[i + 1])) o.threshold.push_back(std::strtof(argv[++i], nullptr));
+      if (o.threshold.empty()) die("\nerror parsing arguments:\n\nthe required argument for option '--threshold-screening' is missing\n");
+    } else if (a == "-o") o.output = need("--output");
+    else if (a == "-i") o.input = need("--input");
+    else {
       die("\nerror parsing arguments:\n\nunrecognised option '" + a + "'\n\n" + kHelp);
     }
   }
@@ -253,6 +263,15 @@ void write_fes(const std::string& fname, const float* fe, std::size_t n, const s
   std::fclose(f);
 }
 
+// tools.cpp:63-69
+void write_clustered_trajectory(const std::string& fname, const std::vector<std::size_t>& traj,
+                                const std::string& header, const Comments& cm) {
+  FILE* f = open_out(fname);
+  std::fputs((with_comments(header, cm) + "#\n# state/cluster id frames are assigned to\n").c_str(), f);
+  for (std::size_t v : traj) std::fprintf(f, "%zu\n", v);
+  std::fclose(f);
+}
+
 void write_neighborhood(const std::string& fname, std::size_t n, const std::uint32_t* nn_idx,
                         const float* nn_d2, const std::uint32_t* hd_idx, const float* hd_d2,
                         const std::string& header, const Comments& cm) {
@@ -319,9 +338,6 @@ int density_main(int argc, char** argv) {
   Options o = parse(argc, argv);
   // like the reference's CUDA build: fail early if there is no GPU (clustering.cpp:110-113)
   const int n_gpus = Clustering::Density::CUDA::get_num_gpus();
-  if (o.screening_requested)
-    die("error: screening / clustering output (-T, -o, -i) is not part of this build;\n"
-        "       use -p/-d/-b here and run the screening step with the reference binary (-D/-B).");
   const std::string header = provenance_header(argc, argv);
   Comments cm = {{"clustering_radius", 0.f}, {"lumping_radius", 0.f}, {"screening_from", 0.f},
                  {"screening_to", 0.f}, {"screening_step", 0.f}, {"minimal_population", 0.f},
@@ -370,8 +386,11 @@ int density_main(int argc, char** argv) {
     fe = read_single_column<float>(o.free_energy_input);
     if (fe.size() != n_rows) die("error: free energy file does not match the number of frames");
     read_comments(o.free_energy_input, cm);
-  } else if (!o.free_energy.empty() || !o.population.empty()) {
+  } else if (!o.free_energy.empty() || !o.population.empty() || !o.output.empty()) {
     if (!o.radii.empty()) {
+      if (!o.output.empty()) die("error: clustering cannot be done with several radii (-R is set).");
+      if (o.free_energy.empty() && o.population.empty())
+        die("error: no output defined for populations or free energies.\n       why did you define -R ?");
       LOG("    calculating free energy and population\n    using radii: ");
       for (float r : o.radii) LOG("%g, ", r);
       LOG("\n    using HIP\n");
@@ -414,7 +433,7 @@ int density_main(int argc, char** argv) {
       const float radius = o.has_radius ? o.radius : radius_lump;
       LOG("    calculating free energy and population\n    using radius: %g\n", radius);
       cm["clustering_radius"] = radius;
-      const bool want_nn = !o.nn.empty() && o.nn_input.empty();
+      const bool want_nn = (!o.nn.empty() || !o.output.empty()) && o.nn_input.empty();
       sweep({radius}, 0, want_nn, pops, fe, nn_idx, nn_d2, hd_idx, hd_d2);
       have_nn = want_nn;
       if (!o.population.empty()) {
@@ -433,7 +452,7 @@ int density_main(int argc, char** argv) {
     LOG("    re-using nearest neighbor: %s\n", o.nn_input.c_str());
     read_neighborhood(o.nn_input, nn_idx, nn_d2, hd_idx, hd_d2);
     read_comments(o.nn_input, cm);
-  } else if (!o.nn.empty()) {
+  } else if (!o.nn.empty() || !o.output.empty()) {
     if (!o.radii.empty())
       die("error: nearest neighbor calculation cannot be done with\n       several radii (-R is set).");
     if (fe.empty())
@@ -466,8 +485,74 @@ int density_main(int argc, char** argv) {
       LOG("    lumping radius: %g\n", radius_lump);
       cm["lumping_radius"] = radius_lump;
     }
-    LOG("    storing nearest neighbors in: %s\n", o.nn.c_str());
-    write_neighborhood(o.nn, n_rows, nn_idx.data(), nn_d2.data(), hd_idx.data(), hd_d2.data(), header, cm);
+    if (!o.nn.empty()) {
+      LOG("    storing nearest neighbors in: %s\n", o.nn.c_str());
+      write_neighborhood(o.nn, n_rows, nn_idx.data(), nn_d2.data(), hd_idx.data(), hd_d2.data(), header, cm);
+    }
+  }
+
+  //// clustering (density_clustering.cpp:739-820)
+  if (!o.output.empty()) {
+    namespace H = Clustering::Density::HIP;
+    if (!o.radii.empty())
+      die("error: output needs to depend on single radius\n       but several radii (-R) are set.");
+    if (fe.size() != n_rows || nn_d2.size() != n_rows)
+      die("error: clustering output needs free energies and nearest neighbors (-r/-D, -B).");
+    std::vector<std::size_t> clustering;
+    if (!o.input.empty()) {
+      LOG("~~~ generating microstates\n");
+      if (o.has_threshold) LOG("warning: screening (-T) is ignored\n");
+      LOG("    reading initial states: %s\n", o.input.c_str());
+      clustering = read_single_column<std::size_t>(o.input);
+      if (clustering.size() != n_rows) die("error: initial state file does not match the number of frames");
+      read_comments(o.input, cm);
+      LOG("    assigning low density states to initial states\n");
+      clustering = H::assign_low_density_frames(clustering, hd_idx, fe);
+      LOG("    sorting and renaming states by decreasing population\n");
+      clustering = H::sorted_cluster_names(clustering);
+      LOG("    storing states in: %s\n", o.output.c_str());
+      write_clustered_trajectory(o.output, clustering, header, cm);
+    } else if (o.has_threshold) {
+      LOG("\n~~~ free energy screening\n");
+      if (o.threshold.size() > 3)
+        die("error: option -T expects at most three floating point arguments: FROM STEP TO.");
+      float t_from = 0.1f, t_step = 0.1f;
+      float t_to = *std::max_element(fe.begin(), fe.end());
+      if (o.threshold.size() >= 1 && o.threshold[0] >= 0.0f) t_from = o.threshold[0];
+      if (o.threshold.size() >= 2) t_step = o.threshold[1];
+      if (o.threshold.size() == 3) t_to = o.threshold[2];
+      auto has2digits = [](float val) {   // density_clustering.cpp:500-504
+        const float val_2digits = (int)(val * 100) / 100.0;
+        return val_2digits == val;
+      };
+      if (!(has2digits(t_from) && has2digits(t_step))) die("error: -T can handle at maximum two digits.");
+      cm["screening_to"] = t_to;
+      cm["screening_from"] = t_from;
+      cm["screening_step"] = t_step;
+      // one radius graph for max_dist = 4*sigma2 serves every threshold of the scan
+      const float max_dist = (float)(4 * sigma2_of(nn_d2));
+      H::RadiusGraph graph;
+      std::string err;
+      if (!H::build_radius_graph(coords.data(), n_rows, n_cols, max_dist, 0, &graph, &err))
+        die("error during screening (radius graph)\n" + err);
+      LOG("    %zu frame pairs within the lumping radius\n", graph.n_pairs);
+      const std::vector<H::FreeEnergy> fe_sorted = H::sorted_free_energies(fe);
+      LOG("\n        fe    frames\n");
+      // upper limit extended to a 10th of the stepsize to circumvent rounding errors (:796-800)
+      const float t_to_low = t_to - t_step / 10.0f + t_step;
+      const float t_to_high = t_to + t_step / 10.0f + t_step;
+      for (float t = t_from; (t < t_to_low) && !(t_to_high < t); t += t_step) {
+        clustering = H::screening_with_graph(fe, fe_sorted, graph, t, clustering);
+        std::size_t below = 0;
+        for (std::size_t c : clustering) below += (c != 0);
+        LOG("    %6.2f %9zu\n", t, below);
+        char suffix[32];
+        std::snprintf(suffix, sizeof(suffix), ".%0.2f", t);
+        write_clustered_trajectory(o.output + suffix, clustering, header, cm);
+      }
+    } else {
+      die("error: one of -T/-i is needed to generate output.");
+    }
   }
   LOG("~~~ freeing memory\n");
   return EXIT_SUCCESS;

@@ -1,6 +1,7 @@
 // density_clustering_hip.cpp -- implementation of density_clustering_hip.hpp over the C ABI.
 // Plain C++ (no HIP headers): everything device-side lives behind include/dc_density.h.
 #include "density_clustering_hip.hpp"
+#include "screening_host.hpp"
 
 #include "../../include/dc_density.h"
 
@@ -127,6 +128,44 @@ std::tuple<Neighborhood, Neighborhood> nearest_neighbors(const float* coords,
     nhhd.emplace_hint(nhhd.end(), i, Clustering::Tools::Neighbor(hd_idx[i], hd_d2[i]));
   }
   return std::make_tuple(nh, nhhd);
+}
+
+std::vector<std::size_t> screening(const std::vector<float>& free_energy, const Neighborhood& nh,
+                                   const float free_energy_threshold, const float* coords,
+                                   const std::size_t n_rows, const std::size_t n_cols,
+                                   const std::vector<std::size_t> initial_clusters) {
+  namespace H = Clustering::Density::HIP;
+  // compute_sigma2 (density_clustering.cpp:334-343): double sum in map (frame) order
+  double sigma2 = 0.0;
+  for (const auto& match : nh) sigma2 += match.second.second;
+  sigma2 /= nh.size();
+  const float max_dist = (float)(4 * sigma2);   // the reference passes 4*sigma2 into a float parameter
+  // one radius graph and one free-energy order per trajectory, shared by the thresholds of a scan
+  struct Cache {
+    const float* coords = nullptr;
+    std::size_t n_rows = 0, n_cols = 0;
+    float max_dist = 0.0f;
+    std::vector<float> fe;
+    H::RadiusGraph graph;
+    std::vector<H::FreeEnergy> fe_sorted;
+  };
+  static Cache cache;
+  if (cache.coords != coords || cache.n_rows != n_rows || cache.n_cols != n_cols ||
+      cache.max_dist != max_dist || cache.fe != free_energy) {
+    std::string err;
+    if (!H::build_radius_graph(coords, n_rows, n_cols, max_dist, 0, &cache.graph, &err)) {
+      std::cerr << "error during screening (radius graph)\n" << err << std::endl;
+      exit(EXIT_FAILURE);
+    }
+    cache.coords = coords;
+    cache.n_rows = n_rows;
+    cache.n_cols = n_cols;
+    cache.max_dist = max_dist;
+    cache.fe = free_energy;
+    cache.fe_sorted = H::sorted_free_energies(free_energy);
+  }
+  return H::screening_with_graph(free_energy, cache.fe_sorted, cache.graph, free_energy_threshold,
+                                 initial_clusters);
 }
 
 }  // namespace CUDA

@@ -64,9 +64,14 @@ std::tuple<Neighborhood, Neighborhood> nearest_neighbors(const float* coords,
                                                          const std::size_t n_cols,
                                                          const std::vector<float>& free_energy);
 
-// NOT provided: screening() (density_clustering_cuda.hpp:47-54).  Screening is outside this
-// library's scope; a USE_CUDA-style host links the reference's CPU
-// Clustering::Density::screening (density_clustering_common.hpp:44-56) instead, see INTEGRATION.md.
+//! free-energy screening for one threshold (density_clustering_cuda.hpp:47-54; CPU semantics
+//! density_clustering_common.cpp:37-134, which the results follow).  The partner lists of ALL frames
+//! for max_dist = 4*sigma2 come from one GPU sweep (dc_hip_radius_pairs) that is cached across the
+//! calls of a -T scan (same coords / n_rows / n_cols / sigma2); see screening_host.hpp.
+std::vector<std::size_t> screening(const std::vector<float>& free_energy, const Neighborhood& nh,
+                                   const float free_energy_threshold, const float* coords,
+                                   const std::size_t n_rows, const std::size_t n_cols,
+                                   const std::vector<std::size_t> initial_clusters);
 
 }  // namespace CUDA
 

@@ -22,8 +22,9 @@ _u64p = C.POINTER(C.c_uint64)
 def build(force=False):
     """Compile the oracle, its timing build and the fast-math probe (gcc only)."""
     want = [os.path.join(_BUILD, n) for n in
-            ("libdc_oracle.so", "libdc_oracle_fast.so", "libfastmath_probe.so")]
-    srcs = [os.path.join(_HERE, n) for n in ("dc_oracle.c", "fastmath_probe.cpp", "Makefile")]
+            ("libdc_oracle.so", "libdc_oracle_fast.so", "libfastmath_probe.so", "libscreening_oracle.so")]
+    srcs = [os.path.join(_HERE, n) for n in ("dc_oracle.c", "fastmath_probe.cpp", "screening_oracle.cpp",
+                                             "Makefile")]
     stale = force or any(not os.path.exists(w) for w in want)
     if not stale:
         newest = max(os.path.getmtime(s) for s in srcs)
@@ -129,6 +130,48 @@ class Oracle:
 
     def lumping_radius(self, sigma2):
         return np.float32(self.lib.dco_lumping_radius(float(sigma2)))
+
+
+class ScreeningOracle:
+    """oracle/screening_oracle.cpp: the reference's screening / microstate assignment, quadratic scans."""
+
+    def __init__(self):
+        path = os.path.join(_BUILD, "libscreening_oracle.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        L.dso_screening.restype = None
+        L.dso_screening.argtypes = [_f32p, _f32p, C.c_float, _f32p, C.c_size_t, C.c_size_t, _u64p, _u64p]
+        L.dso_assign_low_density.restype = None
+        L.dso_assign_low_density.argtypes = [_u64p, _u64p, _f32p, C.c_size_t, _u64p]
+        L.dso_sorted_names.restype = None
+        L.dso_sorted_names.argtypes = [_u64p, C.c_size_t, _u64p]
+
+    def screening(self, fe, nn_d2, threshold, coords, initial=None):
+        c = np.ascontiguousarray(coords, dtype=np.float32)
+        n, d = c.shape
+        fe = np.ascontiguousarray(fe, dtype=np.float32)
+        nn_d2 = np.ascontiguousarray(nn_d2, dtype=np.float32)
+        out = np.zeros(n, dtype=np.uint64)
+        ini = None if initial is None else np.ascontiguousarray(initial, dtype=np.uint64)
+        self.lib.dso_screening(_ptr(fe, _f32p), _ptr(nn_d2, _f32p), float(np.float32(threshold)), _ptr(c, _f32p),
+                               n, d, None if ini is None else _ptr(ini, _u64p), _ptr(out, _u64p))
+        return out
+
+    def assign_low_density(self, initial, hd_idx, fe):
+        ini = np.ascontiguousarray(initial, dtype=np.uint64)
+        hd = np.ascontiguousarray(hd_idx, dtype=np.uint64)
+        fe = np.ascontiguousarray(fe, dtype=np.float32)
+        out = np.zeros(ini.size, dtype=np.uint64)
+        self.lib.dso_assign_low_density(_ptr(ini, _u64p), _ptr(hd, _u64p), _ptr(fe, _f32p), ini.size,
+                                        _ptr(out, _u64p))
+        return out
+
+    def sorted_names(self, clustering):
+        cl = np.ascontiguousarray(clustering, dtype=np.uint64)
+        out = np.zeros(cl.size, dtype=np.uint64)
+        self.lib.dso_sorted_names(_ptr(cl, _u64p), cl.size, _ptr(out, _u64p))
+        return out
 
 
 class Probe:

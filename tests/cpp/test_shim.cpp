@@ -1,5 +1,5 @@
 // test driver for the C++ shim (density_clustering_hip.hpp): calls the reference-shaped entry
-// points Clustering::Density::CUDA::{get_num_gpus, calculate_populations, nearest_neighbors} with
+// points Clustering::Density::CUDA::{get_num_gpus, calculate_populations, nearest_neighbors, screening} with
 // the reference's container types and dumps the results as text for tests/test_gpu_cli.py.
 //   test_shim coords.f32 n_rows n_cols fe.f32 r1 [r2 ...]
 #include "../../clustering_amd/csrc/density_clustering_hip.hpp"
@@ -41,5 +41,13 @@ int main(int argc, char** argv) {
   const auto& hd = std::get<1>(nh);
   for (std::size_t i = 0; i < n_rows; ++i)
     std::printf("nn %zu %zu %.9g %zu %.9g\n", i, nn.at(i).first, nn.at(i).second, hd.at(i).first, hd.at(i).second);
+  // screening, chained over three thresholds like Density::main does (density_clustering.cpp:801-812)
+  std::vector<std::size_t> clustering;
+  for (float t : {0.5f, 1.5f, 3.0f}) {
+    clustering = G::screening(fe, nn, t, coords.data(), n_rows, n_cols, clustering);
+    std::printf("screen %.9g", t);
+    for (std::size_t v : clustering) std::printf(" %zu", v);
+    std::printf("\n");
+  }
   return 0;
 }

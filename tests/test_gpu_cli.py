@@ -101,11 +101,60 @@ def test_cli_without_radius_uses_lumping_radius_and_reuse(tmp_path, oracle):
     assert data_lines(tmp_path / "nn2") == want
 
 
-def test_cli_rejects_screening(tmp_path):
-    (tmp_path / "coords").write_text("0 0\n1 1\n")
-    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "1", "-T", "0.1", "0.1", "-o", "x"],
+def test_cli_screening_matches_the_quadratic_restatement(tmp_path, oracle):
+    """-T FROM STEP TO -o: one radius graph from the GPU + the reference's name bookkeeping must give,
+    threshold by threshold, the clustering of the line-by-line restatement (oracle/screening_oracle.cpp:
+    O(M^2) scans per threshold, explicit renaming loops), chained through the thresholds like
+    density_clustering.cpp:801-812 does."""
+    from oracle.oracle import ScreeningOracle
+    so = ScreeningOracle()
+    c = write_coords(tmp_path / "coords", gaussian_blobs(2500, 3, seed=45))
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "0.05", "-T", "0.5", "0.75", "5.0",
+                        "-o", str(tmp_path / "clust"), "-v"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    pops = oracle.populations(c, [0.05])[0]
+    fe = oracle.free_energies(pops)
+    nn = oracle.nearest_neighbors(c, fe)
+    clustering = None
+    t, n_files = np.float32(0.5), 0
+    t_to, step = np.float32(5.0), np.float32(0.75)
+    while t < t_to - step / np.float32(10.0) + step and not (t_to + step / np.float32(10.0) + step < t):
+        clustering = so.screening(fe, nn[1], t, c, clustering)
+        got = data_lines(str(tmp_path / "clust") + ".%0.2f" % t)
+        assert got == [str(int(v)) for v in clustering], f"threshold {t}"
+        n_files += 1
+        t = np.float32(t + step)
+    assert n_files == 7
+    assert clustering.max() >= 2          # more than one state at the top threshold
+    cm = comments(str(tmp_path / "clust") + ".0.50")
+    assert cm["screening_from"] == "%.5f" % 0.5 and cm["screening_step"] == "%.5f" % 0.75
+    assert cm["screening_to"] == "%.5f" % 5.0
+
+
+def test_cli_microstates_from_initial_states(tmp_path, oracle):
+    """-i initial -o out: frames without a state take the state of their nearest neighbour of lower free
+    energy in order of free energy, then states are renamed by population (density_clustering.cpp:345-360,
+    458-493)."""
+    from oracle.oracle import ScreeningOracle
+    so = ScreeningOracle()
+    c = write_coords(tmp_path / "coords", gaussian_blobs(2000, 4, seed=46))
+    pops = oracle.populations(c, [0.08])[0]
+    fe = oracle.free_energies(pops)
+    nn = oracle.nearest_neighbors(c, fe)
+    initial = so.screening(fe, nn[1], 1.0, c)
+    (tmp_path / "initial").write_text("# initial states\n" + "\n".join(str(int(v)) for v in initial) + "\n")
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "0.08", "-i", str(tmp_path / "initial"),
+                        "-o", str(tmp_path / "micro")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = so.sorted_names(so.assign_low_density(initial, nn[2], fe))
+    assert data_lines(tmp_path / "micro") == [str(int(v)) for v in want]
+
+
+def test_cli_output_needs_a_mode(tmp_path):
+    (tmp_path / "coords").write_text("0 0\n1 1\n0.5 0.5\n")
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "1", "-o", str(tmp_path / "x")],
                        capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "not part of this build" in r.stderr
+    assert r.returncode != 0 and "one of -T/-i is needed" in r.stderr
 
 
 def test_cpp_shim_reference_signatures(tmp_path, oracle):
@@ -134,3 +183,12 @@ def test_cpp_shim_reference_signatures(tmp_path, oracle):
             i = int(i)
             assert int(a) == exp[0][i] and int(cc) == exp[2][i]
             assert np.float32(float(b)) == exp[1][i] and np.float32(float(dd)) == exp[3][i]
+    # CUDA::screening of the shim, three chained thresholds, against the quadratic restatement
+    from oracle.oracle import ScreeningOracle
+    so = ScreeningOracle()
+    want = None
+    screens = [l.split() for l in lines if l.startswith("screen ")]
+    assert [s[1] for s in screens] == ["0.5", "1.5", "3"]
+    for sline in screens:
+        want = so.screening(fe, exp[1], float(sline[1]), c, want)
+        assert [int(x) for x in sline[2:]] == want.tolist()

@@ -123,3 +123,29 @@ def test_reference_run_statistics_c2(oracle):
     assert round(float(means[0]), 1) == 2.8
     assert round(float(means[1])) == 719
     assert round(float(means[2])) == 9223
+
+
+def test_screening_restatement_known_answers(oracle):
+    """Hand-derived screening cases for oracle/screening_oracle.cpp (the reference ships no fixtures).
+    Six frames on a line: {0, 0.1, 0.2}, {5, 5.1}, {9}; r = 0.15 gives pops 2 3 2 2 2 1, so frame 1 has
+    the lowest free energy, frames 0 2 3 4 share ln(3/2) and frame 5 has ln 3.  sigma2 = mean nn d2 =
+    (5 * 0.01 + 15.21) / 6, lumping distance 4 sigma2 = 10.17: 0-1-2 are mutual partners, 3-4 are, the two
+    groups are 23 apart, frame 5 is alone."""
+    from oracle.oracle import ScreeningOracle
+    so = ScreeningOracle()
+    c = np.array([[0.0], [0.1], [0.2], [5.0], [5.1], [9.0]], dtype=np.float32)
+    pops = oracle.populations(c, [0.15])[0]
+    assert list(pops) == [2, 3, 2, 2, 2, 1]
+    fe = oracle.free_energies(pops)
+    nn = oracle.nearest_neighbors(c, fe)
+    # below 0.3 only frame 1; below 0.5 everything but frame 5; states numbered in order of first (lowest
+    # free energy) member, unassigned frames 0
+    assert list(so.screening(fe, nn[1], 0.3, c)) == [0, 1, 0, 0, 0, 0]
+    first = so.screening(fe, nn[1], 0.5, c)
+    assert list(first) == [1, 1, 1, 2, 2, 0]
+    assert list(so.screening(fe, nn[1], 1.2, c, first)) == [1, 1, 1, 2, 2, 3]
+    # microstates: frame 5 joins the state of its nearest lower-free-energy neighbour (frame 4);
+    # renaming by population: the largest state gets the highest number... (sorted ascending, name = K - i)
+    micro = so.assign_low_density(first, nn[2], fe)
+    assert list(micro) == [1, 1, 1, 2, 2, 2]
+    assert list(so.sorted_names(np.array([7, 7, 7, 3, 3, 9], dtype=np.uint64))) == [1, 1, 1, 2, 2, 3]
