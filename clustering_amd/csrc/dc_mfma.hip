@@ -342,6 +342,18 @@ __global__ void edges_flag_kernel(const uint32_t* __restrict__ hdr, unsigned lon
   if (hdr[1] != 0) *count = ~0ull;
 }
 
+// number of unordered pairs from the populations: sum(pop - 1) / 2 (every pair is counted at both ends)
+__global__ void pairs_from_pops_kernel(const uint32_t* __restrict__ pops, uint32_t n_rows,
+                                       unsigned long long* __restrict__ twice) {
+  unsigned long long s = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x)
+    s += pops[i] - 1u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(twice, s);
+}
+__global__ void halve_kernel(unsigned long long* __restrict__ v) { *v >>= 1; }
+
 void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
                          uint32_t* d_pops, uint2* d_pairs, unsigned long long capacity,
                          unsigned long long* d_count, void* d_ws, hipStream_t stream) {
@@ -350,12 +362,19 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
   for (int k = 0; k < kMaxRadiiPerLaunch; ++k) one.v[k] = -1.0f;
   one.v[0] = r2;
   (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
-  const EdgeSink sink{d_pairs, d_count, d_pairs ? capacity : 0ull};
-  pop_pruned_one(d_coords, n_rows, n_cols, 0u, n_rows, one, 1, d_pops, d_ws, &sink, stream);
-  if (d_pairs && capacity)
+  if (d_pairs && capacity) {
+    const EdgeSink sink{d_pairs, d_count, capacity};
+    pop_pruned_one(d_coords, n_rows, n_cols, 0u, n_rows, one, 1, d_pops, d_ws, &sink, stream);
     hipLaunchKernelGGL(edges_to_frames_kernel, dim3(1024), dim3(256), 0, stream, d_pairs,
                        (const unsigned long long*)d_count, capacity,
                        (const uint32_t*)((char*)d_ws + L.off_perm_p));
+  } else {
+    // counting only: the plain population sweep knows the answer
+    pop_pruned_one(d_coords, n_rows, n_cols, 0u, n_rows, one, 1, d_pops, d_ws, nullptr, stream);
+    hipLaunchKernelGGL(pairs_from_pops_kernel, dim3(256), dim3(256), 0, stream, (const uint32_t*)d_pops,
+                       n_rows, d_count);
+    hipLaunchKernelGGL(halve_kernel, dim3(1), dim3(1), 0, stream, d_count);
+  }
   hipLaunchKernelGGL(edges_flag_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)d_ws, d_count);
 }
 

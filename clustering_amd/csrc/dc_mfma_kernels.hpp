@@ -853,13 +853,34 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
       if constexpr (EMIT) {
-        // pairs decided "inside" by the accumulator alone: element r = bit 15 - r of the sign string
+        // pairs decided "inside" by the accumulator alone: element r = bit 15 - r of the sign string.
+        // Only partners at a smaller position are listed (every pair once); one atomic per chain and
+        // wave reserves the slots, then each lane stores its own pairs.
+        const uint32_t pos_q = (qt0 + (uint32_t)qi) * 32u + (uint32_t)c;
         uint32_t inside = e.bits[0] & 0xFFFFu;
-        if (__builtin_amdgcn_ballot_w64(inside != 0) != 0) {
-          const uint32_t pos_q = (qt0 + (uint32_t)qi) * 32u + (uint32_t)c;
-          while (__builtin_amdgcn_ballot_w64(inside != 0) != 0) {
-            const uint32_t pos_r = tile_row(t, 15 - (inside ? __builtin_ctz(inside) : 0), h);
-            emit_edge(sink, (inside != 0) & (pos_r < pos_q), pos_q, pos_r);
+        if (32u * t + 31u >= pos_q) {       // (all rows of earlier tiles are smaller: nothing to mask)
+          uint32_t keep = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) keep |= (tile_row(t, r, h) < pos_q) ? (0x8000u >> r) : 0u;
+          inside &= keep;
+        }
+        const uint32_t k = (uint32_t)__builtin_popcount(inside);
+        if (__builtin_amdgcn_ballot_w64(k != 0) != 0) {
+          uint32_t incl = k;                // inclusive prefix sum over the wave
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+            incl += (lane >= off) ? v : 0u;
+          }
+          unsigned long long base = 0;
+          if (lane == 63) base = atomicAdd(sink.count, (unsigned long long)incl);
+          base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), 63) << 32) |
+                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, 63);
+          unsigned long long idx = base + (incl - k);
+          while (inside != 0) {
+            const int p = __builtin_ctz(inside);
+            if (idx < sink.capacity) sink.edges[idx] = make_uint2(pos_q, tile_row(t, 15 - p, h));
+            ++idx;
             inside &= inside - 1u;
           }
         }

@@ -106,7 +106,13 @@ std::vector<std::size_t> screening_with_graph(const std::vector<float>& free_ene
     local_nh.push_back(frame);
     // lump_initial_clusters (:506-555)
     cluster_names.clear();
-    for (std::size_t j : local_nh) cluster_names.insert(clustering[j] == 0 ? 0 : names.find(clustering[j]));
+    std::size_t last_raw = ~(std::size_t)0;   // partners mostly share one name: skip repeated look-ups
+    for (std::size_t j : local_nh) {
+      const std::size_t raw = clustering[j];
+      if (raw == last_raw) continue;
+      last_raw = raw;
+      cluster_names.insert(raw == 0 ? 0 : names.find(raw));
+    }
     if (!(cluster_names.size() == 1 && cluster_names.count(0) != 1)) {
       cluster_names.erase(0);
       std::size_t common_name;
