@@ -287,3 +287,26 @@ def test_radius_pairs_match_brute_force(dens, n_rows, n_cols, r2):
         deg[a] += 1
         deg[b] += 1
     assert (pops.cpu().numpy().astype(np.int64) == deg).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [None, (20000, 30000)])
+def test_chunked_launches_match_direct(dens, rows):
+    """Launches large enough to be split along the reference axis (gridDim.y > 1: partial populations
+    merged with atomicAdd, partial neighbours with the 64-bit atomicMin, incumbents published between
+    chunks) must equal the direct kernels bit for bit -- on all rows and on a row range (one rank of a
+    sharded run)."""
+    import torch
+    n = 70000
+    c = gaussian_blobs(n, 4, seed=77)
+    ct = torch.from_numpy(c).cuda()
+    lo, hi = rows if rows else (0, n)
+    radii = [0.05, 0.08]
+    pp = dens.calculate_populations_partial(ct, radii, lo, hi, variant="pruned")
+    pd = dens.calculate_populations_partial(ct, radii, lo, hi, variant="direct")
+    assert bool((pp == pd).all())
+    fe = dens.calculate_free_energies(dens.calculate_populations_partial(ct, radii[:1], variant="direct")[0].contiguous())
+    a = dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="pruned")
+    b = dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="direct")
+    for x, y in zip(a, b):
+        assert bool((x.view(torch.int32) == y.view(torch.int32)).all())
