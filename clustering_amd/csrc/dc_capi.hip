@@ -72,7 +72,8 @@ void fill_fe_table(std::vector<float>& table, uint32_t max_pop) {
   const float rec = 1.0f / (float)max_pop;
   const size_t n = table.size();
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned nt = (n < (1u << 16)) ? 1u : std::min(hw, 16u);
+  // about 16k logs per thread (spawning a thread costs as much as a few thousand logs)
+  const unsigned nt = (unsigned)std::min<size_t>(std::min(hw, 16u), std::max<size_t>(1, n >> 14));
   auto work = [&](size_t lo, size_t hi) {
     for (size_t p = lo; p < hi; ++p) table[p] = fe_of_pop((uint32_t)p, rec);
   };
@@ -186,28 +187,51 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
   if (!d_pops || !d_fe) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   if (n_rows + 1 > (size_t)UINT32_MAX) return fail(DC_ERR_TOO_LARGE, "n_rows too large");
   hipStream_t s = (hipStream_t)stream;
-  uint32_t* d_max = nullptr;
-  DC_HIP_TRY(hipMalloc((void**)&d_max, sizeof(uint32_t)));
-  dc::launch_max_u32(d_pops, (uint32_t)n_rows, d_max, s);
+  // per-thread, per-device scratch that lives across calls (no allocation, and no hipFree with its
+  // device-wide synchronisation, on the per-step path): max word + table on the device, table on
+  // the host
+  struct Scratch {
+    int device = -1;
+    uint32_t* d_max = nullptr;
+    float* d_table = nullptr;
+    size_t table_cap = 0;
+    std::vector<float> table;
+  };
+  static thread_local Scratch scratch[16];
+  int dev = 0;
+  DC_HIP_TRY(hipGetDevice(&dev));
+  Scratch& S = scratch[dev & 15];
+  if (S.device != dev) {   // first use on this device (or a slot shared by devices 16 apart)
+    if (S.d_max) (void)hipFree(S.d_max);
+    if (S.d_table) (void)hipFree(S.d_table);
+    S = Scratch();
+    S.device = dev;
+    DC_HIP_TRY(hipMalloc((void**)&S.d_max, sizeof(uint32_t)));
+  }
+  dc::launch_max_u32(d_pops, (uint32_t)n_rows, S.d_max, s);
   uint32_t max_pop = 0;
-  hipError_t e = hipMemcpyAsync(&max_pop, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  hipError_t e = hipMemcpyAsync(&max_pop, S.d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(d_max);
   if (e != hipSuccess) return fail(DC_ERR_HIP, "max population: %s", hipGetErrorString(e));
   if (max_pop_out) *max_pop_out = max_pop;
   // one double log per DISTINCT population value, evaluated by the host libm like the
   // reference (which computes every FE on the host, density_clustering.cpp:687)
-  std::vector<float> table((size_t)max_pop + 1);
-  fill_fe_table(table, max_pop);
-  float* d_table = nullptr;
-  DC_HIP_TRY(hipMalloc((void**)&d_table, sizeof(float) * table.size()));
-  e = hipMemcpyAsync(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, s);
+  S.table.resize((size_t)max_pop + 1);
+  fill_fe_table(S.table, max_pop);
+  if (S.table_cap < S.table.size()) {
+    if (S.d_table) (void)hipFree(S.d_table);
+    S.d_table = nullptr;
+    S.table_cap = 0;
+    DC_HIP_TRY(hipMalloc((void**)&S.d_table, sizeof(float) * S.table.size()));
+    S.table_cap = S.table.size();
+  }
+  e = hipMemcpyAsync(S.d_table, S.table.data(), sizeof(float) * S.table.size(), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
-    dc::launch_fe_gather(d_pops, (uint32_t)n_rows, d_table, d_fe, s);
+    dc::launch_fe_gather(d_pops, (uint32_t)n_rows, S.d_table, d_fe, s);
     e = hipGetLastError();
   }
+  // (the host table must stay untouched until the copy has been consumed: one more sync)
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(d_table);
   if (e != hipSuccess) return fail(DC_ERR_HIP, "free-energy gather: %s", hipGetErrorString(e));
   return DC_OK;
 }
