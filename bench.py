@@ -254,7 +254,8 @@ def main():
                 "workload": f"{n} frames x {d} dims, 3-Gaussian-blob (sigma 0.08, seed 20240), radii {args.radii}, "
                             + ("pop + free energy + nn/nn_hd" if want_nn else "pop + free energy"),
                 "n_rows": n, "n_cols": d, "radii": args.radii, "variant": args.variant,
-                "parallelism": f"rows sharded over {world} GPU(s), coords replicated; all-reduce(pops) + all-gather(nn)",
+                "parallelism": f"rows sharded over {world} GPU(s) (segments of the spatial order), coords replicated; "
+                               "all-reduce(sum) of the populations + all-reduce(min) of the packed (d2, index) neighbour words",
             },
             "phases_ms": {"pop_kernel": 1e3 * pop_t, "nn_kernel": 1e3 * nn_t,
                           "other (fe, collectives, host)": max(0.0, ms_per_step - 1e3 * (pop_t + nn_t))},

@@ -21,6 +21,7 @@ SYMBOLS = (
     "dc_hip_populations_dev", "dc_hip_free_energies_dev", "dc_hip_nearest_neighbors_dev",
     "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs",
+    "dc_hip_populations_segment_dev", "dc_hip_nearest_neighbors_segment_dev",
 )
 
 
@@ -57,6 +58,12 @@ def _load():
     lib.dc_hip_populations.argtypes = [vp, sz, sz, vp, sz, sz, sz, i32, vp]
     lib.dc_hip_nearest_neighbors.restype = i32
     lib.dc_hip_nearest_neighbors.argtypes = [vp, sz, sz, vp, sz, sz, i32, vp, vp, vp, vp]
+    lib.dc_hip_populations_segment_dev.restype = i32
+    lib.dc_hip_populations_segment_dev.argtypes = [vp, sz, sz, C.POINTER(C.c_float), sz, sz, sz, vp, vp, sz,
+                                                   i32, vp]
+    lib.dc_hip_nearest_neighbors_segment_dev.restype = i32
+    lib.dc_hip_nearest_neighbors_segment_dev.argtypes = [vp, sz, sz, vp, sz, sz, vp, vp, vp, vp, vp, sz,
+                                                         i32, vp]
     lib.dc_hip_radius_pairs_dev.restype = i32
     lib.dc_hip_radius_pairs_dev.argtypes = [vp, sz, sz, C.c_float, vp, vp, sz, vp, vp, sz, vp]
     lib.dc_hip_radius_pairs.restype = i32

@@ -134,15 +134,34 @@ int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles, 
   return DC_OK;
 }
 
-int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, const float* radii,
-                           size_t n_radii, size_t i_from, size_t i_to, uint32_t* d_pops,
-                           void* d_workspace, size_t workspace_bytes, int variant, void* stream) {
+}  // extern "C"
+
+namespace {
+// rows of one shard exactly as density_clustering_cuda.cu:149,165-169 (the last one takes the rest)
+void shard_rows(size_t n_rows, size_t n_shards, size_t shard, size_t* lo, size_t* hi) {
+  const size_t rng = n_rows / n_shards;
+  *lo = shard * rng;
+  *hi = (shard == n_shards - 1) ? n_rows : (shard + 1) * rng;
+}
+
+// n_segments == 0: the row range [i_from, i_to).  n_segments > 0: segment `segment` of the spatial
+// order for the pruned matrix-core sweep; whenever that sweep does not run (other variant, n_cols it
+// does not handle, flagged data) the same call answers for row block `segment` instead -- any
+// partition of the rows serves a sharded run, as long as every rank uses the same rule.
+int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const float* radii,
+                     size_t n_radii, size_t i_from, size_t i_to, size_t segment, size_t n_segments,
+                     uint32_t* d_pops, void* d_workspace, size_t workspace_bytes, int variant,
+                     void* stream) {
+  if (n_segments > 0) {
+    if (segment >= n_segments) return fail(DC_ERR_INVALID_ARGUMENT, "segment %zu of %zu", segment, n_segments);
+    shard_rows(n_rows, n_segments, segment, &i_from, &i_to);
+  }
   if (int rc = check_sizes(n_rows, n_cols, i_from, i_to)) return rc;
   if (n_radii == 0 || n_rows == 0) return DC_OK;
   if (!d_coords || !radii || !d_pops) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_radii * n_rows, s));
-  if (i_from == i_to) return DC_OK;
+  if (i_from == i_to && n_segments == 0) return DC_OK;
   const bool mfma = want_mfma(variant, n_cols);
   if ((variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA_PRUNED) && !mfma)
     return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
@@ -166,16 +185,38 @@ int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, 
     if (mfma && variant == DC_VARIANT_MFMA)
       dc::launch_pop_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                           (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
+    else if (mfma && n_segments > 0)
+      dc::launch_pop_pruned_segment(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)segment,
+                                    (uint32_t)n_segments, rad2, n_rad, out, d_workspace, s);
     else if (mfma)
       dc::launch_pop_pruned(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                             (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
-    if (!dc::launch_pop_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
+    if (i_from != i_to && !dc::launch_pop_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                                (uint32_t)i_to, rad2, n_rad, out,
                                mfma ? (const uint32_t*)d_workspace : nullptr, s))
       return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported", n_cols);
     if (int rc = check_launch("population sweep launch")) return rc;
   }
   return DC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n_cols, const float* radii,
+                           size_t n_radii, size_t i_from, size_t i_to, uint32_t* d_pops,
+                           void* d_workspace, size_t workspace_bytes, int variant, void* stream) {
+  return populations_impl(d_coords, n_rows, n_cols, radii, n_radii, i_from, i_to, 0, 0, d_pops,
+                          d_workspace, workspace_bytes, variant, stream);
+}
+
+int dc_hip_populations_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                   const float* radii, size_t n_radii, size_t segment,
+                                   size_t n_segments, uint32_t* d_pops, void* d_workspace,
+                                   size_t workspace_bytes, int variant, void* stream) {
+  if (n_segments == 0) return fail(DC_ERR_INVALID_ARGUMENT, "n_segments must be positive");
+  return populations_impl(d_coords, n_rows, n_cols, radii, n_radii, 0, 0, segment, n_segments, d_pops,
+                          d_workspace, workspace_bytes, variant, stream);
 }
 
 int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
@@ -236,19 +277,26 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
   return DC_OK;
 }
 
-int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_cols,
-                                 const float* d_fe, size_t i_from, size_t i_to, uint32_t* d_nn_idx,
-                                 float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
-                                 void* d_workspace, size_t workspace_bytes, int variant,
-                                 void* stream) {
+}  // extern "C"
+
+namespace {
+// (segments: see populations_impl)
+int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, const float* d_fe,
+                           size_t i_from, size_t i_to, size_t segment, size_t n_segments,
+                           uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
+                           void* d_workspace, size_t workspace_bytes, int variant, void* stream) {
+  if (n_segments > 0) {
+    if (segment >= n_segments) return fail(DC_ERR_INVALID_ARGUMENT, "segment %zu of %zu", segment, n_segments);
+    shard_rows(n_rows, n_segments, segment, &i_from, &i_to);
+  }
   if (int rc = check_sizes(n_rows, n_cols, i_from, i_to)) return rc;
   if (n_rows == 0) return DC_OK;
   if (!d_coords || !d_fe || !d_nn_idx || !d_nn_d2 || !d_hd_idx || !d_hd_d2)
     return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  if (i_from != 0 || i_to != n_rows)
+  if (i_from != 0 || i_to != n_rows || n_segments > 1)
     dc::launch_nn_init((uint32_t)n_rows, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, s);
-  if (i_from == i_to) return check_launch("nn init");
+  if (i_from == i_to && n_segments == 0) return check_launch("nn init");
   const bool mfma = want_mfma(variant, n_cols);
   if ((variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA_PRUNED) && !mfma)
     return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
@@ -264,15 +312,42 @@ int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_
     if (full_sweep)
       dc::launch_nn_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
                          (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
+    else if (n_segments > 0)
+      dc::launch_nn_pruned_segment(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe,
+                                   (uint32_t)segment, (uint32_t)n_segments, d_nn_idx, d_nn_d2,
+                                   d_hd_idx, d_hd_d2, d_workspace, s);
     else
       dc::launch_nn_pruned(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
                            (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
   }
-  if (!dc::launch_nn_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
+  if (i_from != i_to && !dc::launch_nn_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
                             (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2,
                             mfma ? (const uint32_t*)d_workspace : nullptr, s))
     return fail(DC_ERR_INVALID_ARGUMENT, "n_cols=%zu not supported", n_cols);
   return check_launch("nearest-neighbour sweep launch");
+}
+}  // namespace
+
+extern "C" {
+
+int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                 const float* d_fe, size_t i_from, size_t i_to, uint32_t* d_nn_idx,
+                                 float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
+                                 void* d_workspace, size_t workspace_bytes, int variant,
+                                 void* stream) {
+  return nearest_neighbors_impl(d_coords, n_rows, n_cols, d_fe, i_from, i_to, 0, 0, d_nn_idx, d_nn_d2,
+                                d_hd_idx, d_hd_d2, d_workspace, workspace_bytes, variant, stream);
+}
+
+int dc_hip_nearest_neighbors_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                         const float* d_fe, size_t segment, size_t n_segments,
+                                         uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                                         float* d_hd_d2, void* d_workspace, size_t workspace_bytes,
+                                         int variant, void* stream) {
+  if (n_segments == 0) return fail(DC_ERR_INVALID_ARGUMENT, "n_segments must be positive");
+  return nearest_neighbors_impl(d_coords, n_rows, n_cols, d_fe, 0, 0, segment, n_segments, d_nn_idx,
+                                d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, workspace_bytes, variant,
+                                stream);
 }
 
 int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2_out, void* stream) {

@@ -174,9 +174,11 @@ __global__ void fe_rank_kernel(const float* __restrict__ fe, const float* __rest
 // ---- spatial ordering of the frames (pruned sweeps) ----------------------------------------------
 // key = row-major index of the frame's cell in a 2-D grid on columns 0/1 (like compute_box_grid,
 // density_clustering.cpp:41-89) for the rows [i_from, i_to): keys[j], vals[j] = key, id of row i_from+j
-__global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
-                               const uint32_t* __restrict__ hdr, float cell, uint32_t i_from,
-                               uint32_t i_to, uint32_t* __restrict__ keys,
+// frames_per_cell: the cell edge is chosen so that a cell of the bounding box holds about that many of
+// the i_to - i_from frames being ordered (auto_cell)
+__global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t D,
+                               const uint32_t* __restrict__ hdr, float frames_per_cell,
+                               uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ keys,
                                uint32_t* __restrict__ vals) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = i_from + j;
@@ -184,8 +186,8 @@ __global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t n_rows
   vals[j] = i;
   const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
   const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
-  if (cell < 0.0f) cell = auto_cell(hdr, n_rows);
-  // cell edge: the radius, but never so small that a dimension gets more than 60000 cells
+  const float cell = auto_cell(hdr, i_to - i_from, frames_per_cell);
+  // never so small that a dimension gets more than 60000 cells
   float c0 = fmaxf(cell, (max0 - min0) / 60000.0f), c1 = fmaxf(cell, (max1 - min1) / 60000.0f);
   if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
   if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
@@ -287,7 +289,7 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
 // accumulator a radius costs 16 v_alignbit + 8 v_min3 per 1024 pairs, less than the subtract /
 // sign / min triple per radius of a multi-radius epilogue -- and the MFMAs of a repeated sweep hide
 // behind that epilogue.  Radii are therefore swept one after the other (the pruned sweep then also
-// prunes every radius with its own cell size).
+// runs on its own pruned survivor lists).
 static Rad2 single_radius(const Rad2& rad2, int r) {
   Rad2 one;
   for (int k = 0; k < kMaxRadiiPerLaunch; ++k) one.v[k] = -1.0f;
@@ -315,16 +317,41 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
   }
 }
 
-static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
-                           uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
+// rows answered by a pruned sweep: the row range [i_from, i_to), or -- n_segments > 0 -- segment
+// `segment` of the spatial order cut into n_segments runs of whole query groups
+struct QuerySel {
+  uint32_t i_from, i_to, segment, n_segments;
+};
+// query window of a segment in tiles of the reference order (TQ tiles per group)
+static void segment_window(uint32_t T, uint32_t n_rows, int tq, const QuerySel& q, uint32_t* tile_lo,
+                           uint32_t* n_q) {
+  const uint64_t groups = (T + tq - 1) / tq;
+  const uint64_t g_lo = groups * q.segment / q.n_segments, g_hi = groups * (q.segment + 1) / q.n_segments;
+  const uint64_t t_lo = g_lo * tq, t_hi = std::min<uint64_t>(T, g_hi * tq);
+  *tile_lo = (uint32_t)t_lo;
+  const uint64_t r_lo = t_lo * 32, r_hi = std::min<uint64_t>(n_rows, t_hi * 32);
+  *n_q = r_hi > r_lo ? (uint32_t)(r_hi - r_lo) : 0u;
+}
+static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 8 ? 4 : 2; }   // = tq_for<NM>
+
+static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
+                           const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                            const EdgeSink* sink, hipStream_t stream);
 
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                        hipStream_t stream) {
   for (int r = 0; r < n_rad; ++r)
-    pop_pruned_one(d_coords, n_rows, n_cols, i_from, i_to, single_radius(rad2, r), 1,
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, single_radius(rad2, r), 1,
                    d_pops + (size_t)r * n_rows, d_ws, nullptr, stream);
+}
+
+void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
+                               uint32_t segment, uint32_t n_segments, const Rad2& rad2, int n_rad,
+                               uint32_t* d_pops, void* d_ws, hipStream_t stream) {
+  for (int r = 0; r < n_rad; ++r)
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments},
+                   single_radius(rad2, r), 1, d_pops + (size_t)r * n_rows, d_ws, nullptr, stream);
 }
 
 // positions of the sweep's spatial order -> frame ids, for the pairs actually written; a flagged
@@ -364,13 +391,13 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
   (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
   if (d_pairs && capacity) {
     const EdgeSink sink{d_pairs, d_count, capacity};
-    pop_pruned_one(d_coords, n_rows, n_cols, 0u, n_rows, one, 1, d_pops, d_ws, &sink, stream);
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream);
     hipLaunchKernelGGL(edges_to_frames_kernel, dim3(1024), dim3(256), 0, stream, d_pairs,
                        (const unsigned long long*)d_count, capacity,
                        (const uint32_t*)((char*)d_ws + L.off_perm_p));
   } else {
     // counting only: the plain population sweep knows the answer
-    pop_pruned_one(d_coords, n_rows, n_cols, 0u, n_rows, one, 1, d_pops, d_ws, nullptr, stream);
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, nullptr, stream);
     hipLaunchKernelGGL(pairs_from_pops_kernel, dim3(256), dim3(256), 0, stream, (const uint32_t*)d_pops,
                        n_rows, d_count);
     hipLaunchKernelGGL(halve_kernel, dim3(1), dim3(1), 0, stream, d_count);
@@ -378,9 +405,10 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
   hipLaunchKernelGGL(edges_flag_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)d_ws, d_count);
 }
 
-static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
-                           uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
+static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
+                           const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                            const EdgeSink* sink, hipStream_t stream) {
+  const uint32_t i_from = qs.i_from, i_to = qs.i_to;
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
   uint32_t* hdr = (uint32_t*)p;
@@ -389,16 +417,15 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
   uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
   uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
-  float r2max = rad2.v[0];
-  for (int r = 1; r < n_rad; ++r) r2max = std::max(r2max, rad2.v[r]);
-  const float cell = (r2max > 0.0f) ? sqrtf(r2max) : 0.0f;
+  (void)n_rad;
+  constexpr float kCellFramesHere = kPopCellFrames;
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
       grid_tiles((L.T + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
   // order all frames by their 2-D cell, build the reference image and the tile boxes
-  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
-                     (const uint32_t*)hdr, cell, 0u, n_rows, keys_in, vals_in);
+  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
+                     (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
     return;
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
@@ -413,15 +440,21 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                      0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
                      (float*)(p + L.off_coords_p));
   const bool full = (i_from == 0 && i_to == n_rows);
-  const uint32_t n_q = i_to - i_from, T_q = (n_q + 31) / 32;
-  if (full)   // the queries are all rows in the reference order: only their B form is missing
+  uint32_t n_q = i_to - i_from, q_tile_lo = 0;
+  int q_mode = full ? kQueryAll : kQueryOwnOrder;
+  if (qs.n_segments > 0) {
+    q_mode = kQueryWindow;
+    segment_window(L.T, n_rows, tq_of(n_cols), qs, &q_tile_lo, &n_q);
+  }
+  const uint32_t T_q = (n_q + 31) / 32;
+  if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
     hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 1,
                        (uint4*)(p + L.off_img_q), (float*)nullptr);
-  if (!full) {
+  if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the same ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_rows,
-                       n_cols, (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
+    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
+                       (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
@@ -435,8 +468,8 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
 #define X(SV)                                                                                 \
   case SV:                                                                                    \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
-      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, full, rad2, n_rad, d_pops, sink,  \
-                           stream);                                                           \
+      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, q_mode, q_tile_lo, rad2, n_rad,   \
+                           d_pops, sink, stream);                                             \
     break;
     DC_FOR_EACH_S(X)
 #undef X
@@ -445,9 +478,29 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   }
 }
 
+static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
+                          const QuerySel& qs, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                          float* d_hd_d2, void* d_ws, hipStream_t stream);
+
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                       uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream) {
+  nn_pruned_sel(d_coords, n_rows, n_cols, d_fe, QuerySel{i_from, i_to, 0, 0}, d_nn_idx, d_nn_d2,
+                d_hd_idx, d_hd_d2, d_ws, stream);
+}
+
+void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
+                              const float* d_fe, uint32_t segment, uint32_t n_segments,
+                              uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
+                              void* d_ws, hipStream_t stream) {
+  nn_pruned_sel(d_coords, n_rows, n_cols, d_fe, QuerySel{0, n_rows, segment, n_segments}, d_nn_idx,
+                d_nn_d2, d_hd_idx, d_hd_d2, d_ws, stream);
+}
+
+static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
+                          const QuerySel& qs, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                          float* d_hd_d2, void* d_ws, hipStream_t stream) {
+  const uint32_t i_from = qs.i_from, i_to = qs.i_to;
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
   uint32_t* hdr = (uint32_t*)p;
@@ -458,7 +511,7 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   uint32_t* cellkeys = (uint32_t*)(p + L.off_pq);        // scratch: cell key per frame
   uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
   uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
-  const float cell = -1.0f;   // "auto": the kernels derive the cell edge from the bounding box
+  constexpr float kCellFramesHere = kNnCellFrames;
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
       grid_tiles((L.T + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
@@ -467,8 +520,8 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in, hdr);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_fe, n_rows, p + L.fixed_end, tmp_bytes, stream))
     return;
-  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols,
-                     (const uint32_t*)hdr, cell, 0u, n_rows, cellkeys, vals_in);
+  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
+                     (const uint32_t*)hdr, kNnCellFrames, 0u, n_rows, cellkeys, vals_in);
   hipLaunchKernelGGL(gather_key_kernel, grid_n, blk, 0, stream, (const uint32_t*)cellkeys,
                      (const uint32_t*)perm_fe, n_rows, keys_in);
   if (sort_pairs_u32(keys_in, keys_out, perm_fe, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
@@ -485,15 +538,21 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
                      0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
                      (float*)(p + L.off_coords_p));
   const bool full = (i_from == 0 && i_to == n_rows);
-  const uint32_t n_q = i_to - i_from, T_q = (n_q + 31) / 32;
-  if (full)   // the queries are all rows in the reference order: only their B form is missing
+  uint32_t n_q = i_to - i_from, q_tile_lo = 0;
+  int q_mode = full ? kQueryAll : kQueryOwnOrder;
+  if (qs.n_segments > 0) {
+    q_mode = kQueryWindow;
+    segment_window(L.T, n_rows, tq_of(n_cols), qs, &q_tile_lo, &n_q);
+  }
+  const uint32_t T_q = (n_q + 31) / 32;
+  if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
     hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 1,
                        (uint4*)(p + L.off_img_q), (float*)nullptr);
-  if (!full) {
+  if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_rows,
-                       n_cols, (const uint32_t*)hdr, cell, i_from, i_to, keys_in, vals_in);
+    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
+                       (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
@@ -507,7 +566,7 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
-      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, n_q, full ? 1 : 0, -1.0f,         \
+      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, n_q, q_mode, q_tile_lo, -1.0f,    \
                           d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, stream);                        \
     break;
     DC_FOR_EACH_S(X)

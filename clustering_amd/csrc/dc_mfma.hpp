@@ -39,6 +39,16 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                       uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
+// the same for one SEGMENT of the spatial order (segment s of n: a run of whole query groups): the
+// rows a rank of a spatially sharded multi-GPU run answers for.  Outputs as for a row range: zeros /
+// "none" for the rows of other segments.
+void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
+                               uint32_t segment, uint32_t n_segments, const Rad2& rad2, int n_rad,
+                               uint32_t* d_pops_first_row, void* d_ws, hipStream_t stream);
+void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
+                              const float* d_fe, uint32_t segment, uint32_t n_segments,
+                              uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
+                              void* d_ws, hipStream_t stream);
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);

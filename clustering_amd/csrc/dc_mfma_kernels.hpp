@@ -195,13 +195,19 @@ __device__ __forceinline__ uint32_t fkey(float f) {
 __device__ __forceinline__ float fkey_inv(uint32_t k) {
   return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
-// cell edge of the neighbour sweep's ordering: about 8192 frames per cell of the bounding box
-__device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uint32_t n_rows) {
+// Cell edge of the spatial orderings: about `frames_per_cell` of the n_rows frames per cell of the
+// bounding box of columns 0/1.  Small cells make the 32-frame tiles compact in that plane (a tile's
+// box is about its cell), which is what the pruning lives on; a cell should still hold a few tiles.
+// Measured on C3: neighbours 38.6 ms at 8192 frames per cell, 30.0 at 512, 27.4 at 128; populations
+// 36.1 ms with cell = radius (about 15000 frames), 31.7 ms at about 60 frames per cell.
+constexpr float kPopCellFrames = 64.0f, kNnCellFrames = 128.0f;
+__device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uint32_t n_rows,
+                                           float frames_per_cell) {
   const float e0 = fkey_inv(hdr[9]) - fkey_inv(~hdr[8]), e1 = fkey_inv(hdr[11]) - fkey_inv(~hdr[10]);
   const double a0 = (e0 > 0.0f && e0 <= FLT_MAX) ? (double)e0 : 0.0;
   const double a1 = (e1 > 0.0f && e1 <= FLT_MAX) ? (double)e1 : 0.0;
-  const double c = (a0 > 0.0 && a1 > 0.0) ? sqrt(a0 * a1 * 8192.0 / (double)n_rows)
-                                           : (a0 + a1) * 8192.0 / (double)n_rows;
+  const double f = (double)frames_per_cell / (double)(n_rows ? n_rows : 1u);
+  const double c = (a0 > 0.0 && a1 > 0.0) ? sqrt(a0 * a1 * f) : (a0 + a1) * f;
   return (float)c;
 }
 
@@ -678,6 +684,13 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n_blocks
   const uint32_t xcd = b & 7u, idx = b >> 3, n_full = n_blocks >> 3, rem = n_blocks & 7u;
   return xcd * n_full + (xcd < rem ? xcd : rem) + idx;
 }
+
+// which rows a pruned sweep answers for, and where their operands live:
+//   kQueryOwnOrder  a row range [i_from, i_to): its own spatial ordering (img_q / norms_q / perm_q / box_q)
+//   kQueryAll       every row, in the reference order (the reference arrays double as query arrays)
+//   kQueryWindow    a window of the reference order starting at tile q_tile_lo (one segment of a
+//                   spatially sharded multi-GPU run: the segment is as compact as the full sweep's groups)
+enum QueryMode { kQueryOwnOrder = 0, kQueryAll = 1, kQueryWindow = 2 };
 
 constexpr int kListCap = 1024;   // reference tiles scanned per round (LDS list entries per wave)
 constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane and query tile
@@ -1409,7 +1422,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 
   const GuardBand gb = guard_band(__uint_as_float(hdr[0]), 0.0f, (int)n_cols);
   if (cell2 < 0.0f) {
-    const float cl = auto_cell(hdr, n_rows);
+    const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;
   }
 
@@ -1819,6 +1832,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                       const NnPrunedArgs& A, uint32_t T, const uint32_t* hdr,
                       unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
+  if (A.n_q == 0) return;
   const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
   const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor);
   // query rows (original coordinates) + candidate queues, per wave
@@ -1851,19 +1865,24 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
 // all rows spatially ordered ("p"); full_range: the query set is every row -> the two orders coincide
 template <int S, int NRV, int TQV>
 void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
-                       uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
-                       uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
-                       hipStream_t s) {
+                       uint32_t T, uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2,
+                       int n_rad, uint32_t* pops, unsigned long long* chain_counter,
+                       const EdgeSink* sink, hipStream_t s) {
+  if (n_q == 0) return;
   const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
   const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor)), block(256);
-  const uint4* img_q = P.img_q;   // B form of the query rows (all rows, same order, if full_range)
-  const float* norms_q = full_range ? P.norms_p : P.norms_q;
-  const uint32_t* perm_q = full_range ? P.perm_p : P.perm_q;
-  const float4* box_q = full_range ? P.box_p : P.box_q;
+  // B form of the query rows: its own image for a row range, else the B form of all rows in the
+  // reference order (img_q), from the window's first tile on
+  const bool own = q_mode == kQueryOwnOrder;
+  const size_t lo = own ? 0 : q_tile_lo;
+  const uint4* img_q = P.img_q + lo * ((size_t)S * 64);
+  const float* norms_q = (own ? P.norms_q : P.norms_p) + lo * 32;
+  const uint32_t* perm_q = (own ? P.perm_q : P.perm_p) + lo * 32;
+  const float4* box_q = (own ? P.box_q : P.box_p) + lo;
   // query rows (original coordinates) + queues of deferred exact evaluations, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
-  if (sink)   // radius-graph variant: full range only (query positions = reference positions)
+  if (sink)   // radius-graph variant: all rows only (query positions = reference positions)
     hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, true>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                        perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
@@ -1875,19 +1894,20 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
 
 template <int S, int NRV>
 void pop_pruned_tq(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
-                   uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad, uint32_t* pops,
-                   unsigned long long* chain_counter, const EdgeSink* sink, hipStream_t s) {
-  pop_pruned_launch<S, NRV, tq_for<S>>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad,
-                                       pops, chain_counter, sink, s);
+                   uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2, int n_rad,
+                   uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
+                   hipStream_t s) {
+  pop_pruned_launch<S, NRV, tq_for<S>>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_tile_lo, rad2,
+                                       n_rad, pops, chain_counter, sink, s);
 }
 
 template <int S>
 void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
-                         uint32_t T, uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,
-                         uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
-                         hipStream_t s) {
+                         uint32_t T, uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2,
+                         int n_rad, uint32_t* pops, unsigned long long* chain_counter,
+                         const EdgeSink* sink, hipStream_t s) {
   // one radius per sweep (dc_mfma.hip loops over the radii of a call)
-  pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, full_range, rad2, n_rad, pops,
+  pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_tile_lo, rad2, n_rad, pops,
                       chain_counter, sink, s);
 }
 
@@ -1911,10 +1931,10 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                           uint32_t i_from, uint32_t i_to, const Rad2& rad2, int n_rad,           \
                           uint32_t* pops, hipStream_t s);                                        \
   void pop_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,   \
-                            uint32_t n_q, bool full_range, const Rad2& rad2, int n_rad,          \
-                            uint32_t* pops, const EdgeSink* sink, hipStream_t s);                \
+                            uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2,      \
+                            int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s);     \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
-                           void* d_ws, uint32_t n_q, int full_range, float cell2,                \
+                           void* d_ws, uint32_t n_q, int q_mode, uint32_t q_tile_lo, float cell2, \
                            uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,       \
                            hipStream_t s);                                                       \
   void nn_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,      \

@@ -88,6 +88,43 @@ def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="a
     return out
 
 
+def calculate_populations_segment(coords, radii, segment, n_segments, variant="auto", out=None):
+    """Populations of one segment of a sharded run (dc_hip_populations_segment_dev): with the pruned
+    sweep a run of whole query groups of the spatial order, else the reference's row block.  Zeros for
+    the rows of other segments (partials merge by summation)."""
+    n_rows, n_cols = _check_coords(coords)
+    rad = np.ascontiguousarray(radii, dtype=np.float32).reshape(-1)
+    if out is None:
+        out = torch.empty((rad.size, n_rows), dtype=torch.int32, device=coords.device)
+    assert out.shape == (rad.size, n_rows) and out.dtype == torch.int32 and out.is_contiguous()
+    with torch.cuda.device(coords.device):
+        ws, ws_bytes = _workspace(coords.device).get(n_rows, n_cols, rad.size)
+        rc = capi.lib.dc_hip_populations_segment_dev(
+            _dev(coords), n_rows, n_cols, rad.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
+            segment, n_segments, _dev(out), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+    capi.check(rc, "dc_hip_populations_segment_dev")
+    return out
+
+
+def nearest_neighbors_segment(coords, fe, segment, n_segments, variant="auto"):
+    """Neighbours of one segment of a sharded run (dc_hip_nearest_neighbors_segment_dev); the rows of
+    other segments hold (n_rows+1, FLT_MAX)."""
+    n_rows, n_cols = _check_coords(coords)
+    assert fe.is_cuda and fe.dtype == torch.float32 and fe.shape == (n_rows,) and fe.is_contiguous()
+    dev = coords.device
+    nn_idx = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    hd_idx = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    nn_d2 = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    hd_d2 = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
+        rc = capi.lib.dc_hip_nearest_neighbors_segment_dev(
+            _dev(coords), n_rows, n_cols, _dev(fe), segment, n_segments, _dev(nn_idx), _dev(nn_d2),
+            _dev(hd_idx), _dev(hd_d2), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+    capi.check(rc, "dc_hip_nearest_neighbors_segment_dev")
+    return nn_idx, nn_d2, hd_idx, hd_d2
+
+
 def calculate_free_energies(pops):
     """calculate_free_energies (density_clustering.cpp:197-212) for one radius. pops: int32 CUDA [n_rows]."""
     assert pops.is_cuda and pops.dtype == torch.int32 and pops.dim() == 1 and pops.is_contiguous()

@@ -106,6 +106,19 @@ DC_API int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n
                                   uint32_t* d_pops, void* d_workspace, size_t workspace_bytes,
                                   int variant, void* stream);
 
+/* The same sweep for one SEGMENT of a sharded run instead of a row range: rank `segment` of
+ * `n_segments` (density_clustering_cuda.cu:149-169 gives every GPU a contiguous block of rows; any
+ * partition serves, as long as the partial results merge).  With the pruned matrix-core sweep a
+ * segment is a run of whole query groups of the SPATIAL order, so a rank's queries are as compact as
+ * those of a full sweep and prune as well (a block of consecutive rows of a trajectory is spread over
+ * the whole conformational space); with every other variant, n_cols > 32 or non-finite data the
+ * segment is the reference's row block.  d_pops as above: zeros for the rows of other segments, so
+ * that the partials merge by summation. */
+DC_API int dc_hip_populations_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                          const float* radii, size_t n_radii, size_t segment,
+                                          size_t n_segments, uint32_t* d_pops, void* d_workspace,
+                                          size_t workspace_bytes, int variant, void* stream);
+
 /* replaces Clustering::Density::calculate_free_energies (density_clustering.cpp:197-212), which the
  * reference runs on the host in both builds.  fe[i] = (float)-log((double)((float)pop[i] * (1.0f/max)))
  * -- the double log is evaluated by the HOST libm (one value per distinct population, then gathered
@@ -125,6 +138,16 @@ DC_API int dc_hip_nearest_neighbors_dev(const float* d_coords, size_t n_rows, si
                                         uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
                                         float* d_hd_d2, void* d_workspace, size_t workspace_bytes,
                                         int variant, void* stream);
+
+/* neighbour sweep for one segment of a sharded run (see dc_hip_populations_segment_dev); rows of other
+ * segments hold (n_rows+1, FLT_MAX), so partials merge by taking, per row, the minimum of
+ * (d2 bits << 32 | index) -- only the owner's value is smaller than the "none" value. */
+DC_API int dc_hip_nearest_neighbors_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols,
+                                                const float* d_fe, size_t segment, size_t n_segments,
+                                                uint32_t* d_nn_idx, float* d_nn_d2,
+                                                uint32_t* d_hd_idx, float* d_hd_d2,
+                                                void* d_workspace, size_t workspace_bytes,
+                                                int variant, void* stream);
 
 /* replaces Clustering::Density::compute_sigma2 (density_clustering.cpp:334-343): mean of the nearest-
  * neighbour d2 accumulated in double IN FRAME ORDER (bit-stable), on the device (one block, fixed

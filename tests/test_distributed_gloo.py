@@ -33,6 +33,26 @@ class OracleBackend:
                 torch.from_numpy(c.astype(np.int32)), torch.from_numpy(d))
 
 
+class SegmentOracleBackend(OracleBackend):
+    """Offers the segment interface of the HIP backend: segment g of G owns the rows i with i % G == g
+    (scattered on purpose, like the spatial segments of the pruned sweep), so that ShardedDensity takes
+    its all-reduce(min) merge path."""
+
+    def populations_segment(self, coords, radii, segment, n_segments):
+        p = self.populations_partial(coords, radii, 0, coords.shape[0])
+        mask = (torch.arange(coords.shape[0]) % n_segments) == segment
+        return p * mask.to(p.dtype)
+
+    def nearest_neighbors_segment(self, coords, fe, segment, n_segments):
+        n = coords.shape[0]
+        a, b, c, d = self.nearest_neighbors_partial(coords, fe, 0, n)
+        mask = (torch.arange(n) % n_segments) == segment
+        none_i = torch.full_like(a, n + 1)
+        none_d = torch.full_like(b, torch.finfo(torch.float32).max)
+        return (torch.where(mask, a, none_i), torch.where(mask, b, none_d),
+                torch.where(mask, c, none_i), torch.where(mask, d, none_d))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -41,22 +61,26 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_rows, out_dir):
+def _worker(rank, world, port, n_rows, out_dir, segments=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from clustering_amd.distributed import ShardedDensity
         coords = torch.from_numpy(gaussian_blobs(n_rows, 5, seed=99))
-        out = ShardedDensity(OracleBackend()).run(coords, [0.1, 0.2], fe_radius_index=1, want_nn=True)
+        backend = SegmentOracleBackend() if segments else OracleBackend()
+        out = ShardedDensity(backend).run(coords, [0.1, 0.2], fe_radius_index=1, want_nn=True)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_rows", [(2, 1001), (2, 64), (3, 500)])
-def test_sharded_density_matches_single_process(tmp_path, oracle, world, n_rows):
-    mp.spawn(_worker, args=(world, _free_port(), n_rows, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,n_rows,segments", [(2, 1001, False), (2, 64, False), (3, 500, False),
+                                                   (2, 777, True), (3, 500, True)])
+def test_sharded_density_matches_single_process(tmp_path, oracle, world, n_rows, segments):
+    """row blocks + all-gather (segments=False) and scattered segments + all-reduce(min) of the packed
+    (d2, index) words (segments=True: the path the HIP backend takes)"""
+    mp.spawn(_worker, args=(world, _free_port(), n_rows, str(tmp_path), segments), nprocs=world, join=True)
     c = gaussian_blobs(n_rows, 5, seed=99)
     pops = oracle.populations(c, [0.1, 0.2])
     fe = oracle.free_energies(pops[1])

@@ -310,3 +310,35 @@ def test_chunked_launches_match_direct(dens, rows):
     b = dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="direct")
     for x, y in zip(a, b):
         assert bool((x.view(torch.int32) == y.view(torch.int32)).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,n_cols,n_seg", [(5000, 10, 2), (70000, 4, 8), (1000, 30, 3), (37, 2, 5), (4000, 40, 2)])
+def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols, n_seg):
+    """dc_hip_*_segment_dev: the segments of a sharded run (spatial runs of query groups with the pruned
+    sweep, row blocks otherwise -- n_cols = 40 has no matrix-core kernel) partition the rows: summed
+    populations and min-merged (d2, index) words equal the single-device result bit for bit."""
+    import torch
+    c = gaussian_blobs(n_rows, n_cols, seed=5 + n_seg)
+    ct = torch.from_numpy(c).cuda()
+    radii = [0.1, 0.25] if n_cols < 20 else [0.5]
+    full_p = dens.calculate_populations_partial(ct, radii)
+    fe = dens.calculate_free_energies(full_p[0].contiguous())
+    full_n = dens.nearest_neighbors_partial(ct, fe)
+    acc_p = torch.zeros_like(full_p)
+    words = None
+    owned = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+    for g in range(n_seg):
+        p = dens.calculate_populations_segment(ct, radii, g, n_seg)
+        acc_p += p
+        owned += (p[0] != 0).to(torch.int32)
+        a, b, cc, d = dens.nearest_neighbors_segment(ct, fe, g, n_seg)
+        w = torch.stack([(b.view(torch.int32).to(torch.int64) << 32) | (a.to(torch.int64) & 0xFFFFFFFF),
+                         (d.view(torch.int32).to(torch.int64) << 32) | (cc.to(torch.int64) & 0xFFFFFFFF)])
+        words = w if words is None else torch.minimum(words, w)
+    assert bool((owned == 1).all()), "every row belongs to exactly one segment"
+    assert bool((acc_p == full_p).all())
+    assert bool(((words[0] & 0xFFFFFFFF).to(torch.int32) == full_n[0]).all())
+    assert bool(((words[0] >> 32).to(torch.int32) == full_n[1].view(torch.int32)).all())
+    assert bool(((words[1] & 0xFFFFFFFF).to(torch.int32) == full_n[2]).all())
+    assert bool(((words[1] >> 32).to(torch.int32) == full_n[3].view(torch.int32)).all())
