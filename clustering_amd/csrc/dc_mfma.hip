@@ -36,12 +36,28 @@ __global__ void colsum_kernel(const float* __restrict__ coords, uint32_t n_rows,
   if (threadIdx.x < D) atomicAdd(&sums[threadIdx.x], part[threadIdx.x]);
 }
 
-// wave-wide maximum -> one global atomicMax, and only when it would change the word (a plain read
-// of a hot word is an L2 hit; a million same-address atomics are not)
-__device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v) {
+// column means as the float the centring subtracts (one division per column, not per element)
+__global__ void mean_kernel(const double* __restrict__ sums, uint32_t n_rows, uint32_t D,
+                            float* __restrict__ means) {
+  const uint32_t k = threadIdx.x;
+  if (k >= D) return;
+  float muf = (float)(sums[k] / (double)n_rows);
+  if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
+  means[k] = muf;
+}
+
+// block-wide maximum (256 threads) -> one global atomicMax per block, and only when it would change
+// the word (a plain read of a hot word is an L2 hit; thousands of same-address atomics are not)
+__device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v, uint32_t* wave_max /* LDS [4] */) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
-  if ((threadIdx.x & 63) == 0 && v > __atomic_load_n(addr, __ATOMIC_RELAXED)) atomicMax(addr, v);
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (v > __atomic_load_n(addr, __ATOMIC_RELAXED)) atomicMax(addr, v);
+  }
+  __syncthreads();
 }
 
 // Header pass over the frames in natural order: max |x'|^2 (word 0), non-finite / overflow flag
@@ -50,8 +66,9 @@ __device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v) {
 // so word 0 bounds every norm of every operand image built from these coordinates.
 // 256 rows per block staged through LDS (coalesced reads; odd row stride against bank conflicts).
 __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
-                                const double* __restrict__ sums, uint32_t* __restrict__ hdr) {
+                                const float* __restrict__ means, uint32_t* __restrict__ hdr) {
   extern __shared__ float rs_tile[];
+  __shared__ uint32_t wave_max[4];
   const uint32_t Dp = D | 1u;
   const size_t base = (size_t)blockIdx.x * 256 * D, total = (size_t)n_rows * D;
   for (uint32_t e = threadIdx.x; e < 256 * D; e += 256) {
@@ -64,21 +81,19 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   const float* x = rs_tile + threadIdx.x * Dp;
   double nrm = 0.0;
   for (uint32_t k = 0; k < D; ++k) {
-    float muf = (float)(sums[k] / (double)n_rows);
-    if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
-    const float v = x[k] - muf;
+    const float v = x[k] - means[k];
     nrm += (double)v * (double)v;
   }
   const float nf = (float)nrm;
   const bool ok = live && (nf <= kNormLimit);
   if (live && !ok) atomicOr(hdr + 1, 1u);   // NaN / inf / overflow-prone row: MFMA kernels stand down
-  publish_max(hdr, ok ? __float_as_uint(nf) : 0u);
+  publish_max(hdr, ok ? __float_as_uint(nf) : 0u, wave_max);
   const float c0 = x[0], c1 = (D > 1) ? x[1] : 0.0f;
   const bool fin = live && (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
-  publish_max(hdr + 8, fin ? ~fkey(c0) : 0u);
-  publish_max(hdr + 9, fin ? fkey(c0) : 0u);
-  publish_max(hdr + 10, fin ? ~fkey(c1) : 0u);
-  publish_max(hdr + 11, fin ? fkey(c1) : 0u);
+  publish_max(hdr + 8, fin ? ~fkey(c0) : 0u, wave_max);
+  publish_max(hdr + 9, fin ? fkey(c0) : 0u, wave_max);
+  publish_max(hdr + 10, fin ? ~fkey(c1) : 0u, wave_max);
+  publish_max(hdr + 11, fin ? fkey(c1) : 0u, wave_max);
 }
 
 // operand image of the (centred) coordinates in the bf16x3 slot layout (dc_mfma_kernels.hpp), rows
@@ -86,10 +101,13 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
 // writes the 16-byte fragment of one lane of one MFMA of one tile; the threads of MFMA 0, half 0
 // also write the squared norm of their row (norms != nullptr).  b_form: query-side pieces (-2x').
 __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total, uint32_t n_rows,
-                             uint32_t D, uint32_t NM, uint32_t T, const double* __restrict__ sums,
+                             uint32_t D, uint32_t NM, uint32_t T, const float* __restrict__ means,
                              const uint32_t* __restrict__ perm, int b_form, uint4* __restrict__ img,
                              float* __restrict__ norms) {
-  // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image
+  // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image.
+  // (A variant that decodes the 16 slots of a block once into LDS was measured slower: the column
+  //  loads then hang on the table look-ups instead of being issued together.)
+  (void)n_total;
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (size_t)T * NM * 64) return;
   const uint32_t lane = (uint32_t)(id & 63), m = (uint32_t)((id >> 6) % NM), t = (uint32_t)((id >> 6) / NM);
@@ -97,11 +115,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   const bool live = row < n_rows;
   const uint32_t src = live ? (perm ? perm[row] : row) : 0u;
   const float* x = coords + (size_t)src * D;
-  auto col = [&](uint32_t k) -> float {
-    float muf = (float)(sums[k] / (double)n_total);
-    if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
-    return x[k] - muf;                                   // x' = fl(x - mu)
-  };
+  auto col = [&](uint32_t k) -> float { return x[k] - means[k]; };   // x' = fl(x - mu)
   uint32_t w[4] = {0u, 0u, 0u, 0u};
   if (live) {
 #pragma unroll
@@ -126,6 +140,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
 __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                               uint32_t* __restrict__ hdr) {
+  __shared__ uint32_t wave_max[4];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t inv = 0;
   if (i < n_rows) {
@@ -137,9 +152,9 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
     vals[i] = i;
     inv = ~key;
   }
-  // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax); one atomic
-  // per wave
-  publish_max(hdr + 12, inv);
+  // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax); at most one
+  // atomic per block
+  publish_max(hdr + 12, inv, wave_max);
 }
 
 __global__ void fe_scatter_kernel(const uint32_t* __restrict__ perm, const float* __restrict__ fe,
@@ -269,17 +284,19 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
   const uint32_t blocks = (uint32_t)std::min<size_t>(512, ((size_t)n_rows * n_cols + 255) / 256);
   hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_coords, n_rows, n_cols,
                      (double*)(p + kHdrSums));
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, stream, (const double*)(p + kHdrSums), n_rows,
+                     n_cols, (float*)(p + kHdrMeans));
   hipLaunchKernelGGL(rowstats_kernel, dim3((n_rows + 255) / 256), dim3(256),
                      sizeof(float) * 256 * (n_cols | 1u), stream, d_coords, n_rows, n_cols,
-                     (const double*)(p + kHdrSums), (uint32_t*)p);
+                     (const float*)(p + kHdrMeans), (uint32_t*)p);
   // frames in natural order: only the full-sweep kernels read this image
   if (natural_image) {
     const dim3 grid_img((uint32_t)(((size_t)L.T * L.NM * 64 + 255) / 256));
     hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)nullptr, 0,
+                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                        (uint4*)(p + L.off_img), (float*)(p + L.off_norm));
     hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)nullptr, 1,
+                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
                        (uint4*)(p + L.off_img_b), (float*)nullptr);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -429,7 +446,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
     return;
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                     L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 0,
+                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 0,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
@@ -449,7 +466,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   const uint32_t T_q = (n_q + 31) / 32;
   if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
     hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 1,
+                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 1,
                        (uint4*)(p + L.off_img_q), (float*)nullptr);
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the same ordering restricted to [i_from, i_to)
@@ -458,7 +475,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
-                       L.NM, T_q, (const double*)(p + kHdrSums), (const uint32_t*)perm_q, 1,
+                       L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
                        (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
@@ -529,7 +546,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                     L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 0,
+                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 0,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
@@ -547,7 +564,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   const uint32_t T_q = (n_q + 31) / 32;
   if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
     hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm_p, 1,
+                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 1,
                        (uint4*)(p + L.off_img_q), (float*)nullptr);
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
@@ -556,7 +573,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
-                       L.NM, T_q, (const double*)(p + kHdrSums), (const uint32_t*)perm_q, 1,
+                       L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
                        (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
@@ -598,7 +615,7 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
   hipLaunchKernelGGL(fe_rank_kernel, grid_n, blk, 0, stream, d_fe, (const float*)(p + L.off_fe_s),
                      n_rows, (uint32_t*)(p + L.off_pq));
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                     L.NM, L.T, (const double*)(p + kHdrSums), (const uint32_t*)perm, 0,
+                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm, 0,
                      (uint4*)(p + L.off_img_s), (float*)(p + L.off_norm_s));
   switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                \

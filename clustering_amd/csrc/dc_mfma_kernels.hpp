@@ -79,7 +79,8 @@ constexpr int nm_for(int n_cols) { return (6 * n_cols + kConstSlots + 15) / 16; 
 constexpr int kMaxMfma = nm_for(kMaxCols);   // 13
 constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits); word 1: non-finite flag;
                                        // words 8..11: extent of columns 0/1; word 12: ~key of min FE
-constexpr size_t kHdrSums = 256;       // byte 256..: column sums (double) for the centring
+constexpr size_t kHdrSums = 256;       // byte 256..511: column sums (double) for the centring
+constexpr size_t kHdrMeans = 512;      // byte 512..639: column means as float (what x' = x - mu uses)
 constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram form -> flagged
 
 // Workspace layout.  Regions used by the population sweep: hdr, img, norms.  The neighbour sweep
