@@ -557,10 +557,8 @@ int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const 
     return fail(DC_ERR_INVALID_ARGUMENT, "%d devices requested, %d present", n_devices, avail);
   if (n_rows == 0) return DC_OK;
 
-  // row blocks exactly as density_clustering_cuda.cu:149,165-169 / :293,305-308
-  const size_t range = n_rows / (size_t)n_devices;
-  auto row_from = [&](int g) { return (size_t)g * range; };
-  auto row_to = [&](int g) { return g == n_devices - 1 ? n_rows : (size_t)(g + 1) * range; };
+  // one segment per device (dc_hip_*_segment_dev: spatial runs of query groups with the pruned sweep,
+  // the row blocks of density_clustering_cuda.cu:149,165-169 / :293,305-308 otherwise)
 
   std::vector<DeviceJob> jobs(n_devices);
   std::vector<std::vector<uint32_t>> part(n_devices);
@@ -577,9 +575,9 @@ int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const 
       rc = fail(DC_ERR_HIP, "hipMalloc pops: %s", hipGetErrorString(e));
       break;
     }
-    rc = dc_hip_populations_dev(jobs[g].d_coords, n_rows, n_cols, radii, n_radii, row_from(g),
-                                row_to(g), jobs[g].d_pops, jobs[g].d_ws, jobs[g].ws_bytes,
-                                DC_VARIANT_AUTO, jobs[g].stream);
+    rc = dc_hip_populations_segment_dev(jobs[g].d_coords, n_rows, n_cols, radii, n_radii, (size_t)g,
+                                        (size_t)n_devices, jobs[g].d_pops, jobs[g].d_ws,
+                                        jobs[g].ws_bytes, DC_VARIANT_AUTO, jobs[g].stream);
     if (rc != DC_OK) break;
     part[g].resize(n_radii * n_rows);
     e = hipMemcpyAsync(part[g].data(), jobs[g].d_pops, sizeof(uint32_t) * n_radii * n_rows,
@@ -623,9 +621,10 @@ int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const 
         rc = fail(DC_ERR_HIP, "nn setup (device %d): %s", g, hipGetErrorString(e));
         break;
       }
-      rc = dc_hip_nearest_neighbors_dev(j.d_coords, n_rows, n_cols, j.d_fe, row_from(g), row_to(g),
-                                        j.d_idx, j.d_d2, j.d_idx + n_rows, j.d_d2 + n_rows, j.d_ws,
-                                        j.ws_bytes, DC_VARIANT_AUTO, j.stream);
+      rc = dc_hip_nearest_neighbors_segment_dev(j.d_coords, n_rows, n_cols, j.d_fe, (size_t)g,
+                                                (size_t)n_devices, j.d_idx, j.d_d2, j.d_idx + n_rows,
+                                                j.d_d2 + n_rows, j.d_ws, j.ws_bytes, DC_VARIANT_AUTO,
+                                                j.stream);
       if (rc != DC_OK) break;
       pidx[g].resize(2 * n_rows);
       pd2[g].resize(2 * n_rows);
@@ -643,14 +642,28 @@ int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const 
         rc = fail(DC_ERR_HIP, "nn sweep (device %d): %s", g, hipGetErrorString(e));
     }
     if (rc == DC_OK) {
-      // every row is owned by exactly one device (density_clustering_cuda.cu:311-326)
-      for (int g = 0; g < n_devices; ++g)
-        for (size_t i = row_from(g); i < row_to(g); ++i) {
-          nn_idx[i] = pidx[g][i];
-          nn_d2[i] = pd2[g][i];
-          hd_idx[i] = pidx[g][n_rows + i];
-          hd_d2[i] = pd2[g][n_rows + i];
+      // every row is owned by exactly one device (density_clustering_cuda.cu:311-326 copies by
+      // row block); the others hold the "none" value (n_rows+1, FLT_MAX), which is the largest
+      // (d2, index) there is: per row the smallest (d2, index) over the devices is the owner's
+      auto less = [](float da, uint32_t ia, float db, uint32_t ib) {
+        return da < db || (da == db && ia < ib);
+      };
+      for (size_t i = 0; i < n_rows; ++i) {
+        nn_idx[i] = pidx[0][i];
+        nn_d2[i] = pd2[0][i];
+        hd_idx[i] = pidx[0][n_rows + i];
+        hd_d2[i] = pd2[0][n_rows + i];
+        for (int g = 1; g < n_devices; ++g) {
+          if (less(pd2[g][i], pidx[g][i], nn_d2[i], nn_idx[i])) {
+            nn_d2[i] = pd2[g][i];
+            nn_idx[i] = pidx[g][i];
+          }
+          if (less(pd2[g][n_rows + i], pidx[g][n_rows + i], hd_d2[i], hd_idx[i])) {
+            hd_d2[i] = pd2[g][n_rows + i];
+            hd_idx[i] = pidx[g][n_rows + i];
+          }
         }
+      }
     }
   }
   cleanup();

@@ -193,9 +193,10 @@ DC_API int dc_hip_radius_pairs(const float* coords, size_t n_rows, size_t n_cols
                                uint32_t* pairs, size_t capacity, unsigned long long* count);
 
 /* whole path on n_devices GPUs of this process (devices 0..n_devices-1), coords uploaded once per
- * device and kept resident across pop -> FE -> NN.  Row blocks as
- * density_clustering_cuda.cu:149,165-169 (last device takes the remainder); partial populations are
- * summed and neighbour blocks concatenated on the host exactly as cuda.cu:171-180 / :311-326 do.
+ * device and kept resident across pop -> FE -> NN.  One segment per
+ * device (dc_hip_*_segment_dev; the row blocks of density_clustering_cuda.cu:149,165-169 whenever the
+ * pruned sweep does not run); partial populations are summed on the host as cuda.cu:171-180 does,
+ * every neighbour row is taken from the device that owns it (cuda.cu:311-326).
  * radii: n_radii values; FE and NN are computed from radius index fe_radius_index (NN skipped if
  * nn_idx == NULL).  pops HOST [n_radii*n_rows]; fe, nn_*, hd_* HOST [n_rows]. */
 DC_API int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const float* radii,
