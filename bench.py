@@ -118,11 +118,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the density path has no CPU fallback")
+    # DC_BENCH_ONE_DEVICE=1 (development only): all ranks share cuda:0 and talk over gloo, so that the
+    # sharded path can be exercised end to end on a single-GPU box; the timings mean nothing then.
+    one_device = os.environ.get("DC_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from clustering_amd import density
     from clustering_amd.distributed import HipBackend, ShardedDensity
@@ -150,7 +158,9 @@ def main():
     def step(timed):
         if timed:
             ev[0].record()
-        pops = backend.populations_partial(coords, args.radii, lo, hi)
+        # (the same calls ShardedDensity makes: segments of the spatial order when sharded)
+        pops = (backend.populations_segment(coords, args.radii, rank, world) if world > 1
+                else backend.populations_partial(coords, args.radii, lo, hi))
         if timed:
             ev[1].record()
         if world > 1:
@@ -160,7 +170,8 @@ def main():
         if want_nn:
             if timed:
                 ev[2].record()
-            res = backend.nearest_neighbors_partial(coords, fe, lo, hi)
+            res = (backend.nearest_neighbors_segment(coords, fe, rank, world) if world > 1
+                   else backend.nearest_neighbors_partial(coords, fe, lo, hi))
             if timed:
                 ev[3].record()
         return pops, fe, res
@@ -187,12 +198,18 @@ def main():
             nn_ms.append(ev[2].elapsed_time(ev[3]))
     # pairs actually evaluated (the pruned variants skip tile pairs that are provably too far apart):
     # each sweep leaves its 32x32-tile count in the workspace header
-    pops_c = backend.populations_partial(coords, args.radii, lo, hi)
+    pops_c = (backend.populations_segment(coords, args.radii, rank, world) if world > 1
+              else backend.populations_partial(coords, args.radii, lo, hi))
     pop_tiles = density.evaluated_tiles(dev)[0]
     nn_tiles = 0
     if want_nn:
+        if world > 1:
+            dist.all_reduce(pops_c, op=dist.ReduceOp.SUM)
         fe_c = backend.free_energies(pops_c[0].contiguous())
-        backend.nearest_neighbors_partial(coords, fe_c, lo, hi)
+        if world > 1:
+            backend.nearest_neighbors_segment(coords, fe_c, rank, world)
+        else:
+            backend.nearest_neighbors_partial(coords, fe_c, lo, hi)
         nn_tiles = density.evaluated_tiles(dev)[1]
     # reference point for the roofline: the same sweeps with EVERY pair evaluated (DC_VARIANT_MFMA)
     full_ms = None
