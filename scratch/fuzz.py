@@ -34,4 +34,33 @@ for case in range(n_cases):
         if not ok:
             bad += 1
             print(f"MISMATCH case {case} variant {v}: n={n} d={d} kind={kind} radii={radii} rows=[{lo},{hi}) pops_ok={bool((p == ref_p).all())}")
+    # segments of a sharded run merge to the full result; the radius graph agrees with the populations
+    if case % 3 == 0 and n > 1:
+        G = int(rng.integers(2, 9))
+        full_p = dens.calculate_populations_partial(ct, radii, variant="direct")
+        full_n = dens.nearest_neighbors_partial(ct, fe, variant="direct")
+        acc = torch.zeros_like(full_p)
+        words = None
+        for g in range(G):
+            acc += dens.calculate_populations_segment(ct, radii, g, G)
+            a, b, cc, dd = dens.nearest_neighbors_segment(ct, fe, g, G)
+            w = torch.stack([(b.view(torch.int32).to(torch.int64) << 32) | (a.to(torch.int64) & 0xFFFFFFFF),
+                             (dd.view(torch.int32).to(torch.int64) << 32) | (cc.to(torch.int64) & 0xFFFFFFFF)])
+            words = w if words is None else torch.minimum(words, w)
+        ok = bool((acc == full_p).all()) and bool(((words[0] & 0xFFFFFFFF).to(torch.int32) == full_n[0]).all()) \
+            and bool(((words[0] >> 32).to(torch.int32) == full_n[1].view(torch.int32)).all()) \
+            and bool(((words[1] & 0xFFFFFFFF).to(torch.int32) == full_n[2]).all()) \
+            and bool(((words[1] >> 32).to(torch.int32) == full_n[3].view(torch.int32)).all())
+        if not ok:
+            bad += 1
+            print(f"SEGMENT MISMATCH case {case}: n={n} d={d} G={G} kind={kind}")
+        if n <= 40000:
+            r2 = float(np.float32(radii[0]) * np.float32(radii[0]))
+            pairs, pp = dens.radius_pairs(ct, r2)
+            deg = torch.ones(n, dtype=torch.int64, device="cuda")
+            if pairs.shape[0]:
+                deg += torch.bincount(pairs.reshape(-1), minlength=n)
+            if not (bool((deg == full_p[0].to(torch.int64)).all()) and bool((pp == full_p[0]).all())):
+                bad += 1
+                print(f"RADIUS PAIRS MISMATCH case {case}: n={n} d={d} r2={r2} pairs={pairs.shape[0]}")
 print(f"{n_cases} cases, {bad} mismatches, {time.time()-t0:.1f}s")
