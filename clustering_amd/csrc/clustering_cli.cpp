@@ -529,14 +529,24 @@ int density_main(int argc, char** argv) {
       cm["screening_to"] = t_to;
       cm["screening_from"] = t_from;
       cm["screening_step"] = t_step;
-      // one radius graph for max_dist = 4*sigma2 serves every threshold of the scan
+      // one radius graph for max_dist = 4*sigma2 serves every threshold of the scan.  The scan starts
+      // from an empty clustering, so a spanning forest with the same connectivity below every
+      // threshold does (screening_host.hpp); DC_SCREENING_FULL_GRAPH=1 lists all pairs instead.
       const float max_dist = (float)(4 * sigma2_of(nn_d2));
+      const std::vector<H::FreeEnergy> fe_sorted = H::sorted_free_energies(fe);
       H::RadiusGraph graph;
       std::string err;
-      if (!H::build_radius_graph(coords.data(), n_rows, n_cols, max_dist, 0, &graph, &err))
-        die("error during screening (radius graph)\n" + err);
-      LOG("    %zu frame pairs within the lumping radius\n", graph.n_pairs);
-      const std::vector<H::FreeEnergy> fe_sorted = H::sorted_free_energies(fe);
+      const char* full_env = std::getenv("DC_SCREENING_FULL_GRAPH");
+      const bool forest = !(full_env && full_env[0] == '1') && n_rows <= ((std::size_t)1 << 24);
+      if (forest) {
+        if (!H::build_radius_forest(coords.data(), n_rows, n_cols, max_dist, fe_sorted, 0, &graph, &err))
+          die("error during screening (radius forest)\n" + err);
+        LOG("    %zu frame pairs span the graph of the lumping radius\n", graph.n_pairs);
+      } else {
+        if (!H::build_radius_graph(coords.data(), n_rows, n_cols, max_dist, 0, &graph, &err))
+          die("error during screening (radius graph)\n" + err);
+        LOG("    %zu frame pairs within the lumping radius\n", graph.n_pairs);
+      }
       LOG("\n        fe    frames\n");
       // upper limit extended to a 10th of the stepsize to circumvent rounding errors (:796-800)
       const float t_to_low = t_to - t_step / 10.0f + t_step;

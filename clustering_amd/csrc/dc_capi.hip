@@ -391,6 +391,31 @@ int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t n_cols,
   return check_launch("radius pair sweep launch");
 }
 
+int dc_hip_radius_min_edge_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
+                               const uint32_t* d_comp, const uint32_t* d_rank,
+                               unsigned long long* d_best, uint32_t* d_pops, void* d_workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
+  if (n_rows == 0) return DC_OK;
+  if (!d_coords || !d_comp || !d_rank || !d_best || !d_pops)
+    return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  if (!dc::mfma_supports(n_cols))
+    return fail(DC_ERR_INVALID_ARGUMENT, "the radius graph needs n_cols <= 32 (got %zu)", n_cols);
+  if (n_rows > dc::kMinEdgeMaxRows)
+    return fail(DC_ERR_INVALID_ARGUMENT, "min-edge sweeps need n_rows <= %zu (got %zu)",
+                (size_t)dc::kMinEdgeMaxRows, n_rows);
+  if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
+    return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
+                dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
+  hipStream_t s = (hipStream_t)stream;
+  DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_rows, s));
+  if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, false, s))
+    return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
+  dc::launch_radius_min_edge(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, r2, d_comp, d_rank, d_best,
+                             d_pops, d_workspace, s);
+  return check_launch("min-edge sweep launch");
+}
+
 // ------------------------------------------------------------------------------------------
 // host-pointer wrappers
 // ------------------------------------------------------------------------------------------
@@ -496,6 +521,102 @@ int dc_hip_radius_pairs(const float* coords, size_t n_rows, size_t n_cols, float
   }
   if (d_pairs) (void)hipFree(d_pairs);
   if (d_count) (void)hipFree(d_count);
+  j.release();
+  return rc;
+}
+
+int dc_hip_radius_forest(const float* coords, size_t n_rows, size_t n_cols, float r2,
+                         const uint32_t* rank, int device, uint32_t* edges, size_t* n_edges,
+                         uint32_t* n_rounds) {
+  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
+  if (!n_edges) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  *n_edges = 0;
+  if (n_rounds) *n_rounds = 0;
+  if (n_rows <= 1) return DC_OK;
+  if (!coords || !rank || !edges) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  // frame of every rank (and: is it a permutation?)
+  std::vector<uint32_t> frame_of(n_rows, 0xFFFFFFFFu);
+  for (size_t i = 0; i < n_rows; ++i) {
+    if (rank[i] >= n_rows || frame_of[rank[i]] != 0xFFFFFFFFu)
+      return fail(DC_ERR_INVALID_ARGUMENT, "rank is not a permutation of 0..n_rows-1");
+    frame_of[rank[i]] = (uint32_t)i;
+  }
+  DeviceJob j;
+  int rc = job_open(j, device, coords, n_rows, n_cols);
+  uint32_t *d_comp = nullptr, *d_rank = nullptr;
+  unsigned long long* d_best = nullptr;
+  hipError_t e = hipSuccess;
+  if (rc == DC_OK) {
+    e = hipMalloc((void**)&j.d_pops, sizeof(uint32_t) * n_rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_comp, sizeof(uint32_t) * n_rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_rank, sizeof(uint32_t) * n_rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_best, sizeof(unsigned long long) * n_rows);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(d_rank, rank, sizeof(uint32_t) * n_rows, hipMemcpyHostToDevice, j.stream);
+    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "radius forest setup: %s", hipGetErrorString(e));
+  }
+  // components: union-find over frame ids, the smaller id is the root (= the component's id)
+  std::vector<uint32_t> parent(n_rows), comp(n_rows);
+  for (size_t i = 0; i < n_rows; ++i) parent[i] = comp[i] = (uint32_t)i;
+  auto find = [&](uint32_t x) {
+    uint32_t root = x;
+    while (parent[root] != root) root = parent[root];
+    while (parent[x] != root) {
+      const uint32_t next = parent[x];
+      parent[x] = root;
+      x = next;
+    }
+    return root;
+  };
+  std::vector<unsigned long long> best(n_rows);
+  size_t found = 0;
+  uint32_t rounds = 0;
+  // every round at least halves the number of components that still have a partner
+  for (; rc == DC_OK && rounds < 64; ++rounds) {
+    e = hipMemcpyAsync(d_comp, comp.data(), sizeof(uint32_t) * n_rows, hipMemcpyHostToDevice, j.stream);
+    if (e != hipSuccess) {
+      rc = fail(DC_ERR_HIP, "radius forest: %s", hipGetErrorString(e));
+      break;
+    }
+    rc = dc_hip_radius_min_edge_dev(j.d_coords, n_rows, n_cols, r2, d_comp, d_rank, d_best, j.d_pops,
+                                    j.d_ws, j.ws_bytes, j.stream);
+    if (rc != DC_OK) break;
+    uint32_t hdr[2] = {0, 0};
+    e = hipMemcpyAsync(best.data(), d_best, sizeof(unsigned long long) * n_rows, hipMemcpyDeviceToHost,
+                       j.stream);
+    if (e == hipSuccess && rounds == 0)
+      e = hipMemcpyAsync(hdr, j.d_ws, sizeof(hdr), hipMemcpyDeviceToHost, j.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(j.stream);
+    if (e != hipSuccess) {
+      rc = fail(DC_ERR_HIP, "radius forest sweep: %s", hipGetErrorString(e));
+      break;
+    }
+    if (hdr[1] != 0) {
+      rc = fail(DC_ERR_INVALID_ARGUMENT, "the radius graph needs finite coordinates");
+      break;
+    }
+    size_t joined = 0;
+    for (size_t c = 0; c < n_rows; ++c) {
+      if (best[c] == ~0ull) continue;
+      const uint32_t a = frame_of[(uint32_t)(best[c] >> 32)], b = frame_of[(uint32_t)best[c]];
+      const uint32_t ra = find(a), rb = find(b);
+      if (ra == rb) continue;   // the partner component chose the same pair
+      parent[std::max(ra, rb)] = std::min(ra, rb);
+      edges[2 * found] = a;
+      edges[2 * found + 1] = b;
+      ++found;
+      ++joined;
+    }
+    if (joined == 0) break;
+    for (size_t i = 0; i < n_rows; ++i) comp[i] = find((uint32_t)i);
+  }
+  if (rc == DC_OK) {
+    *n_edges = found;
+    if (n_rounds) *n_rounds = rounds + 1;
+  }
+  if (d_comp) (void)hipFree(d_comp);
+  if (d_rank) (void)hipFree(d_rank);
+  if (d_best) (void)hipFree(d_best);
   j.release();
   return rc;
 }

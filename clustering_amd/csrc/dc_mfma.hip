@@ -386,6 +386,13 @@ __global__ void edges_flag_kernel(const uint32_t* __restrict__ hdr, unsigned lon
   if (hdr[1] != 0) *count = ~0ull;
 }
 
+// per-frame values into the sweep's order (component ids, ranks)
+__global__ void gather_u32_kernel(const uint32_t* __restrict__ by_frame, const uint32_t* __restrict__ perm,
+                                  uint32_t n, uint32_t* __restrict__ by_pos) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) by_pos[p] = by_frame[perm[p]];
+}
+
 // number of unordered pairs from the populations: sum(pop - 1) / 2 (every pair is counted at both ends)
 __global__ void pairs_from_pops_kernel(const uint32_t* __restrict__ pops, uint32_t n_rows,
                                        unsigned long long* __restrict__ twice) {
@@ -407,7 +414,7 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
   one.v[0] = r2;
   (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
   if (d_pairs && capacity) {
-    const EdgeSink sink{d_pairs, d_count, capacity};
+    const EdgeSink sink{d_pairs, d_count, capacity, nullptr, nullptr, nullptr};
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream);
     hipLaunchKernelGGL(edges_to_frames_kernel, dim3(1024), dim3(256), 0, stream, d_pairs,
                        (const unsigned long long*)d_count, capacity,
@@ -422,9 +429,21 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
   hipLaunchKernelGGL(edges_flag_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)d_ws, d_count);
 }
 
+void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
+                            const uint32_t* d_comp, const uint32_t* d_rank, unsigned long long* d_best,
+                            uint32_t* d_pops, void* d_ws, hipStream_t stream) {
+  Rad2 one;
+  for (int k = 0; k < kMaxRadiiPerLaunch; ++k) one.v[k] = -1.0f;
+  one.v[0] = r2;
+  (void)hipMemsetAsync(d_best, 0xFF, sizeof(unsigned long long) * n_rows, stream);
+  // comp / rank arrive per FRAME; pop_pruned_one gathers them into the sweep's order
+  const EdgeSink sink{nullptr, nullptr, 0, d_comp, d_rank, d_best};
+  pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream);
+}
+
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           const EdgeSink* sink, hipStream_t stream) {
+                           const EdgeSink* sink_in, hipStream_t stream) {
   const uint32_t i_from = qs.i_from, i_to = qs.i_to;
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
@@ -456,6 +475,20 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
                      0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
                      (float*)(p + L.off_coords_p));
+  // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
+  // buffers are free again)
+  EdgeSink sink_local;
+  const EdgeSink* sink = sink_in;
+  if (sink_in && sink_in->best) {
+    sink_local = *sink_in;
+    hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->comp, (const uint32_t*)perm_p,
+                       n_rows, keys_in);
+    hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->rank, (const uint32_t*)perm_p,
+                       n_rows, keys_out);
+    sink_local.comp = keys_in;
+    sink_local.rank = keys_out;
+    sink = &sink_local;
+  }
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from, q_tile_lo = 0;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;

@@ -12,7 +12,14 @@ struct EdgeSink {
   uint2* edges;                    // nullptr: counting only
   unsigned long long* count;       // total number of pairs found (may exceed capacity)
   unsigned long long capacity;
+  // "lightest outgoing pair" variant (one round of a Boruvka minimum spanning forest of the radius
+  // graph): comp / rank per position of the sweep's order, best per component id (a position):
+  // min over pairs {a in the component, b outside, d2 < r2} of (max(rank_a, rank_b) << 32 | min(..))
+  const uint32_t* comp;
+  const uint32_t* rank;
+  unsigned long long* best;
 };
+enum SinkMode { kSinkNone = 0, kSinkPairs = 1, kSinkMinEdge = 2 };
 
 // true if the MFMA kernels handle this n_cols
 bool mfma_supports(size_t n_cols);
@@ -35,6 +42,13 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
 void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
                          uint32_t* d_pops, uint2* d_pairs, unsigned long long capacity,
                          unsigned long long* d_count, void* d_ws, hipStream_t stream);
+constexpr size_t kMinEdgeMaxRows = (size_t)1 << 24;   // (the sweep's deferred-evaluation queue holds 24-bit positions)
+// one Boruvka round on the radius graph (d2 < r2): for every component (d_comp[frame] = its id, any
+// frame id) the lightest pair that leaves it, by (max(rank), min(rank)) with d_rank[frame] a
+// permutation; d_best[id] = (max << 32 | min) or ~0.  d_pops: [n_rows] scratch (populations).
+void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
+                            const uint32_t* d_comp, const uint32_t* d_rank, unsigned long long* d_best,
+                            uint32_t* d_pops, void* d_ws, hipStream_t stream);
 // neighbour sweep over (cell, free energy)-ordered frames with ring-wise pruning
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,

@@ -488,6 +488,7 @@ __device__ __forceinline__ void pop_chain(const s16x8 (&a)[NM], const s16x8 (&b)
 template <int NR>
 struct PopDelta {
   uint32_t d[NR];
+  unsigned long long key;   // kSinkMinEdge: lightest outgoing pair found among the evaluated entries
 };
 
 // rare: exact re-check of the band pairs of one accumulator tile.  Everything by value and a
@@ -704,6 +705,7 @@ constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane
 // reference row from a copy of the ORIGINAL coordinates gathered into the reference order.
 constexpr uint32_t kPopQueuePosBits = 24;    // entry = position | radius flags << 24
 constexpr uint32_t kPopQueueMaxRows = 1u << kPopQueuePosBits;
+static_assert(kMinEdgeMaxRows == kPopQueueMaxRows, "min-edge sweeps take the queue path only");
 
 // wave-aggregated append: lanes with `have` add one pair each
 __device__ __forceinline__ void emit_edge(const EdgeSink& sink, bool have, uint32_t pos_q, uint32_t pos_r) {
@@ -718,13 +720,24 @@ __device__ __forceinline__ void emit_edge(const EdgeSink& sink, bool have, uint3
   if (have && sink.edges && base + rank < sink.capacity) sink.edges[base + rank] = make_uint2(pos_q, pos_r);
 }
 
-template <int NR, bool EMIT>
+// candidate of the lightest outgoing pair of a query's component (kSinkMinEdge)
+__device__ __forceinline__ unsigned long long min_edge_key(const EdgeSink& sink, uint32_t comp_q,
+                                                           uint32_t rank_q, uint32_t pos_r) {
+  const uint32_t comp_r = sink.comp[pos_r];
+  if (comp_r == comp_q) return ~0ull;
+  const uint32_t rank_r = sink.rank[pos_r];
+  return ((unsigned long long)max(rank_q, rank_r) << 32) | min(rank_q, rank_r);
+}
+
+template <int NR, int MODE>
 __device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queue /* [kQueueCap][64] */,
                                                             uint32_t count, const float* qrow,
                                                             const float* __restrict__ coords_r,
                                                             uint32_t n_cols, Rad2 rad2, int lane,
-                                                            EdgeSink sink, uint32_t pos_q) {
+                                                            EdgeSink sink, uint32_t pos_q,
+                                                            uint32_t comp_q, uint32_t rank_q) {
   PopDelta<NR> out;
+  out.key = ~0ull;
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) out.d[rr] = 0;
 #pragma unroll
@@ -737,7 +750,9 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queu
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
         out.d[rr] += ((((flags >> rr) & 1u) != 0u) & (d2c < rad2.v[rr])) ? 1u : 0u;
-      if constexpr (EMIT) emit_edge(sink, (d2c < rad2.v[0]) & (pos < pos_q), pos_q, pos);
+      if constexpr (MODE == kSinkPairs) emit_edge(sink, (d2c < rad2.v[0]) & (pos < pos_q), pos_q, pos);
+      if constexpr (MODE == kSinkMinEdge)
+        if (d2c < rad2.v[0]) out.key = min(out.key, min_edge_key(sink, comp_q, rank_q, pos));
     }
   }
   return out;
@@ -750,7 +765,7 @@ __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
   return dx * dx + dy * dy;
 }
 
-template <int NM, int NR, int TQ, bool EMIT = false>
+template <int NM, int NR, int TQ, int MODE = kSinkNone>
 __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
@@ -781,8 +796,16 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
                      (size_t)wib * TQ * kQueueCap * 64;
   const bool use_queue = n_rows <= kPopQueueMaxRows;   // positions fit the queue entries
   uint32_t qcount[TQ];
+  // kSinkMinEdge: component and rank of this lane's query, lightest outgoing pair seen so far
+  uint32_t comp_q[TQ], rank_q[TQ];
+  unsigned long long edge_key[TQ];
 #pragma unroll
-  for (int qt = 0; qt < TQ; ++qt) qcount[qt] = 0;
+  for (int qt = 0; qt < TQ; ++qt) {
+    qcount[qt] = 0;
+    comp_q[qt] = 0;
+    rank_q[qt] = 0;
+    edge_key[qt] = ~0ull;
+  }
 
   const PopSetup<NR> P = pop_setup<NR>(hdr, rad2, n_cols);
   float r2max = rad2.v[0];
@@ -806,6 +829,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     jq[qt] = live ? perm_q[pos] : 0u;
     const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
     load_query<NM>(img_q, tl, lane, h, cq, b[qt]);
+    if constexpr (MODE == kSinkMinEdge) {   // (all rows, in the reference order: position = pos)
+      comp_q[qt] = live ? sink.comp[pos] : 0xFFFFFFFFu;
+      rank_q[qt] = live ? sink.rank[pos] : 0u;
+    }
     if (h == 0)   // original coordinates of this lane's query, for the exact path
       for (uint32_t k = 0; k < n_cols; ++k)
         qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
@@ -822,10 +849,12 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   auto flush = [&](int qi) {
     if (__builtin_amdgcn_ballot_w64(qcount[qi] != 0) == 0) return;
     const PopDelta<NR> dl =
-        pop_flush<NR, EMIT>(queues + qi * (kQueueCap * 64), qcount[qi], qrows + (qi * 32 + c) * n_cols,
-                            coords_r, n_cols, rad2, lane, sink, (qt0 + (uint32_t)qi) * 32u + (uint32_t)c);
+        pop_flush<NR, MODE>(queues + qi * (kQueueCap * 64), qcount[qi], qrows + (qi * 32 + c) * n_cols,
+                            coords_r, n_cols, rad2, lane, sink, (qt0 + (uint32_t)qi) * 32u + (uint32_t)c,
+                            comp_q[qi], rank_q[qi]);
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += dl.d[rr];
+    if constexpr (MODE == kSinkMinEdge) edge_key[qi] = min(edge_key[qi], dl.key);
     qcount[qi] = 0;
   };
 
@@ -866,7 +895,18 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
-      if constexpr (EMIT) {
+      if constexpr (MODE == kSinkMinEdge) {
+        // partners decided "inside" by the accumulator alone (element r = bit 15 - r of the sign
+        // string; the query itself is one of them and belongs to its own component): keep the
+        // lightest pair that leaves the component.  Inside elements are sparse (< 1 % at 4 sigma^2).
+        uint32_t inside = e.bits[0] & 0xFFFFu;
+        while (inside != 0) {
+          const int p = __builtin_ctz(inside);
+          edge_key[qi] = min(edge_key[qi], min_edge_key(sink, comp_q[qi], rank_q[qi], tile_row(t, 15 - p, h)));
+          inside &= inside - 1u;
+        }
+      }
+      if constexpr (MODE == kSinkPairs) {
         // pairs decided "inside" by the accumulator alone: element r = bit 15 - r of the sign string.
         // Only partners at a smaller position are listed (every pair once); one atomic per chain and
         // wave reserves the slots, then each lane stores its own pairs.
@@ -1008,6 +1048,11 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) flush(qt);
+  if constexpr (MODE == kSinkMinEdge) {
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt)
+      if (edge_key[qt] != ~0ull) atomicMin(&sink.best[comp_q[qt]], edge_key[qt]);
+  }
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
@@ -1883,14 +1928,20 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // query rows (original coordinates) + queues of deferred exact evaluations, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
-  if (sink)   // radius-graph variant: all rows only (query positions = reference positions)
-    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, true>), grid, block, smem, s, coords, n_rows,
+  // radius-graph variants: all rows only (query positions = reference positions)
+  if (sink && sink->best)
+    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkMinEdge>), grid, block, smem, s, coords,
+                       n_rows, n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q,
+                       norms_q, perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
+  else if (sink)
+    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkPairs>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                        perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
   else
-    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, false>), grid, block, smem, s, coords, n_rows,
+    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkNone>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
-                       perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, EdgeSink{nullptr, nullptr, 0});
+                       perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops,
+                       EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr});
 }
 
 template <int S, int NRV>

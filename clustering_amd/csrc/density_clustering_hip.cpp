@@ -140,23 +140,25 @@ std::vector<std::size_t> screening(const std::vector<float>& free_energy, const 
   for (const auto& match : nh) sigma2 += match.second.second;
   sigma2 /= nh.size();
   const float max_dist = (float)(4 * sigma2);   // the reference passes 4*sigma2 into a float parameter
-  // one radius graph and one free-energy order per trajectory, shared by the thresholds of a scan
+  // one free-energy order and one graph per trajectory, shared by the thresholds of a scan.  A scan
+  // that starts from an empty clustering and feeds every result into the next, higher threshold (the
+  // reference's only use, density_clustering.cpp:786-811) is served by the spanning forest
+  // (screening_host.hpp); any other initial clustering gets the full pair list.
   struct Cache {
     const float* coords = nullptr;
     std::size_t n_rows = 0, n_cols = 0;
     float max_dist = 0.0f;
     std::vector<float> fe;
-    H::RadiusGraph graph;
     std::vector<H::FreeEnergy> fe_sorted;
+    H::RadiusGraph forest, graph;
+    bool have_forest = false, have_graph = false;
+    std::vector<std::size_t> last_result;
+    float last_threshold = 0.0f;
   };
   static Cache cache;
   if (cache.coords != coords || cache.n_rows != n_rows || cache.n_cols != n_cols ||
       cache.max_dist != max_dist || cache.fe != free_energy) {
-    std::string err;
-    if (!H::build_radius_graph(coords, n_rows, n_cols, max_dist, 0, &cache.graph, &err)) {
-      std::cerr << "error during screening (radius graph)\n" << err << std::endl;
-      exit(EXIT_FAILURE);
-    }
+    cache = Cache();
     cache.coords = coords;
     cache.n_rows = n_rows;
     cache.n_cols = n_cols;
@@ -164,8 +166,36 @@ std::vector<std::size_t> screening(const std::vector<float>& free_energy, const 
     cache.fe = free_energy;
     cache.fe_sorted = H::sorted_free_energies(free_energy);
   }
-  return H::screening_with_graph(free_energy, cache.fe_sorted, cache.graph, free_energy_threshold,
-                                 initial_clusters);
+  bool empty_start = initial_clusters.size() != n_rows;
+  if (!empty_start) {
+    empty_start = true;
+    for (std::size_t c : initial_clusters) empty_start = empty_start && (c == 0);
+  }
+  const bool continues_scan = !empty_start && !cache.last_result.empty() &&
+                              !(free_energy_threshold < cache.last_threshold) &&
+                              initial_clusters == cache.last_result;
+  const bool use_forest = (empty_start || continues_scan) && n_rows <= ((std::size_t)1 << 24);
+  std::string err;
+  if (use_forest && !cache.have_forest) {
+    if (!H::build_radius_forest(coords, n_rows, n_cols, max_dist, cache.fe_sorted, 0, &cache.forest, &err)) {
+      std::cerr << "error during screening (radius forest)\n" << err << std::endl;
+      exit(EXIT_FAILURE);
+    }
+    cache.have_forest = true;
+  }
+  if (!use_forest && !cache.have_graph) {
+    if (!H::build_radius_graph(coords, n_rows, n_cols, max_dist, 0, &cache.graph, &err)) {
+      std::cerr << "error during screening (radius graph)\n" << err << std::endl;
+      exit(EXIT_FAILURE);
+    }
+    cache.have_graph = true;
+  }
+  std::vector<std::size_t> result =
+      H::screening_with_graph(free_energy, cache.fe_sorted, use_forest ? cache.forest : cache.graph,
+                              free_energy_threshold, initial_clusters);
+  cache.last_result = result;
+  cache.last_threshold = free_energy_threshold;
+  return result;
 }
 
 }  // namespace CUDA

@@ -22,6 +22,11 @@ std::vector<FreeEnergy> sorted_free_energies(const std::vector<float>& fe) {
   return fe_sorted;
 }
 
+namespace {
+void pairs_to_graph(const std::vector<std::uint32_t>& pairs, std::size_t n_pairs, std::size_t n_rows,
+                    RadiusGraph* out);
+}
+
 bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
                         int device, RadiusGraph* out, std::string* error) {
   unsigned long long count = 0;
@@ -42,17 +47,41 @@ bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_c
     if (error) *error = dc_hip_last_error();
     return false;
   }
-  out->n_pairs = (std::size_t)count;
+  pairs_to_graph(pairs, (std::size_t)count, n_rows, out);
+  return true;
+}
+
+namespace {
+void pairs_to_graph(const std::vector<std::uint32_t>& pairs, std::size_t n_pairs, std::size_t n_rows,
+                    RadiusGraph* out) {
+  out->n_pairs = n_pairs;
   out->offset.assign(n_rows + 1, 0);
-  for (std::size_t k = 0; k < 2 * out->n_pairs; ++k) ++out->offset[pairs[k] + 1];
+  for (std::size_t k = 0; k < 2 * n_pairs; ++k) ++out->offset[pairs[k] + 1];
   for (std::size_t i = 0; i < n_rows; ++i) out->offset[i + 1] += out->offset[i];
-  out->neighbor.resize(2 * out->n_pairs);
+  out->neighbor.resize(2 * n_pairs);
   std::vector<std::uint64_t> fill(out->offset.begin(), out->offset.end() - 1);
-  for (std::size_t k = 0; k < out->n_pairs; ++k) {
+  for (std::size_t k = 0; k < n_pairs; ++k) {
     const std::uint32_t a = pairs[2 * k], b = pairs[2 * k + 1];
     out->neighbor[fill[a]++] = b;
     out->neighbor[fill[b]++] = a;
   }
+}
+}  // namespace
+
+bool build_radius_forest(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
+                         const std::vector<FreeEnergy>& fe_sorted, int device, RadiusGraph* out,
+                         std::string* error) {
+  std::vector<std::uint32_t> rank(n_rows);
+  for (std::size_t i = 0; i < n_rows; ++i) rank[fe_sorted[i].first] = (std::uint32_t)i;
+  std::vector<std::uint32_t> pairs(2 * (n_rows ? n_rows - 1 : 0) + 2);
+  std::size_t n_pairs = 0;
+  const int rc = dc_hip_radius_forest(coords, n_rows, n_cols, max_dist, rank.data(), device, pairs.data(),
+                                      &n_pairs, nullptr);
+  if (rc != DC_OK) {
+    if (error) *error = dc_hip_last_error();
+    return false;
+  }
+  pairs_to_graph(pairs, n_pairs, n_rows, out);
   return true;
 }
 

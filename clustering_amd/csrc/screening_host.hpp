@@ -37,6 +37,17 @@ struct RadiusGraph {
 bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
                         int device, RadiusGraph* out, std::string* error);
 
+//! the same for screenings that START FROM AN EMPTY CLUSTERING (a -T scan): a spanning forest of the
+//! radius graph that, for every threshold, connects the frames below it exactly as the whole graph
+//! does (dc_hip_radius_forest with rank = position in fe_sorted).  At most n_rows-1 pairs, a dozen
+//! pruned sweeps and no pair list -- the whole graph of C3 has 9e8 pairs.  screening_with_graph gives
+//! identical results on it as long as every initial clustering handed to it is the result of a lower
+//! threshold on the same data (frames that come with a state are not expanded by the reference either,
+//! and the names that matter -- the smallest of each component -- are allocated in the same order).
+bool build_radius_forest(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
+                         const std::vector<FreeEnergy>& fe_sorted, int device, RadiusGraph* out,
+                         std::string* error);
+
 //! screening for one threshold (density_clustering_common.cpp:37-134) given the radius graph for
 //! max_dist = 4*sigma2: cluster id per frame, 0 = not assigned (above the threshold)
 std::vector<std::size_t> screening_with_graph(const std::vector<float>& free_energy,

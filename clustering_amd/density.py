@@ -204,6 +204,43 @@ def radius_pairs(coords, r2, capacity=None):
     return pairs[:n].to(torch.int64), pops
 
 
+def radius_min_edge(coords, r2, comp, rank):
+    """One Boruvka round on the radius graph (dc_hip_radius_min_edge_dev): comp, rank int32 CUDA
+    [n_rows] -> (best int64 [n_rows]: (max rank << 32 | min rank) of the lightest pair leaving
+    component id, -1 (all ones) if none; pops int32 [n_rows])."""
+    n_rows, n_cols = _check_coords(coords)
+    dev = coords.device
+    for t in (comp, rank):
+        assert t.is_cuda and t.dtype == torch.int32 and t.shape == (n_rows,) and t.is_contiguous()
+    best = torch.empty(n_rows, dtype=torch.int64, device=dev)
+    pops = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
+        rc = capi.lib.dc_hip_radius_min_edge_dev(_dev(coords), n_rows, n_cols, float(r2), _dev(comp),
+                                                 _dev(rank), _dev(best), _dev(pops), ws, ws_bytes,
+                                                 _stream_ptr())
+    capi.check(rc, "dc_hip_radius_min_edge_dev")
+    return best, pops
+
+
+def radius_forest(coords_host, r2, rank, device=0):
+    """Bottleneck spanning forest of the radius graph (dc_hip_radius_forest).  coords_host: float32
+    numpy [n_rows, n_cols]; rank: permutation of 0..n_rows-1 -> (edges uint32 numpy [n_edges, 2] of
+    frame ids, number of sweeps)."""
+    coords_host = np.ascontiguousarray(coords_host, dtype=np.float32)
+    n_rows, n_cols = coords_host.shape
+    rank = np.ascontiguousarray(rank, dtype=np.uint32)
+    assert rank.shape == (n_rows,)
+    edges = np.empty((max(n_rows - 1, 1), 2), dtype=np.uint32)
+    n_edges, n_rounds = C.c_size_t(0), C.c_uint32(0)
+    rc = capi.lib.dc_hip_radius_forest(coords_host.ctypes.data_as(C.c_void_p), n_rows, n_cols, float(r2),
+                                       rank.ctypes.data_as(C.c_void_p), device,
+                                       edges.ctypes.data_as(C.c_void_p), C.byref(n_edges),
+                                       C.byref(n_rounds))
+    capi.check(rc, "dc_hip_radius_forest")
+    return edges[:n_edges.value].copy(), int(n_rounds.value)
+
+
 def compute_sigma2(nn_d2):
     """compute_sigma2 (density_clustering.cpp:334-343)."""
     out = C.c_double(0.0)

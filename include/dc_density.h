@@ -171,6 +171,22 @@ DC_API int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t 
                                    unsigned long long* d_count, void* d_workspace,
                                    size_t workspace_bytes, void* stream);
 
+/* one Boruvka round on that radius graph, for screenings that only need its CONNECTIVITY below a
+ * free-energy threshold (density_clustering_common.cpp:37-134 started from an empty clustering): for
+ * every component the lightest pair that leaves it.  No pair list is materialised.
+ *   d_comp   [n_rows] uint32 device: component id of every frame (the id is any frame id < n_rows)
+ *   d_rank   [n_rows] uint32 device: a permutation of 0..n_rows-1 (position in order of free energy);
+ *            the weight of a pair is (max(rank), min(rank)), compared lexicographically
+ *   d_best   [n_rows] uint64 device, out: d_best[id] = (max << 32 | min) of the lightest pair with
+ *            canonical d2 < r2 that joins component id to another one, ~0 if there is none
+ *   d_pops   [n_rows] uint32 device, out: populations at that radius
+ * Needs n_cols <= 32, n_rows <= 2^24 and a workspace as above; with coordinates that are not finite
+ * every d_best entry stays ~0 (dc_hip_radius_forest reports the error). */
+DC_API int dc_hip_radius_min_edge_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
+                                      const uint32_t* d_comp, const uint32_t* d_rank,
+                                      unsigned long long* d_best, uint32_t* d_pops, void* d_workspace,
+                                      size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * host-pointer entry points (mirror the reference's per-GPU host functions)
  * ------------------------------------------------------------------------------------- */
@@ -191,6 +207,17 @@ DC_API int dc_hip_nearest_neighbors(const float* coords, size_t n_rows, size_t n
  * larger than capacity, call again with a buffer of that size). */
 DC_API int dc_hip_radius_pairs(const float* coords, size_t n_rows, size_t n_cols, float r2, int device,
                                uint32_t* pairs, size_t capacity, unsigned long long* count);
+
+/* bottleneck spanning forest of the radius graph: Boruvka rounds of dc_hip_radius_min_edge_dev with
+ * the components merged on the host.  For every t the pairs of the forest with max(rank) < t connect
+ * exactly the frames that the pairs of the full graph with max(rank) < t connect -- what a screening
+ * threshold asks for -- with at most n_rows-1 pairs instead of all of them (9e8 at C3).
+ *   rank     HOST [n_rows]: permutation of 0..n_rows-1
+ *   edges    HOST [n_rows-1][2] uint32, out: frame ids of the forest's pairs
+ *   n_edges  out: number of pairs written;  n_rounds (may be NULL): sweeps that were run */
+DC_API int dc_hip_radius_forest(const float* coords, size_t n_rows, size_t n_cols, float r2,
+                                const uint32_t* rank, int device, uint32_t* edges, size_t* n_edges,
+                                uint32_t* n_rounds);
 
 /* whole path on n_devices GPUs of this process (devices 0..n_devices-1), coords uploaded once per
  * device and kept resident across pop -> FE -> NN.  One segment per

@@ -49,5 +49,14 @@ int main(int argc, char** argv) {
     for (std::size_t v : clustering) std::printf(" %zu", v);
     std::printf("\n");
   }
+  // an initial clustering that is NOT the result of a lower threshold (neighbouring frames may carry
+  // different names): the shim must walk the whole radius graph, not the spanning forest
+  std::vector<std::size_t> foreign(n_rows, 0);
+  for (std::size_t i = 0; i < n_rows; ++i)
+    if (fe[i] < 1.0f) foreign[i] = 1 + i % 3;
+  clustering = G::screening(fe, nn, 2.0f, coords.data(), n_rows, n_cols, foreign);
+  std::printf("foreign 2");
+  for (std::size_t v : clustering) std::printf(" %zu", v);
+  std::printf("\n");
   return 0;
 }

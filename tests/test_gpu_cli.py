@@ -101,8 +101,10 @@ def test_cli_without_radius_uses_lumping_radius_and_reuse(tmp_path, oracle):
     assert data_lines(tmp_path / "nn2") == want
 
 
-def test_cli_screening_matches_the_quadratic_restatement(tmp_path, oracle):
-    """-T FROM STEP TO -o: one radius graph from the GPU + the reference's name bookkeeping must give,
+@pytest.mark.parametrize("full_graph", [False, True])
+def test_cli_screening_matches_the_quadratic_restatement(tmp_path, oracle, full_graph):
+    """-T FROM STEP TO -o: the GPU's spanning forest of the radius graph (default) or its full pair list
+    (DC_SCREENING_FULL_GRAPH=1) + the reference's name bookkeeping must give,
     threshold by threshold, the clustering of the line-by-line restatement (oracle/screening_oracle.cpp:
     O(M^2) scans per threshold, explicit renaming loops), chained through the thresholds like
     density_clustering.cpp:801-812 does."""
@@ -110,8 +112,10 @@ def test_cli_screening_matches_the_quadratic_restatement(tmp_path, oracle):
     so = ScreeningOracle()
     c = write_coords(tmp_path / "coords", gaussian_blobs(2500, 3, seed=45))
     r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "0.05", "-T", "0.5", "0.75", "5.0",
-                        "-o", str(tmp_path / "clust"), "-v"], capture_output=True, text=True, timeout=300)
+                        "-o", str(tmp_path / "clust"), "-v"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, DC_SCREENING_FULL_GRAPH="1" if full_graph else "0"))
     assert r.returncode == 0, r.stderr + r.stdout
+    assert ("within the lumping radius" if full_graph else "span the graph") in r.stdout + r.stderr
     pops = oracle.populations(c, [0.05])[0]
     fe = oracle.free_energies(pops)
     nn = oracle.nearest_neighbors(c, fe)
@@ -192,3 +196,7 @@ def test_cpp_shim_reference_signatures(tmp_path, oracle):
     for sline in screens:
         want = so.screening(fe, exp[1], float(sline[1]), c, want)
         assert [int(x) for x in sline[2:]] == want.tolist()
+    # ... and from an initial clustering that no lower threshold produced (full radius graph)
+    foreign = np.where(fe < np.float32(1.0), 1 + np.arange(len(fe)) % 3, 0)
+    fline = [l.split() for l in lines if l.startswith("foreign ")][0]
+    assert [int(x) for x in fline[2:]] == so.screening(fe, exp[1], 2.0, c, foreign).tolist()

@@ -289,6 +289,83 @@ def test_radius_pairs_match_brute_force(dens, n_rows, n_cols, r2):
     assert (pops.cpu().numpy().astype(np.int64) == deg).all()
 
 
+def _components(n, pairs):
+    parent = list(range(n))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b in pairs:
+        ra, rb = find(int(a)), find(int(b))
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+    return np.array([find(i) for i in range(n)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,n_cols,r2,n_comp", [(700, 3, 0.02, 700), (3000, 10, 0.045, 40), (1500, 30, 0.25, 5),
+                                                     (257, 2, 1e-4, 257), (2000, 10, 0.06, 1)])
+def test_min_edge_round_matches_brute_force(dens, n_rows, n_cols, r2, n_comp):
+    """dc_hip_radius_min_edge_dev: for every component the lightest pair (max rank, min rank) of the
+    radius graph that leaves it -- against the brute-force pair set and arbitrary component labels."""
+    import torch
+    from clustering_amd.synth import gaussian_blobs
+    c = gaussian_blobs(n_rows, n_cols, seed=11 + n_cols)
+    rng = np.random.default_rng(n_rows)
+    rank = rng.permutation(n_rows).astype(np.int32)
+    label = rng.integers(0, n_comp, n_rows)
+    comp = np.empty(n_rows, dtype=np.int32)           # id of a component = its smallest frame id
+    for lab in np.unique(label):
+        members = np.nonzero(label == lab)[0]
+        comp[members] = members.min()
+    ct = torch.from_numpy(c).cuda()
+    best, pops = dens.radius_min_edge(ct, r2, torch.from_numpy(comp).cuda(), torch.from_numpy(rank).cuda())
+    best = best.cpu().numpy().view(np.uint64)
+    want = np.full(n_rows, np.iinfo(np.uint64).max, dtype=np.uint64)
+    deg = np.ones(n_rows, dtype=np.int64)
+    for a, b in _brute_pairs(c, r2):
+        deg[a] += 1
+        deg[b] += 1
+        if comp[a] == comp[b]:
+            continue
+        key = np.uint64((int(max(rank[a], rank[b])) << 32) | int(min(rank[a], rank[b])))
+        for f in (a, b):
+            want[comp[f]] = min(want[comp[f]], key)
+    assert (best == want).all()
+    assert (pops.cpu().numpy().astype(np.int64) == deg).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,n_cols,r2", [(700, 3, 0.02), (3000, 10, 0.045), (1500, 30, 0.25), (257, 2, 1e-4),
+                                               (20000, 4, 0.002), (1, 3, 1.0), (2, 3, 100.0)])
+def test_radius_forest_has_the_connectivity_of_the_radius_graph(dens, n_rows, n_cols, r2):
+    """dc_hip_radius_forest: a forest (no cycles) of pairs of the radius graph that, restricted to
+    max(rank) < t, connects exactly what the whole graph restricted to max(rank) < t connects."""
+    import torch
+    from clustering_amd.synth import gaussian_blobs
+    c = gaussian_blobs(n_rows, n_cols, seed=5 + n_cols)
+    rng = np.random.default_rng(n_rows + 1)
+    rank = rng.permutation(n_rows).astype(np.uint32)
+    edges, rounds = dens.radius_forest(c, r2, rank)
+    if n_rows <= 3000:
+        all_pairs = np.array(sorted(_brute_pairs(c, r2)), dtype=np.int64).reshape(-1, 2)
+    else:
+        all_pairs = dens.radius_pairs(torch.from_numpy(c).cuda(), r2)[0].cpu().numpy()
+    pair_set = {(int(min(a, b)), int(max(a, b))) for a, b in all_pairs}
+    assert all((int(min(a, b)), int(max(a, b))) in pair_set for a, b in edges)
+    full = _components(n_rows, all_pairs)
+    assert len(edges) == n_rows - len(np.unique(full)), "not a spanning forest"
+    w_all = np.maximum(rank[all_pairs[:, 0]], rank[all_pairs[:, 1]]) if len(all_pairs) else np.zeros(0)
+    w_for = np.maximum(rank[edges[:, 0]], rank[edges[:, 1]]) if len(edges) else np.zeros(0)
+    for t in [0, n_rows // 7, n_rows // 3, n_rows // 2, (3 * n_rows) // 4, n_rows]:
+        a = _components(n_rows, all_pairs[w_all < t])
+        b = _components(n_rows, edges[w_for < t])
+        assert (a == b).all(), f"connectivity differs below rank {t}"
+    assert 1 <= rounds <= 26 or n_rows <= 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows", [None, (20000, 30000)])
 def test_chunked_launches_match_direct(dens, rows):
