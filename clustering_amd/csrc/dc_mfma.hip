@@ -96,14 +96,14 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   publish_max(hdr + 11, fin ? fkey(c1) : 0u, wave_max);
 }
 
-// operand image of the (centred) coordinates in the bf16x3 slot layout (dc_mfma_kernels.hpp), rows
+// operand image of the (centred, scaled) coordinates in the fp16x2 slot layout (dc_mfma_kernels.hpp), rows
 // in natural order (perm == nullptr) or gathered through perm (an ordered frame list).  One thread
 // writes the 16-byte fragment of one lane of one MFMA of one tile; the threads of MFMA 0, half 0
 // also write the squared norm of their row (norms != nullptr).  b_form: query-side pieces (-2x').
 __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total, uint32_t n_rows,
                              uint32_t D, uint32_t NM, uint32_t T, const float* __restrict__ means,
                              const uint32_t* __restrict__ perm, int b_form, uint4* __restrict__ img,
-                             float* __restrict__ norms) {
+                             float* __restrict__ norms, const uint32_t* __restrict__ hdr) {
   // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image.
   // (A variant that decodes the 16 slots of a block once into LDS was measured slower: the column
   //  loads then hang on the table look-ups instead of being issued together.)
@@ -115,7 +115,8 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   const bool live = row < n_rows;
   const uint32_t src = live ? (perm ? perm[row] : row) : 0u;
   const float* x = coords + (size_t)src * D;
-  auto col = [&](uint32_t k) -> float { return x[k] - means[k]; };   // x' = fl(x - mu)
+  const Scale sc = scale_of(__uint_as_float(hdr[0]));   // (word 0 is final: rowstats_kernel ran before)
+  auto col = [&](uint32_t k) -> float { return (x[k] - means[k]) * sc.s1; };   // x'' = 2^k fl(x - mu)
   uint32_t w[4] = {0u, 0u, 0u, 0u};
   if (live) {
 #pragma unroll
@@ -128,10 +129,10 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   if (norms && m == 0 && h == 0) {
     double nrm = 0.0;
     for (uint32_t k = 0; k < D; ++k) {
-      const float v = live ? col(k) : 0.0f;
+      const float v = live ? x[k] - means[k] : 0.0f;
       nrm += (double)v * (double)v;
     }
-    norms[row] = live ? (float)nrm : INFINITY;           // pad rows can never be "inside"
+    norms[row] = live ? (float)nrm * sc.s2 : INFINITY;   // 4^k |x'|^2; pad rows can never be "inside"
   }
 }
 
@@ -264,7 +265,7 @@ __global__ void gather_key_kernel(const uint32_t* __restrict__ keys_by_frame,
 
 }  // namespace
 
-#define DC_FOR_EACH_S(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#define DC_FOR_EACH_S(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 DC_FOR_EACH_S(DC_DECLARE_STEP)
 
 bool mfma_supports(size_t n_cols) {
@@ -294,10 +295,10 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
     const dim3 grid_img((uint32_t)(((size_t)L.T * L.NM * 64 + 255) / 256));
     hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                       (uint4*)(p + L.off_img), (float*)(p + L.off_norm));
+                       (uint4*)(p + L.off_img), (float*)(p + L.off_norm), (const uint32_t*)p);
     hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                       (uint4*)(p + L.off_img_b), (float*)nullptr);
+                       (uint4*)(p + L.off_img_b), (float*)nullptr, (const uint32_t*)p);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -466,7 +467,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     return;
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                      L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 0,
-                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
+                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
                      (const float*)nullptr, (float2*)nullptr);
@@ -500,7 +501,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
     hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 1,
-                       (uint4*)(p + L.off_img_q), (float*)nullptr);
+                       (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p);
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the same ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
@@ -509,7 +510,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
+                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p);
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
                        (const float*)nullptr, (float2*)nullptr);
@@ -580,7 +581,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                      L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 0,
-                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p));
+                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
                      (float2*)(p + L.off_ferange_p));
@@ -598,7 +599,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
     hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 1,
-                       (uint4*)(p + L.off_img_q), (float*)nullptr);
+                       (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p);
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
@@ -607,7 +608,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q));
+                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p);
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
                        (const float*)nullptr, (float2*)nullptr);
@@ -649,7 +650,7 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
                      n_rows, (uint32_t*)(p + L.off_pq));
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                      L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm, 0,
-                     (uint4*)(p + L.off_img_s), (float*)(p + L.off_norm_s));
+                     (uint4*)(p + L.off_img_s), (float*)(p + L.off_norm_s), (const uint32_t*)p);
   switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                \
   case SV:                                                                                   \

@@ -1,5 +1,5 @@
 // dc_mfma_kernels.hpp -- matrix-core variants of the two pairwise sweeps (gfx950,
-// v_mfma_f32_32x32x16_bf16 on fp32 coordinates split into three bf16 pieces).  Included by
+// v_mfma_f32_32x32x16_f16 on fp32 coordinates split into two fp16 pieces).  Included by
 // dc_mfma.hip (host side) and dc_mfma_step.hip (one translation unit per MFMA count).
 //
 // Idea.  The N x D . D x N distance block is a dense contraction:
@@ -12,32 +12,43 @@
 //     acc >= thr + eps   =>  canonical d2 >= thr
 //     otherwise          =>  the pair is re-evaluated in the canonical order (dist2_canon_rt) from
 //                            the ORIGINAL coordinates, in-kernel, by the lane that owns it.
-// A handful of pairs per frame fall in the band (|d2 - r^2| < ~1e-5), so the re-check costs ~1 %.
+// A handful of pairs per frame fall in the band (|d2 - r^2| < ~1e-5), so the re-check costs a few %.
 // The nearest-neighbour sweep uses the same band around the running minimum: every reference frame
 // whose MFMA distance is within 2.5 eps of the running minimum is evaluated exactly and merged
 // lexicographically on (d2, index), which reproduces "lowest index wins ties" (:270) exactly.
 //
-// Why bf16 pieces.  On gfx950 the fp32-input MFMA runs at the vector rate and shares the vector
-// pipe (its 64 cycles per K=2 step do not overlap the VALU epilogue: measured); the bf16
-// MFMA is 16x faster per flop and runs beside the VALU.  An fp32 value is EXACTLY the sum of three
-// bf16 values (8 + 8 + 8 significant bits, round-to-nearest residuals): v = hi + mid + lo.  Of the
-// nine piece products of x_k * y_k the three smallest (mid*lo, lo*mid, lo*lo <= 2^-24 |x_k y_k|) are
-// dropped into the guard band, the other six are exact in fp32 and summed by the MFMA:
-//     -2 x.y  ~  sum_k  yh*xh + ym*xh + yh*xm + ym*xm + yl*xh + yh*xl       (x pieces of -2x')
-// i.e. 6 D "slots" of the K axis, plus three slots (1 * pieces of a per-query constant c_q) that fold
-// the query norm and the threshold into the accumulator:
+// Why fp16 pieces.  On gfx950 the fp32-input MFMA runs at the vector rate and shares the vector
+// pipe (its 64 cycles per K=2 step do not overlap the VALU epilogue: measured); the
+// 16-bit MFMAs are 16x faster per flop and run beside the VALU.  The accumulation of any MFMA chain
+// already costs tens of u = 2^-24 relative to max |x'|^2 (every addend is truncated to 2^-24 of the
+// largest one), so the operands need to carry the coordinates to about 2^-22, not to the last bit:
+// two fp16 pieces do that, x' = hi + mid + rho with |rho| <= 2^-22 |x'|, and of the products of
+// x_k * y_k only the three largest are kept:
+//     -2 x.y  ~  sum_k  yh*xh + ym*xh + yh*xm                               (x pieces of -2x')
+// (the dropped ym*xm, yh*rho, rho*xh are <= 3 * 2^-22 |x_k y_k|: 27 u max|x'|^2 in the band, against
+// 34 u for the accumulation itself).  That is 3 D "slots" of the K axis, plus two slots
+// (2^15 * pieces of c_q / 2^15, c_q a per-query constant) that fold the query norm and the threshold
+// into the accumulator:
 //     acc = |y'|^2 + c_q - 2 x'.y'   with  c_q = |x'|^2 - (r^2 - eps)   (populations: inside <=> acc < 0)
 //                                          c_q = |x'|^2                 (neighbours:  acc ~ d2)
-// NM = ceil((6 D + 3) / 16) MFMAs per tile (4 for D = 10, against 5 fp32 MFMAs of 4x the cycles).
+// NM = ceil((3 D + 2) / 16) MFMAs per tile: 2 for D = 10 (the first, exact bf16x3 version of these
+// kernels -- git tag bf16x3-r1 -- needed 4; the fp32 MFMA 5 of 4x the cycles), 7 for D = 32.
+// fp16 has a narrow exponent range, so everything the matrix pipe sees is SCALED by a power of two
+// chosen per data set (exact): x'' = 2^k x', S = 4^k with S max|x'|^2 in [2^26, 2^28).  Then
+// |x''_k| < 2^14, |-2 x''_k| < 2^15 and |c_q| / 2^15 < 65504 all fit, and pieces below the smallest
+// normal fp16 (2^-14, i.e. 2^-27 of the largest coordinate) are flushed to zero by the image
+// builder (subnormal MFMA inputs are not exact on this hardware: scratch/mfma_probe_f16.hip); the
+// flush is part of the band.  Norms, thresholds and bands live in the same scaled units; the exact
+// path works on the original coordinates and never sees the scale.
 // Slot order: the constant and the hi*hi products come FIRST, so after the first MFMA(s) the
 // accumulator of a pair near the threshold is already small and the remaining (small) terms are
-// added at a small magnitude -- that is what keeps the accumulation error, and with it eps, at the
-// level of the fp32 chain (the hardware truncates every addend to 2^-24 of the largest one and
-// rounds once per MFMA: measured by scratch/mfma_probe.hip, asserted by tests/cpp/test_mfma_model).
+// added at a small magnitude -- that keeps the accumulation error, and with it eps, at the level of
+// a single MFMA (the hardware truncates every addend to 2^-24 of the largest one and rounds once
+// per MFMA: measured by scratch/mfma_probe_f16.hip, asserted by tests/cpp/test_mfma_model).
 //
 // Mapping (one wave = TQ query tiles of 32 frames, swept against reference tiles of 32 frames):
-//   v_mfma_f32_32x32x16_bf16:  D[i][j] = C[i][j] + sum_k A[i][k] B[k][j];  lane l = (r = l&31, h = l>>5)
-//   holds A[r][8h..8h+7] and B[8h..8h+7][r] (8 bf16 = 4 VGPRs each); D[i][j] sits in lane (j + 32*h),
+//   v_mfma_f32_32x32x16_f16:   D[i][j] = C[i][j] + sum_k A[i][k] B[k][j];  lane l = (r = l&31, h = l>>5)
+//   holds A[r][8h..8h+7] and B[8h..8h+7][r] (8 fp16 = 4 VGPRs each); D[i][j] sits in lane (j + 32*h),
 //   register g with i = (g&3) + 8*(g>>2) + 4*h.
 //     A = reference pieces (streamed: NM x 16 B per lane and tile)
 //     B = query pieces of -2x' and of c_q (resident in VGPRs for the whole sweep)
@@ -73,11 +84,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxCols = 32;           // n_cols handled by the matrix-core kernels
-constexpr int kConstSlots = 3;         // K slots 0..2: 1 (A side) x pieces of the query constant (B side)
-// MFMAs per tile pair: 6 piece products per column + the constant slots, 16 slots per MFMA
-constexpr int nm_for(int n_cols) { return (6 * n_cols + kConstSlots + 15) / 16; }
-constexpr int kMaxMfma = nm_for(kMaxCols);   // 13
-constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits); word 1: non-finite flag;
+constexpr int kConstSlots = 2;         // K slots 0..1: 2^15 (A side) x pieces of c_q / 2^15 (B side)
+constexpr int kPieceGroups = 3;        // piece products per column: hi*hi, mid*hi, hi*mid
+// MFMAs per tile pair: 3 piece products per column + the constant slots, 16 slots per MFMA
+constexpr int nm_for(int n_cols) { return (kPieceGroups * n_cols + kConstSlots + 15) / 16; }
+constexpr int kMaxMfma = nm_for(kMaxCols);   // 7
+constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits, UNSCALED); word 1: non-finite flag;
                                        // words 8..11: extent of columns 0/1; word 12: ~key of min FE
 constexpr size_t kHdrSums = 256;       // byte 256..511: column sums (double) for the centring
 constexpr size_t kHdrMeans = 512;      // byte 512..639: column means as float (what x' = x - mu uses)
@@ -213,17 +225,41 @@ __device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// guard band (DESIGN.md "guard band").  For every pair, with d2 its canonical squared distance,
-// u = 2^-24, M = max |x'|^2 and c_q the folded query constant (see the file header):
+// scale of a data set: everything the matrix pipe sees is multiplied by 2^k (coordinates) / 4^k
+// (norms, thresholds, bands) with 4^k M in [2^26, 2^28), M = max |x'|^2 (header word 0)
+// ---------------------------------------------------------------------------------------------
+struct Scale {
+  float s1;   // 2^k
+  float s2;   // 4^k
+};
+__device__ __forceinline__ Scale scale_of(float M) {
+  int e = 0;
+  (void)frexpf(M, &e);                  // M = f 2^e, f in [0.5, 1); M = 0 -> e = 0
+  int k = (28 - e) >> 1;                // floor: e + 2k in {27, 28}
+  k = k < -62 ? -62 : (k > 62 ? 62 : k);
+  Scale s;
+  s.s1 = ldexpf(1.0f, k);
+  s.s2 = ldexpf(1.0f, 2 * k);
+  return s;
+}
+// thresholds beyond this (scaled) hold every pair (d2 <= 4 M < 2^30) and are clamped to it, so that
+// |c_q| / 2^15 stays below the largest fp16
+constexpr float kThrCap = 1610612736.0f;     // 1.5 * 2^30
+
+// ---------------------------------------------------------------------------------------------
+// guard band (DESIGN.md "guard band"), in SCALED units.  For every pair, with d2 its canonical
+// squared distance, u = 2^-24, M = max |x'|^2 and c_q the folded query constant (file header):
 //     | acc - (d2 + c_q - |x'|^2) |  <=  e0 + kappa * (d2 + |thr|)
 // where thr = r^2 for the population sweep (c_q = |x'|^2 - (r^2 - eps)) and 0 for the neighbour sweep.
 //   u * [ 3 M + thr                                   norms rounded once, c_q = fl(|x'|^2 - thr)
-//       + 4.1 M                                       dropped piece products (mid*lo, lo*mid, lo*lo)
+//       + 4.1 (M + thr)                               c_q carried by two fp16 pieces
+//       + 27 M                                        dropped piece products (mid*mid, hi*rho, rho*hi)
 //       + 17 (2 M + thr) + (nb-1) 18 (4.02 M + thr)   the nb MFMAs that hold c_q and the hi*hi products:
 //                                                     17 addends, each truncated to 2^-24 of the largest
-//       + ns 18 (d2 + thr + 0.0165 M) + (d2 + thr)    the ns MFMAs of small products, accumulator ~ d2 - thr
+//       + ns 18 (d2 + thr + 0.004 M) + (d2 + thr)     the ns MFMAs of small products, accumulator ~ d2 - thr
 //       + (D/4 + 9) d2 + 2 M ]                        canonical summation order + centring (as for fp32)
-// with a further factor 1.25 on everything.  nb = ceil((D + 3) / 16), ns = NM - nb.
+//   + 2^-12 sqrt(D M) + 2                             pieces below 2^-14 flushed to zero (coordinates, c_q)
+// with a further factor 1.25 on everything.  nb = ceil((D + 2) / 16), ns = NM - nb.
 // ---------------------------------------------------------------------------------------------
 struct GuardBand {
   float e0;      // absolute part (M and thr terms)
@@ -235,15 +271,16 @@ __device__ __forceinline__ float next_up(float f) {   // f >= 0 finite; inf / Na
   return __uint_as_float(__float_as_uint(f) + 1u);
 }
 
-__device__ __forceinline__ GuardBand guard_band(float M, float thr, int D) {
+__device__ __forceinline__ GuardBand guard_band(float M, float thr, int D) {   // M, thr: scaled
   const double u = 5.9604644775390625e-8;
   const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
   const double t = (thr > 0.0f) ? (double)thr : 0.0;
-  const double cM = 3.0 + 4.1 + 34.0 + 72.4 * (nb - 1) + 0.3 * ns + 2.0;
-  const double cT = 1.0 + 17.0 + 18.0 * (nb - 1) + 18.0 * ns + 1.0;
+  const double cM = 3.0 + 4.1 + 27.0 + 34.0 + 72.4 * (nb - 1) + 0.072 * ns + 2.0;
+  const double cT = 1.0 + 4.1 + 17.0 + 18.0 * (nb - 1) + 18.0 * ns + 1.0;
   const double cD = 18.0 * ns + 1.0 + 0.25 * D + 9.0;
+  const double flush = 2.44140625e-4 * sqrt((double)D * (double)M) + 2.0;
   GuardBand g;
-  g.e0 = next_up((float)(1.25 * u * (cM * (double)M + cT * t)));
+  g.e0 = next_up((float)(1.25 * (u * (cM * (double)M + cT * t) + flush)));
   g.kappa = next_up((float)(1.25 * u * cD));
   return g;
 }
@@ -255,42 +292,45 @@ __device__ __forceinline__ float guard_eps_pop(float M, float r2max, int D) {
   return next_up(g.e0 + g.kappa * cap);
 }
 
-// ---- fp32 -> three bf16 pieces (exact: v = hi + mid + lo for finite v away from underflow) -------
-__device__ __forceinline__ uint32_t bf16_rne(float f) {   // finite f
-  const uint32_t u = __float_as_uint(f);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+// ---- fp32 (scaled) -> two fp16 pieces: v = hi + mid + rho, |rho| <= max(2^-22 |v|, 2^-14) --------
+constexpr float kF16MinNormal = 6.103515625e-05f;   // 2^-14
+__device__ __forceinline__ uint32_t f16_rne(float f) {   // |f| <= 65504; below 2^-14 -> 0
+  if (!(fabsf(f) >= kF16MinNormal)) return 0u;
+  return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);
 }
-__device__ __forceinline__ float bf16_val(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ float f16_val(uint32_t b) {
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)b);
+}
 struct Pieces {
-  uint32_t hi, mid, lo;   // bf16 bit patterns
+  uint32_t hi, mid;   // fp16 bit patterns
 };
-__device__ __forceinline__ Pieces split3(float v) {
+__device__ __forceinline__ Pieces split2(float v) {
   Pieces p;
-  p.hi = bf16_rne(v);
-  const float r1 = v - bf16_val(p.hi);     // exact
-  p.mid = bf16_rne(r1);
-  const float r2 = r1 - bf16_val(p.mid);   // exact
-  p.lo = bf16_rne(r2);
+  p.hi = f16_rne(v);
+  const float r1 = v - f16_val(p.hi);      // exact
+  p.mid = f16_rne(r1);
   return p;
 }
+constexpr uint32_t kConstA = 0x7800u;       // fp16 2^15: the A side of the constant slots
+constexpr float kConstScale = 3.0517578125e-05f;   // 2^-15: c_q / 2^15 on the B side
 
 // K-slot s of a frame: which piece of which column (or the constant) sits there.
-//   slots 0..2            constant: A side 1.0, B side the pieces (hi, mid, lo) of c_q
-//   slots 3 + g*D + k     column k, piece pair g (A piece x B piece), large products first:
-//                         0 hi*hi, 1 mid*hi, 2 hi*mid, 3 mid*mid, 4 lo*hi, 5 hi*lo
-//   beyond 3 + 6 D        zero padding
-// Returns the bf16 pattern for the A form (reference side) or the B form (query side, column values
-// are those of -2x') of a row whose centred columns are fetched through `col(k)`.
+//   slots 0..1            constant: A side 2^15, B side the pieces (hi, mid) of c_q / 2^15
+//   slots 2 + g*D + k     column k, piece pair g (A piece x B piece), large products first:
+//                         0 hi*hi, 1 mid*hi, 2 hi*mid
+//   beyond 2 + 3 D        zero padding
+// Returns the fp16 pattern for the A form (reference side) or the B form (query side, column values
+// are those of -2x'') of a row whose centred, SCALED columns are fetched through `col(k)`.
 template <class ColFn>
 __device__ __forceinline__ uint32_t slot_value(uint32_t s, uint32_t D, bool b_form, ColFn col) {
-  if (s < (uint32_t)kConstSlots) return b_form ? 0u : 0x3F80u;   // (the kernels patch c_q in)
+  if (s < (uint32_t)kConstSlots) return b_form ? 0u : kConstA;   // (the kernels patch c_q in)
   const uint32_t sp = s - kConstSlots, g = sp / D, k = sp - g * D;
-  if (g >= 6u) return 0u;
+  if (g >= (uint32_t)kPieceGroups) return 0u;
   const float v = b_form ? -2.0f * col(k) : col(k);
-  const Pieces p = split3(v);
-  // piece index (0 hi, 1 mid, 2 lo) per group: A side 0,1,0,1,2,0 ; B side 0,0,1,1,0,2
-  const uint32_t sel = b_form ? ((0x201100u >> (4 * g)) & 3u) : ((0x021010u >> (4 * g)) & 3u);
-  return sel == 0u ? p.hi : (sel == 1u ? p.mid : p.lo);
+  const Pieces p = split2(v);
+  // piece index (0 hi, 1 mid) per group: A side 0,1,0 ; B side 0,0,1
+  const bool mid = b_form ? (g == 2u) : (g == 1u);
+  return mid ? p.mid : p.hi;
 }
 
 template <int NM>
@@ -325,7 +365,7 @@ __device__ __forceinline__ void refill_frag(const uint4* __restrict__ img,
 }
 
 // resident query-side operand of one query tile: B form fragments with the pieces of the per-lane
-// constant c_q patched into slots 0..2 (held by the h = 0 half of the wave)
+// constant c_q (scaled units, |c_q| <= 65504 * 2^15) patched into slots 0..1 (held by the h = 0 half)
 template <int NM>
 __device__ __forceinline__ void load_query(const uint4* __restrict__ img_b, uint32_t tile, int lane,
                                            int h, float cq, s16x8 (&b)[NM]) {
@@ -335,11 +375,10 @@ __device__ __forceinline__ void load_query(const uint4* __restrict__ img_b, uint
     const uint4 v = ip[m * 64];
     b[m] = __builtin_bit_cast(s16x8, v);
   }
-  const Pieces p = split3(cq);
+  const Pieces p = split2(cq * kConstScale);
   if (h == 0) {
     b[0][0] = (short)p.hi;
     b[0][1] = (short)p.mid;
-    b[0][2] = (short)p.lo;
   }
 }
 
@@ -362,12 +401,18 @@ __device__ __forceinline__ f32x16 frag16(const float4 (&v)[4]) {
   return o;
 }
 
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma16(const s16x8& a, const s16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b),
+                                                c, 0, 0, 0);
+}
+
 template <int NM>
 __device__ __forceinline__ f32x16 gram_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM],
                                              const f32x16& c0) {
-  f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+  f32x16 acc = mfma16(a[0], b[0], c0);
 #pragma unroll
-  for (int m = 1; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[m], acc, 0, 0, 0);
+  for (int m = 1; m < NM; ++m) acc = mfma16(a[m], b[m], acc);
   return acc;
 }
 
@@ -386,8 +431,9 @@ __device__ __forceinline__ void constexpr_for_pairs(F&& f) {
 template <int NM>
 constexpr bool kSingleBuffer = NM > 4;
 
-// a query lane that owns no live row: the constant keeps its accumulators hugely positive
-constexpr float kDeadConst = 1.0e30f;
+// a query lane that owns no live row: the constant (the largest the two slots can carry,
+// 65504 * 2^15 ~ 2^31 > 4 S M) keeps its accumulators above every threshold
+constexpr float kDeadConst = 2146435072.0f;
 
 // row of reference tile t held by register r of a lane in half h
 __device__ __forceinline__ uint32_t tile_row(uint32_t t, int r, int h) {
@@ -476,9 +522,9 @@ __device__ __forceinline__ void pop_chain(const s16x8 (&a)[NM], const s16x8 (&b)
                                           PopAcc<NR>& e, const Refill& refill = Refill{}) {
   if constexpr (MI < NM) {
     if constexpr (MI == 0)
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+      acc_new = mfma16(a[0], b[0], c0);
     else
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[MI], b[MI], acc_new, 0, 0, 0);
+      acc_new = mfma16(a[MI], b[MI], acc_new);
     refill(std::integral_constant<int, MI>{});   // fragment MI of the next tile (last chain only)
     pop_epi<NR, (16 * MI) / NM, (16 * (MI + 1)) / NM>(acc_old, dl, e);
     pop_chain<NM, NR, MI + 1, Refill>(a, b, c0, acc_new, acc_old, dl, e, refill);
@@ -536,7 +582,7 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restric
 // thresholds of a population launch, shared by the full and the pruned sweep
 template <int NR>
 struct PopSetup {
-  float eps;
+  float eps;             // (all three in the scaled units of the operand images)
   uint32_t wbits;        // band width 2*eps as an unsigned key, +1 ulp
   Rad2 rad2e;            // r^2 - eps
   PopDeltas<NR> dl;
@@ -546,14 +592,20 @@ template <int NR>
 __device__ __forceinline__ PopSetup<NR> pop_setup(const uint32_t* __restrict__ hdr, const Rad2& rad2,
                                                   uint32_t n_cols) {
   PopSetup<NR> P;
-  float r2max = rad2.v[0];
+  // everything here is in the scaled units of the operand images (exact powers of two)
+  const float M = __uint_as_float(hdr[0]);
+  const Scale sc = scale_of(M);
+  Rad2 r2s;
 #pragma unroll
-  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
-  P.eps = guard_eps_pop(__uint_as_float(hdr[0]), r2max, (int)n_cols);
+  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) r2s.v[rr] = fminf(rad2.v[rr] * sc.s2, kThrCap);
+  float r2max = r2s.v[0];
+#pragma unroll
+  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, r2s.v[rr]);
+  P.eps = guard_eps_pop(M * sc.s2, r2max, (int)n_cols);
   // (delta_r = fl(rad2e_r - rad2e_0) adds at most u * r2max to the band: inside the 1.25 factor)
   P.wbits = __float_as_uint(2.0f * P.eps) + 1u;
 #pragma unroll
-  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) P.rad2e.v[rr] = rad2.v[rr] - P.eps;
+  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) P.rad2e.v[rr] = r2s.v[rr] - P.eps;
   P.dl = pop_deltas<NR>(P.rad2e);
   return P;
 }
@@ -1174,9 +1226,9 @@ __device__ __forceinline__ void nn_chain(const s16x8 (&a)[NM], const s16x8 (&b)[
                                          float& tmin, const Refill& refill = Refill{}) {
   if constexpr (MI < NM) {
     if constexpr (MI == 0)
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+      acc_new = mfma16(a[0], b[0], c0);
     else
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[MI], b[MI], acc_new, 0, 0, 0);
+      acc_new = mfma16(a[MI], b[MI], acc_new);
     refill(std::integral_constant<int, MI>{});   // fragment MI of the next tile (last chain only)
     tile_min<(16 * MI) / NM, (16 * (MI + 1)) / NM>(acc_old, tmin);
     nn_chain<NM, MI + 1, Refill>(a, b, c0, acc_new, acc_old, tmin, refill);
@@ -1198,7 +1250,9 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
   const uint32_t qt0 = i_from / 32 + wave * TQ;
   if (qt0 * 32 >= i_to) return;
 
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]), 0.0f, (int)n_cols);
+  // (scaled units, like the accumulators and the running minima taken from them)
+  const Scale sc = scale_of(__uint_as_float(hdr[0]));
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols);
 
   s16x8 b[TQ][NM];
   NnQ q[TQ];
@@ -1466,7 +1520,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) qcount[qt] = 0;
 
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]), 0.0f, (int)n_cols);
+  // (scaled units, like the accumulators and the running minima taken from them)
+  const Scale sc = scale_of(__uint_as_float(hdr[0]));
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols);
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;
@@ -1503,8 +1559,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       // MFMA values below d2 + eps(d2); the band test adds its usual margin on top.
       g_nn[qt] = __uint_as_float((uint32_t)(merge64[jq[qt]] >> 32));
       g_hd[qt] = __uint_as_float((uint32_t)(merge64[(size_t)n_rows + jq[qt]] >> 32));
-      if (g_nn[qt] < FLT_MAX) q[qt].m_nn = g_nn[qt] + (gb.e0 + gb.kappa * g_nn[qt]);
-      if (g_hd[qt] < FLT_MAX) q[qt].m_hd = g_hd[qt] + (gb.e0 + gb.kappa * g_hd[qt]);
+      const float s_nn = g_nn[qt] * sc.s2, s_hd = g_hd[qt] * sc.s2;   // (exact d2 -> scaled units)
+      if (g_nn[qt] < FLT_MAX) q[qt].m_nn = s_nn + (gb.e0 + gb.kappa * s_nn);
+      if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
     }
     q[qt].bn = nn_band(gb, q[qt].m_nn);
     q[qt].bh = nn_band(gb, q[qt].m_hd);

@@ -11,7 +11,7 @@ t0 = time.time()
 for case in range(n_cases):
     n = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 257, 1000, 3000, 9000, 40000, 150000], p=[.03,.03,.05,.05,.05,.05,.1,.14,.2,.12,.08,.07,.03]))
     d = int(rng.integers(1, 33))
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
     c = gaussian_blobs(n, d, seed=int(rng.integers(1, 1 << 30)), sigma=float(rng.choice([0.02, 0.08, 0.3])))
     if kind == 1:   # duplicates
         c[rng.integers(0, n, n // 3)] = c[rng.integers(0, n, n // 3)]
@@ -19,6 +19,8 @@ for case in range(n_cases):
         c += np.float32(rng.choice([10.0, 1000.0]))
     if kind == 3:   # tiny scale
         c *= np.float32(1e-3)
+    if kind == 4:   # far from 1: the power-of-two scale of the fp16 operand images
+        c *= np.float32(rng.choice([1e-12, 1e-6, 1e4, 1e8]))
     ct = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).cuda()
     scale = float(np.sqrt(d)) * float(c.std(axis=0).mean() if n > 1 else 1.0)
     radii = [float(x) for x in (scale * rng.uniform(0.05, 1.5, size=int(rng.integers(1, 4))))]

@@ -1,14 +1,16 @@
 // test_mfma_model.hip -- GPU self-test of the two hardware facts the guard band of the matrix-core
 // sweeps rests on (dc_mfma_kernels.hpp, DESIGN.md "guard band"):
 //
-//  (1) accumulation model of v_mfma_f32_32x32x16_bf16:  D = C + sum_k a_k b_k with every addend
+//  (1) accumulation model of v_mfma_f32_32x32x16_f16:  D = C + sum_k a_k b_k with every addend
 //      truncated to a multiple of q = 2^(e_max - 24) (e_max: exponent of the largest |addend|,
 //      C included), an exact sum and one final rounding, i.e.
 //          | D_hw - D_exact |  <=  17 q + ulp(D_exact) / 2
-//      checked on crafted worst cases and on random products over wide exponent ranges;
-//  (2) end to end: the accumulator of the bf16x3 Gram chain (operand images built by the product's
-//      own slot_value / split3 / gram_chain) stays within the MFMA + dropped-products part of the
-//      band of its exact value |y'|^2 + c_q - 2 x'.y', for several dimensions and data scales.
+//      checked on crafted worst cases and on random products over the exponent range of normal fp16
+//      operands (the image builder flushes smaller pieces to zero: subnormal inputs are not exact);
+//  (2) end to end: the accumulator of the fp16x2 Gram chain (operand images built by the product's
+//      own scale_of / slot_value / split2 / gram_chain) stays within the MFMA + dropped-products +
+//      flush part of the band of its exact value S (|y'|^2 + c_q - 2 x'.y'), for several dimensions
+//      and data scales (from 1e-3 to 1e3: the power-of-two scale S makes them all alike).
 //
 // Prints a summary and exits 0 when both hold, 1 otherwise.  Built by clustering_amd/csrc/Makefile,
 // run by tests/test_gpu_parity.py (pytest -m gpu).
@@ -44,45 +46,52 @@ __global__ void one_mfma(const unsigned short* A, const unsigned short* B, const
   }
   f32x16 c;
   for (int g = 0; g < 16; ++g) c[g] = C[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r];
-  const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  const f32x16 d = mfma16(a, b, c);
   for (int g = 0; g < 16; ++g) D[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r] = d[g];
 }
 
 // ---- (2) the product's Gram chain on 32 reference x 32 query rows ---------------------------------
 template <int NM>
 __global__ void gram_tile(const float* ref, const float* qry, uint32_t D, const float* ny,
-                          const float* cq, float* out) {
-  // ref/qry: [32][D] centred coordinates; out [32 ref][32 qry]
+                          const float* cq, float M, float* out) {
+  // ref/qry: [32][D] centred coordinates, ny / cq unscaled; out [32 ref][32 qry] in scaled units
   const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+  const Scale sc = scale_of(M);
   s16x8 a[NM], b[NM];
   for (int m = 0; m < NM; ++m)
     for (int j = 0; j < 8; ++j) {
       const uint32_t s = 16 * m + 8 * h + j;
-      a[m][j] = (short)slot_value(s, D, false, [&](uint32_t k) { return ref[c * D + k]; });
-      b[m][j] = (short)slot_value(s, D, true, [&](uint32_t k) { return qry[c * D + k]; });
+      a[m][j] = (short)slot_value(s, D, false, [&](uint32_t k) { return ref[c * D + k] * sc.s1; });
+      b[m][j] = (short)slot_value(s, D, true, [&](uint32_t k) { return qry[c * D + k] * sc.s1; });
     }
-  const Pieces p = split3(cq[c]);
+  const Pieces p = split2(cq[c] * sc.s2 * kConstScale);
   if (h == 0) {
     b[0][0] = (short)p.hi;
     b[0][1] = (short)p.mid;
-    b[0][2] = (short)p.lo;
   }
   f32x16 c0;
-  for (int g = 0; g < 16; ++g) c0[g] = ny[(g & 3) + 8 * (g >> 2) + 4 * h];
+  for (int g = 0; g < 16; ++g) c0[g] = ny[(g & 3) + 8 * (g >> 2) + 4 * h] * sc.s2;
   const f32x16 acc = gram_chain<NM>(a, b, c0);
   for (int g = 0; g < 16; ++g) out[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + c] = acc[g];
 }
 
-static unsigned short f2bf(float f) {  // values with <= 8 significant bits: exact
-  unsigned u;
-  memcpy(&u, &f, 4);
-  return (unsigned short)(u >> 16);
+static unsigned short f2bf(float f) {  // to fp16: normal values with <= 11 significant bits are exact
+  const _Float16 hv = (_Float16)f;
+  unsigned short b;
+  memcpy(&b, &hv, 2);
+  return b;
 }
 static float bf2f(unsigned short b) {
-  unsigned u = (unsigned)b << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
+  _Float16 hv;
+  memcpy(&hv, &b, 2);
+  return (float)hv;
+}
+static double host_scale2(float M) {   // scale_of(M).s2 on the host
+  int e = 0;
+  (void)frexpf(M, &e);
+  int k = (28 - e) >> 1;
+  k = k < -62 ? -62 : (k > 62 ? 62 : k);
+  return ldexp(1.0, 2 * k);
 }
 static double ulp_of(long double v) {   // spacing of floats at |v|
   int e;
@@ -127,17 +136,21 @@ static int run_gram(uint32_t D, float scale, float offset, float thr, double* wo
     CHECK(hipMemcpy(d_qry, qry.data(), 32 * D * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_ny, ny.data(), 128, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_cq, cq.data(), 128, hipMemcpyHostToDevice));
-    gram_tile<NM><<<1, 64>>>(d_ref, d_qry, D, d_ny, d_cq, d_out);
+    const float Mf = (float)M;
+    const double S = host_scale2(Mf), Ms = S * (double)Mf, thrs = S * (double)thr;
+    gram_tile<NM><<<1, 64>>>(d_ref, d_qry, D, d_ny, d_cq, Mf, d_out);
     CHECK(hipMemcpy(out.data(), d_out, 4096, hipMemcpyDeviceToHost));
     for (int i = 0; i < 32; ++i)
       for (int j = 0; j < 32; ++j) {
         long double dot = 0;
         for (uint32_t k = 0; k < D; ++k) dot += (long double)ref[i * D + k] * (long double)qry[j * D + k];
-        const long double E = (long double)ny[i] + (long double)cq[j] - 2.0L * dot;
+        const long double E = (long double)S * ((long double)ny[i] + (long double)cq[j] - 2.0L * dot);
         const double absE = (double)fabsl(E);
-        // MFMA + dropped-products part of the band (no 1.25 factor, no centring / canonical terms)
-        const double bound = u * (4.1 * M + 17.0 * (2.0 * M + thr) + (nb - 1) * 18.0 * (4.02 * M + thr) +
-                                  ns * 18.0 * (absE + 0.0165 * M) + absE);
+        // MFMA + c_q pieces + dropped products + flush part of the band, in scaled units (no 1.25
+        // factor, no centring / canonical terms)
+        const double bound = u * (4.1 * (Ms + thrs) + 27.0 * Ms + 17.0 * (2.0 * Ms + thrs) +
+                                  (nb - 1) * 18.0 * (4.02 * Ms + thrs) + ns * 18.0 * (absE + 0.004 * Ms) + absE) +
+                             ldexp(1.0, -12) * sqrt((double)D * Ms) + 2.0;
         const double err = (double)fabsl((long double)out[i * 32 + j] - E);
         if (err / bound > *worst_ratio) *worst_ratio = err / bound;
         if (err > bound) ++bad;
@@ -164,7 +177,7 @@ int main() {
   int failures = 0;
   double worst_q = 0;   // worst (error - ulp/2) in units of q
   srand(20240);
-  for (int E : {0, 4, 12, 24, 40}) {
+  for (int E : {0, 4, 8, 12}) {   // (operands stay normal fp16: 2^-12 * [1, 2) at the least)
     for (int trial = 0; trial < 300; ++trial) {
       const bool crafted = (E == 0);
       for (int r = 0; r < 32; ++r)
@@ -173,10 +186,11 @@ int main() {
           if (crafted) {
             // every product just below one truncation unit of C = +-1 (or a few units): 255/128 * 2^-25
             // and friends; row-dependent sign patterns
-            const float m = 1.0f + (float)(128 + (rand() & 127)) / 256.0f;   // [1.5, 2)
-            v = ((r + (trial & 1) * k) & 1 ? -m : m) * ldexpf(1.0f, -25 - (rand() % 3));
+            // (the products 2^-25 .. 2^-27 come from A = m 2^-12 .. 2^-14 and B = 2^-13)
+            const float m = 1.0f + (float)(512 + (rand() & 511)) / 1024.0f;   // [1.5, 2)
+            v = ((r + (trial & 1) * k) & 1 ? -m : m) * ldexpf(1.0f, -12 - (rand() % 3));
           } else {
-            const float m = 1.0f + (rand() & 127) / 128.0f;
+            const float m = 1.0f + (rand() & 1023) / 1024.0f;
             v = ((rand() & 1) ? -m : m) * ldexpf(1.0f, -(rand() % (E + 1)));
           }
           A[r * 16 + k] = f2bf(v);
@@ -185,9 +199,9 @@ int main() {
         for (int j = 0; j < 32; ++j) {
           float v;
           if (crafted) {
-            v = 1.0f;
+            v = ldexpf(1.0f, -13);
           } else {
-            const float m = 1.0f + (rand() & 127) / 128.0f;
+            const float m = 1.0f + (rand() & 1023) / 1024.0f;
             v = ((rand() & 1) ? -m : m) * ldexpf(1.0f, -(rand() % (E + 1)));
           }
           B[k * 32 + j] = f2bf(v);
@@ -227,11 +241,12 @@ int main() {
   bad += run_gram<nm_for(10)>(10, 0.1f, 0.5f, 0.04f, &worst_ratio, 60);
   bad += run_gram<nm_for(10)>(10, 0.01f, 3.0f, 0.0004f, &worst_ratio, 60);
   bad += run_gram<nm_for(10)>(10, 100.0f, 1000.0f, 2500.0f, &worst_ratio, 40);
-  bad += run_gram<nm_for(13)>(13, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
   bad += run_gram<nm_for(14)>(14, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
+  bad += run_gram<nm_for(15)>(15, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
+  bad += run_gram<nm_for(10)>(10, 1e-3f, 0.0f, 4e-6f, &worst_ratio, 40);
   bad += run_gram<nm_for(30)>(30, 0.1f, 0.5f, 0.09f, &worst_ratio, 40);
   bad += run_gram<nm_for(32)>(32, 1e-3f, 1e-2f, 1e-5f, &worst_ratio, 40);
-  printf("bf16x3 gram chain: worst error / (MFMA + dropped-product part of the band) = %.3f, violations %d\n",
+  printf("fp16x2 gram chain: worst error / (MFMA + dropped-product part of the band) = %.3f, violations %d\n",
          worst_ratio, bad);
   const bool ok = failures == 0 && bad == 0;
   printf("%s\n", ok ? "OK" : "FAILED");
