@@ -12,8 +12,8 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one
 Metric: frame-pairs/s (density pop+nn) = 2*N^2 / t_step  (ordered pairs of both sweeps per second).
 Prints ONE JSON line on rank 0 (contract in the task statement), including
     "roofline":     dominant kernel, SURVEY.md 8(d): algorithmic 2*D flop per EVALUATED frame pair against
-                    the fp32 MFMA peak (157.3 TFLOP/s).  The sweeps run that contraction as an exact
-                    three-piece bf16 split on the bf16 matrix pipe (2*(6*D+3) flop per pair executed,
+                    the fp32 MFMA peak (157.3 TFLOP/s).  The sweeps run that contraction on two fp16
+                    pieces per coordinate on the 16-bit matrix pipe (2*(3*D+2) flop per pair executed,
                     dense peak 2.5 PFLOP/s), so the fp32 fraction can exceed 1; the executed figure is
                     reported next to it as "matrix_pipe"
     "cpu_baseline": the CPU restatement (oracle, fast build, all host threads) on a bounded sample.
@@ -33,9 +33,9 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md, matrix cores: BF16/F16 ~2.5 P
 
 
 def split_flop_per_pair(d):
-    """MFMA work of the bf16x3 Gram form per frame pair: 6 piece products per column + 3 constant
+    """MFMA work of the fp16x2 Gram form per frame pair: 3 piece products per column + 2 constant
     slots on the K axis, one multiply-add each (zero padding to 16-slot MFMAs not counted)."""
-    return 2 * (6 * d + 3)
+    return 2 * (3 * d + 2)
 
 
 def measured_traffic(kernel, n, d, radii, variant):
@@ -251,7 +251,7 @@ def main():
         else:
             dom, dom_t, dom_pairs = "population_count", pop_t, pop_pairs
         achieved = dom_pairs * 2.0 * d / dom_t / 1e12                        # algorithmic, SURVEY 8(d)
-        executed = dom_pairs * split_flop_per_pair(d) / dom_t / 1e12         # what the bf16 pipe does
+        executed = dom_pairs * split_flop_per_pair(d) / dom_t / 1e12         # what the 16-bit pipe does
         pop_sum = int(out["pops"][0].sum(dtype=torch.int64).item())
         line = {
             "metric": "frame-pairs/s (density pop+nn)" if want_nn else "frame-pairs/s (density pop)",
@@ -264,8 +264,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 (Gram form evaluated as an exact bf16x3 split on the bf16 MFMA pipe, f32 accumulate; "
-                     "undecided pairs re-checked in canonical f32)",
+            "dtype": "f32 (Gram form on two fp16 pieces per coordinate on the f16 MFMA pipe, f32 accumulate, as a "
+                     "classifier with a guard band; undecided pairs re-checked in canonical f32)",
             "data": "synthetic",
             "config": {
                 "workload": f"{n} frames x {d} dims, 3-Gaussian-blob (sigma 0.08, seed 20240), radii {args.radii}, "
@@ -287,10 +287,10 @@ def main():
                 "traffic": measured_traffic(dom, n, d, args.radii, args.variant) if world == 1 else None,
                 "traffic_note": "bytes per launch at the L2's memory side from profiles/r1_pruned_pmc.json (separate "
                                 "rocprofv3 --pmc pass, gfx950 correction applied; includes Infinity-Cache hits); the "
-                                "kernel is matrix-bound, its operand image (128 MB) is re-streamed by every wave through L2",
+                                "kernel is compute-bound, its operand image (64 MB) is re-streamed by every wave through L2",
                 "flop_per_pair": 2 * d,
-                "matrix_pipe": {"what": "flops the bf16 MFMA pipe executes for the split (6 piece products per "
-                                        "column + 3 constant slots), against its dense peak",
+                "matrix_pipe": {"what": "flops the f16 MFMA pipe executes for the split (3 piece products per "
+                                        "column + 2 constant slots), against its dense peak",
                                 "flop_per_pair": split_flop_per_pair(d), "achieved": executed,
                                 "peak": PEAK_BF16_TFLOPS, "frac": executed / PEAK_BF16_TFLOPS},
                 "pairs_per_launch": dom_pairs,

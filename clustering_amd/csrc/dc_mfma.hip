@@ -351,6 +351,7 @@ static void segment_window(uint32_t T, uint32_t n_rows, int tq, const QuerySel& 
   *n_q = r_hi > r_lo ? (uint32_t)(r_hi - r_lo) : 0u;
 }
 static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 8 ? 4 : 2; }   // = tq_for<NM>
+static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
@@ -495,7 +496,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
   if (qs.n_segments > 0) {
     q_mode = kQueryWindow;
-    segment_window(L.T, n_rows, tq_of(n_cols), qs, &q_tile_lo, &n_q);
+    segment_window(L.T, n_rows, tq_pop_of(n_cols), qs, &q_tile_lo, &n_q);
   }
   const uint32_t T_q = (n_q + 31) / 32;
   if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing

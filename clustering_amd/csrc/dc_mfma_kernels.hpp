@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
   auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<NR>& e, uint32_t t) {
     constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr]);   // (16 shifts from 0: 16 bits)
     const bool band = e.tmin < P.wbits;
     if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
       const PopDelta<NR> dl =
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<NR>& e, uint32_t t) {
       constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
-      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr] & 0xFFFFu);
+      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr]);   // (16 shifts from 0: 16 bits)
       if constexpr (MODE == kSinkMinEdge) {
         // partners decided "inside" by the accumulator alone (element r = bit 15 - r of the sign
         // string; the query itself is one of them and belongs to its own component): keep the
@@ -1868,6 +1868,10 @@ __global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ me
 // leave room for at two waves per SIMD; each reference fragment is fetched once per TQ chains
 template <int NM>
 constexpr int tq_for = (NM <= 8) ? 4 : 2;
+// the population sweep keeps less state per query tile: with two MFMAs per chain six tiles fit
+// (measured at C3: 23.6 ms against 25.1 ms with four; eight spill; the neighbour sweep loses at six)
+template <int NM>
+constexpr int tq_pop_for = (NM <= 2) ? 6 : tq_for<NM>;
 // query tiles per wave of the full sweeps (double-buffered reference operands)
 template <int NM>
 constexpr int tq_full_for = (NM <= 4) ? 4 : (NM <= 8) ? 2 : 1;
@@ -2006,7 +2010,7 @@ void pop_pruned_tq(const float* coords, uint32_t n_rows, uint32_t n_cols, const 
                    uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2, int n_rad,
                    uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
                    hipStream_t s) {
-  pop_pruned_launch<S, NRV, tq_for<S>>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_tile_lo, rad2,
+  pop_pruned_launch<S, NRV, tq_pop_for<S>>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_tile_lo, rad2,
                                        n_rad, pops, chain_counter, sink, s);
 }
 

@@ -31,5 +31,6 @@ for what in a.what.split(','):
     t = min(ts) * 1e-3
     tiles = dens.evaluated_tiles(c.device)[0 if what == 'pop' else 1]
     frac = tiles * 1024.0 / (float(hi - lo) * a.n) if tiles else 1.0
+    print(f"   raw counter {tiles}")
     print(f"   evaluated fraction {frac:.3f} -> {frac*(hi-lo)*a.n*2*a.d/t/157.3e12*100:.1f}% fp32 roof on evaluated pairs")
     print(f"{what} {a.variant} n={a.n} d={a.d} radii={len(a.radii)}: {min(ts):.2f} ms  {a.n*a.n/t:.3e} pairs/s  {a.n*a.n*2*a.d/t/157.3e12*100:.1f}% fp32 roof")
