@@ -188,6 +188,21 @@ def test_duplicates_and_offset_data(dens, oracle, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("scale,D", [(1e-12, 10), (1e-6, 3), (1e-3, 10), (1e4, 10), (1e8, 30), (3e17, 5)])
+def test_data_far_from_unit_scale(dens, oracle, scale, D, variant):
+    """The fp16 operand images of the matrix-core sweeps carry a per-data-set power-of-two scale
+    (scale_of in dc_mfma_kernels.hpp): results must not depend on the magnitude of the coordinates.
+    Radii scale with the data, so the populations are those of the unit-scale set."""
+    need(variant, D)
+    base = gaussian_blobs(1300, D, seed=50 + D)
+    c = (base * np.float32(scale)).astype(np.float32)
+    r = float(np.sqrt(D) * 0.08 * 1.1)
+    check_full(dens, oracle, c, [r * scale, 0.6 * r * scale], variant)
+    # and a radius far beyond the data extent / far below the closest pair
+    check_full(dens, oracle, c, [1e6 * scale, 1e-9 * scale], variant)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_non_finite_rows(dens, oracle, variant):
     """rows with inf / NaN coordinates: never inside any radius, never anybody's neighbour (every
     comparison with NaN/inf d2 is false, as in the reference); the MFMA variant hands such inputs
