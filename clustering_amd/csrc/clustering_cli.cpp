@@ -145,7 +145,66 @@ Options parse(int argc, char** argv) {
 
 // ---- IO -------------------------------------------------------------------------------------
 
-// whitespace separated ASCII matrix; n_cols from the first non-empty line (tools.hxx:52-76)
+// NumPy .npy (format 1.0 - 3.0): a C-ordered 2-D array of little-endian float32 or float64 (cast to
+// float like the reference's `ifs >> float` would round a decimal).  An extension of this build
+// (SURVEY.md section 8(f) rank 3): the reference reads ASCII only (tools.hxx:39-111, two passes).
+bool read_npy(const std::string& text, const std::string& fname, std::vector<float>& coords,
+              std::size_t& n_rows, std::size_t& n_cols) {
+  static const char magic[6] = {'\x93', 'N', 'U', 'M', 'P', 'Y'};
+  if (text.size() < 10 || std::memcmp(text.data(), magic, 6) != 0) return false;
+  const unsigned major = (unsigned char)text[6];
+  std::size_t hlen = 0, hoff = 0;
+  if (major == 1) {
+    hlen = (unsigned char)text[8] | ((std::size_t)(unsigned char)text[9] << 8);
+    hoff = 10;
+  } else {
+    if (text.size() < 12) die("error: truncated .npy header in '" + fname + "'");
+    for (int b = 0; b < 4; ++b) hlen |= (std::size_t)(unsigned char)text[8 + b] << (8 * b);
+    hoff = 12;
+  }
+  if (text.size() < hoff + hlen) die("error: truncated .npy header in '" + fname + "'");
+  const std::string hdr = text.substr(hoff, hlen);
+  auto field = [&](const std::string& key) {
+    const std::size_t k = hdr.find("'" + key + "'");
+    if (k == std::string::npos) die("error: .npy header of '" + fname + "' lacks '" + key + "'");
+    return hdr.find(':', k) + 1;
+  };
+  std::size_t d = field("descr");
+  const std::size_t q0 = hdr.find('\'', d), q1 = hdr.find('\'', q0 + 1);
+  const std::string descr = hdr.substr(q0 + 1, q1 - q0 - 1);
+  if (descr != "<f4" && descr != "<f8" && descr != "|f4")
+    die("error: '" + fname + "': .npy dtype '" + descr + "' not supported (need <f4 or <f8)");
+  if (hdr.substr(field("fortran_order")).find("False") > 2)
+    die("error: '" + fname + "': Fortran-ordered .npy arrays are not supported");
+  const std::size_t sh = hdr.find('(', field("shape"));
+  char* e1 = nullptr;
+  const unsigned long long r = std::strtoull(hdr.c_str() + sh + 1, &e1, 10);
+  while (*e1 == ',' || *e1 == ' ') ++e1;
+  char* e2 = nullptr;
+  const unsigned long long c = std::strtoull(e1, &e2, 10);
+  if (e2 == e1) die("error: '" + fname + "': .npy array must be 2-dimensional [frames][columns]");
+  while (*e2 == ',' || *e2 == ' ') ++e2;
+  if (*e2 != ')') die("error: '" + fname + "': .npy array must be 2-dimensional [frames][columns]");
+  const std::size_t item = (descr == "<f8") ? 8 : 4;
+  n_rows = (std::size_t)r;
+  n_cols = (std::size_t)c;
+  if (text.size() - hoff - hlen < n_rows * n_cols * item) die("error: truncated .npy data in '" + fname + "'");
+  coords.resize(n_rows * n_cols);
+  const char* data = text.data() + hoff + hlen;
+  if (item == 4) {
+    std::memcpy(coords.data(), data, coords.size() * 4);
+  } else {
+    for (std::size_t i = 0; i < coords.size(); ++i) {
+      double v;
+      std::memcpy(&v, data + 8 * i, 8);
+      coords[i] = (float)v;
+    }
+  }
+  return true;
+}
+
+// whitespace separated ASCII matrix; n_cols from the first non-empty line (tools.hxx:52-76) -- or a
+// .npy file (recognised by its magic bytes)
 void read_coords(const std::string& fname, std::vector<float>& coords, std::size_t& n_rows,
                  std::size_t& n_cols) {
   std::ifstream ifs(fname, std::ios::binary);
@@ -154,6 +213,10 @@ void read_coords(const std::string& fname, std::vector<float>& coords, std::size
   std::string text((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
   n_rows = 0;
   n_cols = 0;
+  if (read_npy(text, fname, coords, n_rows, n_cols)) {
+    LOG("    with dimensions: %zux%zu (.npy)\n\n", n_rows, n_cols);
+    return;
+  }
   const char* p = text.c_str();
   const char* end = p + text.size();
   // first non-empty line fixes n_cols

@@ -62,6 +62,29 @@ def test_cli_single_radius_full_path(tmp_path, oracle):
     assert "-0.000000e+00" in data_lines(tmp_path / "fe")       # the max-pop frame
 
 
+@pytest.mark.parametrize("dtype", ["<f4", "<f8"])
+def test_cli_reads_npy_coordinates(tmp_path, oracle, dtype):
+    """-f coords.npy (an extension of this build): the same outputs as for the
+    float32 matrix itself; float64 files are rounded to float32 first."""
+    c64 = gaussian_blobs(2000, 7, seed=44).astype(np.float64) + (1e-9 if dtype == "<f8" else 0.0)
+    np.save(tmp_path / "coords.npy", c64.astype(dtype))
+    c = c64.astype(dtype).astype(np.float32)
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords.npy"), "-r", "0.12", "-p", str(tmp_path / "pop"),
+                        "-b", str(tmp_path / "nn"), "-v"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "2000x7 (.npy)" in r.stdout + r.stderr
+    pops = oracle.populations(c, [0.12])[0]
+    nn = oracle.nearest_neighbors(c, oracle.free_energies(pops))
+    assert data_lines(tmp_path / "pop") == [str(int(p)) for p in pops]
+    want = ["%d %s %d %s" % (nn[0][i], fmt_g(nn[1][i]), nn[2][i], fmt_g(nn[3][i])) for i in range(len(c))]
+    assert data_lines(tmp_path / "nn") == want
+    # a 1-D array is refused with a message, not parsed as text
+    np.save(tmp_path / "flat.npy", np.zeros(12, dtype=np.float32))
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "flat.npy"), "-r", "0.1", "-p", str(tmp_path / "p2")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "2-dimensional" in r.stderr + r.stdout
+
+
 def test_cli_multi_radius_files(tmp_path, oracle):
     c = write_coords(tmp_path / "coords", gaussian_blobs(2000, 10, seed=43))
     radii = [0.3, 0.1, 0.2]
