@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -247,14 +248,57 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
     if (S.d_table) (void)hipFree(S.d_table);
     S = Scratch();
     S.device = dev;
-    DC_HIP_TRY(hipMalloc((void**)&S.d_max, sizeof(uint32_t)));
+    // [0] max population, [1] number of flagged rows, [2..] flagged (row, pop) pairs
+    DC_HIP_TRY(hipMalloc((void**)&S.d_max, sizeof(uint32_t) * (2 + 2 * 4096)));
   }
   dc::launch_max_u32(d_pops, (uint32_t)n_rows, S.d_max, s);
+  // Default: every row's free energy from the device's double log, the rows it cannot vouch for
+  // (value within 64 ulp(double) of a float rounding boundary: one in 2^22) recomputed by the host libm
+  // -- one stream synchronisation, no table.  DC_FE_HOST_TABLE=1 (and more flagged rows than the list
+  // holds) takes the table path below: one host log per distinct population.
+  static const bool host_table = [] {
+    const char* v = getenv("DC_FE_HOST_TABLE");
+    return v && v[0] == '1';
+  }();
+  constexpr uint32_t kFlagCap = 4096;
+  // margin around the float rounding boundaries, relative to the value: 64 ulp(double) unless the test
+  // suite widens it (DC_FE_REFEREE_TOL) to drive rows through the referee and the overflow path
+  static const double tol_rel = [] {
+    const char* v = getenv("DC_FE_REFEREE_TOL");
+    const double t = v ? atof(v) : 0.0;
+    return t > 1.5e-14 ? t : 1.5e-14;
+  }();
   uint32_t max_pop = 0;
-  hipError_t e = hipMemcpyAsync(&max_pop, S.d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) return fail(DC_ERR_HIP, "max population: %s", hipGetErrorString(e));
-  if (max_pop_out) *max_pop_out = max_pop;
+  hipError_t e = hipSuccess;
+  if (!host_table) {
+    dc::launch_fe_log(d_pops, (uint32_t)n_rows, S.d_max, d_fe, S.d_max + 1, S.d_max + 2, kFlagCap, tol_rel, s);
+    uint32_t head[2] = {0, 0};   // max_pop, number of flagged rows
+    e = hipMemcpyAsync(head, S.d_max, sizeof(head), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(DC_ERR_HIP, "free energies: %s", hipGetErrorString(e));
+    max_pop = head[0];
+    if (max_pop_out) *max_pop_out = max_pop;
+    if (head[1] == 0) return DC_OK;
+    if (head[1] <= kFlagCap) {
+      std::vector<uint32_t> list(2 * (size_t)head[1]);
+      e = hipMemcpyAsync(list.data(), S.d_max + 2, sizeof(uint32_t) * list.size(), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      const float rec = 1.0f / (float)max_pop;
+      std::vector<float> fixed(head[1]);
+      for (uint32_t k = 0; k < head[1] && e == hipSuccess; ++k) {
+        fixed[k] = fe_of_pop(list[2 * k + 1], rec);
+        e = hipMemcpyAsync(d_fe + list[2 * k], &fixed[k], sizeof(float), hipMemcpyHostToDevice, s);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return fail(DC_ERR_HIP, "free energies (host referee): %s", hipGetErrorString(e));
+      return DC_OK;
+    }
+  } else {
+    e = hipMemcpyAsync(&max_pop, S.d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(DC_ERR_HIP, "max population: %s", hipGetErrorString(e));
+    if (max_pop_out) *max_pop_out = max_pop;
+  }
   // one double log per DISTINCT population value, evaluated by the host libm like the
   // reference (which computes every FE on the host, density_clustering.cpp:687)
   S.table.resize((size_t)max_pop + 1);

@@ -41,6 +41,11 @@ void launch_fe_gather(const uint32_t* d_pops, uint32_t n_rows, const float* d_ta
                       hipStream_t stream);
 // *d_out = max(pops)
 void launch_max_u32(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_out, hipStream_t stream);
+// fe of every row with the device's double log; rows whose value sits within 64 ulp(double) of a float
+// rounding boundary go to d_flag_list as (row, pop) pairs (d_flag_count may exceed flag_cap)
+void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, const uint32_t* d_max, float* d_fe,
+                   uint32_t* d_flag_count, uint32_t* d_flag_list, uint32_t flag_cap, double tol_rel,
+                   hipStream_t stream);
 
 // ---- canonical squared distance, compile-time D ----------------------------------------
 // q: this lane's query row (registers); r: reference row (registers, wave-uniform values).

@@ -308,6 +308,38 @@ __global__ void fe_gather_kernel(const uint32_t* __restrict__ pops, uint32_t n_r
   if (i < n_rows) fe[i] = table[pops[i]];
 }
 
+// Free energies on the device, with the host libm as the referee.  The reference computes
+// fe = (float)(-log((double)((float)pop * (1.0f / max_pop)))) with glibc's double log
+// (density_clustering.cpp:201-209 as compiled).  The device's double log differs from
+// it by at most a few ulp(double); the two can only round to different floats when the double value lies
+// within that distance of a float rounding boundary (a midpoint of neighbouring floats).  Such rows -- one
+// in 2^22 with the margin below -- are listed for the host, which recomputes them with its libm.
+// q, the reciprocal (double division rounded to float = correctly rounded float division, 53 >= 2*24+2)
+// and the final rounding are IEEE operations, identical on both sides.
+__global__ void fe_log_kernel(const uint32_t* __restrict__ pops, uint32_t n_rows,
+                              const uint32_t* __restrict__ max_pop, float* __restrict__ fe,
+                              uint32_t* __restrict__ flag_count, uint2* __restrict__ flag_list,
+                              uint32_t flag_cap, double tol_rel) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const float rec = (float)(1.0 / (double)(float)(*max_pop));
+  const uint32_t pop = pops[i];
+  const float q = (float)pop * rec;
+  const double y = -log((double)q);
+  const float f = (float)y;
+  fe[i] = f;
+  if (fabs(y) <= 1.0e300 && y != 0.0) {
+    const uint32_t fb = __float_as_uint(f);
+    // neighbours of f by magnitude (f != 0, finite: fe is at most -log(2^-24 / 1) = 16.6)
+    const double up = (double)__uint_as_float(fb + 1u), dn = (double)__uint_as_float(fb - 1u);
+    const double tol = tol_rel * fabs(y);   // default 64 ulp(double): device log <= 2 ulp, glibc log <= 1 ulp
+    if (fabs(y - 0.5 * ((double)f + up)) < tol || fabs(y - 0.5 * ((double)f + dn)) < tol) {
+      const uint32_t k = atomicAdd(flag_count, 1u);
+      if (k < flag_cap) flag_list[k] = make_uint2(i, pop);
+    }
+  }
+}
+
 __global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* out) {
   uint32_t m = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -414,6 +446,15 @@ void launch_fe_gather(const uint32_t* d_pops, uint32_t n_rows, const float* d_ta
   if (n_rows == 0) return;
   hipLaunchKernelGGL(fe_gather_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_pops,
                      n_rows, d_table, d_fe);
+}
+
+void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, const uint32_t* d_max, float* d_fe,
+                   uint32_t* d_flag_count, uint32_t* d_flag_list, uint32_t flag_cap, double tol_rel,
+                   hipStream_t stream) {
+  (void)hipMemsetAsync(d_flag_count, 0, sizeof(uint32_t), stream);
+  if (n_rows == 0) return;
+  hipLaunchKernelGGL(fe_log_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_pops, n_rows, d_max,
+                     d_fe, d_flag_count, (uint2*)d_flag_list, flag_cap, tol_rel);
 }
 
 void launch_max_u32(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_out, hipStream_t stream) {

@@ -121,8 +121,9 @@ DC_API int dc_hip_populations_segment_dev(const float* d_coords, size_t n_rows, 
 
 /* replaces Clustering::Density::calculate_free_energies (density_clustering.cpp:197-212), which the
  * reference runs on the host in both builds.  fe[i] = (float)-log((double)((float)pop[i] * (1.0f/max)))
- * -- the double log is evaluated by the HOST libm (one value per distinct population, then gathered
- * on the device) so the bits equal the reference's.  Synchronises the stream once (reads max_pop).
+ * -- with the reference's bits: the device evaluates the double log, and every row whose value lies
+ * within 64 ulp(double) of a float rounding boundary (where a few ulp of difference between two libms
+ * could show) is recomputed by the HOST libm.  Synchronises the stream once (reads max_pop).
  *   d_pops [n_rows] uint32 device (one radius), d_fe [n_rows] float32 device.
  * max_pop_out (optional, host) receives the maximum population. */
 DC_API int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,

@@ -217,6 +217,40 @@ def test_non_finite_rows(dens, oracle, variant):
     check_full(dens, oracle, huge, [2e18], variant)
 
 
+def test_free_energies_device_log_with_host_referee(oracle):
+    """dc_hip_free_energies_dev: device double log + host libm for the rows near a float rounding boundary
+    (default) and the host table path (DC_FE_HOST_TABLE=1, in a child process: the switch is read once)
+    both give the oracle's bits -- on every population value 0..max for several maxima, so that every
+    boundary case of q = pop * (1/max) occurs."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from clustering_amd import density as dens
+from oracle.oracle import Oracle, build
+build(); o = Oracle()
+bad = 0
+for mx in (1, 2, 3, 1000, 65950, 1 << 20, (1 << 24) + 1, 3000001):
+    step = max(1, mx // 700000)
+    p = np.arange(0, mx + 1, step, dtype=np.int64)
+    p[-1] = mx
+    p = p.astype(np.int32)
+    fe = dens.calculate_free_energies(torch.from_numpy(p).cuda()).cpu().numpy()
+    want = o.free_energies(p.astype(np.uint64))
+    bad += int((fe.view(np.uint32) != want.view(np.uint32)).sum())
+print("mismatches", bad)
+'''
+    # default margin; the host table; a margin that sends thousands of rows to the referee; one that
+    # overflows the referee's list (falls back to the table)
+    for table, tol in (("0", "0"), ("1", "0"), ("0", "2e-11"), ("0", "1e-6")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(HERE),
+                           env=dict(os.environ, DC_FE_HOST_TABLE=table, DC_FE_REFEREE_TOL=tol))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "mismatches 0" in r.stdout, (table, tol, r.stdout[-500:])
+
+
 def test_host_pointer_entry_points(oracle):
     """dc_hip_populations / dc_hip_nearest_neighbors / dc_hip_density_all with HOST pointers."""
     from clustering_amd import capi
