@@ -203,18 +203,18 @@ __global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t D,
   const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
   const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
   const float cell = auto_cell(hdr, i_to - i_from, frames_per_cell);
-  // never so small that a dimension gets more than 60000 cells
-  float c0 = fmaxf(cell, (max0 - min0) / 60000.0f), c1 = fmaxf(cell, (max1 - min1) / 60000.0f);
+  // never so small that a dimension gets more than 4000 cells (keys stay below 2^kCellKeyBits)
+  float c0 = fmaxf(cell, (max0 - min0) / 4000.0f), c1 = fmaxf(cell, (max1 - min1) / 4000.0f);
   if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
   if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
   const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
   uint32_t bx = 0, by = 0;
   if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
-    bx = (uint32_t)fminf(fmaxf((x - min0) / c0, 0.0f), 60001.0f);
-    by = (uint32_t)fminf(fmaxf((y - min1) / c1, 0.0f), 60001.0f);
+    bx = (uint32_t)fminf(fmaxf((x - min0) / c0, 0.0f), 4001.0f);
+    by = (uint32_t)fminf(fmaxf((y - min1) / c1, 0.0f), 4001.0f);
   }
-  const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 60001.0f) + 1u;
-  keys[j] = bx * nby + by;   // < 60003^2 < 2^32 - 1
+  const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 4001.0f) + 1u;
+  keys[j] = bx * nby + by;   // < 4002 * 4003 < 2^24
 }
 
 // bounding box (lo0, hi0, lo1, hi1) of the frames of each tile of an ordered frame list
@@ -464,7 +464,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   // order all frames by their 2-D cell, build the reference image and the tile boxes
   hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
     return;
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
                      L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 0,
@@ -507,7 +507,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     // query rows of this call: the same ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
@@ -576,7 +576,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                      (const uint32_t*)hdr, kNnCellFrames, 0u, n_rows, cellkeys, vals_in);
   hipLaunchKernelGGL(gather_key_kernel, grid_n, blk, 0, stream, (const uint32_t*)cellkeys,
                      (const uint32_t*)perm_fe, n_rows, keys_in);
-  if (sort_pairs_u32(keys_in, keys_out, perm_fe, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
+  if (sort_pairs_u32(keys_in, keys_out, perm_fe, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
     return;
   hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
@@ -605,7 +605,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream))
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,

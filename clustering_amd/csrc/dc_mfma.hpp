@@ -67,9 +67,11 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
 
-// dc_sort.hip: key/value radix sort (hipCUB) for the free-energy ordering
+// dc_sort.hip: stable key/value radix sort (rocPRIM Onesweep) on the low key_bits bits of the keys
 size_t sort_temp_bytes(size_t n);
 int sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                   uint32_t* vals_out, size_t n, void* temp, size_t temp_bytes, hipStream_t stream);
+                   uint32_t* vals_out, size_t n, void* temp, size_t temp_bytes, hipStream_t stream,
+                   unsigned key_bits = 32);
+constexpr unsigned kCellKeyBits = 24;   // cell keys of the spatial orderings: < 4002^2 < 2^24
 
 }  // namespace dc
