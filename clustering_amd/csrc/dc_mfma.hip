@@ -466,17 +466,18 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                      (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
     return;
-  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 0,
+  // original rows in the reference order: the deferred exact path reads them without a
+  // permutation look-up, and the operand images are built from them with coalesced reads
+  const float* coords_p = (const float*)(p + L.off_coords_p);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
+                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
+                     (float*)(p + L.off_coords_p));
+  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
+                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
                      (const float*)nullptr, (float2*)nullptr);
-  // original rows in the reference order: the deferred exact path reads them without a
-  // permutation look-up
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
-                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
-                     (float*)(p + L.off_coords_p));
   // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
   // buffers are free again)
   EdgeSink sink_local;
@@ -499,10 +500,16 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     segment_window(L.T, n_rows, tq_pop_of(n_cols), qs, &q_tile_lo, &n_q);
   }
   const uint32_t T_q = (n_q + 31) / 32;
-  if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
-    hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 1,
-                       (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p);
+  if (q_mode != kQueryOwnOrder && n_q > 0) {
+    // queries in the reference order: only their B form is missing -- and only for the tiles of the
+    // window when the call is one segment of a sharded run
+    const uint32_t rows_q = (q_mode == kQueryWindow) ? n_q : n_rows, tiles_q = (rows_q + 31) / 32;
+    hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream,
+                       coords_p + (size_t)q_tile_lo * 32 * n_cols, n_rows, rows_q, n_cols, L.NM, tiles_q,
+                       (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                       (uint4*)(p + L.off_img_q) + (size_t)q_tile_lo * L.NM * 64, (float*)nullptr,
+                       (const uint32_t*)p);
+  }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the same ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
@@ -580,15 +587,16 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     return;
   hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
-  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 0,
+  const float* coords_p = (const float*)(p + L.off_coords_p);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
+                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
+                     (float*)(p + L.off_coords_p));
+  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
+                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
   hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
                      (float2*)(p + L.off_ferange_p));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
-                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
-                     (float*)(p + L.off_coords_p));
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from, q_tile_lo = 0;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
@@ -597,10 +605,16 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     segment_window(L.T, n_rows, tq_of(n_cols), qs, &q_tile_lo, &n_q);
   }
   const uint32_t T_q = (n_q + 31) / 32;
-  if (q_mode != kQueryOwnOrder)   // queries in the reference order: only their B form is missing
-    hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm_p, 1,
-                       (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p);
+  if (q_mode != kQueryOwnOrder && n_q > 0) {
+    // queries in the reference order: only their B form is missing -- and only for the tiles of the
+    // window when the call is one segment of a sharded run
+    const uint32_t rows_q = (q_mode == kQueryWindow) ? n_q : n_rows, tiles_q = (rows_q + 31) / 32;
+    hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream,
+                       coords_p + (size_t)q_tile_lo * 32 * n_cols, n_rows, rows_q, n_cols, L.NM, tiles_q,
+                       (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                       (uint4*)(p + L.off_img_q) + (size_t)q_tile_lo * L.NM * 64, (float*)nullptr,
+                       (const uint32_t*)p);
+  }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
