@@ -103,14 +103,18 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
 __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total, uint32_t n_rows,
                              uint32_t D, uint32_t NM, uint32_t T, const float* __restrict__ means,
                              const uint32_t* __restrict__ perm, int b_form, uint4* __restrict__ img,
-                             float* __restrict__ norms, const uint32_t* __restrict__ hdr) {
+                             float* __restrict__ norms, const uint32_t* __restrict__ hdr,
+                             uint32_t grp_tq = 1, QSeg grp = QSeg{1u, 0u}) {
   // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image.
   // (A variant that decodes the 16 slots of a block once into LDS was measured slower: the column
   //  loads then hang on the table look-ups instead of being issued together.)
   (void)n_total;
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (size_t)T * NM * 64) return;
-  const uint32_t lane = (uint32_t)(id & 63), m = (uint32_t)((id >> 6) % NM), t = (uint32_t)((id >> 6) / NM);
+  const uint32_t lane = (uint32_t)(id & 63), m = (uint32_t)((id >> 6) % NM);
+  // tile: the launch covers the tiles of every grp.stride-th group of grp_tq tiles (all tiles: {1, 0})
+  const uint32_t tc = (uint32_t)((id >> 6) / NM);
+  const uint32_t t = ((tc / grp_tq) * grp.stride + grp.offset) * grp_tq + tc % grp_tq;
+  if (t >= T) return;
   const uint32_t row = 32 * t + (lane & 31), h = lane >> 5;
   const bool live = row < n_rows;
   const uint32_t src = live ? (perm ? perm[row] : row) : 0u;
@@ -125,7 +129,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
       w[j >> 1] |= v << (16 * (j & 1));
     }
   }
-  img[id] = make_uint4(w[0], w[1], w[2], w[3]);          // pad rows: all zero
+  img[((size_t)t * NM + m) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);   // pad rows: all zero
   if (norms && m == 0 && h == 0) {
     double nrm = 0.0;
     for (uint32_t k = 0; k < D; ++k) {
@@ -340,16 +344,6 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 struct QuerySel {
   uint32_t i_from, i_to, segment, n_segments;
 };
-// query window of a segment in tiles of the reference order (TQ tiles per group)
-static void segment_window(uint32_t T, uint32_t n_rows, int tq, const QuerySel& q, uint32_t* tile_lo,
-                           uint32_t* n_q) {
-  const uint64_t groups = (T + tq - 1) / tq;
-  const uint64_t g_lo = groups * q.segment / q.n_segments, g_hi = groups * (q.segment + 1) / q.n_segments;
-  const uint64_t t_lo = g_lo * tq, t_hi = std::min<uint64_t>(T, g_hi * tq);
-  *tile_lo = (uint32_t)t_lo;
-  const uint64_t r_lo = t_lo * 32, r_hi = std::min<uint64_t>(n_rows, t_hi * 32);
-  *n_q = r_hi > r_lo ? (uint32_t)(r_hi - r_lo) : 0u;
-}
 static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 8 ? 4 : 2; }   // = tq_for<NM>
 static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
 
@@ -493,22 +487,23 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     sink = &sink_local;
   }
   const bool full = (i_from == 0 && i_to == n_rows);
-  uint32_t n_q = i_to - i_from, q_tile_lo = 0;
+  uint32_t n_q = i_to - i_from;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
-  if (qs.n_segments > 0) {
-    q_mode = kQueryWindow;
-    segment_window(L.T, n_rows, tq_pop_of(n_cols), qs, &q_tile_lo, &n_q);
+  QSeg q_seg{1u, 0u};
+  if (qs.n_segments > 0) {   // one segment of a sharded run: every n_segments-th query group of all rows
+    q_mode = kQueryAll;
+    n_q = n_rows;
+    q_seg = QSeg{qs.n_segments, qs.segment};
   }
   const uint32_t T_q = (n_q + 31) / 32;
-  if (q_mode != kQueryOwnOrder && n_q > 0) {
-    // queries in the reference order: only their B form is missing -- and only for the tiles of the
-    // window when the call is one segment of a sharded run
-    const uint32_t rows_q = (q_mode == kQueryWindow) ? n_q : n_rows, tiles_q = (rows_q + 31) / 32;
-    hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream,
-                       coords_p + (size_t)q_tile_lo * 32 * n_cols, n_rows, rows_q, n_cols, L.NM, tiles_q,
-                       (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                       (uint4*)(p + L.off_img_q) + (size_t)q_tile_lo * L.NM * 64, (float*)nullptr,
-                       (const uint32_t*)p);
+  if (q_mode != kQueryOwnOrder) {
+    // queries in the reference order: only their B form is missing (of the groups of this segment)
+    const uint32_t tq = (uint32_t)tq_pop_of(n_cols);
+    const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
+    if (tiles_q > 0)
+      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
+                         L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                         (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg);
   }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the same ordering restricted to [i_from, i_to)
@@ -527,7 +522,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
 #define X(SV)                                                                                 \
   case SV:                                                                                    \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
-      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, q_mode, q_tile_lo, rad2, n_rad,   \
+      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, q_mode, q_seg, rad2, n_rad,   \
                            d_pops, sink, stream);                                             \
     break;
     DC_FOR_EACH_S(X)
@@ -598,22 +593,23 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                      (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
                      (float2*)(p + L.off_ferange_p));
   const bool full = (i_from == 0 && i_to == n_rows);
-  uint32_t n_q = i_to - i_from, q_tile_lo = 0;
+  uint32_t n_q = i_to - i_from;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
-  if (qs.n_segments > 0) {
-    q_mode = kQueryWindow;
-    segment_window(L.T, n_rows, tq_of(n_cols), qs, &q_tile_lo, &n_q);
+  QSeg q_seg{1u, 0u};
+  if (qs.n_segments > 0) {   // one segment of a sharded run: every n_segments-th query group of all rows
+    q_mode = kQueryAll;
+    n_q = n_rows;
+    q_seg = QSeg{qs.n_segments, qs.segment};
   }
   const uint32_t T_q = (n_q + 31) / 32;
-  if (q_mode != kQueryOwnOrder && n_q > 0) {
-    // queries in the reference order: only their B form is missing -- and only for the tiles of the
-    // window when the call is one segment of a sharded run
-    const uint32_t rows_q = (q_mode == kQueryWindow) ? n_q : n_rows, tiles_q = (rows_q + 31) / 32;
-    hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream,
-                       coords_p + (size_t)q_tile_lo * 32 * n_cols, n_rows, rows_q, n_cols, L.NM, tiles_q,
-                       (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                       (uint4*)(p + L.off_img_q) + (size_t)q_tile_lo * L.NM * 64, (float*)nullptr,
-                       (const uint32_t*)p);
+  if (q_mode != kQueryOwnOrder) {
+    // queries in the reference order: only their B form is missing (of the groups of this segment)
+    const uint32_t tq = (uint32_t)tq_of(n_cols);
+    const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
+    if (tiles_q > 0)
+      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
+                         L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                         (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg);
   }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
@@ -632,7 +628,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
-      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, n_q, q_mode, q_tile_lo, -1.0f,    \
+      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, n_q, q_mode, q_seg, -1.0f,    \
                           d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, stream);                        \
     break;
     DC_FOR_EACH_S(X)

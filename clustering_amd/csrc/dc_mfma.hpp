@@ -42,6 +42,16 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
 void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
                          uint32_t* d_pops, uint2* d_pairs, unsigned long long capacity,
                          unsigned long long* d_count, void* d_ws, hipStream_t stream);
+// one segment of a sharded sweep: the query groups (TQ consecutive tiles of the sweep's order) number
+// offset, offset + stride, offset + 2 stride, ...  ({1, 0}: all of them).  Dealing the groups out cyclically
+// gives every segment the same mix of dense and sparse regions (contiguous runs of groups differed by up
+// to 16 % in work at 1/8 of C3), and each group stays as compact as in the full sweep.
+struct QSeg {
+  uint32_t stride, offset;
+};
+inline uint32_t seg_groups(uint32_t n_groups, QSeg q) {
+  return n_groups > q.offset ? (n_groups - q.offset + q.stride - 1) / q.stride : 0u;
+}
 constexpr size_t kMinEdgeMaxRows = (size_t)1 << 24;   // (the sweep's deferred-evaluation queue holds 24-bit positions)
 // one Boruvka round on the radius graph (d2 < r2): for every component (d_comp[frame] = its id, any
 // frame id) the lightest pair that leaves it, by (max(rank), min(rank)) with d_rank[frame] a

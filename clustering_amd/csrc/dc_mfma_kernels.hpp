@@ -741,10 +741,9 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n_blocks
 
 // which rows a pruned sweep answers for, and where their operands live:
 //   kQueryOwnOrder  a row range [i_from, i_to): its own spatial ordering (img_q / norms_q / perm_q / box_q)
-//   kQueryAll       every row, in the reference order (the reference arrays double as query arrays)
-//   kQueryWindow    a window of the reference order starting at tile q_tile_lo (one segment of a
-//                   spatially sharded multi-GPU run: the segment is as compact as the full sweep's groups)
-enum QueryMode { kQueryOwnOrder = 0, kQueryAll = 1, kQueryWindow = 2 };
+//   kQueryAll       rows in the reference order (the reference arrays double as query arrays): all of
+//                   them, or the query groups of one segment of a sharded run (QSeg)
+enum QueryMode { kQueryOwnOrder = 0, kQueryAll = 1 };
 
 constexpr int kListCap = 1024;   // reference tiles scanned per round (LDS list entries per wave)
 constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane and query tile
@@ -824,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r,
     const float* __restrict__ coords_r, uint32_t T,
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
-    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q,
+    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
     int n_rad, uint32_t* __restrict__ pops, EdgeSink sink) {
   __shared__ uint32_t lists[4][kListCap];
@@ -834,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
-  const uint32_t wave = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib;
+  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib) * q_seg.stride + q_seg.offset;
   // gridDim.y > 1: the reference tiles are dealt round-robin to gridDim.y waves per query group and
   // the partial counts are merged with atomics (keeps small launches, e.g. one rank of an 8-GPU
   // run, at >= 2 waves per SIMD without giving up the operand reuse of TQ query tiles per wave)
@@ -1495,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ fe_c, const float* __restrict__ coords_c,
     const uint32_t* __restrict__ invpos_r, uint32_t T,
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
-    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q,
+    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
     int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
     unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx,
@@ -1507,7 +1506,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
-  const uint32_t wave = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib;
+  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib) * q_seg.stride + q_seg.offset;
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t qt0 = wave * TQ;
@@ -1848,11 +1847,13 @@ __global__ void nn_merge_fill_kernel(unsigned long long* __restrict__ merge64, u
 
 __global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ merge64,
                                        const uint32_t* __restrict__ perm_q, uint32_t n_q,
-                                       uint32_t n_rows, uint32_t* __restrict__ nn_idx,
-                                       float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
-                                       float* __restrict__ hd_d2) {
+                                       uint32_t n_rows, uint32_t tq, QSeg q_seg,
+                                       uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
+                                       uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_q) return;
+  // (rows of other segments keep what the caller initialised them with)
+  if ((p / (32u * tq)) % q_seg.stride != q_seg.offset) return;
   const uint32_t i = perm_q[p];   // the query rows of this call
   const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
   nn_idx[i] = (uint32_t)a;
@@ -1908,6 +1909,7 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   const float4* box_q;
   unsigned long long* merge64;
   uint32_t n_q;
+  QSeg q_seg;
   int full_range;
   float cell2;
 };
@@ -1940,7 +1942,8 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                       unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   if (A.n_q == 0) return;
-  const uint32_t tiles = (A.n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
+  const uint32_t waves = seg_groups(((A.n_q + 31) / 32 + TQV - 1) / TQV, A.q_seg), tiles = waves * TQV;
+  if (waves == 0) return;
   const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor);
   // query rows (original coordinates) + candidate queues, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
@@ -1950,13 +1953,13 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                        A.merge64, n_rows);
   hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + 3) / 4, n_chunks), dim3(256), smem, s,
                      coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r,
-                     A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q,
+                     A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
                      hd_d2);
   if (n_chunks > 1)
     hipLaunchKernelGGL(nn_merge_unpack_kernel, dim3((A.n_q + 255) / 256), dim3(256), 0, s,
-                       (const unsigned long long*)A.merge64, A.perm_q, A.n_q, n_rows, nn_idx, nn_d2,
-                       hd_idx, hd_d2);
+                       (const unsigned long long*)A.merge64, A.perm_q, A.n_q, n_rows, (uint32_t)TQV, A.q_seg,
+                       nn_idx, nn_d2, hd_idx, hd_d2);
 }
 
 template <int S>
@@ -1972,20 +1975,21 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
 // all rows spatially ordered ("p"); full_range: the query set is every row -> the two orders coincide
 template <int S, int NRV, int TQV>
 void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
-                       uint32_t T, uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2,
+                       uint32_t T, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,
                        int n_rad, uint32_t* pops, unsigned long long* chain_counter,
                        const EdgeSink* sink, hipStream_t s) {
   if (n_q == 0) return;
-  const uint32_t tiles = (n_q + 31) / 32, waves = (tiles + TQV - 1) / TQV;
+  // the query groups of this launch: all of them, or one segment's share
+  const uint32_t waves = seg_groups(((n_q + 31) / 32 + TQV - 1) / TQV, q_seg), tiles = waves * TQV;
+  if (waves == 0) return;
   const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor)), block(256);
-  // B form of the query rows: its own image for a row range, else the B form of all rows in the
-  // reference order (img_q), from the window's first tile on
+  // B form of the query rows: its own image for a row range, else the B form of the rows in the
+  // reference order (img_q)
   const bool own = q_mode == kQueryOwnOrder;
-  const size_t lo = own ? 0 : q_tile_lo;
-  const uint4* img_q = P.img_q + lo * ((size_t)S * 64);
-  const float* norms_q = (own ? P.norms_q : P.norms_p) + lo * 32;
-  const uint32_t* perm_q = (own ? P.perm_q : P.perm_p) + lo * 32;
-  const float4* box_q = (own ? P.box_q : P.box_p) + lo;
+  const uint4* img_q = P.img_q;
+  const float* norms_q = own ? P.norms_q : P.norms_p;
+  const uint32_t* perm_q = own ? P.perm_q : P.perm_p;
+  const float4* box_q = own ? P.box_q : P.box_p;
   // query rows (original coordinates) + queues of deferred exact evaluations, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
@@ -1993,34 +1997,34 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   if (sink && sink->best)
     hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkMinEdge>), grid, block, smem, s, coords,
                        n_rows, n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q,
-                       norms_q, perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
+                       norms_q, perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
   else if (sink)
     hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkPairs>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
-                       perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
+                       perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
   else
     hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkNone>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
-                       perm_q, box_q, n_q, P.hdr, chain_counter, rad2, n_rad, pops,
+                       perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
                        EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr});
 }
 
 template <int S, int NRV>
 void pop_pruned_tq(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
-                   uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2, int n_rad,
+                   uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2, int n_rad,
                    uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
                    hipStream_t s) {
-  pop_pruned_launch<S, NRV, tq_pop_for<S>>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_tile_lo, rad2,
+  pop_pruned_launch<S, NRV, tq_pop_for<S>>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2,
                                        n_rad, pops, chain_counter, sink, s);
 }
 
 template <int S>
 void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
-                         uint32_t T, uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2,
+                         uint32_t T, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,
                          int n_rad, uint32_t* pops, unsigned long long* chain_counter,
                          const EdgeSink* sink, hipStream_t s) {
   // one radius per sweep (dc_mfma.hip loops over the radii of a call)
-  pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_tile_lo, rad2, n_rad, pops,
+  pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2, n_rad, pops,
                       chain_counter, sink, s);
 }
 
@@ -2044,10 +2048,10 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                           uint32_t i_from, uint32_t i_to, const Rad2& rad2, int n_rad,           \
                           uint32_t* pops, hipStream_t s);                                        \
   void pop_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,   \
-                            uint32_t n_q, int q_mode, uint32_t q_tile_lo, const Rad2& rad2,      \
+                            uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,      \
                             int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s);     \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
-                           void* d_ws, uint32_t n_q, int q_mode, uint32_t q_tile_lo, float cell2, \
+                           void* d_ws, uint32_t n_q, int q_mode, QSeg q_seg, float cell2, \
                            uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,       \
                            hipStream_t s);                                                       \
   void nn_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,      \

@@ -19,18 +19,18 @@ void DC_CAT(pop_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint3
 }
 
 void DC_CAT(pop_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
-                                       void* d_ws, uint32_t n_q, int q_mode, uint32_t q_tile_lo,
+                                       void* d_ws, uint32_t n_q, int q_mode, QSeg q_seg,
                                        const Rad2& rad2, int n_rad, uint32_t* pops,
                                        const EdgeSink* sink, hipStream_t s) {
   const Layout L = make_layout(n_rows, n_cols);
   // evaluated-chain counter: header word 2..3 (8-byte aligned)
-  pop_pruned_dispatch<DC_STEP>(coords, n_rows, n_cols, ws_ptrs(d_ws, L), L.T, n_q, q_mode, q_tile_lo,
+  pop_pruned_dispatch<DC_STEP>(coords, n_rows, n_cols, ws_ptrs(d_ws, L), L.T, n_q, q_mode, q_seg,
                                rad2, n_rad, pops, (unsigned long long*)((char*)d_ws + 8), sink, s);
 }
 
 void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
                                       const float* fe, void* d_ws, uint32_t n_q, int q_mode,
-                                      uint32_t q_tile_lo, float cell2, uint32_t* nn_idx, float* nn_d2,
+                                      QSeg q_seg, float cell2, uint32_t* nn_idx, float* nn_d2,
                                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
@@ -45,11 +45,11 @@ void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint
   A.invpos_r = (const uint32_t*)(p + L.off_invpos);
   // query operands: own ordering of a row range, or the reference order (all rows / a window of it)
   const bool own = q_mode == kQueryOwnOrder;
-  const size_t lo = own ? 0 : q_tile_lo;
-  A.img_q = (const uint4*)(p + L.off_img_q) + lo * ((size_t)DC_STEP * 64);   // B form of the query rows
-  A.norms_q = (own ? (const float*)(p + L.off_norm_q) : A.norms_r) + lo * 32;
-  A.perm_q = (own ? (const uint32_t*)(p + L.off_perm_q) : A.perm_r) + lo * 32;
-  A.box_q = (own ? (const float4*)(p + L.off_box_q) : A.box_r) + lo;
+  A.img_q = (const uint4*)(p + L.off_img_q);   // B form of the query rows
+  A.norms_q = own ? (const float*)(p + L.off_norm_q) : A.norms_r;
+  A.perm_q = own ? (const uint32_t*)(p + L.off_perm_q) : A.perm_r;
+  A.box_q = own ? (const float4*)(p + L.off_box_q) : A.box_r;
+  A.q_seg = q_seg;
   A.merge64 = (unsigned long long*)(p + L.off_merge64);
   A.n_q = n_q;
   A.full_range = (q_mode == kQueryAll) ? 1 : 0;   // 0: positions of the queries come from invpos

@@ -109,9 +109,11 @@ DC_API int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n
 /* The same sweep for one SEGMENT of a sharded run instead of a row range: rank `segment` of
  * `n_segments` (density_clustering_cuda.cu:149-169 gives every GPU a contiguous block of rows; any
  * partition serves, as long as the partial results merge).  With the pruned matrix-core sweep a
- * segment is a run of whole query groups of the SPATIAL order, so a rank's queries are as compact as
- * those of a full sweep and prune as well (a block of consecutive rows of a trajectory is spread over
- * the whole conformational space); with every other variant, n_cols > 32 or non-finite data the
+ * segment is every n_segments-th query group of the SPATIAL order (128 - 192 frames of one grid cell):
+ * a rank's queries are as compact as those of a full sweep and prune as well (a block of consecutive
+ * rows of a trajectory is spread over the whole conformational space), and dealing the groups out
+ * cyclically gives every rank the same mix of dense and sparse regions; with every other variant,
+ * n_cols > 32 or non-finite data the
  * segment is the reference's row block.  d_pops as above: zeros for the rows of other segments, so
  * that the partials merge by summation. */
 DC_API int dc_hip_populations_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols,

@@ -17,4 +17,5 @@ for seg in list(range(G)) * 2:
     ev[3].record(); torch.cuda.synchronize()
     tp.append(ev[0].elapsed_time(ev[1])); tf.append(ev[1].elapsed_time(ev[2])); tn.append(ev[2].elapsed_time(ev[3]))
 tp, tf, tn = np.array(tp[G:]), np.array(tf[G:]), np.array(tn[G:])
+print("   nn per segment:", np.round(tn, 2), " pop:", np.round(tp, 2))
 print(f"G={G}: pop seg mean {tp.mean():.2f} max {tp.max():.2f} ms | fe {tf.mean():.2f} | nn seg mean {tn.mean():.2f} max {tn.max():.2f} ms | sum of maxima {tp.max()+tf.mean()+tn.max():.2f} ms")
