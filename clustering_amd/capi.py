@@ -22,6 +22,7 @@ SYMBOLS = (
     "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs", "dc_hip_radius_min_edge_dev", "dc_hip_radius_forest",
     "dc_hip_populations_segment_dev", "dc_hip_nearest_neighbors_segment_dev",
+    "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev",
 )
 
 
@@ -68,6 +69,10 @@ def _load():
     lib.dc_hip_radius_pairs_dev.argtypes = [vp, sz, sz, C.c_float, vp, vp, sz, vp, vp, sz, vp]
     lib.dc_hip_radius_pairs.restype = i32
     lib.dc_hip_radius_pairs.argtypes = [vp, sz, sz, C.c_float, i32, vp, sz, C.POINTER(C.c_uint64)]
+    lib.dc_hip_neighbors_pack_dev.restype = i32
+    lib.dc_hip_neighbors_pack_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.dc_hip_neighbors_unpack_dev.restype = i32
+    lib.dc_hip_neighbors_unpack_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp]
     lib.dc_hip_radius_min_edge_dev.restype = i32
     lib.dc_hip_radius_min_edge_dev.argtypes = [vp, sz, sz, C.c_float, vp, vp, vp, vp, vp, sz, vp]
     lib.dc_hip_radius_forest.restype = i32

@@ -394,6 +394,27 @@ int dc_hip_nearest_neighbors_segment_dev(const float* d_coords, size_t n_rows, s
                                 stream);
 }
 
+int dc_hip_neighbors_pack_dev(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
+                              const float* d_hd_d2, size_t n_rows, unsigned long long* d_words,
+                              void* stream) {
+  if (n_rows == 0) return DC_OK;
+  if (!d_nn_idx || !d_nn_d2 || !d_hd_idx || !d_hd_d2 || !d_words)
+    return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n_rows + 1 > (size_t)UINT32_MAX) return fail(DC_ERR_TOO_LARGE, "n_rows too large");
+  dc::launch_nn_pack(d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, (uint32_t)n_rows, d_words, (hipStream_t)stream);
+  return check_launch("neighbour pack launch");
+}
+
+int dc_hip_neighbors_unpack_dev(const unsigned long long* d_words, size_t n_rows, uint32_t* d_nn_idx,
+                                float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2, void* stream) {
+  if (n_rows == 0) return DC_OK;
+  if (!d_nn_idx || !d_nn_d2 || !d_hd_idx || !d_hd_d2 || !d_words)
+    return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n_rows + 1 > (size_t)UINT32_MAX) return fail(DC_ERR_TOO_LARGE, "n_rows too large");
+  dc::launch_nn_unpack(d_words, (uint32_t)n_rows, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, (hipStream_t)stream);
+  return check_launch("neighbour unpack launch");
+}
+
 int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2_out, void* stream) {
   if (!sigma2_out) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   if (n_rows == 0) {

@@ -41,6 +41,11 @@ void launch_fe_gather(const uint32_t* d_pops, uint32_t n_rows, const float* d_ta
                       hipStream_t stream);
 // *d_out = max(pops)
 void launch_max_u32(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_out, hipStream_t stream);
+// neighbour results <-> [2][n_rows] order-preserving words (d2 bits << 32 | index)
+void launch_nn_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
+                    const float* d_hd_d2, uint32_t n_rows, unsigned long long* d_words, hipStream_t stream);
+void launch_nn_unpack(const unsigned long long* d_words, uint32_t n_rows, uint32_t* d_nn_idx, float* d_nn_d2,
+                      uint32_t* d_hd_idx, float* d_hd_d2, hipStream_t stream);
 // fe of every row with the device's double log; rows whose value sits within 64 ulp(double) of a float
 // rounding boundary go to d_flag_list as (row, pop) pairs (d_flag_count may exceed flag_cap)
 void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, const uint32_t* d_max, float* d_fe,

@@ -340,6 +340,28 @@ __global__ void fe_log_kernel(const uint32_t* __restrict__ pops, uint32_t n_rows
   }
 }
 
+// neighbour results as order-preserving 64-bit words (d2 bits << 32 | index): d2 >= 0, so the words of a
+// row order like the lexicographic (d2, index) and partial results merge with an integer minimum
+__global__ void nn_pack_kernel(const uint32_t* __restrict__ nn_idx, const float* __restrict__ nn_d2,
+                               const uint32_t* __restrict__ hd_idx, const float* __restrict__ hd_d2,
+                               uint32_t n_rows, unsigned long long* __restrict__ words) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  words[i] = ((unsigned long long)__float_as_uint(nn_d2[i]) << 32) | nn_idx[i];
+  words[(size_t)n_rows + i] = ((unsigned long long)__float_as_uint(hd_d2[i]) << 32) | hd_idx[i];
+}
+__global__ void nn_unpack_kernel(const unsigned long long* __restrict__ words, uint32_t n_rows,
+                                 uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
+                                 uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const unsigned long long a = words[i], b = words[(size_t)n_rows + i];
+  nn_idx[i] = (uint32_t)a;
+  nn_d2[i] = __uint_as_float((uint32_t)(a >> 32));
+  hd_idx[i] = (uint32_t)b;
+  hd_d2[i] = __uint_as_float((uint32_t)(b >> 32));
+}
+
 __global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* out) {
   uint32_t m = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -455,6 +477,19 @@ void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, const uint32_t* d_ma
   if (n_rows == 0) return;
   hipLaunchKernelGGL(fe_log_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_pops, n_rows, d_max,
                      d_fe, d_flag_count, (uint2*)d_flag_list, flag_cap, tol_rel);
+}
+
+void launch_nn_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
+                    const float* d_hd_d2, uint32_t n_rows, unsigned long long* d_words, hipStream_t stream) {
+  if (n_rows == 0) return;
+  hipLaunchKernelGGL(nn_pack_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2,
+                     d_hd_idx, d_hd_d2, n_rows, d_words);
+}
+void launch_nn_unpack(const unsigned long long* d_words, uint32_t n_rows, uint32_t* d_nn_idx, float* d_nn_d2,
+                      uint32_t* d_hd_idx, float* d_hd_d2, hipStream_t stream) {
+  if (n_rows == 0) return;
+  hipLaunchKernelGGL(nn_unpack_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_words, n_rows,
+                     d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
 }
 
 void launch_max_u32(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_out, hipStream_t stream) {

@@ -241,6 +241,32 @@ def radius_forest(coords_host, r2, rank, device=0):
     return edges[:n_edges.value].copy(), int(n_rounds.value)
 
 
+def pack_neighbors(nn_idx, nn_d2, hd_idx, hd_d2):
+    """-> int64 CUDA [2, n_rows]: (d2 bits << 32 | index) words of nn and nn_hd (dc_hip_neighbors_pack_dev);
+    partial results of a sharded run merge with all_reduce(min)."""
+    n = nn_idx.shape[0]
+    words = torch.empty((2, n), dtype=torch.int64, device=nn_idx.device)
+    with torch.cuda.device(nn_idx.device):
+        rc = capi.lib.dc_hip_neighbors_pack_dev(_dev(nn_idx), _dev(nn_d2), _dev(hd_idx), _dev(hd_d2), n,
+                                                _dev(words), _stream_ptr())
+    capi.check(rc, "dc_hip_neighbors_pack_dev")
+    return words
+
+
+def unpack_neighbors(words, out=None):
+    """inverse of pack_neighbors -> (nn_idx int32, nn_d2 float32, hd_idx int32, hd_d2 float32)"""
+    n = words.shape[1]
+    dev = words.device
+    if out is None:
+        out = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.float32, device=dev),
+               torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.float32, device=dev))
+    with torch.cuda.device(dev):
+        rc = capi.lib.dc_hip_neighbors_unpack_dev(_dev(words), n, _dev(out[0]), _dev(out[1]), _dev(out[2]),
+                                                  _dev(out[3]), _stream_ptr())
+    capi.check(rc, "dc_hip_neighbors_unpack_dev")
+    return out
+
+
 def compute_sigma2(nn_d2):
     """compute_sigma2 (density_clustering.cpp:334-343)."""
     out = C.c_double(0.0)

@@ -52,6 +52,12 @@ class HipBackend:
     def nearest_neighbors_segment(self, coords, fe, segment, n_segments):
         return self._d.nearest_neighbors_segment(coords, fe, segment, n_segments, variant=self.variant)
 
+    def pack_neighbors(self, nn_idx, nn_d2, hd_idx, hd_d2):
+        return self._d.pack_neighbors(nn_idx, nn_d2, hd_idx, hd_d2)
+
+    def unpack_neighbors(self, words):
+        return self._d.unpack_neighbors(words)
+
 
 class ShardedDensity:
     """pop -> FE -> NN for the rows of this rank, merged across ranks with two collectives."""
@@ -86,14 +92,19 @@ class ShardedDensity:
         if segments:
             nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.nearest_neighbors_segment(coords, fe, rank, world)
             # (d2 bits << 32 | index): d2 >= 0, so the words order like (d2, index); one owner per row
-            packed = torch.empty((2, n_rows), dtype=torch.int64, device=coords.device)
-            packed[0] = (nn_d2.view(torch.int32).to(torch.int64) << 32) | (nn_idx.to(torch.int64) & 0xFFFFFFFF)
-            packed[1] = (hd_d2.view(torch.int32).to(torch.int64) << 32) | (hd_idx.to(torch.int64) & 0xFFFFFFFF)
-            dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=self.group)
-            nn_idx = (packed[0] & 0xFFFFFFFF).to(torch.int32)
-            hd_idx = (packed[1] & 0xFFFFFFFF).to(torch.int32)
-            nn_d2 = (packed[0] >> 32).to(torch.int32).view(torch.float32)
-            hd_d2 = (packed[1] >> 32).to(torch.int32).view(torch.float32)
+            if hasattr(self.backend, "pack_neighbors"):     # two library kernels instead of a dozen torch ops
+                packed = self.backend.pack_neighbors(nn_idx, nn_d2, hd_idx, hd_d2)
+                dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=self.group)
+                nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.unpack_neighbors(packed)
+            else:
+                packed = torch.empty((2, n_rows), dtype=torch.int64, device=coords.device)
+                packed[0] = (nn_d2.view(torch.int32).to(torch.int64) << 32) | (nn_idx.to(torch.int64) & 0xFFFFFFFF)
+                packed[1] = (hd_d2.view(torch.int32).to(torch.int64) << 32) | (hd_idx.to(torch.int64) & 0xFFFFFFFF)
+                dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=self.group)
+                nn_idx = (packed[0] & 0xFFFFFFFF).to(torch.int32)
+                hd_idx = (packed[1] & 0xFFFFFFFF).to(torch.int32)
+                nn_d2 = (packed[0] >> 32).to(torch.int32).view(torch.float32)
+                hd_d2 = (packed[1] >> 32).to(torch.int32).view(torch.float32)
             out.update(nn_idx=nn_idx, nn_d2=nn_d2, hd_idx=hd_idx, hd_d2=hd_d2)
             return out
         nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.nearest_neighbors_partial(coords, fe, lo, hi)

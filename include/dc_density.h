@@ -152,6 +152,18 @@ DC_API int dc_hip_nearest_neighbors_segment_dev(const float* d_coords, size_t n_
                                                 void* d_workspace, size_t workspace_bytes,
                                                 int variant, void* stream);
 
+/* Merging the neighbour partials of a sharded run (density_clustering_cuda.cu:311-326 overwrites row by
+ * row on the host): [2][n_rows] order-preserving 64-bit words (d2 bits << 32 | index) -- nn first, then
+ * nn_hd.  d2 >= 0, so the words of a row order like the lexicographic (d2, index): the owner's word is
+ * the minimum over the ranks (everybody else holds the "none" value (n_rows+1, FLT_MAX)), i.e. ONE
+ * all-reduce(min) of int64 merges all four arrays. */
+DC_API int dc_hip_neighbors_pack_dev(const uint32_t* d_nn_idx, const float* d_nn_d2,
+                                     const uint32_t* d_hd_idx, const float* d_hd_d2, size_t n_rows,
+                                     unsigned long long* d_words, void* stream);
+DC_API int dc_hip_neighbors_unpack_dev(const unsigned long long* d_words, size_t n_rows,
+                                       uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                                       float* d_hd_d2, void* stream);
+
 /* replaces Clustering::Density::compute_sigma2 (density_clustering.cpp:334-343): mean of the nearest-
  * neighbour d2 accumulated in double IN FRAME ORDER (bit-stable), on the device (one block, fixed
  * reduction tree would change bits -- so this is a single ordered pass over a device->host copy).

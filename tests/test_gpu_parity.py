@@ -441,8 +441,8 @@ def test_chunked_launches_match_direct(dens, rows):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_rows,n_cols,n_seg", [(5000, 10, 2), (70000, 4, 8), (1000, 30, 3), (37, 2, 5), (4000, 40, 2)])
 def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols, n_seg):
-    """dc_hip_*_segment_dev: the segments of a sharded run (spatial runs of query groups with the pruned
-    sweep, row blocks otherwise -- n_cols = 40 has no matrix-core kernel) partition the rows: summed
+    """dc_hip_*_segment_dev: the segments of a sharded run (every n_seg-th query group of the spatial order
+    with the pruned sweep, row blocks otherwise -- n_cols = 40 has no matrix-core kernel) partition the rows: summed
     populations and min-merged (d2, index) words equal the single-device result bit for bit."""
     import torch
     c = gaussian_blobs(n_rows, n_cols, seed=5 + n_seg)
@@ -461,6 +461,7 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
         a, b, cc, d = dens.nearest_neighbors_segment(ct, fe, g, n_seg)
         w = torch.stack([(b.view(torch.int32).to(torch.int64) << 32) | (a.to(torch.int64) & 0xFFFFFFFF),
                          (d.view(torch.int32).to(torch.int64) << 32) | (cc.to(torch.int64) & 0xFFFFFFFF)])
+        assert bool((dens.pack_neighbors(a, b, cc, d) == w).all())      # dc_hip_neighbors_pack_dev
         words = w if words is None else torch.minimum(words, w)
     assert bool((owned == 1).all()), "every row belongs to exactly one segment"
     assert bool((acc_p == full_p).all())
@@ -468,3 +469,5 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
     assert bool(((words[0] >> 32).to(torch.int32) == full_n[1].view(torch.int32)).all())
     assert bool(((words[1] & 0xFFFFFFFF).to(torch.int32) == full_n[2]).all())
     assert bool(((words[1] >> 32).to(torch.int32) == full_n[3].view(torch.int32)).all())
+    for got, want in zip(dens.unpack_neighbors(words.contiguous()), full_n):   # dc_hip_neighbors_unpack_dev
+        assert bool((got.view(torch.int32) == want.view(torch.int32)).all())
