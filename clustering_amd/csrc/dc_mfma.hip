@@ -349,14 +349,14 @@ static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           const EdgeSink* sink, hipStream_t stream);
+                           const EdgeSink* sink, hipStream_t stream, bool prep = true);
 
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                        hipStream_t stream) {
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, single_radius(rad2, r), 1,
-                   d_pops + (size_t)r * n_rows, d_ws, nullptr, stream);
+                   d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, r == 0);   // one preparation for all radii
 }
 
 void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
@@ -364,7 +364,7 @@ void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t 
                                uint32_t* d_pops, void* d_ws, hipStream_t stream) {
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments},
-                   single_radius(rad2, r), 1, d_pops + (size_t)r * n_rows, d_ws, nullptr, stream);
+                   single_radius(rad2, r), 1, d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, r == 0);
 }
 
 // positions of the sweep's spatial order -> frame ids, for the pairs actually written; a flagged
@@ -439,7 +439,9 @@ void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_c
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           const EdgeSink* sink_in, hipStream_t stream) {
+                           const EdgeSink* sink_in, hipStream_t stream, bool prep) {
+  // prep == false: the orderings, images and boxes of the previous call (same coordinates, same query
+  // selection) are still in the workspace -- the further radii of one populations call
   const uint32_t i_from = qs.i_from, i_to = qs.i_to;
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
@@ -455,37 +457,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
       grid_tiles((L.T + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
-  // order all frames by their 2-D cell, build the reference image and the tile boxes
-  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
-                     (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
-    return;
-  // original rows in the reference order: the deferred exact path reads them without a
-  // permutation look-up, and the operand images are built from them with coalesced reads
   const float* coords_p = (const float*)(p + L.off_coords_p);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
-                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
-                     (float*)(p + L.off_coords_p));
-  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
-                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
-  hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                     (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
-                     (const float*)nullptr, (float2*)nullptr);
-  // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
-  // buffers are free again)
-  EdgeSink sink_local;
-  const EdgeSink* sink = sink_in;
-  if (sink_in && sink_in->best) {
-    sink_local = *sink_in;
-    hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->comp, (const uint32_t*)perm_p,
-                       n_rows, keys_in);
-    hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->rank, (const uint32_t*)perm_p,
-                       n_rows, keys_out);
-    sink_local.comp = keys_in;
-    sink_local.rank = keys_out;
-    sink = &sink_local;
-  }
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
@@ -496,27 +468,61 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     q_seg = QSeg{qs.n_segments, qs.segment};
   }
   const uint32_t T_q = (n_q + 31) / 32;
-  if (q_mode != kQueryOwnOrder) {
-    // queries in the reference order: only their B form is missing (of the groups of this segment)
-    const uint32_t tq = (uint32_t)tq_pop_of(n_cols);
-    const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
-    if (tiles_q > 0)
-      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
-                         L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                         (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg);
+  EdgeSink sink_local;
+  const EdgeSink* sink = sink_in;
+  if (sink_in && sink_in->best) {   // (component ids and ranks in the sweep's order: gathered below)
+    sink_local = *sink_in;
+    sink_local.comp = keys_in;
+    sink_local.rank = keys_out;
+    sink = &sink_local;
   }
-  if (q_mode == kQueryOwnOrder) {
-    // query rows of this call: the same ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
+  if (prep) {
+    // order all frames by their 2-D cell, build the reference image and the tile boxes
+    hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
+                       (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
       return;
-    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
-                       L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p);
+    // original rows in the reference order: the deferred exact path reads them without a
+    // permutation look-up, and the operand images are built from them with coalesced reads
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
+                       0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
+                       (float*)(p + L.off_coords_p));
+    hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
+                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
+                       (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
     hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
+                       (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
                        (const float*)nullptr, (float2*)nullptr);
+    // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
+    // buffers are free again)
+    if (sink_in && sink_in->best) {
+      hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->comp, (const uint32_t*)perm_p,
+                         n_rows, keys_in);
+      hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->rank, (const uint32_t*)perm_p,
+                         n_rows, keys_out);
+    }
+    if (q_mode != kQueryOwnOrder) {
+      // queries in the reference order: only their B form is missing (of the groups of this segment)
+      const uint32_t tq = (uint32_t)tq_pop_of(n_cols);
+      const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
+      if (tiles_q > 0)
+        hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
+                           L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                           (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg);
+    }
+    if (q_mode == kQueryOwnOrder) {
+      // query rows of this call: the same ordering restricted to [i_from, i_to)
+      hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
+                         (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
+      if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
+        return;
+      hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
+                         L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
+                         (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p);
+      hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
+                         (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
+                         (const float*)nullptr, (float2*)nullptr);
+    }
   }
   switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                 \
