@@ -22,7 +22,7 @@ SYMBOLS = (
     "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs", "dc_hip_radius_min_edge_dev", "dc_hip_radius_forest",
     "dc_hip_populations_segment_dev", "dc_hip_nearest_neighbors_segment_dev",
-    "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev",
+    "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev", "dc_hip_radius_min_edge_segment_dev",
 )
 
 
@@ -75,6 +75,8 @@ def _load():
     lib.dc_hip_neighbors_unpack_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp]
     lib.dc_hip_radius_min_edge_dev.restype = i32
     lib.dc_hip_radius_min_edge_dev.argtypes = [vp, sz, sz, C.c_float, vp, vp, vp, vp, vp, sz, vp]
+    lib.dc_hip_radius_min_edge_segment_dev.restype = i32
+    lib.dc_hip_radius_min_edge_segment_dev.argtypes = [vp, sz, sz, C.c_float, vp, vp, sz, sz, vp, vp, vp, sz, vp]
     lib.dc_hip_radius_forest.restype = i32
     lib.dc_hip_radius_forest.argtypes = [vp, sz, sz, C.c_float, vp, i32, vp, C.POINTER(sz),
                                          C.POINTER(C.c_uint32)]

@@ -460,6 +460,16 @@ int dc_hip_radius_min_edge_dev(const float* d_coords, size_t n_rows, size_t n_co
                                const uint32_t* d_comp, const uint32_t* d_rank,
                                unsigned long long* d_best, uint32_t* d_pops, void* d_workspace,
                                size_t workspace_bytes, void* stream) {
+  return dc_hip_radius_min_edge_segment_dev(d_coords, n_rows, n_cols, r2, d_comp, d_rank, 0, 0, d_best,
+                                            d_pops, d_workspace, workspace_bytes, stream);
+}
+
+int dc_hip_radius_min_edge_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
+                                       const uint32_t* d_comp, const uint32_t* d_rank, size_t segment,
+                                       size_t n_segments, unsigned long long* d_best, uint32_t* d_pops,
+                                       void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (n_segments > 0 && segment >= n_segments)
+    return fail(DC_ERR_INVALID_ARGUMENT, "segment %zu of %zu", segment, n_segments);
   if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
   if (n_rows == 0) return DC_OK;
   if (!d_coords || !d_comp || !d_rank || !d_best || !d_pops)
@@ -477,7 +487,7 @@ int dc_hip_radius_min_edge_dev(const float* d_coords, size_t n_rows, size_t n_co
   if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, false, s))
     return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
   dc::launch_radius_min_edge(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, r2, d_comp, d_rank, d_best,
-                             d_pops, d_workspace, s);
+                             d_pops, d_workspace, s, (uint32_t)segment, (uint32_t)n_segments);
   return check_launch("min-edge sweep launch");
 }
 

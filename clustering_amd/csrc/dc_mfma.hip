@@ -427,14 +427,16 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
 
 void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
                             const uint32_t* d_comp, const uint32_t* d_rank, unsigned long long* d_best,
-                            uint32_t* d_pops, void* d_ws, hipStream_t stream) {
+                            uint32_t* d_pops, void* d_ws, hipStream_t stream, uint32_t segment,
+                            uint32_t n_segments) {
   Rad2 one;
   for (int k = 0; k < kMaxRadiiPerLaunch; ++k) one.v[k] = -1.0f;
   one.v[0] = r2;
   (void)hipMemsetAsync(d_best, 0xFF, sizeof(unsigned long long) * n_rows, stream);
   // comp / rank arrive per FRAME; pop_pruned_one gathers them into the sweep's order
   const EdgeSink sink{nullptr, nullptr, 0, d_comp, d_rank, d_best};
-  pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream);
+  pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments}, one, 1, d_pops, d_ws,
+                 &sink, stream);
 }
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,

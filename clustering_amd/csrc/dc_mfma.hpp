@@ -58,7 +58,8 @@ constexpr size_t kMinEdgeMaxRows = (size_t)1 << 24;   // (the sweep's deferred-e
 // permutation; d_best[id] = (max << 32 | min) or ~0.  d_pops: [n_rows] scratch (populations).
 void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
                             const uint32_t* d_comp, const uint32_t* d_rank, unsigned long long* d_best,
-                            uint32_t* d_pops, void* d_ws, hipStream_t stream);
+                            uint32_t* d_pops, void* d_ws, hipStream_t stream, uint32_t segment = 0,
+                            uint32_t n_segments = 0);   // (n_segments > 0: the pairs seen from one segment's queries)
 // neighbour sweep over (cell, free energy)-ordered frames with ring-wise pruning
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,

@@ -204,10 +204,11 @@ def radius_pairs(coords, r2, capacity=None):
     return pairs[:n].to(torch.int64), pops
 
 
-def radius_min_edge(coords, r2, comp, rank):
-    """One Boruvka round on the radius graph (dc_hip_radius_min_edge_dev): comp, rank int32 CUDA
-    [n_rows] -> (best int64 [n_rows]: (max rank << 32 | min rank) of the lightest pair leaving
-    component id, -1 (all ones) if none; pops int32 [n_rows])."""
+def radius_min_edge(coords, r2, comp, rank, segment=0, n_segments=0):
+    """One Boruvka round on the radius graph (dc_hip_radius_min_edge[_segment]_dev): comp, rank int32
+    CUDA [n_rows] -> (best int64 [n_rows]: (max rank << 32 | min rank) of the lightest pair leaving
+    component id, -1 (all ones) if none; pops int32 [n_rows]).  n_segments > 0: what the queries of one
+    segment of a sharded run see (partials merge by unsigned minimum / summation)."""
     n_rows, n_cols = _check_coords(coords)
     dev = coords.device
     for t in (comp, rank):
@@ -216,10 +217,10 @@ def radius_min_edge(coords, r2, comp, rank):
     pops = torch.empty(n_rows, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
-        rc = capi.lib.dc_hip_radius_min_edge_dev(_dev(coords), n_rows, n_cols, float(r2), _dev(comp),
-                                                 _dev(rank), _dev(best), _dev(pops), ws, ws_bytes,
-                                                 _stream_ptr())
-    capi.check(rc, "dc_hip_radius_min_edge_dev")
+        rc = capi.lib.dc_hip_radius_min_edge_segment_dev(_dev(coords), n_rows, n_cols, float(r2), _dev(comp),
+                                                         _dev(rank), segment, n_segments, _dev(best),
+                                                         _dev(pops), ws, ws_bytes, _stream_ptr())
+    capi.check(rc, "dc_hip_radius_min_edge_segment_dev")
     return best, pops
 
 

@@ -58,6 +58,9 @@ class HipBackend:
     def unpack_neighbors(self, words):
         return self._d.unpack_neighbors(words)
 
+    def radius_min_edge_segment(self, coords, r2, comp, rank, segment, n_segments):
+        return self._d.radius_min_edge(coords, r2, comp, rank, segment, n_segments)[0]
+
 
 class ShardedDensity:
     """pop -> FE -> NN for the rows of this rank, merged across ranks with two collectives."""
@@ -125,3 +128,59 @@ class ShardedDensity:
                 hd_d2[glo:ghi] = recv[g, 3, :ghi - glo].view(torch.float32)
         out.update(nn_idx=nn_idx, nn_d2=nn_d2, hd_idx=hd_idx, hd_d2=hd_d2)
         return out
+
+
+class ShardedForest:
+    """Bottleneck spanning forest of the radius graph (the screening of a -T scan that starts from an empty
+    clustering) with the Boruvka rounds sharded over the ranks: every rank sweeps the
+    query groups of its segment (dc_hip_radius_min_edge_segment_dev), the per-component candidates merge with
+    ONE all-reduce(min) of n_rows int64 words per round, and every rank merges the components itself (same
+    input, same result -- no broadcast)."""
+
+    NONE = (1 << 63) - 1   # "no pair leaves this component" on the wire (the library's ~0 is -1 as int64)
+
+    def __init__(self, backend=None, group=None):
+        self.backend = backend if backend is not None else HipBackend()
+        self.group = group
+
+    def run(self, coords, r2, rank):
+        """coords [N, D] float32 (replicated), rank int32 [N]: a permutation of 0..N-1 (position in order of
+        free energy) on the same device -> (edges int64 numpy [n_edges, 2] of frame ids, rounds)."""
+        import numpy as np
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        if dist.is_available() and dist.is_initialized():
+            me, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        else:
+            me, world = 0, 1
+        n = coords.shape[0]
+        rank_h = rank.cpu().numpy().astype(np.int64)
+        frame_of = np.empty(n, dtype=np.int64)
+        frame_of[rank_h] = np.arange(n)
+        comp_h = np.arange(n, dtype=np.int64)            # id of a component = its smallest frame id
+        edges = []
+        rounds = 0
+        while n > 1 and rounds < 64:
+            rounds += 1
+            comp = torch.from_numpy(comp_h.astype(np.int32)).to(coords.device)
+            best = self.backend.radius_min_edge_segment(coords, r2, comp, rank, me, world if world > 1 else 0)
+            best = torch.where(best < 0, torch.full_like(best, self.NONE), best)
+            if world > 1:
+                dist.all_reduce(best, op=dist.ReduceOp.MIN, group=self.group)
+            b = best.cpu().numpy()
+            picked = np.nonzero(b != self.NONE)[0]
+            if picked.size == 0:
+                break
+            a_f, b_f = frame_of[b[picked] >> 32], frame_of[b[picked] & 0xFFFFFFFF]
+            pairs = np.unique(np.stack([np.minimum(a_f, b_f), np.maximum(a_f, b_f)], axis=1), axis=0)
+            # distinct weights: the picks of one round never close a cycle, every distinct pair is a forest edge
+            edges.append(pairs)
+            g = coo_matrix((np.ones(len(pairs), dtype=np.int8), (comp_h[pairs[:, 0]], comp_h[pairs[:, 1]])),
+                           shape=(n, n))
+            _, lab = connected_components(g, directed=False)
+            lab_of_frame = lab[comp_h]
+            smallest = np.full(lab.max() + 1, n, dtype=np.int64)
+            np.minimum.at(smallest, lab_of_frame, np.arange(n))
+            comp_h = smallest[lab_of_frame]
+        out = np.concatenate(edges) if edges else np.zeros((0, 2), dtype=np.int64)
+        return out, rounds

@@ -201,6 +201,14 @@ DC_API int dc_hip_radius_min_edge_dev(const float* d_coords, size_t n_rows, size
                                       const uint32_t* d_comp, const uint32_t* d_rank,
                                       unsigned long long* d_best, uint32_t* d_pops, void* d_workspace,
                                       size_t workspace_bytes, void* stream);
+/* the same for one segment of a sharded run (n_segments > 0): only the pairs seen from the queries of
+ * that segment enter d_best (every pair is seen from both of its ends, possibly by different segments);
+ * the partial d_best arrays merge by an element-wise UNSIGNED minimum, the partial d_pops by summation. */
+DC_API int dc_hip_radius_min_edge_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
+                                              const uint32_t* d_comp, const uint32_t* d_rank,
+                                              size_t segment, size_t n_segments,
+                                              unsigned long long* d_best, uint32_t* d_pops,
+                                              void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * host-pointer entry points (mirror the reference's per-GPU host functions)

@@ -53,6 +53,87 @@ class SegmentOracleBackend(OracleBackend):
                 torch.where(mask, c, none_i), torch.where(mask, d, none_d))
 
 
+class MinEdgeOracleBackend:
+    """dc_hip_radius_min_edge_segment_dev restated with the oracle's pairwise d2: segment g of G sees the
+    pairs from the query rows i with i % G == g."""
+
+    def __init__(self):
+        from oracle.oracle import Probe, build
+        build()
+        self.p = Probe()
+        self._d2 = None
+
+    def radius_min_edge_segment(self, coords, r2, comp, rank, segment, n_segments):
+        c = coords.numpy()
+        n = c.shape[0]
+        if self._d2 is None:
+            self._d2 = self.p.pairwise_d2(c)
+        comp_h, rank_h = comp.numpy().astype(np.int64), rank.numpy().astype(np.int64)
+        best = np.full(n, -1, dtype=np.int64).view(np.uint64)
+        g = max(n_segments, 1)
+        for i in range(n):
+            if i % g != (segment if n_segments else 0):
+                continue
+            js = np.nonzero((self._d2[i] < np.float32(r2)) & (comp_h != comp_h[i]))[0]
+            if js.size:
+                keys = (np.maximum(rank_h[i], rank_h[js]).astype(np.uint64) << np.uint64(32)) | \
+                    np.minimum(rank_h[i], rank_h[js]).astype(np.uint64)
+                best[comp_h[i]] = min(best[comp_h[i]], keys.min())
+        return torch.from_numpy(best.view(np.int64).copy())
+
+
+def _forest_worker(rank, world, port, n_rows, r2, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clustering_amd.distributed import ShardedForest
+        coords = torch.from_numpy(gaussian_blobs(n_rows, 3, seed=77))
+        fe_rank = torch.from_numpy(np.random.default_rng(5).permutation(n_rows).astype(np.int32))
+        edges, rounds = ShardedForest(MinEdgeOracleBackend()).run(coords, r2, fe_rank)
+        np.savez(os.path.join(out_dir, f"forest{rank}.npz"), edges=edges, rounds=rounds)
+    finally:
+        dist.destroy_process_group()
+
+
+def _components(n, pairs):
+    parent = list(range(n))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b in pairs:
+        ra, rb = find(int(a)), find(int(b))
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+    return np.array([find(i) for i in range(n)])
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_forest_has_the_connectivity_of_the_radius_graph(tmp_path, probe, world):
+    """ShardedForest: Boruvka rounds with the candidates of the segments merged by all-reduce(min) -- a forest
+    of pairs of the radius graph with its connectivity below every rank threshold, identical on all ranks"""
+    n_rows, r2 = 400, 0.01
+    mp.spawn(_forest_worker, args=(world, _free_port(), n_rows, r2, str(tmp_path)), nprocs=world, join=True)
+    c = gaussian_blobs(n_rows, 3, seed=77)
+    d2 = probe.pairwise_d2(c)
+    fe_rank = np.random.default_rng(5).permutation(n_rows).astype(np.int64)
+    ii, jj = np.nonzero(np.triu(d2 < np.float32(r2), k=1))
+    all_pairs = np.stack([ii, jj], axis=1)
+    first = np.load(os.path.join(tmp_path, "forest0.npz"))["edges"]
+    for rank in range(world):
+        assert (np.load(os.path.join(tmp_path, f"forest{rank}.npz"))["edges"] == first).all()
+    pair_set = {(int(a), int(b)) for a, b in all_pairs}
+    assert all((int(min(a, b)), int(max(a, b))) in pair_set for a, b in first)
+    assert len(first) == n_rows - len(np.unique(_components(n_rows, all_pairs))), "not a spanning forest"
+    w_all = np.maximum(fe_rank[all_pairs[:, 0]], fe_rank[all_pairs[:, 1]])
+    w_for = np.maximum(fe_rank[first[:, 0]], fe_rank[first[:, 1]])
+    for t in [0, 60, 150, 250, 400]:
+        assert (_components(n_rows, all_pairs[w_all < t]) == _components(n_rows, first[w_for < t])).all()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

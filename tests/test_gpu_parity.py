@@ -387,6 +387,34 @@ def test_min_edge_round_matches_brute_force(dens, n_rows, n_cols, r2, n_comp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,n_cols,r2,n_seg", [(3000, 10, 0.045, 3), (20000, 4, 0.002, 8), (1500, 30, 0.25, 2)])
+def test_min_edge_segments_merge_to_the_full_round(dens, n_rows, n_cols, r2, n_seg):
+    """dc_hip_radius_min_edge_segment_dev: the candidates seen from the segments' queries merge by unsigned
+    minimum (populations by summation) to those of the whole sweep; and the sharded Boruvka loop of
+    clustering_amd.distributed (single rank here) returns the forest of dc_hip_radius_forest."""
+    import torch
+    from clustering_amd.distributed import ShardedForest
+    c = gaussian_blobs(n_rows, n_cols, seed=21 + n_cols)
+    rng = np.random.default_rng(n_rows + 7)
+    rank = rng.permutation(n_rows).astype(np.int32)
+    comp = (np.arange(n_rows) // 5 * 5).astype(np.int32)           # components of five consecutive frames
+    ct, compt, rankt = torch.from_numpy(c).cuda(), torch.from_numpy(comp).cuda(), torch.from_numpy(rank).cuda()
+    full_b, full_p = dens.radius_min_edge(ct, r2, compt, rankt)
+    acc_b = torch.full_like(full_b, -1)
+    acc_p = torch.zeros_like(full_p)
+    for g in range(n_seg):
+        b, p = dens.radius_min_edge(ct, r2, compt, rankt, g, n_seg)
+        acc_b = torch.from_numpy(np.minimum(acc_b.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+                                 .view(np.int64)).cuda()
+        acc_p += p
+    assert bool((acc_b == full_b).all()) and bool((acc_p == full_p).all())
+    edges, rounds = ShardedForest().run(ct, r2, rankt)
+    want, _ = dens.radius_forest(c, r2, rank.astype(np.uint32))
+    norm = lambda e: sorted((int(min(a, b)), int(max(a, b))) for a, b in e)
+    assert norm(edges) == norm(want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_rows,n_cols,r2", [(700, 3, 0.02), (3000, 10, 0.045), (1500, 30, 0.25), (257, 2, 1e-4),
                                                (20000, 4, 0.002), (1, 3, 1.0), (2, 3, 100.0)])
 def test_radius_forest_has_the_connectivity_of_the_radius_graph(dens, n_rows, n_cols, r2):
