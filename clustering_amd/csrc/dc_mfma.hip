@@ -123,10 +123,32 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   auto col = [&](uint32_t k) -> float { return (x[k] - means[k]) * sc.s1; };   // x'' = 2^k fl(x - mu)
   uint32_t w[4] = {0u, 0u, 0u, 0u};
   if (live) {
+    // the 8 consecutive slots of this fragment (slot_value's layout, with ONE division for the first
+    // coordinate slot instead of one per slot: the divisions were most of this kernel's time)
+    const uint32_t s0 = 16 * m + 8 * h;
+    uint32_t g = 0, k = 0;
+    if (s0 >= (uint32_t)kConstSlots) {
+      g = (s0 - kConstSlots) / D;
+      k = (s0 - kConstSlots) - g * D;
+    }
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
-      const uint32_t v = slot_value(16 * m + 8 * h + j, D, b_form != 0, col) & 0xFFFFu;
-      w[j >> 1] |= v << (16 * (j & 1));
+      uint32_t v;
+      if (s0 + j < (uint32_t)kConstSlots) {
+        v = b_form ? 0u : kConstA;
+      } else {
+        v = 0u;
+        if (g < (uint32_t)kPieceGroups) {
+          const Pieces pc = split2(b_form ? -2.0f * col(k) : col(k));
+          const bool mid = b_form ? (g == 2u) : (g == 1u);
+          v = mid ? pc.mid : pc.hi;
+        }
+        if (++k == D) {
+          k = 0;
+          ++g;
+        }
+      }
+      w[j >> 1] |= (v & 0xFFFFu) << (16 * (j & 1));
     }
   }
   img[((size_t)t * NM + m) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);   // pad rows: all zero
