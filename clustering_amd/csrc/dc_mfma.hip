@@ -270,6 +270,36 @@ __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
   if (ferange) ferange[t] = make_float2(flo, fhi);
 }
 
+// the same from rows that are already gathered into the ordered list (coords_o, fe_o in list order): one
+// lane per row, a half-wave per tile (box_kernel's one thread per tile is latency-bound: 27 - 40 us at C3)
+__global__ void box_rows_kernel(const float* __restrict__ coords_o, uint32_t D, uint32_t n_used,
+                                uint32_t T, float4* __restrict__ boxes, const float* __restrict__ fe_o,
+                                float2* __restrict__ ferange) {
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;   // 32 consecutive lanes = one tile
+  const uint32_t t = pos >> 5;
+  if (t >= T) return;                                           // (whole half-waves leave together)
+  const bool live = pos < n_used;
+  const float x = live ? coords_o[(size_t)pos * D] : 0.0f;
+  const float y = (live && D > 1) ? coords_o[(size_t)pos * D + 1] : 0.0f;
+  float lo0 = live ? x : INFINITY, hi0 = live ? x : -INFINITY;
+  float lo1 = live ? y : INFINITY, hi1 = live ? y : -INFINITY;
+  const float f = (live && fe_o) ? fe_o[pos] : 0.0f;
+  float flo = (live && fe_o) ? f : INFINITY, fhi = (live && fe_o) ? f : -INFINITY;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    lo0 = fminf(lo0, __shfl_xor(lo0, off, 64));
+    hi0 = fmaxf(hi0, __shfl_xor(hi0, off, 64));
+    lo1 = fminf(lo1, __shfl_xor(lo1, off, 64));
+    hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
+    flo = fminf(flo, __shfl_xor(flo, off, 64));
+    fhi = fmaxf(fhi, __shfl_xor(fhi, off, 64));
+  }
+  if ((pos & 31u) == 0) {
+    boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
+    if (ferange) ferange[t] = make_float2(flo, fhi);
+  }
+}
+
 // original coordinates gathered into an ordered frame list (the exact path then needs no
 // permutation look-up before it can fetch a row)
 __global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
@@ -514,9 +544,8 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                        (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
-    hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p),
-                       (const float*)nullptr, (float2*)nullptr);
+    hipLaunchKernelGGL(box_rows_kernel, grid_t, blk, 0, stream, coords_p, n_cols, n_rows, L.T,
+                       (float4*)(p + L.off_box_p), (const float*)nullptr, (float2*)nullptr);
     // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
     // buffers are free again)
     if (sink_in && sink_in->best) {
@@ -619,8 +648,8 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
                      L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
-  hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                     (const uint32_t*)perm_p, n_rows, L.T, (float4*)(p + L.off_box_p), d_fe,
+  hipLaunchKernelGGL(box_rows_kernel, grid_t, blk, 0, stream, coords_p, n_cols, n_rows, L.T,
+                     (float4*)(p + L.off_box_p), (const float*)(p + L.off_fe_s),
                      (float2*)(p + L.off_ferange_p));
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
