@@ -169,19 +169,61 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
                               uint32_t* __restrict__ hdr) {
   __shared__ uint32_t wave_max[4];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t inv = 0;
+  uint32_t inv = 0, top = 0;
   if (i < n_rows) {
     const float f = fe[i];
     if (f != f) atomicOr(hdr + 1, 1u);
     const uint32_t u = __float_as_uint(f);
     const uint32_t key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-    keys[i] = key;
-    vals[i] = i;
+    if (keys) {
+      keys[i] = key;
+      vals[i] = i;
+    }
     inv = ~key;
+    top = (fabsf(f) <= FLT_MAX) ? key : 0u;
   }
-  // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax); at most one
-  // atomic per block
+  // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax), largest FINITE
+  // one -> word 13 (as key); at most one atomic per block and word
   publish_max(hdr + 12, inv, wave_max);
+  publish_max(hdr + 13, top, wave_max);
+}
+
+// ordering key of the pruned neighbour sweep: (cell of columns 0/1, free energy) in ONE 32-bit word --
+// the cell index in the high bits, the free energy quantised to the remaining bits (linear between the
+// smallest and the largest finite value of the data set).  The order inside a cell only shapes the tiles'
+// free-energy ranges (the kernels read the ranges, they assume no order), so the quantisation costs a
+// little pruning at worst and saves one of the two stable sorts.
+__global__ void cellfe_key_kernel(const float* __restrict__ coords, uint32_t D,
+                                  const float* __restrict__ fe, const uint32_t* __restrict__ hdr,
+                                  float frames_per_cell, uint32_t n_rows, uint32_t* __restrict__ keys,
+                                  uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  vals[i] = i;
+  const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
+  const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
+  const float cell = auto_cell(hdr, n_rows, frames_per_cell);
+  float c0 = fmaxf(cell, (max0 - min0) / 4000.0f), c1 = fmaxf(cell, (max1 - min1) / 4000.0f);
+  if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
+  if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
+  const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
+  uint32_t bx = 0, by = 0;
+  if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
+    bx = (uint32_t)fminf(fmaxf((x - min0) / c0, 0.0f), 4001.0f);
+    by = (uint32_t)fminf(fmaxf((y - min1) / c1, 0.0f), 4001.0f);
+  }
+  const uint32_t nbx = (uint32_t)fminf(fmaxf((max0 - min0) / c0, 0.0f), 4001.0f) + 1u;
+  const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 4001.0f) + 1u;
+  const uint32_t cells = nbx * nby;                               // <= 4002^2 < 2^24
+  const uint32_t cell_bits = 32u - (uint32_t)__builtin_clz(cells | 1u);
+  const uint32_t fe_bits = 32u - cell_bits;                       // >= 8
+  const float fe_lo = fkey_inv(~hdr[12]), fe_hi = fkey_inv(hdr[13]);
+  const float span = fe_hi - fe_lo;
+  float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
+  u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
+  const uint32_t levels = (fe_bits >= 32u) ? 0xFFFFFFFFu : ((1u << fe_bits) - 1u);
+  const uint32_t q = (uint32_t)((double)u * (double)levels);
+  keys[i] = ((bx * nby + by) << fe_bits) | q;
 }
 
 __global__ void fe_scatter_kernel(const uint32_t* __restrict__ perm, const float* __restrict__ fe,
@@ -620,8 +662,6 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
   uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
   uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
-  uint32_t* perm_fe = (uint32_t*)(p + L.off_perm);       // scratch: FE order
-  uint32_t* cellkeys = (uint32_t*)(p + L.off_pq);        // scratch: cell key per frame
   uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
   uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
   constexpr float kCellFramesHere = kNnCellFrames;
@@ -629,15 +669,13 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
       grid_tiles((L.T + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
-  // 1. frames by ascending free energy (stable), 2. stable sort of that order by cell key
-  hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in, hdr);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_fe, n_rows, p + L.fixed_end, tmp_bytes, stream))
-    return;
-  hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
-                     (const uint32_t*)hdr, kNnCellFrames, 0u, n_rows, cellkeys, vals_in);
-  hipLaunchKernelGGL(gather_key_kernel, grid_n, blk, 0, stream, (const uint32_t*)cellkeys,
-                     (const uint32_t*)perm_fe, n_rows, keys_in);
-  if (sort_pairs_u32(keys_in, keys_out, perm_fe, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
+  // frames by (cell, free energy): ONE sort on a combined key (cellfe_key_kernel); the pass over the free
+  // energies before it finds their range (and raises the flag for NaNs)
+  hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
+                     (uint32_t*)nullptr, hdr);
+  hipLaunchKernelGGL(cellfe_key_kernel, grid_n, blk, 0, stream, d_coords, n_cols, d_fe,
+                     (const uint32_t*)hdr, kNnCellFrames, n_rows, keys_in, vals_in);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
     return;
   hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
