@@ -168,20 +168,22 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                               uint32_t* __restrict__ hdr) {
   __shared__ uint32_t wave_max[4];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t inv = 0, top = 0;
-  if (i < n_rows) {
+  bool nan = false;
+  // grid-stride: a block publishes its extrema once (two block reductions), however many rows it sees
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
     const float f = fe[i];
-    if (f != f) atomicOr(hdr + 1, 1u);
+    nan = nan | (f != f);
     const uint32_t u = __float_as_uint(f);
     const uint32_t key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
     if (keys) {
       keys[i] = key;
       vals[i] = i;
     }
-    inv = ~key;
-    top = (fabsf(f) <= FLT_MAX) ? key : 0u;
+    inv = max(inv, ~key);
+    top = max(top, (fabsf(f) <= FLT_MAX) ? key : 0u);
   }
+  if (nan) atomicOr(hdr + 1, 1u);
   // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax), largest FINITE
   // one -> word 13 (as key); at most one atomic per block and word
   publish_max(hdr + 12, inv, wave_max);
@@ -671,7 +673,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
   // frames by (cell, free energy): ONE sort on a combined key (cellfe_key_kernel); the pass over the free
   // energies before it finds their range (and raises the flag for NaNs)
-  hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
+  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
                      (uint32_t*)nullptr, hdr);
   hipLaunchKernelGGL(cellfe_key_kernel, grid_n, blk, 0, stream, d_coords, n_cols, d_fe,
                      (const uint32_t*)hdr, kNnCellFrames, n_rows, keys_in, vals_in);
@@ -747,7 +749,7 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
   uint32_t* perm = (uint32_t*)(p + L.off_perm);
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
-  hipLaunchKernelGGL(fe_key_kernel, grid_n, blk, 0, stream, d_fe, n_rows, keys_in, vals_in,
+  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, keys_in, vals_in,
                      (uint32_t*)p);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm, n_rows, p + L.fixed_end,
                      sort_temp_bytes(n_rows), stream) != 0)
