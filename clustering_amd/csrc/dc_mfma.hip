@@ -70,30 +70,44 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   extern __shared__ float rs_tile[];
   __shared__ uint32_t wave_max[4];
   const uint32_t Dp = D | 1u;
-  const size_t base = (size_t)blockIdx.x * 256 * D, total = (size_t)n_rows * D;
-  for (uint32_t e = threadIdx.x; e < 256 * D; e += 256) {
-    const uint32_t r = e / D, k = e - r * D;
-    rs_tile[r * Dp + k] = (base + e < total) ? coords[base + e] : 0.0f;
+  const size_t total = (size_t)n_rows * D;
+  const uint32_t n_chunks = (n_rows + 255) / 256;
+  uint32_t m_norm = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  bool bad = false;
+  // chunks of 256 rows, grid-stride: the block publishes its five extrema once at the end
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const size_t base = (size_t)chunk * 256 * D;
+    __syncthreads();   // (the previous chunk's rows have been read)
+    for (uint32_t e = threadIdx.x; e < 256 * D; e += 256) {
+      const uint32_t r = e / D, k = e - r * D;
+      rs_tile[r * Dp + k] = (base + e < total) ? coords[base + e] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t row = chunk * 256 + threadIdx.x;
+    const bool live = row < n_rows;
+    const float* x = rs_tile + threadIdx.x * Dp;
+    double nrm = 0.0;
+    for (uint32_t k = 0; k < D; ++k) {
+      const float v = x[k] - means[k];
+      nrm += (double)v * (double)v;
+    }
+    const float nf = (float)nrm;
+    const bool ok = live && (nf <= kNormLimit);
+    bad = bad | (live && !ok);   // NaN / inf / overflow-prone row: MFMA kernels stand down
+    m_norm = max(m_norm, ok ? __float_as_uint(nf) : 0u);
+    const float c0 = x[0], c1 = (D > 1) ? x[1] : 0.0f;
+    const bool fin = live && (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
+    m0 = max(m0, fin ? ~fkey(c0) : 0u);
+    m1 = max(m1, fin ? fkey(c0) : 0u);
+    m2 = max(m2, fin ? ~fkey(c1) : 0u);
+    m3 = max(m3, fin ? fkey(c1) : 0u);
   }
-  __syncthreads();
-  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
-  const bool live = row < n_rows;
-  const float* x = rs_tile + threadIdx.x * Dp;
-  double nrm = 0.0;
-  for (uint32_t k = 0; k < D; ++k) {
-    const float v = x[k] - means[k];
-    nrm += (double)v * (double)v;
-  }
-  const float nf = (float)nrm;
-  const bool ok = live && (nf <= kNormLimit);
-  if (live && !ok) atomicOr(hdr + 1, 1u);   // NaN / inf / overflow-prone row: MFMA kernels stand down
-  publish_max(hdr, ok ? __float_as_uint(nf) : 0u, wave_max);
-  const float c0 = x[0], c1 = (D > 1) ? x[1] : 0.0f;
-  const bool fin = live && (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
-  publish_max(hdr + 8, fin ? ~fkey(c0) : 0u, wave_max);
-  publish_max(hdr + 9, fin ? fkey(c0) : 0u, wave_max);
-  publish_max(hdr + 10, fin ? ~fkey(c1) : 0u, wave_max);
-  publish_max(hdr + 11, fin ? fkey(c1) : 0u, wave_max);
+  if (bad) atomicOr(hdr + 1, 1u);
+  publish_max(hdr, m_norm, wave_max);
+  publish_max(hdr + 8, m0, wave_max);
+  publish_max(hdr + 9, m1, wave_max);
+  publish_max(hdr + 10, m2, wave_max);
+  publish_max(hdr + 11, m3, wave_max);
 }
 
 // operand image of the (centred, scaled) coordinates in the fp16x2 slot layout (dc_mfma_kernels.hpp), rows
@@ -387,7 +401,7 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
                      (double*)(p + kHdrSums));
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, stream, (const double*)(p + kHdrSums), n_rows,
                      n_cols, (float*)(p + kHdrMeans));
-  hipLaunchKernelGGL(rowstats_kernel, dim3((n_rows + 255) / 256), dim3(256),
+  hipLaunchKernelGGL(rowstats_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 1024u)), dim3(256),
                      sizeof(float) * 256 * (n_cols | 1u), stream, d_coords, n_rows, n_cols,
                      (const float*)(p + kHdrMeans), (uint32_t*)p);
   // frames in natural order: only the full-sweep kernels read this image
