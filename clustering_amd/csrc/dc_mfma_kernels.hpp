@@ -1862,6 +1862,23 @@ __global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ me
   hd_d2[i] = __uint_as_float((uint32_t)(b >> 32));
 }
 
+// the same by FRAME (coalesced) when the queries are the rows of the reference order: frame i sits at
+// position invpos[i], which tells whether one of this launch's groups owns it
+__global__ void nn_merge_unpack_rows_kernel(const unsigned long long* __restrict__ merge64,
+                                            const uint32_t* __restrict__ invpos, uint32_t n_rows,
+                                            uint32_t tq, QSeg q_seg, uint32_t* __restrict__ nn_idx,
+                                            float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
+                                            float* __restrict__ hd_d2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  if (q_seg.stride > 1 && (invpos[i] / (32u * tq)) % q_seg.stride != q_seg.offset) return;
+  const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
+  nn_idx[i] = (uint32_t)a;
+  nn_d2[i] = __uint_as_float((uint32_t)(a >> 32));
+  hd_idx[i] = (uint32_t)b;
+  hd_d2[i] = __uint_as_float((uint32_t)(b >> 32));
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch helpers (one MFMA count per translation unit; the template parameter S below is NM)
 // ---------------------------------------------------------------------------------------------
@@ -1956,7 +1973,11 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
                      hd_d2);
-  if (n_chunks > 1)
+  if (n_chunks > 1 && A.full_range)
+    hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
+                       (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)TQV, A.q_seg,
+                       nn_idx, nn_d2, hd_idx, hd_d2);
+  else if (n_chunks > 1)
     hipLaunchKernelGGL(nn_merge_unpack_kernel, dim3((A.n_q + 255) / 256), dim3(256), 0, s,
                        (const unsigned long long*)A.merge64, A.perm_q, A.n_q, n_rows, (uint32_t)TQV, A.q_seg,
                        nn_idx, nn_d2, hd_idx, hd_d2);
