@@ -747,6 +747,7 @@ enum QueryMode { kQueryOwnOrder = 0, kQueryAll = 1 };
 
 constexpr int kListCap = 1024;   // reference tiles scanned per round (LDS list entries per wave)
 constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane and query tile
+constexpr int kSeedNeighbours = 4;   // neighbour sweep: frames on either side of a query evaluated up front
 
 // ---- deferred exact re-check (pruned sweep) --------------------------------------------------------
 // A band pair is not evaluated the moment it appears (one or two lanes busy for a full, dependent
@@ -1573,6 +1574,35 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     gbox.y = fmaxf(gbox.y, qbox[qt].y);
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
+  }
+  // Seeds: the frames next to each query in the sweep's order (same cell, neighbouring free energy; the
+  // ones before it have a lower free energy) are evaluated exactly before the first ring.  They are
+  // ordinary candidates; what they buy is finite running minima from the start -- without them the first
+  // tiles of a sweep park every element, and query groups in sparse regions (wide boxes, long first ring)
+  // spent a microsecond per chain in the candidate path.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (query rows: written by the h = 0 lanes)
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const bool live = (livemask[qt] >> lane) & 1;
+    NnPQ& Q = q[qt];
+    // (only the first reference share: the later ones start from what the earlier ones published)
+    if (live && chunk == 0) {
+      const float* qrow = qrows + (qt * 32 + c) * n_cols;
+      for (int k = 1; k <= kSeedNeighbours; ++k) {
+        const long long p2 = (long long)Q.spos + (h ? -k : k);
+        if (p2 >= 0 && p2 < (long long)n_rows) {
+          const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)p2 * n_cols, 1, (int)n_cols);
+          const uint32_t j = perm_r[p2];
+          lexi_update(true, Q.bd_nn, Q.bj_nn, d2c, j, n_rows);
+          lexi_update(fe_c[p2] < Q.feq, Q.bd_hd, Q.bj_hd, d2c, j, n_rows);
+        }
+      }
+      const float s_nn = Q.bd_nn * sc.s2, s_hd = Q.bd_hd * sc.s2;
+      if (Q.bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
+      if (Q.bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
+      Q.bn = nn_band(gb, Q.m_nn);
+      Q.bh = nn_band(gb, Q.m_hd);
+    }
   }
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
   // ordering pass): a query at that level has no lower-FE neighbour

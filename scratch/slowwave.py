@@ -1,3 +1,4 @@
+"""probe build only (scratch/build_variant.sh with the counters patched in): slowest wave of every segment"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from clustering_amd import density as dens
@@ -8,5 +9,5 @@ pops = dens.calculate_populations_partial(c, [0.2])
 fe = dens.calculate_free_energies(pops[0].contiguous())
 for seg in range(G):
     dens.nearest_neighbors_segment(c, fe, seg, G)
-    v = dens.evaluated_tiles(c.device)[1]
-    print(f"segment {seg}: slowest wave {(v >> 40) / 100.0:.1f} us, chains {(v >> 20) & 0xFFFFF}, group {v & 0xFFFFF}")
+    w, v = dens.evaluated_tiles(c.device)
+    print(f"segment {seg}: slowest wave {(v >> 44) / 100.0:.1f} us, chains {(v >> 28) & 0xFFFF}, rare {(v >> 14) & 0x3FFF}, special {v & 0x3FFF} | trig {(w >> 30) & 0x3FFF}, flush slots {(w >> 14) & 0xFFFF}, rings {(w >> 6) & 0xFF}")
