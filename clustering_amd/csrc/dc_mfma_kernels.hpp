@@ -1602,6 +1602,14 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       if (Q.bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
       Q.bn = nn_band(gb, Q.m_nn);
       Q.bh = nn_band(gb, Q.m_hd);
+      // published at once: the other shares of this group start while this wave is still sweeping
+      if (n_chunks > 1) {
+        if (Q.bd_nn < FLT_MAX)
+          atomicMin(&merge64[jq[qt]], ((unsigned long long)__float_as_uint(Q.bd_nn) << 32) | Q.bj_nn);
+        if (Q.bd_hd < FLT_MAX)
+          atomicMin(&merge64[(size_t)n_rows + jq[qt]],
+                    ((unsigned long long)__float_as_uint(Q.bd_hd) << 32) | Q.bj_hd);
+      }
     }
   }
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the

@@ -10,4 +10,4 @@ fe = dens.calculate_free_energies(pops[0].contiguous())
 for seg in range(G):
     dens.nearest_neighbors_segment(c, fe, seg, G)
     w, v = dens.evaluated_tiles(c.device)
-    print(f"segment {seg}: slowest wave {(v >> 44) / 100.0:.1f} us, chains {(v >> 28) & 0xFFFF}, rare {(v >> 14) & 0x3FFF}, special {v & 0x3FFF} | trig {(w >> 30) & 0x3FFF}, flush slots {(w >> 14) & 0xFFFF}, rings {(w >> 6) & 0xFF}")
+    print(f"segment {seg}: slowest wave {(v >> 44) / 100.0:.1f} us, chains {(v >> 28) & 0xFFFF}, rare {(v >> 14) & 0x3FFF}, special {v & 0x3FFF} | trig {(w >> 30) & 0x3FFF}, flush slots {(w >> 14) & 0xFFFF}, rings {(w >> 6) & 0xFF}, chunk {w & 0x3F}")
