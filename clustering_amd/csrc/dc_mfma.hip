@@ -369,13 +369,6 @@ __global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
   out[e] = coords[(size_t)perm[pos] * D + k];
 }
 
-// stable second sort pass: key of the frame that currently sits at position p
-__global__ void gather_key_kernel(const uint32_t* __restrict__ keys_by_frame,
-                                  const uint32_t* __restrict__ perm, uint32_t n,
-                                  uint32_t* __restrict__ keys_out) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) keys_out[p] = keys_by_frame[perm[p]];
-}
 
 }  // namespace
 
