@@ -158,7 +158,7 @@ def main():
     def step(timed):
         if timed:
             ev[0].record()
-        # (the same calls ShardedDensity makes: segments of the spatial order when sharded)
+        # (the same calls ShardedDensity makes: every world-th query group of the spatial order when sharded)
         pops = (backend.populations_segment(coords, args.radii, rank, world) if world > 1
                 else backend.populations_partial(coords, args.radii, lo, hi))
         if timed:
@@ -271,7 +271,7 @@ def main():
                 "workload": f"{n} frames x {d} dims, 3-Gaussian-blob (sigma 0.08, seed 20240), radii {args.radii}, "
                             + ("pop + free energy + nn/nn_hd" if want_nn else "pop + free energy"),
                 "n_rows": n, "n_cols": d, "radii": args.radii, "variant": args.variant,
-                "parallelism": f"rows sharded over {world} GPU(s) (segments of the spatial order), coords replicated; "
+                "parallelism": f"rows sharded over {world} GPU(s) (every {world}-th query group of the spatial order), coords replicated; "
                                "all-reduce(sum) of the populations + all-reduce(min) of the packed (d2, index) neighbour words",
             },
             "phases_ms": {"pop_kernel": 1e3 * pop_t, "nn_kernel": 1e3 * nn_t,
