@@ -62,7 +62,8 @@ const char* kHelp =
     "options:\n"
     "  -h [ --help ]                         show this help.\n"
     "  -f [ --file ] arg                     input (required): phase space coordinates\n"
-    "                                        (space separated ASCII).\n"
+    "                                        (space separated ASCII; this build also\n"
+    "                                        reads NumPy .npy, float32/float64 C order).\n"
     "  -r [ --radius ] arg                   parameter: hypersphere radius. If not used, the\n"
     "                                        lumping radius will be used instead.\n"
     "  -R [ --radii ] arg                    parameter: list of radii for population/free energy\n"
