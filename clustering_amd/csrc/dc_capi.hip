@@ -444,7 +444,7 @@ int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t n_cols,
   }
   if (!d_coords || !d_pops) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   if (!dc::mfma_supports(n_cols))
-    return fail(DC_ERR_INVALID_ARGUMENT, "radius pairs need n_cols <= 32 (got %zu)", n_cols);
+    return fail(DC_ERR_INVALID_ARGUMENT, "radius pairs need n_cols <= 64 (got %zu)", n_cols);
   if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
     return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                 dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
@@ -475,7 +475,7 @@ int dc_hip_radius_min_edge_segment_dev(const float* d_coords, size_t n_rows, siz
   if (!d_coords || !d_comp || !d_rank || !d_best || !d_pops)
     return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   if (!dc::mfma_supports(n_cols))
-    return fail(DC_ERR_INVALID_ARGUMENT, "the radius graph needs n_cols <= 32 (got %zu)", n_cols);
+    return fail(DC_ERR_INVALID_ARGUMENT, "the radius graph needs n_cols <= 64 (got %zu)", n_cols);
   if (n_rows > dc::kMinEdgeMaxRows)
     return fail(DC_ERR_INVALID_ARGUMENT, "min-edge sweeps need n_rows <= %zu (got %zu)",
                 (size_t)dc::kMinEdgeMaxRows, n_rows);

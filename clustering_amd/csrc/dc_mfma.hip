@@ -17,8 +17,8 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 __global__ void colsum_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                               double* __restrict__ sums) {
-  __shared__ double part[32];
-  if (threadIdx.x < 32) part[threadIdx.x] = 0.0;
+  __shared__ double part[kMaxCols];
+  if (threadIdx.x < (uint32_t)kMaxCols) part[threadIdx.x] = 0.0;
   __syncthreads();
   const uint32_t nthreads = gridDim.x * blockDim.x;
   const uint32_t used = (nthreads / D) * D;             // stride is a multiple of D: fixed column
@@ -372,7 +372,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
 
 }  // namespace
 
-#define DC_FOR_EACH_S(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define DC_FOR_EACH_S(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 DC_FOR_EACH_S(DC_DECLARE_STEP)
 
 bool mfma_supports(size_t n_cols) {
@@ -447,7 +447,7 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 struct QuerySel {
   uint32_t i_from, i_to, segment, n_segments;
 };
-static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 8 ? 4 : 2; }   // = tq_for<NM>
+static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 5 ? 4 : 2; }   // = tq_for<NM>
 static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,

@@ -32,7 +32,7 @@
 //     acc = |y'|^2 + c_q - 2 x'.y'   with  c_q = |x'|^2 - (r^2 - eps)   (populations: inside <=> acc < 0)
 //                                          c_q = |x'|^2                 (neighbours:  acc ~ d2)
 // NM = ceil((3 D + 2) / 16) MFMAs per tile: 2 for D = 10 (the first, exact bf16x3 version of these
-// kernels -- git tag bf16x3-r1 -- needed 4; the fp32 MFMA 5 of 4x the cycles), 7 for D = 32.
+// kernels -- git tag bf16x3-r1 -- needed 4; the fp32 MFMA 5 of 4x the cycles), 7 for D = 32, 13 for D = 64 (kMaxCols).
 // fp16 has a narrow exponent range, so everything the matrix pipe sees is SCALED by a power of two
 // chosen per data set (exact): x'' = 2^k x', S = 4^k with S max|x'|^2 in [2^26, 2^28).  Then
 // |x''_k| < 2^14, |-2 x''_k| < 2^15 and |c_q| / 2^15 < 65504 all fit, and pieces below the smallest
@@ -83,16 +83,18 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kMaxCols = 32;           // n_cols handled by the matrix-core kernels
+constexpr int kMaxCols = 64;           // n_cols handled by the matrix-core kernels
 constexpr int kConstSlots = 2;         // K slots 0..1: 2^15 (A side) x pieces of c_q / 2^15 (B side)
 constexpr int kPieceGroups = 3;        // piece products per column: hi*hi, mid*hi, hi*mid
 // MFMAs per tile pair: 3 piece products per column + the constant slots, 16 slots per MFMA
 constexpr int nm_for(int n_cols) { return (kPieceGroups * n_cols + kConstSlots + 15) / 16; }
-constexpr int kMaxMfma = nm_for(kMaxCols);   // 7
+constexpr int kMaxMfma = nm_for(kMaxCols);   // 13
 constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits, UNSCALED); word 1: non-finite flag;
                                        // words 8..11: extent of columns 0/1; word 12: ~key of min FE
-constexpr size_t kHdrSums = 256;       // byte 256..511: column sums (double) for the centring
-constexpr size_t kHdrMeans = 512;      // byte 512..639: column means as float (what x' = x - mu uses)
+constexpr size_t kHdrSums = 256;       // byte 256..767: column sums (double) for the centring
+constexpr size_t kHdrMeans = 768;      // byte 768..1023: column means as float (what x' = x - mu uses)
+static_assert(kHdrSums + 8 * kMaxCols <= kHdrMeans && kHdrMeans + 4 * kMaxCols <= kHdrBytes,
+              "header regions sized for kMaxCols columns");
 constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram form -> flagged
 
 // Workspace layout.  Regions used by the population sweep: hdr, img, norms.  The neighbour sweep
@@ -1921,9 +1923,11 @@ __global__ void nn_merge_unpack_rows_kernel(const unsigned long long* __restrict
 // launch helpers (one MFMA count per translation unit; the template parameter S below is NM)
 // ---------------------------------------------------------------------------------------------
 // query tiles per wave (pruned sweeps): as many as the resident B fragments (4 * TQ * NM registers)
-// leave room for at two waves per SIMD; each reference fragment is fetched once per TQ chains
+// leave room for at two waves per SIMD; each reference fragment is fetched once per TQ chains.  Measured at
+// 300k rows: NM = 5 (D = 24) 5.6 / 6.2 ms with four tiles against 6.4 / 6.5 with two; NM = 6 (D = 30) 7.8 / 9.3 against
+// 7.1 / 7.4; NM = 7 (D = 32) 8.2 / 10.0 against 7.7 / 8.3; NM = 8 (D = 40) 11.0 / 11.4 against 8.8 / 10.0.
 template <int NM>
-constexpr int tq_for = (NM <= 8) ? 4 : 2;
+constexpr int tq_for = (NM <= 5) ? 4 : 2;
 // the population sweep keeps less state per query tile: with two MFMAs per chain six tiles fit
 // (measured at C3: 23.6 ms against 25.1 ms with four; eight spill; the neighbour sweep loses at six)
 template <int NM>

@@ -113,7 +113,7 @@ DC_API int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n
  * a rank's queries are as compact as those of a full sweep and prune as well (a block of consecutive
  * rows of a trajectory is spread over the whole conformational space), and dealing the groups out
  * cyclically gives every rank the same mix of dense and sparse regions; with every other variant,
- * n_cols > 32 or non-finite data the
+ * n_cols > 64 or non-finite data the
  * segment is the reference's row block.  d_pops as above: zeros for the rows of other segments, so
  * that the partials merge by summation. */
 DC_API int dc_hip_populations_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols,
@@ -180,7 +180,7 @@ DC_API int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2
  *            pair once; may be NULL with capacity 0 to count only
  *   d_count  device uint64, out: number of pairs found -- if it exceeds capacity only the first
  *            `capacity` were written (call again with a larger buffer); ~0 if the coordinates are not
- *            finite (no pairs are produced then).  Needs n_cols <= 32 and a workspace as above. */
+ *            finite (no pairs are produced then).  Needs n_cols <= 64 and a workspace as above. */
 DC_API int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
                                    uint32_t* d_pops, uint32_t* d_pairs, size_t capacity,
                                    unsigned long long* d_count, void* d_workspace,
@@ -195,7 +195,7 @@ DC_API int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t 
  *   d_best   [n_rows] uint64 device, out: d_best[id] = (max << 32 | min) of the lightest pair with
  *            canonical d2 < r2 that joins component id to another one, ~0 if there is none
  *   d_pops   [n_rows] uint32 device, out: populations at that radius
- * Needs n_cols <= 32, n_rows <= 2^24 and a workspace as above; with coordinates that are not finite
+ * Needs n_cols <= 64, n_rows <= 2^24 and a workspace as above; with coordinates that are not finite
  * every d_best entry stays ~0 (dc_hip_radius_forest reports the error). */
 DC_API int dc_hip_radius_min_edge_dev(const float* d_coords, size_t n_rows, size_t n_cols, float r2,
                                       const uint32_t* d_comp, const uint32_t* d_rank,

@@ -10,7 +10,7 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     n = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 257, 1000, 3000, 9000, 40000, 150000], p=[.03,.03,.05,.05,.05,.05,.1,.14,.2,.12,.08,.07,.03]))
-    d = int(rng.integers(1, 33))
+    d = int(rng.integers(1, 65)) if rng.random() < 0.3 else int(rng.integers(1, 33))
     kind = rng.integers(0, 5)
     c = gaussian_blobs(n, d, seed=int(rng.integers(1, 1 << 30)), sigma=float(rng.choice([0.02, 0.08, 0.3])))
     if kind == 1:   # duplicates
@@ -58,7 +58,12 @@ for case in range(n_cases):
             print(f"SEGMENT MISMATCH case {case}: n={n} d={d} G={G} kind={kind}")
         if n <= 40000:
             r2 = float(np.float32(radii[0]) * np.float32(radii[0]))
-            pairs, pp = dens.radius_pairs(ct, r2)
+            try:
+                pairs, pp = dens.radius_pairs(ct, r2)
+            except Exception as e:
+                print(f"RADIUS PAIRS ERROR case {case}: n={n} d={d} kind={kind} r2={r2} absmax={float(np.abs(c).max())}: {e}")
+                bad += 1
+                continue
             deg = torch.ones(n, dtype=torch.int64, device="cuda")
             if pairs.shape[0]:
                 deg += torch.bincount(pairs.reshape(-1), minlength=n)

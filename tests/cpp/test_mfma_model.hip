@@ -246,6 +246,8 @@ int main() {
   bad += run_gram<nm_for(10)>(10, 1e-3f, 0.0f, 4e-6f, &worst_ratio, 40);
   bad += run_gram<nm_for(30)>(30, 0.1f, 0.5f, 0.09f, &worst_ratio, 40);
   bad += run_gram<nm_for(32)>(32, 1e-3f, 1e-2f, 1e-5f, &worst_ratio, 40);
+  bad += run_gram<nm_for(48)>(48, 0.1f, 0.5f, 0.3f, &worst_ratio, 30);
+  bad += run_gram<nm_for(64)>(64, 0.05f, 2.0f, 0.2f, &worst_ratio, 30);
   printf("fp16x2 gram chain: worst error / (MFMA + dropped-product part of the band) = %.3f, violations %d\n",
          worst_ratio, bad);
   const bool ok = failures == 0 && bad == 0;

@@ -99,12 +99,22 @@ def test_parity_templated_dims(dens, oracle, D, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("D", [33, 40, 100])
+@pytest.mark.parametrize("D", [33, 40, 48, 64, 65, 100])
 def test_parity_generic_dims(dens, oracle, D, variant):
     if not _supported(variant, D):
         pytest.skip("variant does not support this n_cols")
     c = gaussian_blobs(1500, D, seed=2000 + D)
     check_full(dens, oracle, c, [0.08 * np.sqrt(2.0 * D), 0.1 * np.sqrt(2.0 * D)], variant, fe_from=1)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n_rows,D", [(64, 37), (100, 61), (257, 64), (33, 48)])
+def test_parity_wide_rows_small_sets(dens, oracle, n_rows, D, variant):
+    """33 .. 64 columns on a handful of frames (the header of the workspace holds per-column sums and
+    means: sized for 64 columns; a fuzz run caught it while it was still sized for 32)"""
+    need(variant, D)
+    c = gaussian_blobs(n_rows, D, seed=3000 + D)
+    check_full(dens, oracle, c, [0.08 * np.sqrt(2.0 * D), 0.11 * np.sqrt(2.0 * D)], variant)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -467,10 +477,10 @@ def test_chunked_launches_match_direct(dens, rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_rows,n_cols,n_seg", [(5000, 10, 2), (70000, 4, 8), (1000, 30, 3), (37, 2, 5), (4000, 40, 2)])
+@pytest.mark.parametrize("n_rows,n_cols,n_seg", [(5000, 10, 2), (70000, 4, 8), (1000, 30, 3), (37, 2, 5), (4000, 40, 2), (3000, 70, 2)])
 def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols, n_seg):
     """dc_hip_*_segment_dev: the segments of a sharded run (every n_seg-th query group of the spatial order
-    with the pruned sweep, row blocks otherwise -- n_cols = 40 has no matrix-core kernel) partition the rows: summed
+    with the pruned sweep, row blocks otherwise -- n_cols = 70 has no matrix-core kernel) partition the rows: summed
     populations and min-merged (d2, index) words equal the single-device result bit for bit."""
     import torch
     c = gaussian_blobs(n_rows, n_cols, seed=5 + n_seg)
