@@ -747,7 +747,10 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n_blocks
 //                   them, or the query groups of one segment of a sharded run (QSeg)
 enum QueryMode { kQueryOwnOrder = 0, kQueryAll = 1 };
 
-constexpr int kListCap = 1024;   // reference tiles scanned per round (LDS list entries per wave)
+// reference tiles scanned per round (LDS list entries per wave).  512, not more: with the query rows and the
+// queues a block then stays below 80 KB of LDS -- two blocks per CU -- for every column count up to 64
+// (1024: D = 25, 26 and 57..64 fell to one block per CU; 300k x 26: 7.4 / 8.1 ms -> 5.8 / 6.7 ms; C3 unchanged)
+constexpr int kListCap = 512;
 constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane and query tile
 constexpr int kSeedNeighbours = 4;   // neighbour sweep: frames on either side of a query evaluated up front
 
