@@ -128,3 +128,24 @@ def test_c5_shape_one_segment_of_eight(dens, fast_oracle):
     assert (block[:, lo:lo + 700].astype(np.uint64) == want[:, lo:lo + 700]).all()
     mine = rows[(rows >= lo) & (rows < lo + 700)]
     assert len(mine) > 20 and (seg[:, mine] == block[:, mine]).all()
+
+
+def test_c4_eight_segments_merge_to_the_single_device_result(dens):
+    """C4 = C3 sharded over 8 GPUs: the eight segments a rank each would compute, merged the way
+    clustering_amd.distributed merges them (sum of the populations, minimum of the packed neighbour words),
+    equal the single-device result on every row."""
+    import torch
+    n, d, r, G = 1_000_000, 10, 0.2, 8
+    ct = torch.from_numpy(gaussian_blobs(n, d)).cuda()
+    full_p = dens.calculate_populations_partial(ct, [r])
+    fe = dens.calculate_free_energies(full_p[0].contiguous())
+    full_n = dens.nearest_neighbors_partial(ct, fe)
+    acc_p = torch.zeros_like(full_p)
+    words = None
+    for g in range(G):
+        acc_p += dens.calculate_populations_segment(ct, [r], g, G)
+        w = dens.pack_neighbors(*dens.nearest_neighbors_segment(ct, fe, g, G))
+        words = w if words is None else torch.minimum(words, w)
+    assert bool((acc_p == full_p).all())
+    for got, want in zip(dens.unpack_neighbors(words), full_n):
+        assert bool((got.view(torch.int32) == want.view(torch.int32)).all())
