@@ -85,6 +85,27 @@ def test_cli_reads_npy_coordinates(tmp_path, oracle, dtype):
     assert r.returncode != 0 and "2-dimensional" in r.stderr + r.stdout
 
 
+def test_cli_parses_large_ascii_files_in_pieces(tmp_path, oracle):
+    """files above 8 MB are parsed by several threads, cut at line ends: same matrix, same outputs; a token
+    that is not a number ends the data there (the reference's `ifs >> float` fails at it, tools.hxx:80-108)"""
+    c = write_coords(tmp_path / "coords", gaussian_blobs(260000, 4, seed=47))
+    assert os.path.getsize(tmp_path / "coords") > (2 << 22)
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "0.03", "-p", str(tmp_path / "pop"), "-v"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "260000x4" in r.stdout + r.stderr
+    assert data_lines(tmp_path / "pop") == [str(int(p)) for p in oracle.populations(c, [0.03])[0]]
+    # a bad token two thirds into the file: the frames before it are the data set
+    lines = open(tmp_path / "coords").read().split("\n")
+    lines[170000] = "0.1 0.2 oops 0.4"
+    open(tmp_path / "broken", "w").write("\n".join(lines))
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "broken"), "-r", "0.03", "-p", str(tmp_path / "pop2"), "-v"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "170000x4" in r.stdout + r.stderr          # 170000 full rows + two values of the broken line
+    assert data_lines(tmp_path / "pop2") == [str(int(p)) for p in oracle.populations(c[:170000], [0.03])[0]]
+
+
 def test_cli_multi_radius_files(tmp_path, oracle):
     c = write_coords(tmp_path / "coords", gaussian_blobs(2000, 10, seed=43))
     radii = [0.3, 0.1, 0.2]
