@@ -312,7 +312,8 @@ def main():
                 "pop": full(full_ms["pop_kernel"]),
                 "nn": None if full_ms["nn_kernel"] is None else full(full_ms["nn_kernel"]),
             }
-        if args.cpu_sample > 0:
+        # (rank 0 of a single-GPU run only: the other ranks of a sharded run would wait for it at the barrier)
+        if args.cpu_sample > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(coords_np, args.radii, min(args.cpu_sample, n), want_nn)
         else:
             line["cpu_baseline"] = None
