@@ -116,6 +116,7 @@ struct Layout {
       off_ferange_p,   // per reference tile (fe_lo, fe_hi) -- pruned neighbour sweep
       off_coords_p,    // ORIGINAL coordinates gathered into the reference order (exact path reads)
       off_merge64,     // [2][n_rows] packed (d2, id) for merging reference chunks (neighbour sweep)
+      off_box_t,       // tile boxes regrouped by reference share (neighbour sweep: contiguous scans)
       fixed_end;
 };
 
@@ -150,7 +151,8 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_ferange_p = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.T);
   L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.T);
   L.off_merge64 = align256(L.off_coords_p + sizeof(float) * n_rows * n_cols);
-  L.fixed_end = align256(L.off_merge64 + sizeof(unsigned long long) * 2 * n_rows);
+  L.off_box_t = align256(L.off_merge64 + sizeof(unsigned long long) * 2 * n_rows);
+  L.fixed_end = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.T + 64));
   return L;
 }
 
@@ -1496,7 +1498,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ fe, const uint4* __restrict__ img_r,
     const float* __restrict__ norms_r, const uint32_t* __restrict__ perm_r,
-    const float4* __restrict__ box_r, const float2* __restrict__ ferange_r,
+    const float4* __restrict__ box_r, const float4* __restrict__ box_t,
+    const float2* __restrict__ ferange_r,
     const float* __restrict__ fe_c, const float* __restrict__ coords_c,
     const uint32_t* __restrict__ invpos_r, uint32_t T,
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
@@ -1639,6 +1642,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scans only touch their own boxes)
   const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
+  const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
@@ -1648,12 +1652,15 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       uint32_t cnt = 0;
       const uint32_t lim = min(U - base, (uint32_t)kListCap);
       auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
-      float4 rb_next = ((uint32_t)lane < lim) ? box_r[tile_of(base + lane)]
+      // (box_t: the boxes of this share stored contiguously -- a step of the scan reads 1 KB instead of
+      //  gathering 64 cache lines gridDim.y tiles apart)
+      const float4* box_s = box_t + (size_t)chunk * U_stride;
+      float4 rb_next = ((uint32_t)lane < lim) ? box_s[base + lane]
                                               : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
       for (uint32_t k = 0; k < lim; k += 64) {
         const uint32_t t = tile_of(base + k + lane);
         const float4 rb = rb_next;   // fetched one step ahead: the scan is latency-bound otherwise
-        if (k + 64 + lane < lim) rb_next = box_r[tile_of(base + k + 64 + lane)];
+        if (k + 64 + lane < lim) rb_next = box_s[base + k + 64 + lane];
         bool ok = false;
         if (k + lane < lim) {
           const float g2 = box_gap2(gbox, rb);
@@ -1956,11 +1963,22 @@ void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const P
                      P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
 }
 
+// tile boxes regrouped by reference share: share c holds the tiles c, c + n, c + 2n, ... at
+// box_t[c * ceil(T / n) + u]
+__global__ void box_by_share_kernel(const float4* __restrict__ box_r, uint32_t T, uint32_t n_chunks,
+                                    float4* __restrict__ box_t) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const uint32_t stride = (T + n_chunks - 1) / n_chunks;
+  box_t[(size_t)(t % n_chunks) * stride + t / n_chunks] = box_r[t];
+}
+
 struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy) ordering
   const uint4* img_r;
   const float* norms_r;
   const uint32_t* perm_r;
   const float4* box_r;
+  float4* box_t;
   const float2* ferange_r;
   const float* fe_c;
   const float* coords_c;
@@ -2013,8 +2031,9 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
   if (n_chunks > 1)
     hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s,
                        A.merge64, n_rows);
+  hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
   hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + 3) / 4, n_chunks), dim3(256), smem, s,
-                     coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, A.ferange_r,
+                     coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
                      hd_d2);

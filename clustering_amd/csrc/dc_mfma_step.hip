@@ -39,6 +39,7 @@ void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint
   A.norms_r = (const float*)(p + L.off_norm_p);
   A.perm_r = (const uint32_t*)(p + L.off_perm_p);
   A.box_r = (const float4*)(p + L.off_box_p);
+  A.box_t = (float4*)(p + L.off_box_t);
   A.ferange_r = (const float2*)(p + L.off_ferange_p);
   A.fe_c = (const float*)(p + L.off_fe_s);
   A.coords_c = (const float*)(p + L.off_coords_p);
