@@ -1716,7 +1716,12 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               hmin = fminf(hmin, (fef[r] < Q.feq) ? v : INFINITY);
             }
           }
-          const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+          // (the two half-wave lanes of a query see different rows of every tile: what either of them has
+          //  found bounds the answer of both, so the running minima are shared whenever they move -- the
+          //  records of one sequence over all rows instead of two over half of them each)
+          float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+          new_nn = fminf(new_nn, __shfl_xor(new_nn, 32, 64));
+          new_hd = fminf(new_hd, __shfl_xor(new_hd, 32, 64));
           const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
           const bool trig = (tmin < bn) | (hmin < bh);
           if (__builtin_amdgcn_ballot_w64(trig) != 0) {
