@@ -63,7 +63,8 @@ typedef enum dc_status {
 typedef enum dc_variant {
   DC_VARIANT_AUTO = 0,        /* fastest available: pruned MFMA when n_cols allows, else direct */
   DC_VARIANT_DIRECT = 1,      /* VALU, direct differences in the canonical order: exact by construction */
-  DC_VARIANT_MFMA = 2,        /* fp32 MFMA Gram form + guard band + canonical re-check, every pair evaluated */
+  DC_VARIANT_MFMA = 2,        /* matrix-core Gram form (two fp16 pieces per coordinate, n_cols <= 64) as a
+                                 classifier + guard band + canonical re-check; every pair evaluated */
   DC_VARIANT_MFMA_PRUNED = 3  /* the same on spatially ordered frames, skipping tile pairs farther apart than
                                  the radius (the GPU counterpart of the reference's box grid,
                                  density_clustering.cpp:41-89); identical results */
