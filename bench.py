@@ -11,11 +11,13 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one
     1 000 000 frames x 10 dims, 3-Gaussian-blob generator of SURVEY.md 8(d) (seed 20240), r = 0.2.
 Metric: frame-pairs/s (density pop+nn) = 2*N^2 / t_step  (ordered pairs of both sweeps per second).
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-    "roofline":     dominant kernel, SURVEY.md 8(d): algorithmic 2*D flop per EVALUATED frame pair against
-                    the fp32 MFMA peak (157.3 TFLOP/s).  The sweeps run that contraction on two fp16
-                    pieces per coordinate on the 16-bit matrix pipe (2*(3*D+2) flop per pair executed,
-                    dense peak 2.5 PFLOP/s), so the fp32 fraction can exceed 1; the executed figure is
-                    reported next to it as "matrix_pipe"
+    "roofline":     dominant kernel against the pipe it runs on: the sweeps execute the distance contraction on
+                    two fp16 pieces per coordinate on the f16 MFMA pipe (NM 32x32x16 MFMAs = 32*NM flop per
+                    EVALUATED frame pair, dense peak 2.5 PFLOP/s): "achieved" = executed flop/s, "frac" <= 1.
+                    Beside it "frac_algorithmic" (SURVEY.md 8(d)'s 2*D flop per evaluated pair against the same
+                    peak) and "fp32_equivalent" (the same flops against the fp32 MFMA peak 157.3 TFLOP/s, the
+                    figure BASELINE.json's ">= 60 % of the fp32 MFMA roofline" refers to; it exceeds 1 because
+                    the contraction does not run on the fp32 pipe); pruned-away pairs earn no credit anywhere
     "cpu_baseline": the CPU restatement (oracle, fast build, all host threads) on a bounded sample.
 """
 import argparse
@@ -32,30 +34,57 @@ PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector == fp32-input MFM
 PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md, matrix cores: BF16/F16 ~2.5 PF dense
 
 
-def split_flop_per_pair(d):
-    """MFMA work of the fp16x2 Gram form per frame pair: 3 piece products per column + 2 constant
-    slots on the K axis, one multiply-add each (zero padding to 16-slot MFMAs not counted)."""
-    return 2 * (3 * d + 2)
+def n_mfma(d):
+    """v_mfma_f32_32x32x16_f16 per 32x32 tile pair: 3 piece products per column + 2 constant slots on
+    the K axis, 16 slots per MFMA (dc_mfma_kernels.hpp: nm_for)."""
+    return (3 * d + 2 + 15) // 16
 
 
-def measured_traffic(kernel, n, d, radii, variant):
-    """HBM-side bytes per launch of the dominant kernel: not measurable from inside the timed run (PMC
-    counters need their own rocprofv3 passes), so the figure comes from the committed counter summary
-    of the SAME workload (profiles/r1_pruned_pmc.json, produced with scratch/pmc_summary.py); None for
-    any other workload or variant."""
-    path = os.path.join(ROOT, "profiles", "r1_pruned_pmc.json")
-    try:
-        prof = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    w = prof.get("workload", {})
-    if (w.get("n_rows"), w.get("n_cols"), w.get("radii")) != (n, d, list(radii)) or variant not in ("auto", "pruned"):
-        return None
-    tag = "pop_pruned_kernel" if kernel == "population_count" else "nn_pruned_kernel"
-    for name, e in prof.get("kernels", {}).items():
-        if tag in name:
-            return e.get("traffic_bytes")
-    return None
+def executed_flop_per_pair(d):
+    """what the f16 matrix pipe executes per frame pair, zero-padded K slots included: NM * 16 * 2"""
+    return 32 * n_mfma(d)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves (one process per GPU, RCCL), as a
+    CHILD process and before this process has touched torch or HIP, relay its output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+PMC_PROFILES = ("r2_c3_pmc.json", "r1_pruned_pmc.json")   # newest first
+
+
+def measured_counters(kernel, n, d, radii, variant):
+    """Counter figures of the dominant kernel (memory-side bytes per launch, matrix-pipe busy, VALU
+    instructions per tile pair): not measurable from inside the timed run (PMC counters need their own
+    rocprofv3 passes), so they come from the committed counter summary of the SAME workload
+    (profiles/r*_pmc.json, produced with scratch/pmc_summary.py); {} for any other workload or variant."""
+    if variant not in ("auto", "pruned"):
+        return {}
+    for fname in PMC_PROFILES:
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        except (OSError, ValueError):
+            continue
+        w = prof.get("workload", {})
+        if (w.get("n_rows"), w.get("n_cols"), w.get("radii")) != (n, d, list(radii)):
+            continue
+        tag = "pop_pruned_kernel" if kernel == "population_count" else "nn_pruned_kernel"
+        for name, e in prof.get("kernels", {}).items():
+            if tag in name:
+                return {"traffic": e.get("traffic_bytes"), "mfma_busy": e.get("matrix_pipe_utilisation"),
+                        "valu_insts_per_tile_pair": e.get("valu_insts_per_32x32_tile_pair"),
+                        "source": "profiles/" + fname}
+    return {}
 
 
 def parse_args():
@@ -105,6 +134,8 @@ def cpu_baseline(coords_np, radii, sample_rows, want_nn):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -113,8 +144,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the density path has no CPU fallback")
@@ -235,24 +264,61 @@ def main():
     pairs_per_step = sweeps * float(n) * float(n)
     ms_per_step = 1e3 * elapsed / args.steps
     value = pairs_per_step / (elapsed / args.steps)
+    # tile pairs the sweeps of ALL ranks evaluated in one step (from the kernels' own counters)
+    tiles_all = torch.tensor([pop_tiles, nn_tiles], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tiles_all, op=dist.ReduceOp.SUM)
+    tiles_all = [int(v) for v in tiles_all.tolist()]
 
     if rank == 0:
         pop_t = float(np.mean(pop_ms)) * 1e-3
         nn_t = float(np.mean(nn_ms)) * 1e-3 if want_nn else 0.0
-        local_rows = hi - lo
         # dominant kernel = the longer of the two sweeps on this rank.  Work = ordered (query, reference)
-        # pairs the kernel EVALUATED (all of them for the full sweeps; the counted 32x32 tiles for the
-        # pruned variants), 2*D flop each; pruned-away pairs earn no roofline credit.
-        full_pairs = float(local_rows) * n
+        # pairs the kernel EVALUATED: the 32x32 tile pairs it counted itself (all pairs of the rank's rows
+        # for the variants that do not prune); pruned-away pairs earn no roofline credit.
+        full_pairs = float(n) * n / world          # this rank's share of the N^2 ordered pairs
         pop_pairs = pop_tiles * 1024.0 if pop_tiles else full_pairs
         nn_pairs = nn_tiles * 1024.0 if nn_tiles else full_pairs
         if nn_t > pop_t:
             dom, dom_t, dom_pairs = "nearest_neighbor_search", nn_t, nn_pairs
         else:
             dom, dom_t, dom_pairs = "population_count", pop_t, pop_pairs
-        achieved = dom_pairs * 2.0 * d / dom_t / 1e12                        # algorithmic, SURVEY 8(d)
-        executed = dom_pairs * split_flop_per_pair(d) / dom_t / 1e12         # what the 16-bit pipe does
+        matrix = args.variant != "direct" and d <= 64
+        algorithmic = dom_pairs * 2.0 * d / dom_t / 1e12                     # 2*D flop per pair
+        executed = dom_pairs * executed_flop_per_pair(d) / dom_t / 1e12      # what the f16 pipe does
+        pmc = measured_counters(dom, n, d, args.radii, args.variant) if world == 1 else {}
         pop_sum = int(out["pops"][0].sum(dtype=torch.int64).item())
+        evaluated_all = (tiles_all[0] + tiles_all[1]) * 1024.0 if tiles_all[0] else pairs_per_step
+        if matrix:
+            roof = {
+                "bound": "mfma", "pipe": "f16 (v_mfma_f32_32x32x16_f16, dense)", "kernel": dom,
+                "achieved": executed, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": executed / PEAK_BF16_TFLOPS,
+                "flop_per_pair_executed": executed_flop_per_pair(d),
+                "frac_algorithmic": algorithmic / PEAK_BF16_TFLOPS, "flop_per_pair_algorithmic": 2 * d,
+                "fp32_equivalent": {"achieved": algorithmic, "peak": PEAK_FP32_TFLOPS,
+                                    "frac": algorithmic / PEAK_FP32_TFLOPS,
+                                    "what": "2*D flop per evaluated pair against the fp32 MFMA/VALU peak "
+                                            "(BASELINE.json's target figure); > 1 is possible because the "
+                                            "contraction runs on the f16 pipe"},
+            }
+        else:
+            roof = {"bound": "mfma", "pipe": "fp32 VALU (direct kernels)", "kernel": dom,
+                    "achieved": algorithmic, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": algorithmic / PEAK_FP32_TFLOPS, "flop_per_pair_algorithmic": 2 * d}
+        roof.update({
+            "traffic": pmc.get("traffic"),
+            "traffic_note": "bytes per launch at the L2's memory side (TCC_EA0 read requests x 128 B + write "
+                            "requests x 64 B, separate rocprofv3 --pmc pass, Infinity-Cache hits included) from "
+                            + str(pmc.get("source")) + "; algorithmic bytes per launch = N*D*4 + outputs = "
+                            f"{n * d * 4 + n * 16} B: the kernel is compute-bound and re-streams its operand image through L2",
+            "mfma_busy": pmc.get("mfma_busy"),
+            "valu_insts_per_tile_pair": pmc.get("valu_insts_per_tile_pair"),
+            "pairs_per_launch": dom_pairs,
+            "pairs_per_launch_unpruned": full_pairs,
+            "launch_ms": 1e3 * dom_t,
+            "evaluated_fraction": {"pop": pop_pairs / full_pairs, "nn": nn_pairs / full_pairs},
+        })
         line = {
             "metric": "frame-pairs/s (density pop+nn)" if want_nn else "frame-pairs/s (density pop)",
             "value": value,
@@ -273,44 +339,35 @@ def main():
                 "n_rows": n, "n_cols": d, "radii": args.radii, "variant": args.variant,
                 "parallelism": f"rows sharded over {world} GPU(s) (every {world}-th query group of the spatial order), coords replicated; "
                                "all-reduce(sum) of the populations + all-reduce(min) of the packed (d2, index) neighbour words",
+                "backend": (dist.get_backend() if world > 1 else "none (single process)"),
+                "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
             },
+            "value_note": "value = sweeps * N^2 / t: ordered pairs ANSWERED per second (pairs pruned away by the "
+                          "spatial ordering count, like the reference's box grid skips them); "
+                          "evaluated_pairs_per_s = pairs the kernels actually evaluated per second",
+            "evaluated_pairs_per_s": evaluated_all / (elapsed / args.steps),
             "phases_ms": {"pop_kernel": 1e3 * pop_t, "nn_kernel": 1e3 * nn_t,
                           "other (fe, collectives, host)": max(0.0, ms_per_step - 1e3 * (pop_t + nn_t))},
-            "check": {"mean_pop_r0": pop_sum / n, "max_pop_r0": int(out["pops"][0].max().item())},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": dom,
-                "achieved": achieved,
-                "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_TFLOPS,
-                "traffic": measured_traffic(dom, n, d, args.radii, args.variant) if world == 1 else None,
-                "traffic_note": "bytes per launch at the L2's memory side from profiles/r1_pruned_pmc.json (separate "
-                                "rocprofv3 --pmc pass, gfx950 correction applied; includes Infinity-Cache hits); the "
-                                "kernel is compute-bound, its operand image (64 MB) is re-streamed by every wave through L2",
-                "flop_per_pair": 2 * d,
-                "matrix_pipe": {"what": "flops the f16 MFMA pipe executes for the split (3 piece products per "
-                                        "column + 2 constant slots), against its dense peak",
-                                "flop_per_pair": split_flop_per_pair(d), "achieved": executed,
-                                "peak": PEAK_BF16_TFLOPS, "frac": executed / PEAK_BF16_TFLOPS},
-                "pairs_per_launch": dom_pairs,
-                "pairs_per_launch_unpruned": full_pairs,
-                "launch_ms": 1e3 * dom_t,
-                "evaluated_fraction": {"pop": pop_pairs / full_pairs, "nn": nn_pairs / full_pairs},
-            },
+            "check": {"mean_pop_r0": pop_sum / n, "max_pop_r0": int(out["pops"][0].max().item()),
+                      "sigma2": (density.compute_sigma2(out["nn_d2"]) if want_nn else None),
+                      "reference_run": "BASELINE.md: mean 7233.1, max 65950, sigma2 0.00704766 at C3"},
+            "roofline": roof,
         }
         if full_ms is not None:
             # the unpruned sweeps (every ordered pair evaluated) for comparison
-            fl = float(local_rows) * n * split_flop_per_pair(d)
-            fl32 = float(local_rows) * n * 2.0 * d
+            fl = float(n) * n / world * executed_flop_per_pair(d)
+            fl32 = float(n) * n / world * 2.0 * d
 
             def full(ms):
-                return {"launch_ms": ms, "frac": fl32 / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                        "frac_matrix_pipe": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+                return {"launch_ms": ms, "frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "frac_algorithmic": fl32 / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "fp32_equivalent_frac": fl32 / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
             line["roofline_full_sweep"] = {
-                "variant": "mfma (no pruning)", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "variant": "mfma (no pruning)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "pop": full(full_ms["pop_kernel"]),
                 "nn": None if full_ms["nn_kernel"] is None else full(full_ms["nn_kernel"]),
+                "frame_pairs_per_s": (sweeps * float(n) * n / world
+                                      / (1e-3 * (full_ms["pop_kernel"] + (full_ms["nn_kernel"] or 0.0)))),
             }
         # (rank 0 of a single-GPU run only: the other ranks of a sharded run would wait for it at the barrier)
         if args.cpu_sample > 0 and world == 1:

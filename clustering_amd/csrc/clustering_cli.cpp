@@ -11,8 +11,8 @@
 //   "#@   key = %.5f" header lines carry clustering_radius / lumping_radius between stages
 //   (tools.cpp:229-277) and are honoured when -D / -B re-use earlier results.
 // Boost is not available here, so the options are parsed by hand; the option names, their
-// meaning and the error texts follow the reference.  Screening / clustering output (-T, -o, -i) is
-// outside this build's scope and rejected with a clear message.
+// meaning and the error texts follow the reference.  Screening (-T), clustering output (-o) and
+// microstates from initial states (-i) run on the GPU-built radius graph (screening_host.cpp).
 // There is no CPU implementation behind this binary: without a HIP device it exits like the
 // reference's CUDA build does (clustering.cpp:110-113).
 #include "../../include/dc_density.h"

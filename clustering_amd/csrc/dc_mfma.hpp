@@ -1,4 +1,5 @@
-// dc_mfma.hpp -- fp32-MFMA (Gram form + guard band + canonical re-check) variants.
+// dc_mfma.hpp -- matrix-core variants (fp16x2 Gram form on the f16 MFMA as a classifier + guard band +
+// canonical fp32 re-check of the undecided pairs): host-side entry points.
 #pragma once
 #include "dc_common.hpp"
 

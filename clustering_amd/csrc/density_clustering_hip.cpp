@@ -66,6 +66,13 @@ Pops calculate_populations_partial(const float* coords, std::size_t n_rows, std:
   return calculate_populations_per_gpu(coords, n_rows, n_cols, radii, i_from, i_to, i_gpu);
 }
 
+Pops calculate_populations_partial(const float* coords, const std::vector<float>& /*sorted_coords*/,
+                                   const std::vector<float>& /*blimits*/, std::size_t n_rows,
+                                   std::size_t n_cols, std::vector<float> radii, std::size_t i_from,
+                                   std::size_t i_to, int i_gpu) {
+  return calculate_populations_per_gpu(coords, n_rows, n_cols, radii, i_from, i_to, i_gpu);
+}
+
 Pops calculate_populations(const float* coords, const std::size_t n_rows, const std::size_t n_cols,
                            std::vector<float> radii) {
   std::sort(radii.begin(), radii.end(), std::greater<float>());   // density_clustering_cuda.cu:147

@@ -46,6 +46,14 @@ Pops calculate_populations_partial(const float* coords, std::size_t n_rows, std:
 Pops calculate_populations_per_gpu(const float* coords, std::size_t n_rows, std::size_t n_cols,
                                    std::vector<float> radii, std::size_t i_from, std::size_t i_to,
                                    int i_gpu);
+//! the signature the reference's header declares (density_clustering_cuda.hpp:21-30; never defined
+//! there).  sorted_coords / blimits belong to a column-0-sorted pruning scheme (tools.hxx:120-204) that
+//! the reference's kernels never used; the sweeps here build their own spatial ordering on the device,
+//! so both are ignored (result-neutral, like the CPU path's box grid).
+Pops calculate_populations_partial(const float* coords, const std::vector<float>& sorted_coords,
+                                   const std::vector<float>& blimits, std::size_t n_rows,
+                                   std::size_t n_cols, std::vector<float> radii, std::size_t i_from,
+                                   std::size_t i_to, int i_gpu);
 
 //! populations for several radii in one sweep, rows sharded over all GPUs
 //! (density_clustering_cuda.hpp:32-36, density_clustering_cuda.cu:139-182)

@@ -1,21 +1,54 @@
-"""C5 shape (5M x 30, 8 radii): what one rank of an 8-GPU run computes (segment 3 of 8), timed per phase."""
-import sys, time
+"""C5 shape (BASELINE.json configs[4]: 5M x 30, 8 radii, 8 GPUs): what ONE rank of the 8-GPU run computes
+(segment 3 of 8 of the sweep's spatial order), timed per phase with HIP events on the launch stream, as one
+bench-style JSON line.  Used under rocprofv3 by scratch/profile_r2.sh (kernel stats + TCC_EA0 counters)."""
+import argparse, json, sys
 import numpy as np, torch
 sys.path.insert(0, '.')
 from clustering_amd import density as dens
 from clustering_amd.synth import gaussian_blobs
-n, d, G = 5_000_000, 30, 8
-radii = [0.30, 0.35, 0.40, 0.45, 0.50, 0.55, 0.60, 0.65]
+ap = argparse.ArgumentParser()
+ap.add_argument('--n', type=int, default=5_000_000)
+ap.add_argument('--d', type=int, default=30)
+ap.add_argument('--segments', type=int, default=8)
+ap.add_argument('--segment', type=int, default=3)
+ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--radii', type=float, nargs='+', default=[0.30, 0.35, 0.40, 0.45, 0.50, 0.55, 0.60, 0.65])
+a = ap.parse_args()
+n, d, G = a.n, a.d, a.segments
 c = torch.from_numpy(gaussian_blobs(n, d)).cuda()
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-for rep in range(2):
-    ev[0].record()
-    p = dens.calculate_populations_segment(c, radii, 3, G)
-    ev[1].record(); torch.cuda.synchronize()
-    print(f"pops, 8 radii, segment 3/8: {ev[0].elapsed_time(ev[1]):.1f} ms")
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+def timed(fn):
+    ts = []
+    for _ in range(a.reps):
+        ev[0].record(); out = fn(); ev[1].record(); torch.cuda.synchronize()
+        ts.append(ev[0].elapsed_time(ev[1]))
+    return out, min(ts)
+p, pop_ms = timed(lambda: dens.calculate_populations_segment(c, a.radii, a.segment, G))
+pop_tiles = dens.evaluated_tiles(c.device)[0]
 # FE needs the populations of all rows: one full single-radius sweep here (a real run all-reduces the segments)
-t0 = time.time(); pf = dens.calculate_populations_partial(c, [0.5]); torch.cuda.synchronize(); print(f"full single-radius sweep: {1e3*(time.time()-t0):.1f} ms")
+pf, full_ms = timed(lambda: dens.calculate_populations_partial(c, [a.radii[len(a.radii) // 2]]))
+full_tiles = dens.evaluated_tiles(c.device)[0]
 fe = dens.calculate_free_energies(pf[0].contiguous())
-for rep in range(2):
-    ev[0].record(); nn = dens.nearest_neighbors_segment(c, fe, 3, G); ev[1].record(); torch.cuda.synchronize()
-    print(f"nn segment 3/8: {ev[0].elapsed_time(ev[1]):.1f} ms; evaluated tiles {dens.evaluated_tiles(c.device)[1]}")
+nn, nn_ms = timed(lambda: dens.nearest_neighbors_segment(c, fe, a.segment, G))
+nn_tiles = dens.evaluated_tiles(c.device)[1]
+nm = (3 * d + 2 + 15) // 16
+rows = int((p[0] != 0).sum().item())
+def roof(tiles, ms):
+    return {"tile_pairs": tiles, "executed_tflops": tiles * 1024.0 * 32 * nm / (ms * 1e-3) / 1e12,
+            "frac_f16_mfma_peak_2500": tiles * 1024.0 * 32 * nm / (ms * 1e-3) / 2.5e15}
+line = {
+    "workload": f"{n} x {d}, radii {a.radii}, segment {a.segment} of {G} (one rank of the 8-GPU run)",
+    "rows_of_the_segment": rows, "mfma_per_tile_pair": nm,
+    "pop_8_radii_ms": pop_ms, "pop_per_radius_ms": pop_ms / len(a.radii), "nn_ms": nn_ms,
+    "full_single_radius_sweep_all_rows_ms": full_ms,
+    "frame_pairs_per_s_this_rank": {"pop": len(a.radii) * float(rows) * n / (pop_ms * 1e-3), "nn": float(rows) * n / (nn_ms * 1e-3)},
+    "evaluated_fraction": {"pop (mean over radii)": pop_tiles * 1024.0 / (len(a.radii) * float(rows) * n),
+                           "nn": nn_tiles * 1024.0 / (float(rows) * n),
+                           "full sweep": full_tiles * 1024.0 / (float(n) * n)},
+    "roofline_pop": roof(pop_tiles, pop_ms), "roofline_nn": roof(nn_tiles, nn_ms),
+    "hbm_model": {"Q_res": rows, "note": "all query rows of the rank are resident in one launch (TQ*32 per wave, every wave "
+                  "streams the surviving reference tiles), so the streamed model of SURVEY 8(d) is one pass over the coordinates",
+                  "algorithmic_bytes_per_sweep": n * d * 4 + rows * 16,
+                  "operand_image_bytes": ((n + 31) // 32) * nm * 1024},
+}
+print(json.dumps(line))

@@ -1,40 +1,54 @@
 #!/usr/bin/env python3
-"""profiles/r1_pruned_pmc.json from rocprofv3 --pmc passes (gpurun_out/pmc_f1, pmc_f2: SQ sets; pmc_f3: TCC_EA0)."""
-import csv, json, subprocess, sys
-sq = json.loads(subprocess.check_output(['python3', 'scratch/pmc_summary.py', 'gpurun_out/pmc_f1', 'gpurun_out/pmc_f2']))
-mem = json.loads(subprocess.check_output(['python3', 'scratch/pmc_summary.py', 'gpurun_out/pmc_f3']))
-bench = json.load(open('profiles/r1_pruned_bench.json'))
-frac = bench['roofline']['evaluated_fraction']
+"""profiles/<tag>_pmc.json from rocprofv3 --pmc passes.
+usage: make_pmc_profile.py <tag> <bench.json> <workload-json> <sq dirs...> -- <tcc dirs...>
+  bench.json: a bench.py line (roofline.evaluated_fraction + config) or a scratch/c5_bench.py line (roofline_pop/nn.tile_pairs)."""
+import csv, glob, json, subprocess, sys
+tag, bench_path, workload = sys.argv[1], sys.argv[2], json.loads(sys.argv[3])
+rest = sys.argv[4:]
+sq_dirs, tcc_dirs = rest[:rest.index('--')], rest[rest.index('--') + 1:]
+sq = json.loads(subprocess.check_output(['python3', 'scratch/pmc_summary.py'] + sq_dirs)) if sq_dirs else {}
+mem = json.loads(subprocess.check_output(['python3', 'scratch/pmc_summary.py'] + tcc_dirs)) if tcc_dirs else {}
+bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
+if 'roofline_pop' in bench:
+    chains = {'pop': bench['roofline_pop']['tile_pairs'], 'nn': bench['roofline_nn']['tile_pairs']}
+else:
+    fr = bench['roofline']['evaluated_fraction']
+    t = (bench['config']['n_rows'] + 31) // 32
+    chains = {'pop': fr['pop'] * t * t * len(bench['config']['radii']), 'nn': fr['nn'] * t * t}
 dur = {}
-for r in csv.DictReader(open('gpurun_out/pmc_f1/s_kernel_trace.csv')):
-    k = r['Kernel_Name'][:64]
-    if k in sq:
-        dur.setdefault(k, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9)
-chains = {'pop': frac['pop'] * (31250 ** 2), 'nn': frac['nn'] * (31250 ** 2)}
-out = {"note": "rocprofv3 --kernel-trace --pmc, counters in their own passes (two passes for the SQ sets, one for the two "
-               "TCC_EA0 request counters; FETCH_SIZE hung the profiler on this kernel and is not used), on "
-               "`scratch/kbench.py --n 1000000 --d 10 --variant pruned --reps 1` (C3: 1M x 10, r = 0.2). Values are per "
-               "dispatch, summed over XCDs/SEs as rocprofv3 reports them. traffic_bytes = TCC_EA0_RDREQ_sum * 128 B + "
-               "TCC_EA0_WRREQ_sum * 64 B: on gfx950 the memory-side read requests of 16-byte-per-lane streaming loads are "
-               "128-B requests tallied at 64 B (MI355X_MICROARCH.md, HBM section: double FETCH_SIZE = RDREQ x 64 B); "
-               "Infinity-Cache hits are included, so this is an upper bound of the HBM bytes. clock_ghz = GRBM_GUI_ACTIVE / "
-               "8 XCDs / duration; matrix_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); "
-               "valu_insts_per_32x32_tile_pair divides by the evaluated tile pairs of profiles/r1_pruned_bench.json.",
-       "workload": {"n_rows": 1000000, "n_cols": 10, "radii": [0.2], "variant": "pruned"}, "kernels": {}}
-for k in sq:
-    e = dict(sq[k])
+for d in sq_dirs + tcc_dirs:
+    for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur.setdefault(r['Kernel_Name'][:64], []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9)
+out = {"note": "rocprofv3 --kernel-trace --pmc, counters in their own passes (SQ sets and the two TCC_EA0 request counters "
+               "separately). Values are per dispatch, summed over XCDs/SEs as rocprofv3 reports them. traffic_bytes = "
+               "TCC_EA0_RDREQ_sum * 128 B + TCC_EA0_WRREQ_sum * 64 B (gfx950: the memory-side read requests of 16-byte-per-lane "
+               "streaming loads are 128-B requests, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are included, so "
+               "this is an upper bound of the HBM bytes. clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / duration; "
+               "matrix_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); "
+               "valu_insts_per_32x32_tile_pair divides by the evaluated tile pairs the kernels counted themselves. "
+               "A population call sweeps once per radius: per-dispatch values are per radius.",
+       "workload": workload, "kernels": {}}
+for k in set(sq) | set(mem):
+    e = dict(sq.get(k, {}))
     mk = [m for m in mem if m[:50] == k[:50]]
     if mk:
-        e.update({c: v for c, v in mem[mk[0]].items() if c != 'dispatches'})
+        e.update({c: v for c, v in mem[mk[0]].items() if c != 'dispatches' or 'dispatches' not in e})
     key = 'pop' if 'pop_' in k else 'nn'
-    d = min(dur[k]); cyc = e['GRBM_GUI_ACTIVE'] / 8
-    e['duration_ms_under_counters'] = d * 1e3
-    e['clock_ghz'] = cyc / d / 1e9
-    e['matrix_pipe_utilisation'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc)
-    e['valu_insts_per_32x32_tile_pair'] = e['SQ_INSTS_VALU'] / chains[key]
+    ds = dur.get(k, [])
+    if ds:
+        e['duration_ms_under_counters'] = 1e3 * sum(ds) / len(ds)
+    if 'GRBM_GUI_ACTIVE' in e and ds:
+        cyc = e['GRBM_GUI_ACTIVE'] / 8
+        e['clock_ghz'] = cyc / (sum(ds) / len(ds)) / 1e9
+        e['matrix_pipe_utilisation'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc)
+        n_disp = workload.get('dispatches_per_call', {}).get(key, 1)
+        e['valu_insts_per_32x32_tile_pair'] = e['SQ_INSTS_VALU'] * n_disp / chains[key]
     if 'TCC_EA0_RDREQ_sum' in e:
         e['traffic_bytes'] = e['TCC_EA0_RDREQ_sum'] * 128 + e['TCC_EA0_WRREQ_sum'] * 64
+        if ds:
+            e['traffic_tb_per_s'] = e['traffic_bytes'] / (sum(ds) / len(ds)) / 1e12
     out['kernels'][k] = e
-json.dump(out, open('profiles/r1_pruned_pmc.json', 'w'), indent=1)
+json.dump(out, open(f'profiles/{tag}_pmc.json', 'w'), indent=1)
 for k, e in out['kernels'].items():
-    print(k[-45:], {x: round(e[x], 3) for x in ['duration_ms_under_counters', 'clock_ghz', 'matrix_pipe_utilisation', 'valu_insts_per_32x32_tile_pair'] if x in e}, e.get('traffic_bytes'))
+    print(k[-45:], {x: round(e[x], 3) for x in ['duration_ms_under_counters', 'clock_ghz', 'matrix_pipe_utilisation', 'valu_insts_per_32x32_tile_pair', 'traffic_tb_per_s'] if x in e}, e.get('traffic_bytes'))

@@ -51,3 +51,28 @@ def test_no_gpu_means_exit_not_fallback(tmp_path):
     assert r.returncode != 0
     assert "no HIP-compatible GPUs found" in r.stderr
     assert not (tmp_path / "pop").exists()
+
+
+def test_shim_header_is_legal_next_to_the_reference_headers(tmp_path):
+    """INTEGRATION.md section 2 claims density_clustering_hip.hpp can be included next to the reference's
+    own headers (it re-declares Tools::Neighbor / Neighborhood and the CUDA:: entry points).  Syntax check
+    only, in the build container only: tools.hpp is read where it lies under /root/reference, its
+    cmake-generated config.hpp is produced from the reference's own template the way configure_file does
+    (CMakeLists.txt:57,88); nothing of the reference is copied into the repo or travels to the GPU box.
+    (density_clustering_common.hpp cannot take part: it pulls in Boost, which this image lacks.)"""
+    import pytest
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "src", "tools.hpp")):
+        pytest.skip("reference sources are only present in the build container")
+    template = open(os.path.join(ref, "config.hpp.cmake.in")).read()
+    (tmp_path / "config.hpp").write_text(template.replace("@DC_MEM_ALIGNMENT@", "32"))
+    shim = os.path.join(os.path.dirname(CLI), "..", "csrc", "density_clustering_hip.hpp")
+    (tmp_path / "tu.cpp").write_text(
+        '#include "tools.hpp"\n#include "%s"\n'
+        "static_assert(std::is_same<Clustering::Density::CUDA::Neighborhood, Clustering::Tools::Neighborhood>::value, \"\");\n"
+        "namespace Clustering { namespace Density { typedef std::map<float, std::vector<std::size_t>> Pops; } }\n"
+        "int main() { return 0; }\n" % os.path.abspath(shim))
+    # (-include limits: tools.hxx:244 relies on a transitive include that GCC 11 no longer provides)
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-include", "limits", "-I", str(tmp_path), "-I", os.path.join(ref, "src"),
+                        str(tmp_path / "tu.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -57,6 +57,8 @@ def test_c3_full_path(dens, fast_oracle):
     ph = pops[0].cpu().numpy().astype(np.int64)
     # check values of the normative generator (seed 20240), as every variant has produced them
     assert ph.sum() == 7233139928 and ph.max() == 65950
+    # ... and as the REFERENCE's own run printed them (mean 7233.1, max 65950)
+    assert round(ph.sum() / n, 1) == 7233.1
     assert (ph.sum() - n) % 2 == 0 and ph.min() >= 1
     rng = np.random.default_rng(3)
     starts = [0, int(rng.integers(1000, n - 3000)), n - 1500]
@@ -92,7 +94,12 @@ def test_c3_full_path(dens, fast_oracle):
     hs = sample[has_hd[sample]]
     assert (bits(canonical_d2_rows(fast_oracle, c, hs, hd_idx[hs])) == bits(hd_d2[hs])).all()
     # sigma2: double sum in frame order (density_clustering.cpp:334-343); numpy's cumsum adds sequentially
-    assert dens.compute_sigma2(nn[1]) == float(np.cumsum(nn_d2.astype(np.float64))[-1] / n)
+    sigma2 = dens.compute_sigma2(nn[1])
+    assert sigma2 == float(np.cumsum(nn_d2.astype(np.float64))[-1] / n)
+    # the reference's own run of this workload (BASELINE.md:34,46): sigma2 = 0.00704766, the only
+    # reference-derived value on the neighbour side; lumping radius sqrt(4 sigma2) = 0.1679
+    assert abs(sigma2 - 0.00704766) < 5e-9
+    assert abs(float(np.float32(np.sqrt(4.0 * sigma2))) - 0.1679) < 5e-5
 
 
 def test_c2_three_radii_against_the_oracle(dens, fast_oracle):
@@ -105,29 +112,115 @@ def test_c2_three_radii_against_the_oracle(dens, fast_oracle):
     for variant in ("pruned", "mfma", "direct"):
         pops = dens.calculate_populations_partial(ct, radii, variant=variant).cpu().numpy()
         assert (pops.astype(np.uint32).astype(np.uint64) == want).all(), variant
+        # the reference's own run of this workload: mean pops 2.8 / 719 / 9223
+        means = pops.astype(np.float64).mean(axis=1)
+        assert round(means[0], 1) == 2.8 and round(means[1]) == 719 and round(means[2]) == 9223, means
     for k in range(3):
         fe = dens.calculate_free_energies(torch.from_numpy(want[k].astype(np.int32)).cuda())
         assert (bits(fe.cpu().numpy()) == bits(fast_oracle.free_energies(want[k]))).all()
     assert (want[0] <= want[1]).all() and (want[1] <= want[2]).all()          # monotone in the radius
 
 
-def test_c5_shape_one_segment_of_eight(dens, fast_oracle):
-    """C5 = 5M x 30 on 8 GPUs: what ONE rank computes (segment 3 of 8) for two of the eight radii, against
-    the oracle on rows of that segment, and against the row-block call of the reference's partition."""
+C5_RADII = [0.30, 0.35, 0.40, 0.45, 0.50, 0.55, 0.60, 0.65]
+
+
+def test_c5_one_segment_of_eight_all_radii_and_neighbours(dens, fast_oracle):
+    """C5 = 5M x 30, 8 radii, on 8 GPUs (BASELINE.json configs[4]): what ONE rank computes -- segment 3 of 8 --
+    for ALL eight radii and for nn / nn_hd, against the oracle on > 500 rows of that segment (each against
+    all 5M reference frames), against the row-block call of the reference's partition, and through
+    size-independent properties on every row of the segment."""
     import torch
-    n, d, radii = 5_000_000, 30, [0.45, 0.65]
+    n, d, G, seg_id = 5_000_000, 30, 8, 3
     c = gaussian_blobs(n, d)
     ct = torch.from_numpy(c).cuda()
-    seg = dens.calculate_populations_segment(ct, radii, 3, 8).cpu().numpy().astype(np.uint32)
+    seg = dens.calculate_populations_segment(ct, C5_RADII, seg_id, G).cpu().numpy().astype(np.uint32)
     rows = np.nonzero(seg[0])[0]                      # populations are >= 1 on the rows of the segment
-    assert abs(len(rows) - n / 8) < 0.02 * n and (seg[1][rows] >= seg[0][rows]).all()
-    assert (np.nonzero(seg[1])[0] == rows).all()
-    lo = int(rows[len(rows) // 2])
-    block = dens.calculate_populations_partial(ct, radii, lo, lo + 700).cpu().numpy().astype(np.uint32)
-    want = fast_oracle.populations(c, radii, lo, lo + 700)
+    assert abs(len(rows) - n / G) < 0.02 * n
+    for k in range(1, len(C5_RADII)):                 # same support, monotone in the radius
+        assert (np.nonzero(seg[k])[0] == rows).all() and (seg[k][rows] >= seg[k - 1][rows]).all()
+    lo, width = int(rows[len(rows) // 2]), 4400       # a row block that holds > 500 rows of the segment
+    mine = rows[(rows >= lo) & (rows < lo + width)]
+    assert len(mine) >= 500
+    want = fast_oracle.populations(c, C5_RADII, lo, lo + width)
+    assert (seg[:, mine].astype(np.uint64) == want[:, mine]).all()
+    block = dens.calculate_populations_partial(ct, C5_RADII, lo, lo + 700).cpu().numpy().astype(np.uint32)
     assert (block[:, lo:lo + 700].astype(np.uint64) == want[:, lo:lo + 700]).all()
-    mine = rows[(rows >= lo) & (rows < lo + 700)]
-    assert len(mine) > 20 and (seg[:, mine] == block[:, mine]).all()
+    # free energies of ALL frames at r = 0.5 (a real run all-reduces the eight segments; here one full sweep)
+    full = dens.calculate_populations_partial(ct, [0.5])
+    fh = full[0].cpu().numpy().astype(np.uint32)
+    assert (fh[rows] == seg[4][rows]).all() and (fh.astype(np.int64).sum() - n) % 2 == 0
+    fe = dens.calculate_free_energies(full[0].contiguous())
+    fe_h = fe.cpu().numpy()
+    assert (bits(fe_h) == bits(fast_oracle.free_energies(fh.astype(np.uint64)))).all()
+    nn = dens.nearest_neighbors_segment(ct, fe, seg_id, G)
+    nn_idx, nn_d2, hd_idx, hd_d2 = [t.cpu().numpy() for t in nn]
+    nn_idx = nn_idx.astype(np.uint32).astype(np.int64)
+    hd_idx = hd_idx.astype(np.uint32).astype(np.int64)
+    exp = fast_oracle.nearest_neighbors(c, fe_h, lo, lo + width)
+    assert (nn_idx[mine] == exp[0][mine].astype(np.int64)).all() and (hd_idx[mine] == exp[2][mine].astype(np.int64)).all()
+    assert (bits(nn_d2[mine]) == bits(exp[1][mine])).all() and (bits(hd_d2[mine]) == bits(exp[3][mine])).all()
+    # rows of other segments hold the "none" value; properties on all rows of this one
+    other = np.ones(n, dtype=bool)
+    other[rows] = False
+    fmax = np.finfo(np.float32).max
+    assert (nn_idx[other] == n + 1).all() and (nn_d2[other] == fmax).all() and (hd_idx[other] == n + 1).all()
+    assert (nn_idx[rows] != rows).all() and (nn_idx[rows] < n).all() and (nn_d2[rows] <= hd_d2[rows]).all()
+    has_hd = rows[hd_idx[rows] < n]
+    assert (fe_h[hd_idx[has_hd]] < fe_h[has_hd]).all()
+    no_hd = rows[hd_idx[rows] > n]
+    assert (fe_h[no_hd] == fe_h.min()).all() and (hd_d2[no_hd] == fmax).all()
+    rng = np.random.default_rng(5)
+    sample = rng.choice(rows, 3000, replace=False)
+    assert (bits(canonical_d2_rows(fast_oracle, c, sample, nn_idx[sample])) == bits(nn_d2[sample])).all()
+    hs = sample[hd_idx[sample] < n]
+    assert (bits(canonical_d2_rows(fast_oracle, c, hs, hd_idx[hs])) == bits(hd_d2[hs])).all()
+    # a neighbour can be no farther than the population radius allows: pop(r) > 1  <=>  nn_d2 < r^2
+    for k, r in enumerate(C5_RADII):
+        r2 = np.float32(r) * np.float32(r)
+        assert ((seg[k][rows] > 1) == (nn_d2[rows] < r2)).all()
+
+
+def test_screening_forest_at_30_dims(dens, fast_oracle, tmp_path):
+    """-T at D = 30 (C5's screened lumping, density_clustering.cpp:773-817) on 240 000 frames: the GPU's
+    bottleneck spanning forest + the reference's name bookkeeping must reproduce, threshold by threshold,
+    the quadratic restatement (oracle/screening_oracle.cpp) run on the frames below each threshold."""
+    import os
+    import subprocess
+    import torch
+    from oracle.oracle import ScreeningOracle
+    from clustering_amd import capi
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "..", "bin", "clustering")
+    n, d, r = 240_000, 30, 0.5
+    c = gaussian_blobs(n, d, seed=77)
+    np.save(tmp_path / "c.npy", c)
+    ct = torch.from_numpy(c).cuda()
+    pops = dens.calculate_populations_partial(ct, [r])
+    fe = dens.calculate_free_energies(pops[0].contiguous())
+    nn = dens.nearest_neighbors_partial(ct, fe)
+    fe_h, nn_d2 = fe.cpu().numpy(), nn[1].cpu().numpy()
+    # thresholds: three levels that put 1 % .. 6 % of the frames below them (the restatement is quadratic in those)
+    q = np.quantile(fe_h, [0.01, 0.06])
+    t_from = float(np.round(q[0], 2))
+    step = float(np.round((q[1] - q[0]) / 2.0, 2))
+    assert step > 0.0
+    t_to = t_from + 2.0 * step
+    run = subprocess.run([cli, "density", "-f", str(tmp_path / "c.npy"), "-r", str(r), "-T", "%.2f" % t_from,
+                          "%.2f" % step, "%.2f" % t_to, "-o", str(tmp_path / "clust"), "-v"],
+                         capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr + run.stdout
+    assert "span the graph" in run.stdout + run.stderr
+    so = ScreeningOracle()
+    clustering, n_files = None, 0
+    t, st, tt = np.float32("%.2f" % t_from), np.float32("%.2f" % step), np.float32("%.2f" % t_to)
+    while t < tt - st / np.float32(10.0) + st and not (tt + st / np.float32(10.0) + st < t):
+        clustering = so.screening(fe_h, nn_d2, t, c, clustering)
+        with open(str(tmp_path / "clust") + ".%0.2f" % t) as f:
+            got = np.array([int(x) for x in f if x.strip() and not x.startswith("#")], dtype=np.uint64)
+        assert (got == clustering).all(), f"threshold {t}"
+        assert (got != 0).sum() == (fe_h < t).sum()
+        n_files += 1
+        t = np.float32(t + st)
+    assert n_files == 3 and (clustering != 0).sum() > 0.04 * n
 
 
 def test_c4_eight_segments_merge_to_the_single_device_result(dens):
