@@ -23,6 +23,10 @@ SYMBOLS = (
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs", "dc_hip_radius_min_edge_dev", "dc_hip_radius_forest",
     "dc_hip_populations_segment_dev", "dc_hip_nearest_neighbors_segment_dev",
     "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev", "dc_hip_radius_min_edge_segment_dev",
+    "dc_hip_session_open", "dc_hip_session_close", "dc_hip_session_devices", "dc_hip_session_uses_rccl",
+    "dc_hip_session_counters", "dc_hip_session_populations", "dc_hip_session_free_energies",
+    "dc_hip_session_set_free_energies", "dc_hip_session_nearest_neighbors", "dc_hip_session_radius_pairs",
+    "dc_hip_session_radius_forest",
 )
 
 
@@ -82,6 +86,28 @@ def _load():
                                          C.POINTER(C.c_uint32)]
     lib.dc_hip_density_all.restype = i32
     lib.dc_hip_density_all.argtypes = [vp, sz, sz, vp, sz, sz, i32, vp, vp, vp, vp, vp, vp]
+    lib.dc_hip_session_open.restype = i32
+    lib.dc_hip_session_open.argtypes = [vp, sz, sz, C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    lib.dc_hip_session_close.restype = None
+    lib.dc_hip_session_close.argtypes = [vp]
+    lib.dc_hip_session_devices.restype = i32
+    lib.dc_hip_session_devices.argtypes = [vp]
+    lib.dc_hip_session_uses_rccl.restype = i32
+    lib.dc_hip_session_uses_rccl.argtypes = [vp]
+    lib.dc_hip_session_counters.restype = i32
+    lib.dc_hip_session_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.dc_hip_session_populations.restype = i32
+    lib.dc_hip_session_populations.argtypes = [vp, vp, sz, vp]
+    lib.dc_hip_session_free_energies.restype = i32
+    lib.dc_hip_session_free_energies.argtypes = [vp, sz, vp, C.POINTER(C.c_uint32)]
+    lib.dc_hip_session_set_free_energies.restype = i32
+    lib.dc_hip_session_set_free_energies.argtypes = [vp, vp]
+    lib.dc_hip_session_nearest_neighbors.restype = i32
+    lib.dc_hip_session_nearest_neighbors.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
+    lib.dc_hip_session_radius_pairs.restype = i32
+    lib.dc_hip_session_radius_pairs.argtypes = [vp, C.c_float, vp, sz, C.POINTER(C.c_uint64)]
+    lib.dc_hip_session_radius_forest.restype = i32
+    lib.dc_hip_session_radius_forest.argtypes = [vp, C.c_float, vp, vp, C.POINTER(sz), C.POINTER(C.c_uint32)]
     return lib
 
 

@@ -461,7 +461,15 @@ int density_main(int argc, char** argv) {
   read_coords(o.file, coords, n_rows, n_cols);
   if (n_rows == 0) die("error: no frames in '" + o.file + "'");
 
+  // ONE session for the whole run (density_clustering.cpp:597-817): the coordinates go to the GPUs once
+  // and stay there across pop -> FE -> NN -> sigma2 -> (second pop + NN at the lumping radius) -> forest
+  dc_hip_session* session = nullptr;
+  auto sess = [&]() {
+    if (!session) must(dc_hip_session_open(coords.data(), n_rows, n_cols, nullptr, n_gpus, &session), "uploading the coordinates");
+    return session;
+  };
   std::vector<float> fe;
+  bool fe_resident = false;          // the session holds exactly `fe`
   std::vector<std::uint32_t> pops;   // single-radius populations
   auto sweep = [&](const std::vector<float>& radii, std::size_t fe_index, bool want_nn,
                    std::vector<std::uint32_t>& pops_out, std::vector<float>& fe_out,
@@ -469,17 +477,17 @@ int density_main(int argc, char** argv) {
                    std::vector<std::uint32_t>& hd_idx, std::vector<float>& hd_d2) {
     pops_out.assign(radii.size() * n_rows, 0);
     fe_out.assign(n_rows, 0.f);
+    must(dc_hip_session_populations(sess(), radii.data(), radii.size(), pops_out.data()), "population sweep");
+    must(dc_hip_session_free_energies(sess(), fe_index, fe_out.data(), nullptr), "free energies");
+    fe_resident = (&fe_out == &fe);
     if (want_nn) {
       nn_idx.assign(n_rows, 0);
       hd_idx.assign(n_rows, 0);
       nn_d2.assign(n_rows, 0.f);
       hd_d2.assign(n_rows, 0.f);
+      must(dc_hip_session_nearest_neighbors(sess(), nn_idx.data(), nn_d2.data(), hd_idx.data(), hd_d2.data(), nullptr),
+           "nearest-neighbour sweep");
     }
-    must(dc_hip_density_all(coords.data(), n_rows, n_cols, radii.data(), radii.size(), fe_index,
-                            n_gpus, pops_out.data(), fe_out.data(),
-                            want_nn ? nn_idx.data() : nullptr, want_nn ? nn_d2.data() : nullptr,
-                            want_nn ? hd_idx.data() : nullptr, want_nn ? hd_d2.data() : nullptr),
-         "density sweep");
   };
   auto sigma2_of = [&](const std::vector<float>& nn_d2) {
     double s = 0.0;   // frame order, double (density_clustering.cpp:334-343)
@@ -575,22 +583,12 @@ int density_main(int argc, char** argv) {
       hd_idx.assign(n_rows, 0);
       nn_d2.assign(n_rows, 0.f);
       hd_d2.assign(n_rows, 0.f);
-      // rows sharded over the GPUs like density_clustering_cuda.cu:293-326
-      const std::size_t range = n_rows / n_gpus;
-      std::vector<std::uint32_t> pi(n_rows), ph(n_rows);
-      std::vector<float> pd(n_rows), pdh(n_rows);
-      for (int g = 0; g < n_gpus; ++g) {
-        const std::size_t lo = g * range, hi = (g == n_gpus - 1) ? n_rows : (g + 1) * range;
-        must(dc_hip_nearest_neighbors(coords.data(), n_rows, n_cols, fe.data(), lo, hi, g, pi.data(),
-                                      pd.data(), ph.data(), pdh.data()),
-             "nearest-neighbour sweep");
-        for (std::size_t i = lo; i < hi; ++i) {
-          nn_idx[i] = pi[i];
-          nn_d2[i] = pd[i];
-          hd_idx[i] = ph[i];
-          hd_d2[i] = pdh[i];
-        }
-      }
+      // one segment per GPU, concurrently, merged on the devices (density_clustering_cuda.cu:293-326 shards
+      // row blocks); the free energies are resident unless they came from a file (-D)
+      if (!fe_resident) must(dc_hip_session_set_free_energies(sess(), fe.data()), "uploading the free energies");
+      fe_resident = true;
+      must(dc_hip_session_nearest_neighbors(sess(), nn_idx.data(), nn_d2.data(), hd_idx.data(), hd_d2.data(), nullptr),
+           "nearest-neighbour sweep");
     }
     if (cm["lumping_radius"] == 0.) {
       const float radius_lump = (float)std::sqrt(4 * sigma2_of(nn_d2));
@@ -651,11 +649,11 @@ int density_main(int argc, char** argv) {
       const char* full_env = std::getenv("DC_SCREENING_FULL_GRAPH");
       const bool forest = !(full_env && full_env[0] == '1') && n_rows <= ((std::size_t)1 << 24);
       if (forest) {
-        if (!H::build_radius_forest(coords.data(), n_rows, n_cols, max_dist, fe_sorted, 0, &graph, &err))
+        if (!H::build_radius_forest(sess(), n_rows, max_dist, fe_sorted, &graph, &err))
           die("error during screening (radius forest)\n" + err);
         LOG("    %zu frame pairs span the graph of the lumping radius\n", graph.n_pairs);
       } else {
-        if (!H::build_radius_graph(coords.data(), n_rows, n_cols, max_dist, 0, &graph, &err))
+        if (!H::build_radius_graph(sess(), n_rows, max_dist, &graph, &err))
           die("error during screening (radius graph)\n" + err);
         LOG("    %zu frame pairs within the lumping radius\n", graph.n_pairs);
       }
@@ -677,6 +675,7 @@ int density_main(int argc, char** argv) {
     }
   }
   LOG("~~~ freeing memory\n");
+  dc_hip_session_close(session);
   return EXIT_SUCCESS;
 }
 

@@ -1,7 +1,8 @@
 // dc_capi.hip -- the C ABI of include/dc_density.h on top of the HIP kernels (gfx950).
 // Host-side orchestration only: argument checks, memsets, launches, the host-libm free-energy
-// table and the host-pointer convenience wrappers that mirror the reference's per-GPU functions
-// (density_clustering_cuda.cu:45-137, :184-284).  No CPU implementation of the sweeps exists
+// referee and the host-pointer wrappers that mirror the reference's per-GPU functions
+// (density_clustering_cuda.cu:45-137, :184-284).  The resident multi-GPU path (sessions, RCCL) is
+// dc_session.hip.  No CPU implementation of the sweeps exists
 // here: without a HIP device every compute entry point fails with DC_ERR_NO_DEVICE / DC_ERR_HIP.
 #include "../../include/dc_density.h"
 #include "dc_common.hpp"
@@ -15,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,6 +42,18 @@ int fail(int code, const char* fmt, ...) {
       return fail(DC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                   __LINE__);                                                               \
   } while (0)
+
+}  // namespace
+
+namespace dc {
+// the calling thread's last error (also used by dc_session.hip)
+int set_error(int code, const char* msg) {
+  g_last_error = msg ? msg : "";
+  return code;
+}
+}  // namespace dc
+
+namespace {
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -229,7 +243,7 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
   if (!d_pops || !d_fe) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   if (n_rows + 1 > (size_t)UINT32_MAX) return fail(DC_ERR_TOO_LARGE, "n_rows too large");
   hipStream_t s = (hipStream_t)stream;
-  // per-thread, per-device scratch that lives across calls (no allocation, and no hipFree with its
+  // per-device scratch that lives across calls (no allocation, and no hipFree with its
   // device-wide synchronisation, on the per-step path): max word + table on the device, table on
   // the host
   struct Scratch {
@@ -239,9 +253,11 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
     size_t table_cap = 0;
     std::vector<float> table;
   };
-  static thread_local Scratch scratch[16];
+  static Scratch scratch[16];
+  static std::mutex scratch_mutex[16];
   int dev = 0;
   DC_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(scratch_mutex[dev & 15]);   // (one call at a time per device)
   Scratch& S = scratch[dev & 15];
   if (S.device != dev) {   // first use on this device (or a slot shared by devices 16 apart)
     if (S.d_max) (void)hipFree(S.d_max);
@@ -562,140 +578,6 @@ int dc_hip_populations(const float* coords, size_t n_rows, size_t n_cols, const 
   return rc;
 }
 
-int dc_hip_radius_pairs(const float* coords, size_t n_rows, size_t n_cols, float r2, int device,
-                        uint32_t* pairs, size_t capacity, unsigned long long* count) {
-  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
-  if (!count) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
-  *count = 0;
-  if (n_rows == 0) return DC_OK;
-  if (!coords || (capacity && !pairs)) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
-  DeviceJob j;
-  int rc = job_open(j, device, coords, n_rows, n_cols);
-  uint32_t* d_pairs = nullptr;
-  unsigned long long* d_count = nullptr;
-  hipError_t e = hipSuccess;
-  if (rc == DC_OK) {
-    e = hipMalloc((void**)&j.d_pops, sizeof(uint32_t) * n_rows);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_count, sizeof(unsigned long long));
-    if (e == hipSuccess && capacity) e = hipMalloc((void**)&d_pairs, sizeof(uint32_t) * 2 * capacity);
-    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "radius pairs setup: %s", hipGetErrorString(e));
-  }
-  if (rc == DC_OK)
-    rc = dc_hip_radius_pairs_dev(j.d_coords, n_rows, n_cols, r2, j.d_pops, d_pairs, capacity, d_count,
-                                 j.d_ws, j.ws_bytes, j.stream);
-  if (rc == DC_OK) {
-    e = hipMemcpyAsync(count, d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, j.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(j.stream);
-    if (e == hipSuccess && *count == ~0ull) {
-      rc = fail(DC_ERR_INVALID_ARGUMENT, "radius pairs need finite coordinates");
-    } else if (e == hipSuccess && capacity) {
-      const size_t n = (size_t)std::min<unsigned long long>(*count, capacity);
-      if (n) e = hipMemcpy(pairs, d_pairs, sizeof(uint32_t) * 2 * n, hipMemcpyDeviceToHost);
-    }
-    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "radius pair sweep: %s", hipGetErrorString(e));
-  }
-  if (d_pairs) (void)hipFree(d_pairs);
-  if (d_count) (void)hipFree(d_count);
-  j.release();
-  return rc;
-}
-
-int dc_hip_radius_forest(const float* coords, size_t n_rows, size_t n_cols, float r2,
-                         const uint32_t* rank, int device, uint32_t* edges, size_t* n_edges,
-                         uint32_t* n_rounds) {
-  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
-  if (!n_edges) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
-  *n_edges = 0;
-  if (n_rounds) *n_rounds = 0;
-  if (n_rows <= 1) return DC_OK;
-  if (!coords || !rank || !edges) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
-  // frame of every rank (and: is it a permutation?)
-  std::vector<uint32_t> frame_of(n_rows, 0xFFFFFFFFu);
-  for (size_t i = 0; i < n_rows; ++i) {
-    if (rank[i] >= n_rows || frame_of[rank[i]] != 0xFFFFFFFFu)
-      return fail(DC_ERR_INVALID_ARGUMENT, "rank is not a permutation of 0..n_rows-1");
-    frame_of[rank[i]] = (uint32_t)i;
-  }
-  DeviceJob j;
-  int rc = job_open(j, device, coords, n_rows, n_cols);
-  uint32_t *d_comp = nullptr, *d_rank = nullptr;
-  unsigned long long* d_best = nullptr;
-  hipError_t e = hipSuccess;
-  if (rc == DC_OK) {
-    e = hipMalloc((void**)&j.d_pops, sizeof(uint32_t) * n_rows);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_comp, sizeof(uint32_t) * n_rows);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_rank, sizeof(uint32_t) * n_rows);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_best, sizeof(unsigned long long) * n_rows);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(d_rank, rank, sizeof(uint32_t) * n_rows, hipMemcpyHostToDevice, j.stream);
-    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "radius forest setup: %s", hipGetErrorString(e));
-  }
-  // components: union-find over frame ids, the smaller id is the root (= the component's id)
-  std::vector<uint32_t> parent(n_rows), comp(n_rows);
-  for (size_t i = 0; i < n_rows; ++i) parent[i] = comp[i] = (uint32_t)i;
-  auto find = [&](uint32_t x) {
-    uint32_t root = x;
-    while (parent[root] != root) root = parent[root];
-    while (parent[x] != root) {
-      const uint32_t next = parent[x];
-      parent[x] = root;
-      x = next;
-    }
-    return root;
-  };
-  std::vector<unsigned long long> best(n_rows);
-  size_t found = 0;
-  uint32_t rounds = 0;
-  // every round at least halves the number of components that still have a partner
-  for (; rc == DC_OK && rounds < 64; ++rounds) {
-    e = hipMemcpyAsync(d_comp, comp.data(), sizeof(uint32_t) * n_rows, hipMemcpyHostToDevice, j.stream);
-    if (e != hipSuccess) {
-      rc = fail(DC_ERR_HIP, "radius forest: %s", hipGetErrorString(e));
-      break;
-    }
-    rc = dc_hip_radius_min_edge_dev(j.d_coords, n_rows, n_cols, r2, d_comp, d_rank, d_best, j.d_pops,
-                                    j.d_ws, j.ws_bytes, j.stream);
-    if (rc != DC_OK) break;
-    uint32_t hdr[2] = {0, 0};
-    e = hipMemcpyAsync(best.data(), d_best, sizeof(unsigned long long) * n_rows, hipMemcpyDeviceToHost,
-                       j.stream);
-    if (e == hipSuccess && rounds == 0)
-      e = hipMemcpyAsync(hdr, j.d_ws, sizeof(hdr), hipMemcpyDeviceToHost, j.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(j.stream);
-    if (e != hipSuccess) {
-      rc = fail(DC_ERR_HIP, "radius forest sweep: %s", hipGetErrorString(e));
-      break;
-    }
-    if (hdr[1] != 0) {
-      rc = fail(DC_ERR_INVALID_ARGUMENT, "the radius graph needs finite coordinates");
-      break;
-    }
-    size_t joined = 0;
-    for (size_t c = 0; c < n_rows; ++c) {
-      if (best[c] == ~0ull) continue;
-      const uint32_t a = frame_of[(uint32_t)(best[c] >> 32)], b = frame_of[(uint32_t)best[c]];
-      const uint32_t ra = find(a), rb = find(b);
-      if (ra == rb) continue;   // the partner component chose the same pair
-      parent[std::max(ra, rb)] = std::min(ra, rb);
-      edges[2 * found] = a;
-      edges[2 * found + 1] = b;
-      ++found;
-      ++joined;
-    }
-    if (joined == 0) break;
-    for (size_t i = 0; i < n_rows; ++i) comp[i] = find((uint32_t)i);
-  }
-  if (rc == DC_OK) {
-    *n_edges = found;
-    if (n_rounds) *n_rounds = rounds + 1;
-  }
-  if (d_comp) (void)hipFree(d_comp);
-  if (d_rank) (void)hipFree(d_rank);
-  if (d_best) (void)hipFree(d_best);
-  j.release();
-  return rc;
-}
-
 int dc_hip_nearest_neighbors(const float* coords, size_t n_rows, size_t n_cols, const float* fe,
                              size_t i_from, size_t i_to, int device, uint32_t* nn_idx, float* nn_d2,
                              uint32_t* hd_idx, float* hd_d2) {
@@ -732,137 +614,6 @@ int dc_hip_nearest_neighbors(const float* coords, size_t n_rows, size_t n_cols, 
     if (e != hipSuccess) rc = fail(DC_ERR_HIP, "nn sweep: %s", hipGetErrorString(e));
   }
   j.release();
-  return rc;
-}
-
-int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const float* radii,
-                       size_t n_radii, size_t fe_radius_index, int n_devices, uint32_t* pops,
-                       float* fe, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2) {
-  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
-  if (!coords || !radii || !pops || n_radii == 0)
-    return fail(DC_ERR_INVALID_ARGUMENT, "coords, radii and pops are required");
-  if (fe_radius_index >= n_radii) return fail(DC_ERR_INVALID_ARGUMENT, "fe_radius_index");
-  const bool want_nn = nn_idx != nullptr;
-  if (want_nn && (!fe || !nn_d2 || !hd_idx || !hd_d2))
-    return fail(DC_ERR_INVALID_ARGUMENT, "nn outputs incomplete");
-  int avail = dc_hip_device_count();
-  if (avail < 0) return avail;
-  if (avail == 0) return fail(DC_ERR_NO_DEVICE, "no HIP device found");
-  if (n_devices <= 0) n_devices = avail;
-  if (n_devices > avail)
-    return fail(DC_ERR_INVALID_ARGUMENT, "%d devices requested, %d present", n_devices, avail);
-  if (n_rows == 0) return DC_OK;
-
-  // one segment per device (dc_hip_*_segment_dev: spatial runs of query groups with the pruned sweep,
-  // the row blocks of density_clustering_cuda.cu:149,165-169 / :293,305-308 otherwise)
-
-  std::vector<DeviceJob> jobs(n_devices);
-  std::vector<std::vector<uint32_t>> part(n_devices);
-  int rc = DC_OK;
-  auto cleanup = [&]() {
-    for (auto& j : jobs) j.release();
-  };
-  // phase 1: populations, all devices in flight at once
-  for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
-    rc = job_open(jobs[g], g, coords, n_rows, n_cols);
-    if (rc != DC_OK) break;
-    hipError_t e = hipMalloc((void**)&jobs[g].d_pops, sizeof(uint32_t) * n_radii * n_rows);
-    if (e != hipSuccess) {
-      rc = fail(DC_ERR_HIP, "hipMalloc pops: %s", hipGetErrorString(e));
-      break;
-    }
-    rc = dc_hip_populations_segment_dev(jobs[g].d_coords, n_rows, n_cols, radii, n_radii, (size_t)g,
-                                        (size_t)n_devices, jobs[g].d_pops, jobs[g].d_ws,
-                                        jobs[g].ws_bytes, DC_VARIANT_AUTO, jobs[g].stream);
-    if (rc != DC_OK) break;
-    part[g].resize(n_radii * n_rows);
-    e = hipMemcpyAsync(part[g].data(), jobs[g].d_pops, sizeof(uint32_t) * n_radii * n_rows,
-                       hipMemcpyDeviceToHost, jobs[g].stream);
-    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "pops D2H: %s", hipGetErrorString(e));
-  }
-  for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
-    (void)hipSetDevice(g);
-    hipError_t e = hipStreamSynchronize(jobs[g].stream);
-    if (e != hipSuccess) rc = fail(DC_ERR_HIP, "population sweep (device %d): %s", g,
-                                   hipGetErrorString(e));
-  }
-  if (rc != DC_OK) {
-    cleanup();
-    return rc;
-  }
-  // merge = sum of the zero-padded partials (density_clustering_cuda.cu:171-180)
-  std::fill(pops, pops + n_radii * n_rows, 0u);
-  for (int g = 0; g < n_devices; ++g)
-    for (size_t k = 0; k < n_radii * n_rows; ++k) pops[k] += part[g][k];
-  part.clear();
-
-  if (fe) {
-    const uint32_t* p = pops + fe_radius_index * n_rows;
-    const uint32_t max_pop = *std::max_element(p, p + n_rows);
-    const float rec = 1.0f / (float)max_pop;
-    for (size_t i = 0; i < n_rows; ++i) fe[i] = fe_of_pop(p[i], rec);
-  }
-  if (want_nn) {
-    std::vector<std::vector<uint32_t>> pidx(n_devices);
-    std::vector<std::vector<float>> pd2(n_devices);
-    for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
-      DeviceJob& j = jobs[g];
-      (void)hipSetDevice(g);
-      hipError_t e = hipMalloc((void**)&j.d_fe, sizeof(float) * n_rows);
-      if (e == hipSuccess) e = hipMalloc((void**)&j.d_idx, sizeof(uint32_t) * 2 * n_rows);
-      if (e == hipSuccess) e = hipMalloc((void**)&j.d_d2, sizeof(float) * 2 * n_rows);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(j.d_fe, fe, sizeof(float) * n_rows, hipMemcpyHostToDevice, j.stream);
-      if (e != hipSuccess) {
-        rc = fail(DC_ERR_HIP, "nn setup (device %d): %s", g, hipGetErrorString(e));
-        break;
-      }
-      rc = dc_hip_nearest_neighbors_segment_dev(j.d_coords, n_rows, n_cols, j.d_fe, (size_t)g,
-                                                (size_t)n_devices, j.d_idx, j.d_d2, j.d_idx + n_rows,
-                                                j.d_d2 + n_rows, j.d_ws, j.ws_bytes, DC_VARIANT_AUTO,
-                                                j.stream);
-      if (rc != DC_OK) break;
-      pidx[g].resize(2 * n_rows);
-      pd2[g].resize(2 * n_rows);
-      e = hipMemcpyAsync(pidx[g].data(), j.d_idx, sizeof(uint32_t) * 2 * n_rows,
-                         hipMemcpyDeviceToHost, j.stream);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(pd2[g].data(), j.d_d2, sizeof(float) * 2 * n_rows, hipMemcpyDeviceToHost,
-                           j.stream);
-      if (e != hipSuccess) rc = fail(DC_ERR_HIP, "nn D2H: %s", hipGetErrorString(e));
-    }
-    for (int g = 0; g < n_devices && rc == DC_OK; ++g) {
-      (void)hipSetDevice(g);
-      hipError_t e = hipStreamSynchronize(jobs[g].stream);
-      if (e != hipSuccess)
-        rc = fail(DC_ERR_HIP, "nn sweep (device %d): %s", g, hipGetErrorString(e));
-    }
-    if (rc == DC_OK) {
-      // every row is owned by exactly one device (density_clustering_cuda.cu:311-326 copies by
-      // row block); the others hold the "none" value (n_rows+1, FLT_MAX), which is the largest
-      // (d2, index) there is: per row the smallest (d2, index) over the devices is the owner's
-      auto less = [](float da, uint32_t ia, float db, uint32_t ib) {
-        return da < db || (da == db && ia < ib);
-      };
-      for (size_t i = 0; i < n_rows; ++i) {
-        nn_idx[i] = pidx[0][i];
-        nn_d2[i] = pd2[0][i];
-        hd_idx[i] = pidx[0][n_rows + i];
-        hd_d2[i] = pd2[0][n_rows + i];
-        for (int g = 1; g < n_devices; ++g) {
-          if (less(pd2[g][i], pidx[g][i], nn_d2[i], nn_idx[i])) {
-            nn_d2[i] = pd2[g][i];
-            nn_idx[i] = pidx[g][i];
-          }
-          if (less(pd2[g][n_rows + i], pidx[g][n_rows + i], hd_d2[i], hd_idx[i])) {
-            hd_d2[i] = pd2[g][n_rows + i];
-            hd_idx[i] = pidx[g][n_rows + i];
-          }
-        }
-      }
-    }
-  }
-  cleanup();
   return rc;
 }
 

@@ -92,6 +92,11 @@ struct DensityResult {
   std::vector<float> nn_d2, hd_d2;
   double sigma2 = 0.0;                          // mean nn d2 (compute_sigma2, density_clustering.cpp:334-343)
 };
+//! The CUDA:: entry points above keep the trajectory they were last called with resident on the GPUs
+//! (one upload for populations, neighbours and screening; keyed on pointer, shape and a sampled
+//! fingerprint).  This drops it: frees the device memory, and is REQUIRED before re-using the same host
+//! buffer for different coordinates of the same shape.
+void release_resident();
 //! whole path (pop -> FE -> NN) with coordinates kept resident on the devices between the phases
 DensityResult density_all(const float* coords, std::size_t n_rows, std::size_t n_cols,
                           const std::vector<float>& radii, std::size_t fe_radius_index,

@@ -27,17 +27,29 @@ void pairs_to_graph(const std::vector<std::uint32_t>& pairs, std::size_t n_pairs
                     RadiusGraph* out);
 }
 
-bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
-                        int device, RadiusGraph* out, std::string* error) {
+namespace {
+// a session for the duration of one call, for the callers that hold none
+struct ScopedSession {
+  dc_hip_session* s = nullptr;
+  bool open(const float* coords, std::size_t n_rows, std::size_t n_cols, int device, std::string* error) {
+    if (dc_hip_session_open(coords, n_rows, n_cols, &device, 1, &s) == DC_OK) return true;
+    if (error) *error = dc_hip_last_error();
+    return false;
+  }
+  ~ScopedSession() { dc_hip_session_close(s); }
+};
+}  // namespace
+
+bool build_radius_graph(dc_hip_session* session, std::size_t n_rows, float max_dist, RadiusGraph* out,
+                        std::string* error) {
   unsigned long long count = 0;
   // counting sweep, then the listing sweep with a buffer of exactly that size
-  int rc = dc_hip_radius_pairs(coords, n_rows, n_cols, max_dist, device, nullptr, 0, &count);
+  int rc = dc_hip_session_radius_pairs(session, max_dist, nullptr, 0, &count);
   std::vector<std::uint32_t> pairs;
   if (rc == DC_OK && count > 0) {
     pairs.resize(2 * (std::size_t)count);
     unsigned long long again = 0;
-    rc = dc_hip_radius_pairs(coords, n_rows, n_cols, max_dist, device, pairs.data(), (std::size_t)count,
-                             &again);
+    rc = dc_hip_session_radius_pairs(session, max_dist, pairs.data(), (std::size_t)count, &again);
     if (rc == DC_OK && again != count) {
       if (error) *error = "radius pair sweeps disagree";
       return false;
@@ -49,6 +61,12 @@ bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_c
   }
   pairs_to_graph(pairs, (std::size_t)count, n_rows, out);
   return true;
+}
+
+bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
+                        int device, RadiusGraph* out, std::string* error) {
+  ScopedSession tmp;
+  return tmp.open(coords, n_rows, n_cols, device, error) && build_radius_graph(tmp.s, n_rows, max_dist, out, error);
 }
 
 namespace {
@@ -68,21 +86,27 @@ void pairs_to_graph(const std::vector<std::uint32_t>& pairs, std::size_t n_pairs
 }
 }  // namespace
 
-bool build_radius_forest(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
-                         const std::vector<FreeEnergy>& fe_sorted, int device, RadiusGraph* out,
-                         std::string* error) {
+bool build_radius_forest(dc_hip_session* session, std::size_t n_rows, float max_dist,
+                         const std::vector<FreeEnergy>& fe_sorted, RadiusGraph* out, std::string* error) {
   std::vector<std::uint32_t> rank(n_rows);
   for (std::size_t i = 0; i < n_rows; ++i) rank[fe_sorted[i].first] = (std::uint32_t)i;
   std::vector<std::uint32_t> pairs(2 * (n_rows ? n_rows - 1 : 0) + 2);
   std::size_t n_pairs = 0;
-  const int rc = dc_hip_radius_forest(coords, n_rows, n_cols, max_dist, rank.data(), device, pairs.data(),
-                                      &n_pairs, nullptr);
+  const int rc = dc_hip_session_radius_forest(session, max_dist, rank.data(), pairs.data(), &n_pairs, nullptr);
   if (rc != DC_OK) {
     if (error) *error = dc_hip_last_error();
     return false;
   }
   pairs_to_graph(pairs, n_pairs, n_rows, out);
   return true;
+}
+
+bool build_radius_forest(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
+                         const std::vector<FreeEnergy>& fe_sorted, int device, RadiusGraph* out,
+                         std::string* error) {
+  ScopedSession tmp;
+  return tmp.open(coords, n_rows, n_cols, device, error) &&
+         build_radius_forest(tmp.s, n_rows, max_dist, fe_sorted, out, error);
 }
 
 namespace {

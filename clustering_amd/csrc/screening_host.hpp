@@ -17,6 +17,8 @@
 #include <utility>
 #include <vector>
 
+struct dc_hip_session;   // include/dc_density.h: a trajectory resident on the GPUs
+
 namespace Clustering {
 namespace Density {
 namespace HIP {
@@ -36,6 +38,9 @@ struct RadiusGraph {
 //! returns false and sets *error on failure (no exit here; the shim adds the reference's convention)
 bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
                         int device, RadiusGraph* out, std::string* error);
+//! the same on the coordinates an open session already holds on the device (no second upload)
+bool build_radius_graph(dc_hip_session* session, std::size_t n_rows, float max_dist, RadiusGraph* out,
+                        std::string* error);
 
 //! the same for screenings that START FROM AN EMPTY CLUSTERING (a -T scan): a spanning forest of the
 //! radius graph that, for every threshold, connects the frames below it exactly as the whole graph
@@ -47,6 +52,9 @@ bool build_radius_graph(const float* coords, std::size_t n_rows, std::size_t n_c
 bool build_radius_forest(const float* coords, std::size_t n_rows, std::size_t n_cols, float max_dist,
                          const std::vector<FreeEnergy>& fe_sorted, int device, RadiusGraph* out,
                          std::string* error);
+//! the same on an open session: all its devices take part (one segment each, candidates merged over RCCL)
+bool build_radius_forest(dc_hip_session* session, std::size_t n_rows, float max_dist,
+                         const std::vector<FreeEnergy>& fe_sorted, RadiusGraph* out, std::string* error);
 
 //! screening for one threshold (density_clustering_common.cpp:37-134) given the radius graph for
 //! max_dist = 4*sigma2: cluster id per frame, 0 = not assigned (above the threshold)

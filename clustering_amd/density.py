@@ -275,3 +275,92 @@ def compute_sigma2(nn_d2):
         rc = capi.lib.dc_hip_sigma2_dev(_dev(nn_d2), nn_d2.shape[0], C.byref(out), _stream_ptr())
     capi.check(rc, "dc_hip_sigma2_dev")
     return out.value
+
+
+class Session:
+    """A trajectory resident on the GPUs of this process across pop -> FE -> NN -> forest
+    (dc_hip_session_*, include/dc_density.h): HOST numpy arrays in and out, one upload per device, partial
+    results of several devices merged on the devices over RCCL.  This is the path the C++ shim and the
+    command line take; tests use it to compare the resident flow with the call-by-call one."""
+
+    def __init__(self, coords_host, n_devices=0, devices=None):
+        c = np.ascontiguousarray(coords_host, dtype=np.float32)
+        assert c.ndim == 2
+        self.n_rows, self.n_cols = c.shape
+        self._h = C.c_void_p(0)
+        devs = None
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*devices)
+            n_devices = len(devices)
+        capi.check(capi.lib.dc_hip_session_open(c.ctypes.data_as(C.c_void_p), self.n_rows, self.n_cols, devs,
+                                                n_devices, C.byref(self._h)), "dc_hip_session_open")
+
+    def close(self):
+        if self._h:
+            capi.lib.dc_hip_session_close(self._h)
+            self._h = C.c_void_p(0)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def n_devices(self):
+        return int(capi.lib.dc_hip_session_devices(self._h))
+
+    @property
+    def uses_rccl(self):
+        return bool(capi.lib.dc_hip_session_uses_rccl(self._h))
+
+    def counters(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        capi.check(capi.lib.dc_hip_session_counters(self._h, C.byref(a), C.byref(b)), "dc_hip_session_counters")
+        return int(a.value), int(b.value)
+
+    def populations(self, radii, fetch=True):
+        rad = np.ascontiguousarray(radii, dtype=np.float32).reshape(-1)
+        out = np.empty((rad.size, self.n_rows), dtype=np.uint32) if fetch else None
+        capi.check(capi.lib.dc_hip_session_populations(self._h, rad.ctypes.data_as(C.c_void_p), rad.size,
+                                                       out.ctypes.data_as(C.c_void_p) if fetch else None),
+                   "dc_hip_session_populations")
+        return out
+
+    def free_energies(self, radius_index=0, fetch=True):
+        out = np.empty(self.n_rows, dtype=np.float32) if fetch else None
+        capi.check(capi.lib.dc_hip_session_free_energies(self._h, radius_index,
+                                                         out.ctypes.data_as(C.c_void_p) if fetch else None, None),
+                   "dc_hip_session_free_energies")
+        return out
+
+    def set_free_energies(self, fe):
+        f = np.ascontiguousarray(fe, dtype=np.float32)
+        assert f.shape == (self.n_rows,)
+        capi.check(capi.lib.dc_hip_session_set_free_energies(self._h, f.ctypes.data_as(C.c_void_p)),
+                   "dc_hip_session_set_free_energies")
+
+    def nearest_neighbors(self):
+        """-> (nn_idx u32, nn_d2 f32, hd_idx u32, hd_d2 f32, sigma2)"""
+        n = self.n_rows
+        nn_idx, hd_idx = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+        nn_d2, hd_d2 = np.empty(n, dtype=np.float32), np.empty(n, dtype=np.float32)
+        s2 = C.c_double(0.0)
+        capi.check(capi.lib.dc_hip_session_nearest_neighbors(
+            self._h, nn_idx.ctypes.data_as(C.c_void_p), nn_d2.ctypes.data_as(C.c_void_p),
+            hd_idx.ctypes.data_as(C.c_void_p), hd_d2.ctypes.data_as(C.c_void_p), C.byref(s2)),
+            "dc_hip_session_nearest_neighbors")
+        return nn_idx, nn_d2, hd_idx, hd_d2, s2.value
+
+    def radius_forest(self, r2, rank):
+        rank = np.ascontiguousarray(rank, dtype=np.uint32)
+        assert rank.shape == (self.n_rows,)
+        edges = np.empty((max(self.n_rows - 1, 1), 2), dtype=np.uint32)
+        n_edges, n_rounds = C.c_size_t(0), C.c_uint32(0)
+        capi.check(capi.lib.dc_hip_session_radius_forest(self._h, float(r2), rank.ctypes.data_as(C.c_void_p),
+                                                         edges.ctypes.data_as(C.c_void_p), C.byref(n_edges),
+                                                         C.byref(n_rounds)), "dc_hip_session_radius_forest")
+        return edges[:n_edges.value].copy(), int(n_rounds.value)

@@ -243,17 +243,66 @@ DC_API int dc_hip_radius_forest(const float* coords, size_t n_rows, size_t n_col
                                 const uint32_t* rank, int device, uint32_t* edges, size_t* n_edges,
                                 uint32_t* n_rounds);
 
-/* whole path on n_devices GPUs of this process (devices 0..n_devices-1), coords uploaded once per
- * device and kept resident across pop -> FE -> NN.  One segment per
- * device (dc_hip_*_segment_dev; the row blocks of density_clustering_cuda.cu:149,165-169 whenever the
- * pruned sweep does not run); partial populations are summed on the host as cuda.cu:171-180 does,
- * every neighbour row is taken from the device that owns it (cuda.cu:311-326).
- * radii: n_radii values; FE and NN are computed from radius index fe_radius_index (NN skipped if
- * nn_idx == NULL).  pops HOST [n_radii*n_rows]; fe, nn_*, hd_* HOST [n_rows]. */
+/* whole path on n_devices GPUs of this process (devices 0..n_devices-1; <= 0: all): ONE session (below)
+ * -- open, populations, free energies of radius index fe_radius_index, neighbours, close.  Replaces the
+ * pair CUDA::calculate_populations / CUDA::nearest_neighbors (density_clustering_cuda.cu:139-182,
+ * :286-328), which upload the coordinates twice and merge every partial result on the host.
+ * pops HOST [n_radii*n_rows]; fe, nn_*, hd_* HOST [n_rows] (fe may be NULL if nn_idx is; NN skipped if
+ * nn_idx == NULL). */
 DC_API int dc_hip_density_all(const float* coords, size_t n_rows, size_t n_cols, const float* radii,
                               size_t n_radii, size_t fe_radius_index, int n_devices, uint32_t* pops,
                               float* fe, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
                               float* hd_d2);
+
+/* ---------------------------------------------------------------------------------------
+ * sessions: a trajectory resident on the GPUs across the phases of density_clustering.cpp:597-817
+ * ------------------------------------------------------------------------------------- */
+/* The reference's GPU host code allocates, uploads the coordinates and frees again inside every call
+ * (density_clustering_cuda.cu:65-81, :133-135, :201-225, :278-281) and merges per-GPU partials on the
+ * host (:171-180, :311-326).  A session uploads once per device and keeps coordinates, operand
+ * workspace, populations, free energies and neighbours in HBM; one host thread drives each device
+ * (like :152-157, :295-299); with more than one device the partial results merge ON the devices with
+ * RCCL over xGMI -- all-reduce(sum, uint32) of the [n_radii][n_rows] populations, all-reduce(min,
+ * uint64) of the packed neighbour words and of the forest's candidates -- and only final arrays cross
+ * PCIe, from device 0.  Every device answers for one segment (dc_hip_*_segment_dev).  Host output
+ * pointers may be NULL (the result then only stays resident for the next phase).  A session is used
+ * by one host thread at a time. */
+typedef struct dc_hip_session dc_hip_session;
+
+/* devices: n_devices device ordinals, or NULL for 0..n_devices-1; n_devices <= 0: all devices.
+ * coords: HOST, read during the call only.  RCCL (librccl.so.1) is loaded on first need, i.e. when a
+ * session spans more than one device; failing to load it is an error (there is no host-merge path). */
+DC_API int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const int* devices,
+                               int n_devices, dc_hip_session** session);
+DC_API void dc_hip_session_close(dc_hip_session* session);
+DC_API int dc_hip_session_devices(const dc_hip_session* session);      /* number of devices */
+DC_API int dc_hip_session_uses_rccl(const dc_hip_session* session);    /* 1 if partials merge over RCCL */
+/* 32x32 frame-pair tiles the last population call / neighbour call evaluated, summed over devices */
+DC_API int dc_hip_session_counters(const dc_hip_session* session, uint64_t* pop_tiles, uint64_t* nn_tiles);
+
+/* CUDA::calculate_populations (density_clustering_cuda.cu:139-182) on the resident coordinates:
+ * populations for n_radii radii, in the order given.  pops: HOST [n_radii*n_rows] or NULL. */
+DC_API int dc_hip_session_populations(dc_hip_session* session, const float* radii, size_t n_radii,
+                                      uint32_t* pops);
+/* calculate_free_energies (density_clustering.cpp:197-212) of the resident populations of radius index
+ * radius_index, on every device.  fe: HOST [n_rows] or NULL; max_pop: optional. */
+DC_API int dc_hip_session_free_energies(dc_hip_session* session, size_t radius_index, float* fe,
+                                        uint32_t* max_pop);
+/* free energies from the caller instead (-D re-use, density_clustering.cpp:600-611; and the reference's
+ * nearest_neighbors(coords, ..., free_energy) signature).  fe: HOST [n_rows]. */
+DC_API int dc_hip_session_set_free_energies(dc_hip_session* session, const float* fe);
+/* CUDA::nearest_neighbors (density_clustering_cuda.cu:286-328) from the resident free energies, and
+ * compute_sigma2 (density_clustering.cpp:334-343: double sum in frame order).  All outputs HOST
+ * [n_rows] or NULL; sigma2 optional. */
+DC_API int dc_hip_session_nearest_neighbors(dc_hip_session* session, uint32_t* nn_idx, float* nn_d2,
+                                            uint32_t* hd_idx, float* hd_d2, double* sigma2);
+/* dc_hip_radius_pairs on the resident coordinates (device 0 of the session). */
+DC_API int dc_hip_session_radius_pairs(dc_hip_session* session, float r2, uint32_t* pairs, size_t capacity,
+                                       unsigned long long* count);
+/* dc_hip_radius_forest on the resident coordinates; with several devices every Boruvka round is one
+ * segment sweep per device + one all-reduce(min, uint64) of the per-component candidates. */
+DC_API int dc_hip_session_radius_forest(dc_hip_session* session, float r2, const uint32_t* rank,
+                                        uint32_t* edges, size_t* n_edges, uint32_t* n_rounds);
 
 #ifdef __cplusplus
 }

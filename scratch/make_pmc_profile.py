@@ -16,10 +16,21 @@ else:
     t = (bench['config']['n_rows'] + 31) // 32
     chains = {'pop': fr['pop'] * t * t * len(bench['config']['radii']), 'nn': fr['nn'] * t * t}
 dur = {}
+seen = set()
 for d in sq_dirs + tcc_dirs:
-    for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
-        for r in csv.DictReader(open(f)):
-            dur.setdefault(r['Kernel_Name'][:64], []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9)
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        grids = {}
+        for r in rows:
+            grids.setdefault(r['Kernel_Name'][:64], set()).add(r['Grid_Size'])
+        for r in rows:
+            k = r['Kernel_Name'][:64]
+            if len(grids[k]) > 1:
+                k += ' grid=' + r['Grid_Size']
+            if (f, r['Dispatch_Id']) in seen:
+                continue
+            seen.add((f, r['Dispatch_Id']))
+            dur.setdefault(k, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9)
 out = {"note": "rocprofv3 --kernel-trace --pmc, counters in their own passes (SQ sets and the two TCC_EA0 request counters "
                "separately). Values are per dispatch, summed over XCDs/SEs as rocprofv3 reports them. traffic_bytes = "
                "TCC_EA0_RDREQ_sum * 128 B + TCC_EA0_WRREQ_sum * 64 B (gfx950: the memory-side read requests of 16-byte-per-lane "
@@ -31,7 +42,7 @@ out = {"note": "rocprofv3 --kernel-trace --pmc, counters in their own passes (SQ
        "workload": workload, "kernels": {}}
 for k in set(sq) | set(mem):
     e = dict(sq.get(k, {}))
-    mk = [m for m in mem if m[:50] == k[:50]]
+    mk = [m for m in mem if m == k] or [m for m in mem if m[:50] == k[:50]]
     if mk:
         e.update({c: v for c, v in mem[mk[0]].items() if c != 'dispatches' or 'dispatches' not in e})
     key = 'pop' if 'pop_' in k else 'nn'

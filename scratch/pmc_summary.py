@@ -4,10 +4,20 @@ usage: pmc_summary.py <dir> [<dir> ...]  -> JSON on stdout"""
 import csv, glob, json, sys, collections
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
+rows = []
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
+        rows += list(csv.DictReader(open(f)))
+# a kernel launched with several grid sizes (a full sweep and one segment of it) is reported per grid size
+grids = collections.defaultdict(set)
+for r in rows:
+    grids[r["Kernel_Name"][:64]].add(r["Grid_Size"])
+for _ in [0]:
+    for _ in [0]:
+        for r in rows:
             k = r["Kernel_Name"][:64]
+            if len(grids[k]) > 1:
+                k += " grid=" + r["Grid_Size"]
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 out = {}

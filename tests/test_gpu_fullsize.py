@@ -156,28 +156,38 @@ def test_c5_one_segment_of_eight_all_radii_and_neighbours(dens, fast_oracle):
     nn_idx, nn_d2, hd_idx, hd_d2 = [t.cpu().numpy() for t in nn]
     nn_idx = nn_idx.astype(np.uint32).astype(np.int64)
     hd_idx = hd_idx.astype(np.uint32).astype(np.int64)
-    exp = fast_oracle.nearest_neighbors(c, fe_h, lo, lo + width)
-    assert (nn_idx[mine] == exp[0][mine].astype(np.int64)).all() and (hd_idx[mine] == exp[2][mine].astype(np.int64)).all()
-    assert (bits(nn_d2[mine]) == bits(exp[1][mine])).all() and (bits(hd_d2[mine]) == bits(exp[3][mine])).all()
-    # rows of other segments hold the "none" value; properties on all rows of this one
-    other = np.ones(n, dtype=bool)
-    other[rows] = False
+    # the neighbour sweep cuts its OWN spatial order (cells of columns 0/1, then free energy) into segments:
+    # segment 3 of the neighbour sweep holds other rows than segment 3 of the population sweep (any
+    # partition serves a sharded run, as long as the partials of each sweep merge)
     fmax = np.finfo(np.float32).max
-    assert (nn_idx[other] == n + 1).all() and (nn_d2[other] == fmax).all() and (hd_idx[other] == n + 1).all()
-    assert (nn_idx[rows] != rows).all() and (nn_idx[rows] < n).all() and (nn_d2[rows] <= hd_d2[rows]).all()
-    has_hd = rows[hd_idx[rows] < n]
+    nrows = np.nonzero(nn_idx <= n)[0]
+    assert abs(len(nrows) - n / G) < 0.02 * n
+    other = np.ones(n, dtype=bool)
+    other[nrows] = False
+    assert (nn_idx[other] == n + 1).all() and (nn_d2[other] == fmax).all()
+    assert (hd_idx[other] == n + 1).all() and (hd_d2[other] == fmax).all()
+    mine_n = nrows[(nrows >= lo) & (nrows < lo + width)]
+    assert len(mine_n) >= 500
+    exp = fast_oracle.nearest_neighbors(c, fe_h, lo, lo + width)
+    assert (nn_idx[mine_n] == exp[0][mine_n].astype(np.int64)).all() and (hd_idx[mine_n] == exp[2][mine_n].astype(np.int64)).all()
+    assert (bits(nn_d2[mine_n]) == bits(exp[1][mine_n])).all() and (bits(hd_d2[mine_n]) == bits(exp[3][mine_n])).all()
+    # properties on all rows of the segment
+    assert (nn_idx[nrows] != nrows).all() and (nn_idx[nrows] < n).all() and (nn_d2[nrows] <= hd_d2[nrows]).all()
+    has_hd = nrows[hd_idx[nrows] < n]
     assert (fe_h[hd_idx[has_hd]] < fe_h[has_hd]).all()
-    no_hd = rows[hd_idx[rows] > n]
+    no_hd = nrows[hd_idx[nrows] > n]
     assert (fe_h[no_hd] == fe_h.min()).all() and (hd_d2[no_hd] == fmax).all()
     rng = np.random.default_rng(5)
-    sample = rng.choice(rows, 3000, replace=False)
+    sample = rng.choice(nrows, 3000, replace=False)
     assert (bits(canonical_d2_rows(fast_oracle, c, sample, nn_idx[sample])) == bits(nn_d2[sample])).all()
     hs = sample[hd_idx[sample] < n]
     assert (bits(canonical_d2_rows(fast_oracle, c, hs, hd_idx[hs])) == bits(hd_d2[hs])).all()
     # a neighbour can be no farther than the population radius allows: pop(r) > 1  <=>  nn_d2 < r^2
+    both = np.intersect1d(rows, nrows)
+    assert len(both) > 0.005 * n
     for k, r in enumerate(C5_RADII):
         r2 = np.float32(r) * np.float32(r)
-        assert ((seg[k][rows] > 1) == (nn_d2[rows] < r2)).all()
+        assert ((seg[k][both] > 1) == (nn_d2[both] < r2)).all()
 
 
 def test_screening_forest_at_30_dims(dens, fast_oracle, tmp_path):
