@@ -277,8 +277,13 @@ void read_coords(const std::string& fname, std::vector<float>& coords, std::size
         continue;
       }
       char* next = nullptr;
-      const float v = std::strtof(q, &next);
-      if (next == q) {      // not a number: the reference's `ifs >> buf` fails here as well
+      const float v = std::strtof(q, &next);   // (this program never calls setlocale: "C" locale)
+      // what `ifs >> float` takes is a plain decimal number: strtof's "nan", "inf" and hex floats are
+      // not numbers to the reference (tools.hxx:99-101) and stop the read here as well
+      bool plain = next != q;
+      for (const char* r = q; plain && r < next; ++r)
+        plain = (*r >= '0' && *r <= '9') || *r == '+' || *r == '-' || *r == '.' || *r == 'e' || *r == 'E';
+      if (!plain) {
         stopped[i] = 1;
         break;
       }
@@ -304,8 +309,23 @@ void read_coords(const std::string& fname, std::vector<float>& coords, std::size
     coords.insert(coords.end(), piece[i].begin(), piece[i].end());
     if (stopped[i]) break;
   }
-  n_rows = coords.size() / n_cols;
-  coords.resize(n_rows * n_cols);
+  // rows = non-empty lines, like the reference counts them (tools.hxx:66-72); it then reads rows x
+  // columns numbers in stream order whatever the line structure is, and garbage once the stream fails.
+  // A file whose numbers do not fill that shape exactly is refused here instead.
+  std::size_t n_lines = 0;
+  for (const char* q = p; q < end;) {
+    const char* eol = static_cast<const char*>(std::memchr(q, '\n', end - q));
+    if (!eol) eol = end;
+    n_lines += (eol > q) ? 1 : 0;
+    q = eol + 1;
+  }
+  n_rows = n_lines;
+  if (coords.size() != n_rows * n_cols) {
+    char msg[256];
+    std::snprintf(msg, sizeof(msg), "error: '%s' has %zu non-empty lines of %zu columns but %zu readable numbers",
+                  fname.c_str(), n_rows, n_cols, coords.size());
+    die(msg);
+  }
   LOG("    with dimensions: %zux%zu\n\n", n_rows, n_cols);
 }
 

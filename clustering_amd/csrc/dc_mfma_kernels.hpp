@@ -73,6 +73,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -152,7 +153,7 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.T);
   L.off_merge64 = align256(L.off_coords_p + sizeof(float) * n_rows * n_cols);
   L.off_box_t = align256(L.off_merge64 + sizeof(unsigned long long) * 2 * n_rows);
-  L.fixed_end = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.T + 64));
+  L.fixed_end = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.T + L.T / 32 + 64));   // (+ one pad box per share)
   return L;
 }
 
@@ -2010,14 +2011,32 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
 constexpr uint32_t kPopWaveTarget = 98304, kNnWaveTarget = 98304;
 constexpr uint32_t kPopShareFloor = 512, kNnShareFloor = 900;
+// L2-sized shares.  Every wave streams its share of the operand image from the XCD's L2; a share larger than
+// the L2 (4 MiB per XCD) is re-fetched through the fabric by the waves that have drifted apart, and beyond the
+// Infinity Cache (C5: 0.96 GB image) that is HBM traffic -- measured at 5M x 30: 22 TB moved at 7.4 TB/s for one
+// full sweep, the sweep bound by it (profiles/r2_c5_pmc.json).  Workgroups are dispatched x-fastest, i.e. all
+// query groups of reference share 0 first, then share 1, ...: with shares of `share_bytes` the waves resident
+// on an XCD at any time read the same few megabytes and the fabric sees each share about once per XCD.
+inline uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return (v && v[0]) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
 inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles,
-                            uint32_t share_floor) {
+                            uint32_t share_floor, size_t tile_bytes) {
   const uint32_t waves = (tiles + tq - 1) / tq;
-  if (waves >= target) return 1u;
-  uint32_t r = (target + waves - 1) / waves;
+  uint32_t r = waves >= target ? 1u : (target + waves - 1) / waves;
   const uint32_t by_share = ref_tiles / share_floor;
   const uint32_t cap = by_share < 64u ? by_share : 64u;
   r = r > cap ? cap : r;
+  // shares no larger than DC_SHARE_KB of operand image (0: off), at least DC_SHARE_MIN_TILES tiles each
+  static const uint32_t share_kb = env_u32("DC_SHARE_KB", 0u), min_tiles = env_u32("DC_SHARE_MIN_TILES", 64u);
+  if (share_kb) {
+    const size_t image = (size_t)ref_tiles * tile_bytes;
+    uint32_t by_l2 = (uint32_t)((image + (size_t)share_kb * 1024 - 1) / ((size_t)share_kb * 1024));
+    const uint32_t l2_cap = ref_tiles / (min_tiles ? min_tiles : 1u);
+    by_l2 = by_l2 > l2_cap ? l2_cap : by_l2;
+    r = by_l2 > r ? by_l2 : r;
+  }
   return r < 1u ? 1u : r;
 }
 
@@ -2029,7 +2048,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
   if (A.n_q == 0) return;
   const uint32_t waves = seg_groups(((A.n_q + 31) / 32 + TQV - 1) / TQV, A.q_seg), tiles = waves * TQV;
   if (waves == 0) return;
-  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor);
+  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor, (size_t)S * 1024 + 128);
   // query rows (original coordinates) + candidate queues, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
@@ -2072,7 +2091,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // the query groups of this launch: all of them, or one segment's share
   const uint32_t waves = seg_groups(((n_q + 31) / 32 + TQV - 1) / TQV, q_seg), tiles = waves * TQV;
   if (waves == 0) return;
-  const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor)), block(256);
+  const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128)), block(256);
   // B form of the query rows: its own image for a row range, else the B form of the rows in the
   // reference order (img_q)
   const bool own = q_mode == kQueryOwnOrder;

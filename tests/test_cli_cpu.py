@@ -76,3 +76,17 @@ def test_shim_header_is_legal_next_to_the_reference_headers(tmp_path):
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-include", "limits", "-I", str(tmp_path), "-I", os.path.join(ref, "src"),
                         str(tmp_path / "tu.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_malformed_coordinate_files_are_refused(tmp_path):
+    """The reference counts non-empty lines as rows and then reads rows x columns numbers with `ifs >> float`
+    (tools.hxx:52-108): a ragged file, a comment or a token iostream does not take ('nan', 'inf', hex) makes
+    it read garbage.  This reader refuses such files before any GPU work (so the check runs without a GPU)."""
+    cases = {"ragged": "0 1\n2 3 4\n5 6\n", "comment": "# x y\n0 1\n2 3\n", "nan": "0 1\nnan 3\n",
+             "inf": "0 1\n2 inf\n", "hex": "0 1\n0x1p3 3\n", "short": "0 1\n2\n"}
+    for name, text in cases.items():
+        f = tmp_path / name
+        f.write_text(text)
+        r = run("density", "-f", str(f), "-r", "1", "-p", str(tmp_path / "pop"))
+        assert r.returncode != 0, name
+        assert ("readable numbers" in r.stderr) or ("no HIP" in r.stderr) or ("GPU" in r.stderr), (name, r.stderr)

@@ -244,3 +244,20 @@ def test_cpp_shim_reference_signatures(tmp_path, oracle):
     foreign = np.where(fe < np.float32(1.0), 1 + np.arange(len(fe)) % 3, 0)
     fline = [l.split() for l in lines if l.startswith("foreign ")][0]
     assert [int(x) for x in fline[2:]] == so.screening(fe, exp[1], 2.0, c, foreign).tolist()
+
+
+def test_cli_refuses_malformed_coordinate_files(tmp_path):
+    """see tests/test_cli_cpu.py::test_malformed_coordinate_files_are_refused -- here with a GPU present, so
+    that the reader itself is reached"""
+    cases = {"ragged": "0 1\n2 3 4\n5 6\n", "comment": "# x y\n0 1\n2 3\n", "nan": "0 1\nnan 3\n",
+             "inf": "0 1\n2 inf\n", "hex": "0 1\n0x1p3 3\n", "short": "0 1\n2\n"}
+    for name, text in cases.items():
+        (tmp_path / name).write_text(text)
+        r = subprocess.run([CLI, "density", "-f", str(tmp_path / name), "-r", "1", "-p", str(tmp_path / "pop")],
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "readable numbers" in r.stderr, (name, r.stderr)
+    (tmp_path / "ok").write_text("0 1\n\n2 3\n   4   5\n")     # empty lines are skipped, blanks are separators
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "ok"), "-r", "1.5", "-p", str(tmp_path / "pop")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert data_lines(tmp_path / "pop") == ["2", "2", "1"]
