@@ -449,6 +449,12 @@ struct QuerySel {
 };
 static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 5 ? 4 : 2; }   // = tq_for<NM>
 static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
+// query tiles per group of the population sweep that will run: the unit segments are dealt out in and the
+// query image is built for (pop_shared_kernel: the four waves of a workgroup form one group)
+static uint32_t pop_group_tiles(uint32_t n_rows, uint32_t n_cols, bool sink) {
+  if (!sink && pop_shared_wanted(n_rows, n_cols)) return 4u * (uint32_t)tq_shared_of(n_cols);
+  return (uint32_t)tq_pop_of(n_cols);
+}
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
@@ -607,7 +613,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     }
     if (q_mode != kQueryOwnOrder) {
       // queries in the reference order: only their B form is missing (of the groups of this segment)
-      const uint32_t tq = (uint32_t)tq_pop_of(n_cols);
+      const uint32_t tq = pop_group_tiles(n_rows, n_cols, sink_in != nullptr);
       const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
       if (tiles_q > 0)
         hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,

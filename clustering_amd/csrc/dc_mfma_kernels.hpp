@@ -502,6 +502,10 @@ __device__ __forceinline__ void pop_epi_begin(PopAcc<NR>& e) {
 // elements [R0, R1) of one accumulator tile (element r ends up at bit 15 - r of the sign strings)
 template <int NR, int R0, int R1>
 __device__ __forceinline__ void pop_epi(const f32x16& acc, const PopDeltas<NR>& dl, PopAcc<NR>& e) {
+#ifdef DC_EXP_NOEPI   // (timing experiments only: keeps the chain alive, inspects one element)
+  if constexpr (R0 == 0) e.tmin = min(e.tmin, __float_as_uint(acc[0]));
+  return;
+#endif
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
 #pragma unroll
@@ -1136,6 +1140,8 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     }
   }
 }
+
+#include "dc_mfma_shared.hpp"
 
 // =============================================================================================
 // nearest neighbour / nearest neighbour with lower free energy
@@ -2102,6 +2108,17 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // query rows (original coordinates) + queues of deferred exact evaluations, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
+  if (!sink && NRV == 1 && pop_shared_wanted(n_rows, n_cols)) {
+    constexpr int kTQS = tq_shared_for<S>;
+    const uint32_t groups = seg_groups(((n_q + 31) / 32 + 4 * kTQS - 1) / (4 * kTQS), q_seg);
+    if (groups == 0) return;
+    const dim3 grid_s(groups, pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
+    const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * (kWaveQueue + 2 * kTQS * 32);
+    hipLaunchKernelGGL((pop_shared_kernel<S, kTQS>), grid_s, block, smem_s, s, coords, n_rows, n_cols, P.img_p,
+                       P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
+                       chain_counter, rad2, pops);
+    return;
+  }
   // radius-graph variants: all rows only (query positions = reference positions)
   if (sink && sink->best)
     hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkMinEdge>), grid, block, smem, s, coords,

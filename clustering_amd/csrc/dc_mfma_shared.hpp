@@ -1,0 +1,296 @@
+// dc_mfma_shared.hpp -- population sweep with the reference operands SHARED THROUGH LDS by the four waves
+// of a workgroup (included by dc_mfma_kernels.hpp, inside namespace dc::{anonymous}).
+//
+// pop_pruned_kernel lets every wave stream its own copy of the surviving reference tiles from L2: NM KB
+// per tile for TQ chains.  That is fine while the operand image lives in the caches (C3: 64 MB), but at
+// C5 (5M x 30: NM = 6, image 0.96 GB > Infinity Cache) the sweep moved 22 TB through the fabric at
+// 7.4 TB/s and was bound by it (profiles/r2_c5_pmc.json).  Here the workgroup is the unit: its 4 x TQ query
+// tiles share one survivor list, every surviving reference tile is fetched ONCE per workgroup, straight into
+// an eight-slot LDS ring (`global_load_lds_dwordx4`: no staging registers), and read from there by the four
+// waves -- a quarter of the L2 traffic per chain, and `ds_read_b128` instead of global loads in the hot loop.
+// Wave w fetches the tiles i = w (mod 4) of the survivor sequence.  Every fourth tile:
+//     s_waitcnt vmcnt(0) (the wave's own tile of this window has landed)  ->  barrier (all four tiles of the
+//     window are visible, and everybody has left the previous window: its slots are free)  ->  issue the
+//     loads of the NEXT window
+// then four tiles of ds_read + TQ chains + epilogues (as pop_pruned_kernel) without further synchronisation:
+// one barrier per four reference tiles, loads four tiles (25 KB per workgroup at NM = 6) ahead of their use.
+// Counting, guard band, deferred exact re-check, reference shares (gridDim.y) and segments are those of
+// pop_pruned_kernel (single radius, no pair sinks).
+constexpr int kShareSub = 128;   // boxes scanned per wave and round
+constexpr int kRing = 8;         // LDS slots: two windows of four reference tiles
+constexpr int kWaveQueue = 128;  // deferred exact evaluations per wave (flushed in batches of 64)
+
+template <int NM>
+constexpr int kTileUnits = NM * 64 + 8;   // 16-byte units of one staged tile: NM fragments + 32 norms
+
+// evaluates the queued band pairs of a wave, 64 at a time (one per lane), and credits the owners of the
+// queries through their LDS counters.  Out of line: the hot loop calls it once every few hundred chains.
+__device__ __attribute__((noinline)) void pop_wave_flush(const uint32_t* queue, uint32_t qn,
+                                                         const uint32_t* jq_tab, uint32_t* fix_tab,
+                                                         const float* __restrict__ coords,
+                                                         const float* __restrict__ coords_r, uint32_t n_cols,
+                                                         float r2, int lane) {
+  for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
+    if (k0 + lane < qn) {
+      const uint32_t ent = queue[k0 + lane];
+      const uint32_t pos = ent & (kPopQueueMaxRows - 1u), qidx = ent >> kPopQueuePosBits;
+      const float d2c = dist2_canon_rt(coords + (size_t)jq_tab[qidx] * n_cols, 1, coords_r + (size_t)pos * n_cols, 1,
+                                       (int)n_cols);
+      if (d2c < r2) atomicAdd(&fix_tab[qidx], 1u);
+    }
+  }
+}
+
+template <int NM, int TQ>
+__global__ __launch_bounds__(256, 2) void pop_shared_kernel(
+    const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
+    const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
+    const float4* __restrict__ box_r, const float* __restrict__ coords_r, uint32_t T,
+    const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
+    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
+    const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
+    uint32_t* __restrict__ pops) {
+  static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+  __shared__ uint32_t lists[4][kShareSub];
+  __shared__ uint32_t list_cnt[4];
+  __shared__ float4 wave_box[4];
+  // dynamic LDS: operand ring [kRing][kTileUnits] x 16 B, then per wave the compact queue of deferred exact
+  // evaluations [kWaveQueue], the frame ids of its queries [TQ*32] and their exact-path counts [TQ*32].  (The
+  // query rows of the exact path stay in global memory here: staged in LDS like pop_pruned_kernel does they
+  // would take 61 KB at D = 30 with four tiles per wave and leave one workgroup per CU.)
+  extern __shared__ __attribute__((aligned(16))) float shared_dyn[];
+  if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
+  constexpr int kUnits = kTileUnits<NM>;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31, wib = tid >> 6;
+  const uint32_t group = xcd_contiguous(blockIdx.x, gridDim.x) * q_seg.stride + q_seg.offset;
+  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
+  const uint32_t TQT = (n_q + 31) / 32;
+  if (group * (4u * TQ) >= TQT) return;   // whole workgroup leaves
+  const uint32_t qt0 = (group * 4u + (uint32_t)wib) * TQ;
+  const bool wave_live = qt0 < TQT;       // (a wave without tiles keeps loading and meeting the barriers)
+  uint4* ring = reinterpret_cast<uint4*>(shared_dyn);
+  uint32_t* wave_lds = reinterpret_cast<uint32_t*>(shared_dyn + kRing * kUnits * 4) +
+                       (size_t)wib * (kWaveQueue + 2 * TQ * 32);
+  uint32_t* queue = wave_lds;                    // entry = reference position | (query tile * 32 + column) << 24
+  uint32_t* jq_tab = wave_lds + kWaveQueue;      // frame id of query (qt, c)
+  uint32_t* fix_tab = jq_tab + TQ * 32;          // band pairs of that query that the exact path found inside
+  uint32_t qn = 0;                               // queued entries (wave-uniform)
+
+  const PopSetup<1> P = pop_setup<1>(hdr, rad2, n_cols);
+  const float far2 = rad2.v[0] * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
+
+  s16x8 b[TQ][NM];
+  uint32_t cnt_q[TQ], jq[TQ];
+  uint64_t livemask[TQ];
+  float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const uint32_t tile = qt0 + qt;
+    const uint32_t tl = tile < TQT ? tile : TQT - 1;
+    const uint32_t pos = tile * 32 + c;
+    const bool live = (tile < TQT) && (pos < n_q);
+    livemask[qt] = __builtin_amdgcn_ballot_w64(live);
+    jq[qt] = live ? perm_q[pos] : 0u;
+    const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
+    load_query<NM>(img_q, tl, lane, h, cq, b[qt]);
+    cnt_q[qt] = 0;
+    if (h == 0) {
+      jq_tab[qt * 32 + c] = jq[qt];
+      fix_tab[qt * 32 + c] = 0;
+    }
+    const float4 qb = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    gbox.x = fminf(gbox.x, qb.x);
+    gbox.y = fmaxf(gbox.y, qb.y);
+    gbox.z = fminf(gbox.z, qb.z);
+    gbox.w = fmaxf(gbox.w, qb.w);
+  }
+  if (lane == 0) wave_box[wib] = gbox;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {   // the workgroup's box: one survivor list for all four waves
+    const float4 wb = wave_box[w];
+    gbox.x = fminf(gbox.x, wb.x);
+    gbox.y = fmaxf(gbox.y, wb.y);
+    gbox.z = fminf(gbox.z, wb.z);
+    gbox.w = fmaxf(gbox.w, wb.w);
+  }
+
+  // Deferred exact re-check, wave-wide.  A band pair is not evaluated where it appears (one or two lanes busy
+  // for a dependent memory latency) and not kept per lane either (pop_pruned_kernel's per-lane queues flush
+  // when ONE lane is full, with most lanes idle): the wave appends (reference position, query) to ONE compact
+  // list and evaluates 64 entries at a time, one per lane -- two independent row fetches and one canonical
+  // distance per lane and batch.  The owner of the query is credited through an LDS counter.  At C5's radii
+  // (r^2 near the typical pair distance: a band pair every five chains) the per-lane scheme cost 30 - 40 %
+  // of the sweep.
+  auto flush = [&]() {
+#ifndef DC_EXP_NOFLUSH
+    pop_wave_flush(queue, qn, jq_tab, fix_tab, coords, coords_r, n_cols, rad2.v[0], lane);
+#endif
+    qn = 0;
+  };
+  // the rest of an epilogue: count, band test, parking of the band pairs (positions fit the queue entries:
+  // the launcher sends larger problems to pop_pruned_kernel)
+  auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<1>& e, uint32_t t) {
+    constexpr int qi = decltype(qi_c)::value;
+    cnt_q[qi] += __builtin_popcount(e.bits[0]);
+    const bool band = e.tmin < P.wbits;
+#ifdef DC_EXP_NOBAND
+    if (false) {
+#else
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
+#endif
+      const float w = __uint_as_float(P.wbits);
+      uint32_t below = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[r] - w), 31);
+      uint32_t m = below & ~e.bits[0] & 0xFFFFu;   // 0 <= t < w, element r at bit 15 - r
+      // (pad rows (acc = +inf) and idle lanes (acc ~ 1e30) are never in the band; a compare per element into
+      //  scalar lane masks instead of the two sign strings was measured 20 % slower at C5)
+      for (;;) {
+        const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
+        if (have == 0) break;
+        const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
+        if (qn + n_new > (uint32_t)kWaveQueue) flush();
+        if (m != 0) {
+          const int p = __builtin_ctz(m);
+          const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
+          queue[slot] = tile_row(t, 15 - p, h) | ((uint32_t)(qi * 32 + c) << kPopQueuePosBits);
+          m &= m - 1;
+        }
+        qn += n_new;
+      }
+      if (qn >= 64u) flush();
+    }
+  };
+
+  uint32_t chains = 0;
+  const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
+  auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
+  for (uint32_t base = 0; base < U; base += 4 * kShareSub) {
+    // ---- scan: every wave tests its quarter of the round's boxes against the workgroup's box
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kShareSub; k += 64) {
+      const uint32_t u = base + (uint32_t)wib * kShareSub + k + lane;
+      bool ok = false;
+      uint32_t t = 0;
+      if (u < U) {
+        t = tile_of(u);
+        ok = box_gap2(gbox, box_r[t]) < far2;
+      }
+      const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+      if (ok) lists[wib][cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+      cnt += (uint32_t)__builtin_popcountll(m);
+    }
+    if (lane == 0) list_cnt[wib] = cnt;
+    __syncthreads();
+    const uint32_t o1 = list_cnt[0], o2 = o1 + list_cnt[1], o3 = o2 + list_cnt[2], total = o3 + list_cnt[3];
+    if (total != 0) {
+      auto entry = [&](uint32_t i) {
+        i = i < total ? i : total - 1;
+        const uint32_t w = (i >= o1 ? 1u : 0u) + (i >= o2 ? 1u : 0u) + (i >= o3 ? 1u : 0u);
+        const uint32_t off = i - (w == 0 ? 0u : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
+        return (uint32_t)__builtin_amdgcn_readfirstlane(lists[w][off]);
+      };
+      // reference tile t -> ring slot, by this wave alone: NM fragments of 1 KB (lane l lands at +16 l) and the
+      // 32 row norms (lanes 0..7)
+      auto fetch = [&](uint32_t t, uint32_t slot_id) {
+        __attribute__((address_space(3))) uint4* dst =
+            (__attribute__((address_space(3))) uint4*)(ring + slot_id * kUnits);
+        const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) __builtin_amdgcn_global_load_lds(src + m * 64, dst + m * 64, 16, 0, 0);
+        if (lane < 8)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane,
+                                           dst + NM * 64, 16, 0, 0);
+      };
+      f32x16 accA, accB;   // accB: the chain whose epilogue is pending (+inf everywhere: contributes nothing)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
+      uint32_t tB = 0;
+      if ((uint32_t)wib < total) fetch(entry((uint32_t)wib), (uint32_t)wib);
+      for (uint32_t i = 0; i < total; ++i) {
+        if ((i & 3u) == 0) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's tile of the window starting at i
+          __syncthreads();
+          const uint32_t nxt = i + 4 + (uint32_t)wib;
+          if (nxt < total) fetch(entry(nxt), nxt % kRing);
+        }
+        const uint32_t t = entry(i);
+        const uint4* slot = ring + (i % kRing) * kUnits;
+        s16x8 a[NM];
+        float4 nv[4];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) a[m] = __builtin_bit_cast(s16x8, slot[m * 64 + lane]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nv[g] = reinterpret_cast<const float4*>(slot + NM * 64)[2 * g + h];
+        if (wave_live) {
+          const f32x16 c0 = frag16(nv);
+          chains += TQ;
+          constexpr_for_pairs<TQ>([&](auto qt_c) {
+            constexpr int qt = decltype(qt_c)::value;
+            constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
+            PopAcc<1> e;
+            pop_epi_begin<1>(e);
+            pop_chain<NM, 1>(a, b[qt], c0, accA, accB, P.dl, e);
+            finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
+            pop_epi_begin<1>(e);
+            pop_chain<NM, 1>(a, b[qt + 1], c0, accB, accA, P.dl, e);
+            finish(accA, std::integral_constant<int, qt>{}, e, t);
+          });
+          tB = t;
+        }
+      }
+      if (wave_live) {  // drain: epilogue of the last pending chain of this round
+        PopAcc<1> e;
+        pop_epi_begin<1>(e);
+        pop_epi<1, 0, 16>(accB, P.dl, e);
+        finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
+      }
+    }
+    __syncthreads();   // lists and ring are free for the next round
+  }
+  if (lane == 0 && chain_counter && wave_live) atomicAdd(chain_counter, (unsigned long long)chains);
+  flush();
+
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const bool live = (livemask[qt] >> lane) & 1;
+    const uint32_t total = cnt_q[qt] + (uint32_t)__shfl_xor((int)cnt_q[qt], 32, 64) + fix_tab[qt * 32 + c];
+    if (h == 0 && live) {
+      // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2; the reference
+      // starts every population at 1 (:132-134): corrected once, by chunk 0
+      uint32_t v = total;
+      if (chunk == 0) {
+        const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
+        v += 1u - ((dself < rad2.v[0]) ? 1u : 0u);
+      }
+      if (n_chunks == 1)
+        pops[jq[qt]] = v;
+      else
+        atomicAdd(&pops[jq[qt]], v);   // pops was zero-filled by the caller
+    }
+  }
+}
+
+// Which shapes take the shared-operand sweep, and its query tiles per wave.  Measured (pop, one MI355X, per-wave
+// streams -> shared): 5M x 30 one segment of eight 202 -> 166 ms (r = 0.35), 286 -> 204 ms (r = 0.6), all rows
+// 2785 -> 1822 ms; 1M x 30 73.4 -> 59.6 ms; 1M x 40 97.3 -> 87.8 ms; 3M x 24 497 -> 482 ms; but 300k x 26
+// 5.81 -> 5.94 ms, 2M x 20 181 -> 190 ms, 4M x 12 536 -> 563 ms, 1M x 10 23.7 -> 28.4 ms: with few MFMAs per
+// chain the sweep is bound by its epilogue, not by the operand stream, and the workgroup-wide survivor list
+// prunes less than a wave's own.  So: five or more MFMAs per chain and an operand image beyond the caches'
+// comfortable reach.  DC_POP_SHARED = 0 / 1 forces it off / on (tests, measurements).
+template <int NM>
+constexpr int tq_shared_for = (NM <= 6) ? 4 : 2;   // (NM = 8 with four tiles: 52 spilled registers)
+inline int tq_shared_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 6 ? 4 : 2; }   // = tq_shared_for<NM>
+inline bool pop_shared_wanted(uint32_t n_rows, uint32_t n_cols) {
+  static const int forced = [] {
+    const char* v = getenv("DC_POP_SHARED");
+    return (v && v[0]) ? atoi(v) : -1;
+  }();
+  const int nm = nm_for((int)n_cols);
+  if (n_rows > kPopQueueMaxRows || nm > 8) return false;
+  if (forced >= 0) return forced != 0;
+  const size_t image = (size_t)((n_rows + 31) / 32) * (size_t)nm * 1024;
+  return nm >= 5 && image > ((size_t)96 << 20);
+}
