@@ -509,3 +509,43 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
     assert bool(((words[1] >> 32).to(torch.int32) == full_n[3].view(torch.int32)).all())
     for got, want in zip(dens.unpack_neighbors(words.contiguous()), full_n):   # dc_hip_neighbors_unpack_dev
         assert bool((got.view(torch.int32) == want.view(torch.int32)).all())
+
+
+SHARED_CHILD = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from clustering_amd import density as dens
+from clustering_amd.synth import gaussian_blobs
+rng = np.random.default_rng(7)
+for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 0.2), (700, 3, 0.1), (4097, 17, 0.35),
+                (33, 30, 0.5), (1, 26, 0.5)]:
+    c = gaussian_blobs(n, d, seed=n + d)
+    c[rng.integers(0, n, n // 5)] = c[rng.integers(0, n, n // 5)]          # duplicates
+    ct = torch.from_numpy(c).cuda()
+    want = dens.calculate_populations_partial(ct, [r, 0.8 * r], variant="direct")
+    got = dens.calculate_populations_partial(ct, [r, 0.8 * r], variant="pruned")
+    assert bool((got == want).all()), (n, d, "all rows")
+    lo, hi = n // 3, n // 3 + max(1, n // 2)
+    assert bool((dens.calculate_populations_partial(ct, [r], lo, hi, variant="pruned")
+                 == dens.calculate_populations_partial(ct, [r], lo, hi, variant="direct")).all()), (n, d, "row range")
+    acc = torch.zeros_like(want[:1])
+    for g in range(3):
+        acc += dens.calculate_populations_segment(ct, [r], g, 3)
+    assert bool((acc == want[:1]).all()), (n, d, "segments")
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_shared_operand_population_sweep():
+    """pop_shared_kernel (reference operands shared through LDS by the workgroup; taken by itself only for wide
+    rows and large images, e.g. C5) forced on for small shapes of every kind -- all rows, a row range, the
+    segments of a sharded run, duplicates, 1..8 MFMAs per chain -- against the direct kernels, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", SHARED_CHILD, root], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DC_POP_SHARED="1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
