@@ -1869,6 +1869,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     if (any_blind) {
       r2_hi = r2_hi * 4.0f;
     } else {
+      // (an intermediate ring at 0.35 .. 0.7 of this radius, to tighten the incumbents before the confirming
+      //  ring, was measured 3 % slower at C3: the incumbents of the first ring are already close to final)
       r2_hi = fmaxf(wave_max(need) * 1.001f, r2_hi * 1.001f);
     }
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
