@@ -14,7 +14,7 @@ if 'roofline_pop' in bench:
 else:
     fr = bench['roofline']['evaluated_fraction']
     t = (bench['config']['n_rows'] + 31) // 32
-    chains = {'pop': fr['pop'] * t * t * len(bench['config']['radii']), 'nn': fr['nn'] * t * t}
+    chains = {'pop': fr['pop'] * t * t, 'nn': fr['nn'] * t * t}   # (the counter sums over the radii of a call)
 dur = {}
 seen = set()
 for d in sq_dirs + tcc_dirs:
