@@ -451,9 +451,14 @@ static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 5 ? 4 : 2; }  
 static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
 // query tiles per group of the population sweep that will run: the unit segments are dealt out in and the
 // query image is built for (pop_shared_kernel: the four waves of a workgroup form one group)
-static uint32_t pop_group_tiles(uint32_t n_rows, uint32_t n_cols, bool sink) {
-  if (!sink && pop_shared_wanted(n_rows, n_cols)) return 4u * (uint32_t)tq_shared_of(n_cols);
+static uint32_t pop_group_tiles(uint32_t n_rows, uint32_t n_cols, bool sink, int n_rad) {
+  if (!sink && pop_shared_wanted(n_rows, n_cols)) return 4u * (uint32_t)tq_shared_of(n_cols, n_rad);
   return (uint32_t)tq_pop_of(n_cols);
+}
+// radii per sweep: one (the folded-threshold sweeps), except the shared-operand sweep of wide rows: up to eight
+static bool pop_multi_radius(uint32_t n_rows, uint32_t n_cols, int n_rad) {
+  const int nm = nm_for((int)n_cols);
+  return n_rad > 1 && nm >= 5 && nm <= 8 && pop_shared_wanted(n_rows, n_cols);
 }
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
@@ -463,6 +468,10 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                        hipStream_t stream) {
+  if (pop_multi_radius(n_rows, n_cols, n_rad)) {
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, rad2, n_rad, d_pops, d_ws, nullptr, stream);
+    return;
+  }
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, single_radius(rad2, r), 1,
                    d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, r == 0);   // one preparation for all radii
@@ -471,6 +480,11 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
 void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
                                uint32_t segment, uint32_t n_segments, const Rad2& rad2, int n_rad,
                                uint32_t* d_pops, void* d_ws, hipStream_t stream) {
+  if (pop_multi_radius(n_rows, n_cols, n_rad)) {
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments}, rad2, n_rad, d_pops, d_ws,
+                   nullptr, stream);
+    return;
+  }
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments},
                    single_radius(rad2, r), 1, d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, r == 0);
@@ -613,7 +627,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     }
     if (q_mode != kQueryOwnOrder) {
       // queries in the reference order: only their B form is missing (of the groups of this segment)
-      const uint32_t tq = pop_group_tiles(n_rows, n_cols, sink_in != nullptr);
+      const uint32_t tq = pop_group_tiles(n_rows, n_cols, sink_in != nullptr, n_rad);
       const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
       if (tiles_q > 0)
         hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,

@@ -2110,15 +2110,16 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // query rows (original coordinates) + queues of deferred exact evaluations, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
-  if (!sink && NRV == 1 && pop_shared_wanted(n_rows, n_cols)) {
-    constexpr int kTQS = tq_shared_for<S>;
+  if (!sink && pop_shared_wanted(n_rows, n_cols)) {
+    // reference operands shared through LDS (dc_mfma_shared.hpp); NRV radii in this one sweep
+    constexpr int kTQS = tq_shared_for<S, NRV>;
     const uint32_t groups = seg_groups(((n_q + 31) / 32 + 4 * kTQS - 1) / (4 * kTQS), q_seg);
     if (groups == 0) return;
     const dim3 grid_s(groups, pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
-    const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * (kWaveQueue + 2 * kTQS * 32);
-    hipLaunchKernelGGL((pop_shared_kernel<S, kTQS>), grid_s, block, smem_s, s, coords, n_rows, n_cols, P.img_p,
+    const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * shared_wave_words(kTQS, NRV);
+    hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, block, smem_s, s, coords, n_rows, n_cols, P.img_p,
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                       chain_counter, rad2, pops);
+                       chain_counter, rad2, n_rad, pops);
     return;
   }
   // radius-graph variants: all rows only (query positions = reference positions)
@@ -2151,7 +2152,17 @@ void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, 
                          uint32_t T, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,
                          int n_rad, uint32_t* pops, unsigned long long* chain_counter,
                          const EdgeSink* sink, hipStream_t s) {
-  // one radius per sweep (dc_mfma.hip loops over the radii of a call)
+  // one radius per sweep (dc_mfma.hip loops over the radii of a call) -- except the shared-operand sweep of wide
+  // rows, which takes up to eight (dc_mfma_shared.hpp; S >= 5 only: no instances for the narrow shapes)
+  if constexpr (S >= 5 && S <= 8) {
+    if (!sink && n_rad > 1 && pop_shared_wanted(n_rows, n_cols)) {
+      if (n_rad <= 4)
+        pop_pruned_launch<S, 4, 2>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2, n_rad, pops, chain_counter, sink, s);
+      else
+        pop_pruned_launch<S, 8, 2>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2, n_rad, pops, chain_counter, sink, s);
+      return;
+    }
+  }
   pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2, n_rad, pops,
                       chain_counter, sink, s);
 }

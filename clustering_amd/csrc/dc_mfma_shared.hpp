@@ -19,43 +19,102 @@
 constexpr int kShareSub = 128;   // boxes scanned per wave and round
 constexpr int kRing = 8;         // LDS slots: two windows of four reference tiles
 constexpr int kWaveQueue = 128;  // deferred exact evaluations per wave (flushed in batches of 64)
+// 32-bit words of LDS per wave behind the ring: queue (8 B entries), frame ids, exact-path counts per radius
+constexpr size_t shared_wave_words(int tq, int nr) { return 2 * kWaveQueue + (size_t)(1 + nr) * tq * 32; }
 
 template <int NM>
 constexpr int kTileUnits = NM * 64 + 8;   // 16-byte units of one staged tile: NM fragments + 32 norms
 
+// ---- epilogue for NR radii per sweep ---------------------------------------------------------------------
+// With five and more MFMAs per chain the distances are worth more than the compares: ONE sweep serves up to
+// eight radii (C5: eight radii, NM = 6 -- eight single-radius sweeps cost 8 x (4 x 26 + 24 x 6) = 1 984 cycles
+// per tile pair by the issue model of DESIGN.md section 5, one sweep 4 x 8 x 33 + 24 x 6 = 1 200).  Per radius
+// and element: t = acc - delta_r (two elements per v_pk_add_f32), the sign into that radius' bit string
+// (v_alignbit), and the radius' own unsigned minimum (v_min3_u32, two elements per instruction) -- the band
+// test then knows WHICH radii have a pair in their band, and only those build the second sign string.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NR>
+struct MrAcc {
+  uint32_t bits[NR];   // sign bits of t_r, one per element, shifted in from the right
+  uint32_t tmin[NR];   // unsigned minimum over the elements of bits(t_r)
+};
+template <int NR>
+__device__ __forceinline__ void mr_begin(MrAcc<NR>& e) {
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+    e.bits[rr] = 0;
+    e.tmin[rr] = 0xFFFFFFFFu;
+  }
+}
+template <int NR, int R0, int R1>   // elements [R0, R1), both even
+__device__ __forceinline__ void mr_epi(const f32x16& acc, const PopDeltas<NR>& dl, MrAcc<NR>& e) {
+  static_assert(R0 % 2 == 0 && R1 % 2 == 0, "elements are handled in pairs");
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+#pragma unroll
+    for (int r = R0; r < R1; r += 2) {
+      f32x2 t = {acc[r], acc[r + 1]};
+      if (rr != 0) t = t - f32x2{dl.d[rr], dl.d[rr]};
+      const uint32_t u0 = __float_as_uint(t.x), u1 = __float_as_uint(t.y);
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], u0, 31);
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], u1, 31);
+      e.tmin[rr] = min(min(e.tmin[rr], u0), u1);
+    }
+  }
+}
+template <int NM, int NR, int MI = 0>
+__device__ __forceinline__ void mr_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM], const f32x16& c0,
+                                         f32x16& acc_new, const f32x16& acc_old, const PopDeltas<NR>& dl,
+                                         MrAcc<NR>& e) {
+  if constexpr (MI < NM) {
+    if constexpr (MI == 0)
+      acc_new = mfma16(a[0], b[0], c0);
+    else
+      acc_new = mfma16(a[MI], b[MI], acc_new);
+    mr_epi<NR, 2 * ((8 * MI) / NM), 2 * ((8 * (MI + 1)) / NM)>(acc_old, dl, e);
+    mr_chain<NM, NR, MI + 1>(a, b, c0, acc_new, acc_old, dl, e);
+  }
+}
+
 // evaluates the queued band pairs of a wave, 64 at a time (one per lane), and credits the owners of the
-// queries through their LDS counters.  Out of line: the hot loop calls it once every few hundred chains.
-__device__ __attribute__((noinline)) void pop_wave_flush(const uint32_t* queue, uint32_t qn,
+// queries through their LDS counters (fix_tab[radius][query]).  Entry: x = reference position, y = query
+// (tile * 32 + column) | radii whose band holds the pair << 8.  Out of line: the hot loop calls it once
+// every few hundred chains.
+template <int NR>
+__device__ __attribute__((noinline)) void pop_wave_flush(const uint2* queue, uint32_t qn,
                                                          const uint32_t* jq_tab, uint32_t* fix_tab,
-                                                         const float* __restrict__ coords,
+                                                         uint32_t n_queries, const float* __restrict__ coords,
                                                          const float* __restrict__ coords_r, uint32_t n_cols,
-                                                         float r2, int lane) {
+                                                         Rad2 rad2, int lane) {
   for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
     if (k0 + lane < qn) {
-      const uint32_t ent = queue[k0 + lane];
-      const uint32_t pos = ent & (kPopQueueMaxRows - 1u), qidx = ent >> kPopQueuePosBits;
-      const float d2c = dist2_canon_rt(coords + (size_t)jq_tab[qidx] * n_cols, 1, coords_r + (size_t)pos * n_cols, 1,
+      const uint2 ent = queue[k0 + lane];
+      const uint32_t qidx = ent.y & 0xFFu, flags = ent.y >> 8;
+      const float d2c = dist2_canon_rt(coords + (size_t)jq_tab[qidx] * n_cols, 1, coords_r + (size_t)ent.x * n_cols, 1,
                                        (int)n_cols);
-      if (d2c < r2) atomicAdd(&fix_tab[qidx], 1u);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr)
+        if (((flags >> rr) & 1u) && d2c < rad2.v[rr]) atomicAdd(&fix_tab[rr * n_queries + qidx], 1u);
     }
   }
 }
 
-template <int NM, int TQ>
+template <int NM, int TQ, int NR>
 __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
     const float4* __restrict__ box_r, const float* __restrict__ coords_r, uint32_t T,
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
-    const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
+    const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2, int n_rad,
     uint32_t* __restrict__ pops) {
   static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+  static_assert(NR >= 1 && NR <= 8 && TQ * 32 <= 256, "queue entries: 8 radius flags, 8 bits of query index");
   __shared__ uint32_t lists[4][kShareSub];
   __shared__ uint32_t list_cnt[4];
   __shared__ float4 wave_box[4];
   // dynamic LDS: operand ring [kRing][kTileUnits] x 16 B, then per wave the compact queue of deferred exact
-  // evaluations [kWaveQueue], the frame ids of its queries [TQ*32] and their exact-path counts [TQ*32].  (The
+  // evaluations [kWaveQueue] x 8 B, the frame ids of its queries [TQ*32] and their exact-path counts [NR][TQ*32].  (The
   // query rows of the exact path stay in global memory here: staged in LDS like pop_pruned_kernel does they
   // would take 61 KB at D = 30 with four tiles per wave and leave one workgroup per CU.)
   extern __shared__ __attribute__((aligned(16))) float shared_dyn[];
@@ -70,17 +129,20 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   const bool wave_live = qt0 < TQT;       // (a wave without tiles keeps loading and meeting the barriers)
   uint4* ring = reinterpret_cast<uint4*>(shared_dyn);
   uint32_t* wave_lds = reinterpret_cast<uint32_t*>(shared_dyn + kRing * kUnits * 4) +
-                       (size_t)wib * (kWaveQueue + 2 * TQ * 32);
-  uint32_t* queue = wave_lds;                    // entry = reference position | (query tile * 32 + column) << 24
-  uint32_t* jq_tab = wave_lds + kWaveQueue;      // frame id of query (qt, c)
-  uint32_t* fix_tab = jq_tab + TQ * 32;          // band pairs of that query that the exact path found inside
-  uint32_t qn = 0;                               // queued entries (wave-uniform)
+                       (size_t)wib * shared_wave_words(TQ, NR);
+  uint2* queue = reinterpret_cast<uint2*>(wave_lds);   // (reference position, query | radius flags << 8)
+  uint32_t* jq_tab = wave_lds + 2 * kWaveQueue;        // frame id of query (qt, c)
+  uint32_t* fix_tab = jq_tab + TQ * 32;                // [NR][TQ*32]: band pairs the exact path found inside
+  uint32_t qn = 0;                                     // queued entries (wave-uniform)
 
-  const PopSetup<1> P = pop_setup<1>(hdr, rad2, n_cols);
-  const float far2 = rad2.v[0] * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
+  const PopSetup<NR> P = pop_setup<NR>(hdr, rad2, n_cols);
+  float r2max = rad2.v[0];
+#pragma unroll
+  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
+  const float far2 = r2max * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
 
   s16x8 b[TQ][NM];
-  uint32_t cnt_q[TQ], jq[TQ];
+  uint32_t cnt_q[TQ][NR], jq[TQ];
   uint64_t livemask[TQ];
   float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
 #pragma unroll
@@ -93,10 +155,12 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     jq[qt] = live ? perm_q[pos] : 0u;
     const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
     load_query<NM>(img_q, tl, lane, h, cq, b[qt]);
-    cnt_q[qt] = 0;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) cnt_q[qt][rr] = 0;
     if (h == 0) {
       jq_tab[qt * 32 + c] = jq[qt];
-      fix_tab[qt * 32 + c] = 0;
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) fix_tab[rr * (TQ * 32) + qt * 32 + c] = 0;
     }
     const float4 qb = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
     gbox.x = fminf(gbox.x, qb.x);
@@ -124,28 +188,46 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   // of the sweep.
   auto flush = [&]() {
 #ifndef DC_EXP_NOFLUSH
-    pop_wave_flush(queue, qn, jq_tab, fix_tab, coords, coords_r, n_cols, rad2.v[0], lane);
+    pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords, coords_r, n_cols, rad2, lane);
 #endif
     qn = 0;
   };
-  // the rest of an epilogue: count, band test, parking of the band pairs (positions fit the queue entries:
+  // the rest of an epilogue: counts, band test, parking of the band pairs (positions fit the queue entries:
   // the launcher sends larger problems to pop_pruned_kernel)
-  auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<1>& e, uint32_t t) {
+  auto finish = [&](const f32x16& acc, auto qi_c, const MrAcc<NR>& e, uint32_t t) {
     constexpr int qi = decltype(qi_c)::value;
-    cnt_q[qi] += __builtin_popcount(e.bits[0]);
-    const bool band = e.tmin < P.wbits;
+    uint32_t tmin = e.tmin[0];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      cnt_q[qi][rr] += __builtin_popcount(e.bits[rr]);   // (16 shifts from 0: 16 bits)
+      tmin = min(tmin, e.tmin[rr]);
+    }
 #ifdef DC_EXP_NOBAND
     if (false) {
 #else
-    if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(tmin < P.wbits) & livemask[qi]) != 0, 0)) {
 #endif
+      // Band <=> 0 <= t_r < w: the sign string of (t_r - w) minus the sign string of t_r, element r at bit
+      // 15 - r -- built only for the radii whose minimum says that some lane has a pair in the band.  Pad rows
+      // (acc = +inf) and idle lanes (acc ~ 1e30) are never in a band.  (A compare per element into scalar lane
+      // masks instead of the second sign string was measured 20 % slower at C5.)
       const float w = __uint_as_float(P.wbits);
-      uint32_t below = 0;
+      uint32_t fl[NR];
+      uint32_t m = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[r] - w), 31);
-      uint32_t m = below & ~e.bits[0] & 0xFFFFu;   // 0 <= t < w, element r at bit 15 - r
-      // (pad rows (acc = +inf) and idle lanes (acc ~ 1e30) are never in the band; a compare per element into
-      //  scalar lane masks instead of the two sign strings was measured 20 % slower at C5)
+      for (int rr = 0; rr < NR; ++rr) {
+        fl[rr] = 0;
+        if (__builtin_amdgcn_ballot_w64(e.tmin[rr] < P.wbits) != 0) {
+          uint32_t below = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {   // (t_r with the roundings of mr_epi, then the shift by w)
+            const float tv = rr == 0 ? acc[r] : acc[r] - P.dl.d[rr];
+            below = __builtin_amdgcn_alignbit(below, __float_as_uint(tv - w), 31);
+          }
+          fl[rr] = below & ~e.bits[rr] & 0xFFFFu;
+          m |= fl[rr];
+        }
+      }
       for (;;) {
         const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
         if (have == 0) break;
@@ -153,8 +235,11 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
         if (qn + n_new > (uint32_t)kWaveQueue) flush();
         if (m != 0) {
           const int p = __builtin_ctz(m);
+          uint32_t flags = 0;
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) flags |= ((fl[rr] >> p) & 1u) << rr;
           const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
-          queue[slot] = tile_row(t, 15 - p, h) | ((uint32_t)(qi * 32 + c) << kPopQueuePosBits);
+          queue[slot] = make_uint2(tile_row(t, 15 - p, h), (uint32_t)(qi * 32 + c) | (flags << 8));
           m &= m - 1;
         }
         qn += n_new;
@@ -230,21 +315,21 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
           constexpr_for_pairs<TQ>([&](auto qt_c) {
             constexpr int qt = decltype(qt_c)::value;
             constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
-            PopAcc<1> e;
-            pop_epi_begin<1>(e);
-            pop_chain<NM, 1>(a, b[qt], c0, accA, accB, P.dl, e);
+            MrAcc<NR> e;
+            mr_begin<NR>(e);
+            mr_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
             finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
-            pop_epi_begin<1>(e);
-            pop_chain<NM, 1>(a, b[qt + 1], c0, accB, accA, P.dl, e);
+            mr_begin<NR>(e);
+            mr_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e);
             finish(accA, std::integral_constant<int, qt>{}, e, t);
           });
           tB = t;
         }
       }
       if (wave_live) {  // drain: epilogue of the last pending chain of this round
-        PopAcc<1> e;
-        pop_epi_begin<1>(e);
-        pop_epi<1, 0, 16>(accB, P.dl, e);
+        MrAcc<NR> e;
+        mr_begin<NR>(e);
+        mr_epi<NR, 0, 16>(accB, P.dl, e);
         finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
       }
     }
@@ -256,19 +341,23 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
     const bool live = (livemask[qt] >> lane) & 1;
-    const uint32_t total = cnt_q[qt] + (uint32_t)__shfl_xor((int)cnt_q[qt], 32, 64) + fix_tab[qt * 32 + c];
-    if (h == 0 && live) {
-      // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2; the reference
-      // starts every population at 1 (:132-134): corrected once, by chunk 0
-      uint32_t v = total;
-      if (chunk == 0) {
-        const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
-        v += 1u - ((dself < rad2.v[0]) ? 1u : 0u);
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      const uint32_t total = cnt_q[qt][rr] + (uint32_t)__shfl_xor((int)cnt_q[qt][rr], 32, 64) +
+                             fix_tab[rr * (TQ * 32) + qt * 32 + c];
+      if (h == 0 && live && rr < n_rad) {
+        // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2; the reference
+        // starts every population at 1 (:132-134): corrected once, by chunk 0
+        uint32_t v = total;
+        if (chunk == 0) {
+          const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
+          v += 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
+        }
+        if (n_chunks == 1)
+          pops[(size_t)rr * n_rows + jq[qt]] = v;
+        else
+          atomicAdd(&pops[(size_t)rr * n_rows + jq[qt]], v);   // pops was zero-filled by the caller
       }
-      if (n_chunks == 1)
-        pops[jq[qt]] = v;
-      else
-        atomicAdd(&pops[jq[qt]], v);   // pops was zero-filled by the caller
     }
   }
 }
@@ -280,9 +369,14 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
 // chain the sweep is bound by its epilogue, not by the operand stream, and the workgroup-wide survivor list
 // prunes less than a wave's own.  So: five or more MFMAs per chain and an operand image beyond the caches'
 // comfortable reach.  DC_POP_SHARED = 0 / 1 forces it off / on (tests, measurements).
-template <int NM>
-constexpr int tq_shared_for = (NM <= 6) ? 4 : 2;   // (NM = 8 with four tiles: 52 spilled registers)
-inline int tq_shared_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 6 ? 4 : 2; }   // = tq_shared_for<NM>
+// query tiles per wave: four while the registers allow (one radius, NM <= 6; NM = 8 with four tiles spilled 52
+// registers), two with several radii per sweep (eight counters and sixteen epilogue registers per tile more)
+template <int NM, int NR>
+constexpr int tq_shared_for = (NM <= 6 && NR == 1) ? 4 : 2;
+inline int nr_shared_of(int n_rad) { return n_rad <= 1 ? 1 : (n_rad <= 4 ? 4 : 8); }   // radii per sweep instance
+inline int tq_shared_of(uint32_t n_cols, int n_rad) {   // = tq_shared_for<NM, NR>
+  return (nm_for((int)n_cols) <= 6 && nr_shared_of(n_rad) == 1) ? 4 : 2;
+}
 inline bool pop_shared_wanted(uint32_t n_rows, uint32_t n_cols) {
   static const int forced = [] {
     const char* v = getenv("DC_POP_SHARED");

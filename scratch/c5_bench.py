@@ -46,6 +46,8 @@ line = {
                            "nn": nn_tiles * 1024.0 / (float(rows) * n),
                            "full sweep": full_tiles * 1024.0 / (float(n) * n)},
     "roofline_pop": roof(pop_tiles, pop_ms), "roofline_nn": roof(nn_tiles, nn_ms),
+    "note_pop": "eight radii in ONE sweep (pop_shared_kernel<6, 2, 8>): the tile pairs above are evaluated once for all radii, "
+                "the time is the per-radius epilogue (8 x 33 VALU instructions per tile pair), not the matrix pipe",
     "hbm_model": {"Q_res": rows, "note": "all query rows of the rank are resident in one launch (TQ*32 per wave, every wave "
                   "streams the surviving reference tiles), so the streamed model of SURVEY 8(d) is one pass over the coordinates",
                   "algorithmic_bytes_per_sweep": n * d * 4 + rows * 16,

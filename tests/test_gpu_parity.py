@@ -533,6 +533,15 @@ for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 
     for g in range(3):
         acc += dens.calculate_populations_segment(ct, [r], g, 3)
     assert bool((acc == want[:1]).all()), (n, d, "segments")
+    # several radii in ONE sweep (wide rows only: 5..8 MFMAs per chain), 2..17 radii in any order
+    for n_rad in (2, 4, 5, 8, 9, 17):
+        radii = [float(x) for x in r * rng.uniform(0.5, 1.3, n_rad)]
+        want_m = dens.calculate_populations_partial(ct, radii, variant="direct")
+        assert bool((dens.calculate_populations_partial(ct, radii, variant="pruned") == want_m).all()), (n, d, n_rad)
+        acc = torch.zeros_like(want_m)
+        for g in range(2):
+            acc += dens.calculate_populations_segment(ct, radii, g, 2)
+        assert bool((acc == want_m).all()), (n, d, n_rad, "segments")
 print("ok")
 """
 
@@ -541,7 +550,8 @@ print("ok")
 def test_shared_operand_population_sweep():
     """pop_shared_kernel (reference operands shared through LDS by the workgroup; taken by itself only for wide
     rows and large images, e.g. C5) forced on for small shapes of every kind -- all rows, a row range, the
-    segments of a sharded run, duplicates, 1..8 MFMAs per chain -- against the direct kernels, bit for bit."""
+    segments of a sharded run, duplicates, 1..8 MFMAs per chain, and (wide rows) up to eight radii per sweep --
+    against the direct kernels, bit for bit."""
     import os
     import subprocess
     import sys
