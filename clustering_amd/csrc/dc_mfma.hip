@@ -452,13 +452,13 @@ static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq
 // query tiles per group of the population sweep that will run: the unit segments are dealt out in and the
 // query image is built for (pop_shared_kernel: the four waves of a workgroup form one group)
 static uint32_t pop_group_tiles(uint32_t n_rows, uint32_t n_cols, bool sink, int n_rad) {
-  if (!sink && pop_shared_wanted(n_rows, n_cols)) return 4u * (uint32_t)tq_shared_of(n_cols, n_rad);
+  if (!sink && pop_shared_wanted(n_rows, n_cols, n_rad)) return 4u * (uint32_t)tq_shared_of(n_cols, n_rad);
   return (uint32_t)tq_pop_of(n_cols);
 }
 // radii per sweep: one (the folded-threshold sweeps), except the shared-operand sweep of wide rows: up to eight
 static bool pop_multi_radius(uint32_t n_rows, uint32_t n_cols, int n_rad) {
   const int nm = nm_for((int)n_cols);
-  return n_rad > 1 && nm >= 5 && nm <= 8 && pop_shared_wanted(n_rows, n_cols);
+  return n_rad > 1 && nm >= 3 && nm <= 8 && pop_shared_wanted(n_rows, n_cols, n_rad);
 }
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,

@@ -1141,6 +1141,11 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   }
 }
 
+inline uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return (v && v[0]) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
 #include "dc_mfma_shared.hpp"
 
 // =============================================================================================
@@ -2025,10 +2030,6 @@ constexpr uint32_t kPopShareFloor = 512, kNnShareFloor = 900;
 // full sweep, the sweep bound by it (profiles/r2_c5_pmc.json).  Workgroups are dispatched x-fastest, i.e. all
 // query groups of reference share 0 first, then share 1, ...: with shares of `share_bytes` the waves resident
 // on an XCD at any time read the same few megabytes and the fabric sees each share about once per XCD.
-inline uint32_t env_u32(const char* name, uint32_t dflt) {
-  const char* v = getenv(name);
-  return (v && v[0]) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
-}
 inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles,
                             uint32_t share_floor, size_t tile_bytes) {
   const uint32_t waves = (tiles + tq - 1) / tq;
@@ -2110,7 +2111,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // query rows (original coordinates) + queues of deferred exact evaluations, per wave
   const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
                       sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
-  if (!sink && pop_shared_wanted(n_rows, n_cols)) {
+  if (!sink && pop_shared_wanted(n_rows, n_cols, n_rad)) {
     // reference operands shared through LDS (dc_mfma_shared.hpp); NRV radii in this one sweep
     constexpr int kTQS = tq_shared_for<S, NRV>;
     const uint32_t groups = seg_groups(((n_q + 31) / 32 + 4 * kTQS - 1) / (4 * kTQS), q_seg);
@@ -2153,9 +2154,9 @@ void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, 
                          int n_rad, uint32_t* pops, unsigned long long* chain_counter,
                          const EdgeSink* sink, hipStream_t s) {
   // one radius per sweep (dc_mfma.hip loops over the radii of a call) -- except the shared-operand sweep of wide
-  // rows, which takes up to eight (dc_mfma_shared.hpp; S >= 5 only: no instances for the narrow shapes)
-  if constexpr (S >= 5 && S <= 8) {
-    if (!sink && n_rad > 1 && pop_shared_wanted(n_rows, n_cols)) {
+  // rows, which takes up to eight (dc_mfma_shared.hpp; S >= 3 only: no instances for the narrow shapes)
+  if constexpr (S >= 3 && S <= 8) {
+    if (!sink && n_rad > 1 && pop_shared_wanted(n_rows, n_cols, n_rad)) {
       if (n_rad <= 4)
         pop_pruned_launch<S, 4, 2>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2, n_rad, pops, chain_counter, sink, s);
       else

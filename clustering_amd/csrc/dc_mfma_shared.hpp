@@ -362,22 +362,24 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   }
 }
 
-// Which shapes take the shared-operand sweep, and its query tiles per wave.  Measured (pop, one MI355X, per-wave
-// streams -> shared): 5M x 30 one segment of eight 202 -> 166 ms (r = 0.35), 286 -> 204 ms (r = 0.6), all rows
-// 2785 -> 1822 ms; 1M x 30 73.4 -> 59.6 ms; 1M x 40 97.3 -> 87.8 ms; 3M x 24 497 -> 482 ms; but 300k x 26
-// 5.81 -> 5.94 ms, 2M x 20 181 -> 190 ms, 4M x 12 536 -> 563 ms, 1M x 10 23.7 -> 28.4 ms: with few MFMAs per
-// chain the sweep is bound by its epilogue, not by the operand stream, and the workgroup-wide survivor list
-// prunes less than a wave's own.  So: five or more MFMAs per chain and an operand image beyond the caches'
-// comfortable reach.  DC_POP_SHARED = 0 / 1 forces it off / on (tests, measurements).
-// query tiles per wave: four while the registers allow (one radius, NM <= 6; NM = 8 with four tiles spilled 52
-// registers), two with several radii per sweep (eight counters and sixteen epilogue registers per tile more)
+// Which calls take the shared-operand sweep.  Measured (pop, one MI355X, per-wave streams -> shared), ONE radius:
+// 5M x 30 one segment of eight 202 -> 166 ms (r = 0.35), 286 -> 204 ms (r = 0.6), all rows 2785 -> 1822 ms; 1M x 30
+// 73.4 -> 59.6 ms; 1M x 40 97.3 -> 87.8 ms; 3M x 24 497 -> 482 ms; but 300k x 26 5.81 -> 5.94 ms, 2M x 20 181 -> 190 ms,
+// 4M x 12 536 -> 563 ms, 1M x 10 23.7 -> 28.4 ms: with few MFMAs per chain a single-radius sweep is bound by its epilogue,
+// not by the operand stream, and the workgroup-wide survivor list prunes less than a wave's own -- five or more MFMAs
+// per chain and an operand image beyond the caches' comfortable reach.  SEVERAL radii in one call (one sweep for up to
+// eight of them against one sweep per radius): 5M x 30 segment, 8 radii 1449 -> 845 ms; 300k x 26, 8 radii 39.1 -> 24.7 ms;
+// 2M x 20, 8 radii 1390 -> 1068 ms; 1M x 16, 8 radii 300 -> 222 ms, 4 radii 153 -> 127 ms; 600k x 12, 8 radii 90 -> 77 ms
+// (the distances are computed once; by the issue model the gain is (4*26 + 24*NM) R against 4*33 R + 24*NM cycles):
+// three or more MFMAs per chain and three or more radii, or five or more MFMAs and two radii.
+// DC_POP_SHARED = 0 / 1 forces it off / on (tests, measurements).
 template <int NM, int NR>
 constexpr int tq_shared_for = (NM <= 6 && NR == 1) ? 4 : 2;
 inline int nr_shared_of(int n_rad) { return n_rad <= 1 ? 1 : (n_rad <= 4 ? 4 : 8); }   // radii per sweep instance
 inline int tq_shared_of(uint32_t n_cols, int n_rad) {   // = tq_shared_for<NM, NR>
   return (nm_for((int)n_cols) <= 6 && nr_shared_of(n_rad) == 1) ? 4 : 2;
 }
-inline bool pop_shared_wanted(uint32_t n_rows, uint32_t n_cols) {
+inline bool pop_shared_wanted(uint32_t n_rows, uint32_t n_cols, int n_rad) {
   static const int forced = [] {
     const char* v = getenv("DC_POP_SHARED");
     return (v && v[0]) ? atoi(v) : -1;
@@ -386,5 +388,6 @@ inline bool pop_shared_wanted(uint32_t n_rows, uint32_t n_cols) {
   if (n_rows > kPopQueueMaxRows || nm > 8) return false;
   if (forced >= 0) return forced != 0;
   const size_t image = (size_t)((n_rows + 31) / 32) * (size_t)nm * 1024;
-  return nm >= 5 && image > ((size_t)96 << 20);
+  if (nm >= 5 && image > ((size_t)96 << 20)) return true;
+  return n_rows >= 50000u && ((nm >= 3 && n_rad >= 3) || (nm >= 5 && n_rad >= 2));
 }

@@ -27,3 +27,16 @@ for n, d in [(9000, 30), (5000, 24), (3000, 40), (4097, 27), (33, 30), (20000, 3
             bad += 1
             print("MISMATCH", n, d, n_rad, ok, ok2, ok3)
 print("multi-radius check:", "ok" if bad == 0 else f"{bad} mismatches")
+# default rule (no forcing needed): rows >= 50000, three or more MFMAs per chain, several radii
+if len(sys.argv) > 1 and sys.argv[1] == "auto":
+    for n, d, n_rad in [(60000, 16, 5), (80000, 30, 2), (50000, 12, 3), (70000, 40, 8)]:
+        c = gaussian_blobs(n, d, seed=n + d)
+        ct = torch.from_numpy(c).cuda()
+        radii = [float(x) for x in float(np.sqrt(2 * d)) * 0.08 * rng.uniform(0.5, 1.1, n_rad)]
+        want = dens.calculate_populations_partial(ct, radii, variant="direct")
+        assert bool((dens.calculate_populations_partial(ct, radii) == want).all()), (n, d, n_rad)
+        acc = torch.zeros_like(want)
+        for g in range(4):
+            acc += dens.calculate_populations_segment(ct, radii, g, 4)
+        assert bool((acc == want).all()), (n, d, n_rad, "segments")
+    print("auto rule: ok")
