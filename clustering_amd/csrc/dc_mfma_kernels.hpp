@@ -502,10 +502,6 @@ __device__ __forceinline__ void pop_epi_begin(PopAcc<NR>& e) {
 // elements [R0, R1) of one accumulator tile (element r ends up at bit 15 - r of the sign strings)
 template <int NR, int R0, int R1>
 __device__ __forceinline__ void pop_epi(const f32x16& acc, const PopDeltas<NR>& dl, PopAcc<NR>& e) {
-#ifdef DC_EXP_NOEPI   // (timing experiments only: keeps the chain alive, inspects one element)
-  if constexpr (R0 == 0) e.tmin = min(e.tmin, __float_as_uint(acc[0]));
-  return;
-#endif
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
 #pragma unroll
@@ -1791,9 +1787,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
       uint32_t tB = 0;
       float2 frB = make_float2(INFINITY, INFINITY);
-      auto compute = [&](s16x8 (&a)[NM], float4 (&nv)[4], uint32_t t, uint32_t t_next) {
+      // (fr: the tile's free-energy range, fetched with its operands one tile ahead -- read at the start of the
+      //  tile's own chains the scalar load's latency sat in front of the second chain of every tile)
+      auto compute = [&](s16x8 (&a)[NM], float4 (&nv)[4], uint32_t t, uint32_t t_next, float2 fr) {
         const f32x16 c0 = frag16(nv);
-        const float2 fr = ferange_r[t];
         chains += TQ;
         static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
         auto refill = [&](auto mi_c) {
@@ -1820,24 +1817,30 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       if constexpr (kSingleBuffer<NM>) {
         uint32_t t0 = entry(0);
         load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+        float2 f0 = ferange_r[t0];
         for (uint32_t i = 0; i < cnt; ++i) {
           const uint32_t t1 = entry(i + 1);
-          compute(a0, n0, t0, t1);
+          const float2 f1 = ferange_r[t1];
+          compute(a0, n0, t0, t1, f0);
           t0 = t1;
+          f0 = f1;
         }
       } else {
         s16x8 a1[NM];
         float4 n1[4];
         uint32_t t0 = entry(0), t1;
         load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+        float2 f0 = ferange_r[t0], f1;
         for (uint32_t i = 0; i < cnt; i += 2) {
           t1 = entry(i + 1);
           load_tile<NM>(img_r, norms_r, t1, lane, h, a1, n1);
-          compute(a0, n0, t0, t1);
+          f1 = ferange_r[t1];
+          compute(a0, n0, t0, t1, f0);
           if (i + 1 < cnt) {
             t0 = entry(i + 2);
             load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
-            compute(a1, n1, t1, t0);
+            f0 = ferange_r[t0];
+            compute(a1, n1, t1, t0, f1);
           }
         }
       }
@@ -2024,28 +2027,13 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
 constexpr uint32_t kPopWaveTarget = 98304, kNnWaveTarget = 98304;
 constexpr uint32_t kPopShareFloor = 512, kNnShareFloor = 900;
-// L2-sized shares.  Every wave streams its share of the operand image from the XCD's L2; a share larger than
-// the L2 (4 MiB per XCD) is re-fetched through the fabric by the waves that have drifted apart, and beyond the
-// Infinity Cache (C5: 0.96 GB image) that is HBM traffic -- measured at 5M x 30: 22 TB moved at 7.4 TB/s for one
-// full sweep, the sweep bound by it (profiles/r2_c5_pmc.json).  Workgroups are dispatched x-fastest, i.e. all
-// query groups of reference share 0 first, then share 1, ...: with shares of `share_bytes` the waves resident
-// on an XCD at any time read the same few megabytes and the fabric sees each share about once per XCD.
 inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles,
-                            uint32_t share_floor, size_t tile_bytes) {
+                            uint32_t share_floor, size_t /*tile_bytes*/) {
   const uint32_t waves = (tiles + tq - 1) / tq;
   uint32_t r = waves >= target ? 1u : (target + waves - 1) / waves;
   const uint32_t by_share = ref_tiles / share_floor;
   const uint32_t cap = by_share < 64u ? by_share : 64u;
   r = r > cap ? cap : r;
-  // shares no larger than DC_SHARE_KB of operand image (0: off), at least DC_SHARE_MIN_TILES tiles each
-  static const uint32_t share_kb = env_u32("DC_SHARE_KB", 0u), min_tiles = env_u32("DC_SHARE_MIN_TILES", 64u);
-  if (share_kb) {
-    const size_t image = (size_t)ref_tiles * tile_bytes;
-    uint32_t by_l2 = (uint32_t)((image + (size_t)share_kb * 1024 - 1) / ((size_t)share_kb * 1024));
-    const uint32_t l2_cap = ref_tiles / (min_tiles ? min_tiles : 1u);
-    by_l2 = by_l2 > l2_cap ? l2_cap : by_l2;
-    r = by_l2 > r ? by_l2 : r;
-  }
   return r < 1u ? 1u : r;
 }
 

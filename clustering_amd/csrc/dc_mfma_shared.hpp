@@ -187,9 +187,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   // (r^2 near the typical pair distance: a band pair every five chains) the per-lane scheme cost 30 - 40 %
   // of the sweep.
   auto flush = [&]() {
-#ifndef DC_EXP_NOFLUSH
     pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords, coords_r, n_cols, rad2, lane);
-#endif
     qn = 0;
   };
   // the rest of an epilogue: counts, band test, parking of the band pairs (positions fit the queue entries:
@@ -202,11 +200,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
       cnt_q[qi][rr] += __builtin_popcount(e.bits[rr]);   // (16 shifts from 0: 16 bits)
       tmin = min(tmin, e.tmin[rr]);
     }
-#ifdef DC_EXP_NOBAND
-    if (false) {
-#else
     if (__builtin_expect((__builtin_amdgcn_ballot_w64(tmin < P.wbits) & livemask[qi]) != 0, 0)) {
-#endif
       // Band <=> 0 <= t_r < w: the sign string of (t_r - w) minus the sign string of t_r, element r at bit
       // 15 - r -- built only for the radii whose minimum says that some lane has a pair in the band.  Pad rows
       // (acc = +inf) and idle lanes (acc ~ 1e30) are never in a band.  (A compare per element into scalar lane
