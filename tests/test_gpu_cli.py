@@ -119,6 +119,22 @@ def test_cli_multi_radius_files(tmp_path, oracle):
         assert data_lines(str(tmp_path / "fe") + name) == [fmt_e(v) for v in oracle.free_energies(pops[k])]
 
 
+def test_cli_multi_radius_wide_rows_one_sweep(tmp_path):
+    """-R with five radii on 52 000 x 30 (.npy in): wide rows with several radii are answered by ONE shared-operand
+    sweep (dc_mfma_shared.hpp) inside the command line's session; files per radius as for the narrow case."""
+    from oracle.oracle import Oracle
+    fast = Oracle()
+    c = gaussian_blobs(52000, 30, seed=53)
+    np.save(tmp_path / "c.npy", c)
+    radii = [0.62, 0.45, 0.55, 0.5, 0.58]
+    r = subprocess.run([CLI, "density", "-f", str(tmp_path / "c.npy"), "-R", *[str(x) for x in radii],
+                        "-p", str(tmp_path / "pop")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    pops = fast.populations(c, radii)
+    for k, rad in enumerate(radii):
+        assert data_lines(str(tmp_path / "pop") + "_%f" % np.float32(rad)) == [str(int(p)) for p in pops[k]]
+
+
 def test_cli_without_radius_uses_lumping_radius_and_reuse(tmp_path, oracle):
     """no -r: provisional pop(r=1)+FE+NN pass, radius = sqrt(4 sigma^2) (density_clustering.cpp:649-673);
     then -D/-B re-use (file-level checkpoint/resume)."""
