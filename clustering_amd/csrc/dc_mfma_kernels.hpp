@@ -412,6 +412,13 @@ __device__ __forceinline__ f32x16 mfma16(const s16x8& a, const s16x8& b, const f
                                                 c, 0, 0, 0);
 }
 
+// The row norms of a reference tile are the C operand of the FIRST MFMA of every chain on that tile.  hipcc
+// picks the two-address form (vdst = srcC) for the one chain at which that operand dies -- the last of the
+// tile -- and, the destination being the loop-carried accumulator, pays for it with a 16-register copy per
+// tile (8 v_mov_b64).  An empty asm that reads the operand after the last chain keeps it alive, so every
+// chain gets the three-address form.
+__device__ __forceinline__ void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }
+
 template <int NM>
 __device__ __forceinline__ f32x16 gram_chain(const s16x8 (&a)[NM], const s16x8 (&b)[NM],
                                              const f32x16& c0) {
@@ -691,6 +698,7 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
         finish(accA, std::integral_constant<int, qt>{}, e, t);
       });
     }
+    keep_alive(c0);
     tB = t;
   };
 
@@ -1072,6 +1080,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
           pop_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e);
         finish(accA, std::integral_constant<int, qt>{}, e, t);
       });
+      keep_alive(c0);
       tB = t;
     };
     if constexpr (kSingleBuffer<NM>) {
@@ -1352,6 +1361,7 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
         finish(accA, std::integral_constant<int, qt>{}, tmin, t);
       });
     }
+    keep_alive(c0);
     tB = t;
   };
 
@@ -1811,6 +1821,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
             nn_chain<NM>(a, b[qt + 1], c0, accB, accA, tmin);
           finish(accA, std::integral_constant<int, qt>{}, tmin, t, fr);
         });
+        keep_alive(c0);
         tB = t;
         frB = fr;
       };

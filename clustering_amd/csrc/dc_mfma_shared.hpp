@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
             mr_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e);
             finish(accA, std::integral_constant<int, qt>{}, e, t);
           });
+          keep_alive(c0);
           tB = t;
         }
       }
