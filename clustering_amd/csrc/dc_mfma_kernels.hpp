@@ -763,6 +763,7 @@ enum QueryMode { kQueryOwnOrder = 0, kQueryAll = 1 };
 // (1024: D = 25, 26 and 57..64 fell to one block per CU; 300k x 26: 7.4 / 8.1 ms -> 5.8 / 6.7 ms; C3 unchanged)
 constexpr int kListCap = 512;
 constexpr int kQueueCap = 4;     // deferred exact evaluations: entries per lane and query tile
+constexpr int kWaveQueue = 128;  // ... or per WAVE, in one compact list (flushed in batches of 64)
 constexpr int kSeedNeighbours = 4;   // neighbour sweep: frames on either side of a query evaluated up front
 
 // ---- deferred exact re-check (pruned sweep) --------------------------------------------------------
@@ -826,6 +827,27 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queu
   return out;
 }
 
+// Wave-wide deferred exact re-check of the plain population sweep (one radius, no pair sink).  The per-lane
+// queues above flush when ONE lane is full, with most lanes idle, and every flush walks kQueueCap slots; here
+// the wave appends (reference position, query) to ONE compact list and evaluates 64 entries at a time, one
+// per lane.  The owner of the query is credited through an LDS counter.  Measured at C3 (A/B): -0.7 % (the
+// flushes are a small part there; at C5's radii, in pop_shared_kernel, the same change took 222 -> 204 ms).
+// (A build without any band handling runs the C3 sweep in 18.1 instead of 22.5 ms -- but mostly because the
+// compiler then also drops the 8 v_min3_u32 of the band DETECTION from every chain, not because of this path.)
+__device__ __attribute__((noinline)) void pop_wave_flush_rows(const uint32_t* queue, uint32_t qn,
+                                                              const float* qrows, uint32_t* fix_tab,
+                                                              const float* __restrict__ coords_r,
+                                                              uint32_t n_cols, float r2, int lane) {
+  for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
+    if (k0 + lane < qn) {
+      const uint32_t ent = queue[k0 + lane];
+      const uint32_t pos = ent & (kPopQueueMaxRows - 1u), qidx = ent >> kPopQueuePosBits;
+      const float d2c = dist2_canon_rt(qrows + (size_t)qidx * n_cols, 1, coords_r + (size_t)pos * n_cols, 1, (int)n_cols);
+      if (d2c < r2) atomicAdd(&fix_tab[qidx], 1u);
+    }
+  }
+}
+
 __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
   // boxes are (lo0, hi0, lo1, hi1); squared distance between them in the (col 0, col 1) plane
   const float dx = fmaxf(0.0f, fmaxf(a.x - b.y, b.x - a.y));
@@ -863,6 +885,11 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   uint32_t* queues = reinterpret_cast<uint32_t*>(pop_qrows_all + (size_t)4 * (TQ * 32) * n_cols) +
                      (size_t)wib * TQ * kQueueCap * 64;
   const bool use_queue = n_rows <= kPopQueueMaxRows;   // positions fit the queue entries
+  // plain sweep of one radius: ONE compact list per wave (carved out of the same LDS region: 128 entries and a
+  // counter per query instead of TQ x kQueueCap x 64 entries)
+  constexpr bool kWaveWide = (MODE == kSinkNone) && (NR == 1) && (TQ * 32 <= 256) && (TQ * kQueueCap * 64 >= kWaveQueue + TQ * 32);
+  uint32_t* fix_tab = queues + kWaveQueue;   // [TQ*32]: band pairs of a query that the exact path found inside
+  uint32_t qn = 0;                           // queued entries (wave-uniform)
   uint32_t qcount[TQ];
   // kSinkMinEdge: component and rank of this lane's query, lightest outgoing pair seen so far
   uint32_t comp_q[TQ], rank_q[TQ];
@@ -901,9 +928,11 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       comp_q[qt] = live ? sink.comp[pos] : 0xFFFFFFFFu;
       rank_q[qt] = live ? sink.rank[pos] : 0u;
     }
-    if (h == 0)   // original coordinates of this lane's query, for the exact path
+    if (h == 0) {   // original coordinates of this lane's query, for the exact path
       for (uint32_t k = 0; k < n_cols; ++k)
         qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
+      if constexpr (kWaveWide) fix_tab[qt * 32 + c] = 0;
+    }
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] = 0;
     qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
@@ -913,8 +942,13 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
 
+  auto flush_wave = [&]() {
+    pop_wave_flush_rows(queues, qn, qrows, fix_tab, coords_r, n_cols, rad2.v[0], lane);
+    qn = 0;
+  };
   // evaluate and empty the queue of query tile qi (all lanes in parallel per slot)
   auto flush = [&](int qi) {
+    if constexpr (kWaveWide) return;
     if (__builtin_amdgcn_ballot_w64(qcount[qi] != 0) == 0) return;
     const PopDelta<NR> dl =
         pop_flush<NR, MODE>(queues + qi * (kQueueCap * 64), qcount[qi], qrows + (qi * 32 + c) * n_cols,
@@ -1029,6 +1063,23 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
           uint32_t m = 0;
 #pragma unroll
           for (int rr = 0; rr < NR; ++rr) m |= fl[rr];
+          if constexpr (kWaveWide) {
+            for (;;) {
+              const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
+              if (have == 0) break;
+              const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
+              if (qn + n_new > (uint32_t)kWaveQueue) flush_wave();
+              if (m != 0) {
+                const int p = __builtin_ctz(m);
+                const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
+                queues[slot] = tile_row(t, 15 - p, h) | ((uint32_t)(qi * 32 + c) << kPopQueuePosBits);
+                m &= m - 1;
+              }
+              qn += n_new;
+            }
+            if (qn >= 64u) flush_wave();
+            return;
+          }
           uint32_t* qu = queues + qi * (kQueueCap * 64);
           while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
             if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qi] == (uint32_t)kQueueCap)) != 0)
@@ -1117,6 +1168,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) flush(qt);
+  if constexpr (kWaveWide) flush_wave();
   if constexpr (MODE == kSinkMinEdge) {
 #pragma unroll
     for (int qt = 0; qt < TQ; ++qt)
@@ -1128,7 +1180,8 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const bool live = (livemask[qt] >> lane) & 1;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-      const uint32_t total = q[qt].cnt[rr] + (uint32_t)__shfl_xor((int)q[qt].cnt[rr], 32, 64);
+      uint32_t total = q[qt].cnt[rr] + (uint32_t)__shfl_xor((int)q[qt].cnt[rr], 32, 64);
+      if constexpr (kWaveWide) total += fix_tab[qt * 32 + c];
       if (h == 0 && live && rr < n_rad) {
         // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2;
         // the reference starts every population at 1 (:132-134): corrected once, by chunk 0

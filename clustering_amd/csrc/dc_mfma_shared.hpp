@@ -18,7 +18,6 @@
 // pop_pruned_kernel (single radius, no pair sinks).
 constexpr int kShareSub = 128;   // boxes scanned per wave and round
 constexpr int kRing = 8;         // LDS slots: two windows of four reference tiles
-constexpr int kWaveQueue = 128;  // deferred exact evaluations per wave (flushed in batches of 64)
 // 32-bit words of LDS per wave behind the ring: queue (8 B entries), frame ids, exact-path counts per radius
 constexpr size_t shared_wave_words(int tq, int nr) { return 2 * kWaveQueue + (size_t)(1 + nr) * tq * 32; }
 
