@@ -48,3 +48,26 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower() or f == "capi.py" and False, (dirpath, f)
+
+
+def test_sessions_without_a_device_fail_with_a_status():
+    """dc_hip_session_open on a box without a GPU: a status and a message, never a crash or a CPU path."""
+    import ctypes as C
+    import numpy as np
+    from clustering_amd import capi
+    if capi.device_count() > 0:
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    c = np.zeros((8, 3), dtype=np.float32)
+    h = C.c_void_p(0)
+    rc = capi.lib.dc_hip_session_open(c.ctypes.data_as(C.c_void_p), 8, 3, None, 0, C.byref(h))
+    assert rc == -2 and not h.value                       # DC_ERR_NO_DEVICE
+    assert b"no HIP device" in capi.lib.dc_hip_last_error()
+    assert capi.lib.dc_hip_session_open(c.ctypes.data_as(C.c_void_p), 8, 0, None, 0, C.byref(h)) == -1   # n_cols = 0
+    assert capi.lib.dc_hip_session_devices(None) == 0 and capi.lib.dc_hip_session_uses_rccl(None) == 0
+    capi.lib.dc_hip_session_close(None)                   # a null session is a no-op
+    pops = np.zeros(8, dtype=np.uint32)
+    r = np.array([0.5], dtype=np.float32)
+    assert capi.lib.dc_hip_session_populations(None, r.ctypes.data_as(C.c_void_p), 1, pops.ctypes.data_as(C.c_void_p)) == -1
+    assert capi.lib.dc_hip_density_all(c.ctypes.data_as(C.c_void_p), 8, 3, r.ctypes.data_as(C.c_void_p), 1, 0, 0,
+                                       pops.ctypes.data_as(C.c_void_p), None, None, None, None, None) == -2
