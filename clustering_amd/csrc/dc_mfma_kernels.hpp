@@ -1527,30 +1527,32 @@ __device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ 
 // ---- deferred exact evaluation -------------------------------------------------------------------
 // The neighbour sweep does not evaluate a candidate the moment it appears (one or two lanes busy, a
 // full memory latency each time); it parks (position, kind) in a small per-lane LDS queue and
-// evaluates whole queue slots at once: every lane of the wave then fetches and evaluates ITS entry
+// evaluates them in batches: every lane of the wave then fetches and evaluates ONE entry
 // in parallel.  The approximate running minima that select candidates never depend on exact
 // values, so deferring changes nothing but the order of the lexicographic merges.
 constexpr uint32_t kQueuePosMask = 0x3FFFFFFFu;   // entry = position | nn-flag << 30 | hd-flag << 31
 
-__device__ __attribute__((noinline)) NnBest nn_flush(const uint32_t* queue /* [kQueueCap][64] */,
-                                                     uint32_t count, const float* qrow,
-                                                     const float* __restrict__ coords_c,
-                                                     const uint32_t* __restrict__ perm,
-                                                     uint32_t n_rows, uint32_t n_cols, NnBest best,
-                                                     int lane) {
-#pragma unroll
-  for (int k = 0; k < kQueueCap; ++k) {
-    if (__builtin_amdgcn_ballot_w64((uint32_t)k < count) == 0) break;
-    if ((uint32_t)k < count) {
-      const uint32_t ent = queue[k * 64 + lane];
-      const uint32_t pos = ent & kQueuePosMask;
+// Wave-wide form (the pruned neighbour sweep): candidates of all lanes go into ONE compact list (x = position |
+// nn-flag << 30 | hd-flag << 31, y = query tile * 32 + column) and are evaluated 64 at a time, one per lane.
+// The exact incumbents of a query live in LDS as order-preserving words (d2 bits << 32 | frame id): the lexicographic
+// merge "strict < on d2 scanning ascending j" is a 64-bit unsigned minimum (d2 >= 0; the initial (FLT_MAX, n_rows + 1)
+// is the largest word a real candidate can be compared with), shared by the two half-wave lanes of the query.
+__device__ __attribute__((noinline)) void nn_wave_flush(const uint2* queue, uint32_t qn, const float* qrows,
+                                                        unsigned long long* best /* [2][n_queries] */,
+                                                        uint32_t n_queries, const float* __restrict__ coords_c,
+                                                        const uint32_t* __restrict__ perm, uint32_t n_cols,
+                                                        int lane) {
+  for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
+    if (k0 + lane < qn) {
+      const uint2 ent = queue[k0 + lane];
+      const uint32_t pos = ent.x & kQueuePosMask, qidx = ent.y;
       const uint32_t j = perm[pos];
-      const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)pos * n_cols, 1, (int)n_cols);
-      lexi_update((ent >> 30) & 1u, best.bd_nn, best.bj_nn, d2c, j, n_rows);
-      lexi_update((ent >> 31) & 1u, best.bd_hd, best.bj_hd, d2c, j, n_rows);
+      const float d2c = dist2_canon_rt(qrows + (size_t)qidx * n_cols, 1, coords_c + (size_t)pos * n_cols, 1, (int)n_cols);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d2c) << 32) | j;
+      if ((ent.x >> 30) & 1u) atomicMin(&best[qidx], key);
+      if ((ent.x >> 31) & 1u) atomicMin(&best[n_queries + qidx], key);
     }
   }
-  return best;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -1595,9 +1597,12 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   float* qrows = qrows_all + (size_t)wib * (TQ * 32) * n_cols;
   uint32_t* queues = reinterpret_cast<uint32_t*>(qrows_all + (size_t)4 * (TQ * 32) * n_cols) +
                      (size_t)wib * TQ * kQueueCap * 64;
-  uint32_t qcount[TQ];
-#pragma unroll
-  for (int qt = 0; qt < TQ; ++qt) qcount[qt] = 0;
+  // the wave's LDS behind the query rows (TQ * kQueueCap * 64 words): the compact candidate list (kWaveQueue
+  // entries of 8 B) and the packed exact incumbents [2][TQ*32] of 8 B
+  static_assert(TQ * kQueueCap * 64 >= 2 * kWaveQueue + 4 * TQ * 32, "candidate list + incumbents fit the queue region");
+  uint2* cand = reinterpret_cast<uint2*>(queues);
+  unsigned long long* best64 = reinterpret_cast<unsigned long long*>(queues + 2 * kWaveQueue);
+  uint32_t qn = 0;   // queued candidates (wave-uniform)
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = scale_of(__uint_as_float(hdr[0]));
@@ -1676,6 +1681,15 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           lexi_update(fe_c[p2] < Q.feq, Q.bd_hd, Q.bj_hd, d2c, j, n_rows);
         }
       }
+      // (the two half-wave lanes looked at the frames after / before the query: merge, then both hold the result)
+      {
+        float od = __shfl_xor(Q.bd_nn, 32, 64);
+        uint32_t oj = (uint32_t)__shfl_xor((int)Q.bj_nn, 32, 64);
+        lexi_update(oj <= n_rows, Q.bd_nn, Q.bj_nn, od, oj, n_rows);
+        od = __shfl_xor(Q.bd_hd, 32, 64);
+        oj = (uint32_t)__shfl_xor((int)Q.bj_hd, 32, 64);
+        lexi_update(oj <= n_rows, Q.bd_hd, Q.bj_hd, od, oj, n_rows);
+      }
       const float s_nn = Q.bd_nn * sc.s2, s_hd = Q.bd_hd * sc.s2;
       if (Q.bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
       if (Q.bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
@@ -1691,22 +1705,32 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       }
     }
   }
+  // the exact incumbents of the wave's queries, as order-preserving words in LDS (see nn_wave_flush)
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt)
+    if (h == 0) {
+      best64[qt * 32 + c] = ((unsigned long long)__float_as_uint(q[qt].bd_nn) << 32) | q[qt].bj_nn;
+      best64[TQ * 32 + qt * 32 + c] = ((unsigned long long)__float_as_uint(q[qt].bd_hd) << 32) | q[qt].bj_hd;
+    }
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
   // ordering pass): a query at that level has no lower-FE neighbour
   const float fe_floor = fkey_inv(~hdr[12]);
 
-  // evaluate and empty the candidate queue of query tile qi (all lanes in parallel per slot)
-  auto flush = [&](int qi) {
-    if (__builtin_amdgcn_ballot_w64(qcount[qi] != 0) == 0) return;
-    NnPQ& Q = q[qi];
-    NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-    best = nn_flush(queues + qi * (kQueueCap * 64), qcount[qi], qrows + (qi * 32 + c) * n_cols,
-                    coords_c, perm_r, n_rows, n_cols, best, lane);
-    Q.bd_nn = best.bd_nn;
-    Q.bj_nn = best.bj_nn;
-    Q.bd_hd = best.bd_hd;
-    Q.bj_hd = best.bj_hd;
-    qcount[qi] = 0;
+  // evaluate and empty the candidate list (64 candidates at a time, one per lane)
+  auto flush = [&]() {
+    nn_wave_flush(cand, qn, qrows, best64, TQ * 32, coords_c, perm_r, n_cols, lane);
+    qn = 0;
+  };
+  // the registers' copy of the exact incumbents (both half-wave lanes of a query hold the same)
+  auto reload = [&]() {
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt) {
+      const unsigned long long a = best64[qt * 32 + c], b2 = best64[TQ * 32 + qt * 32 + c];
+      q[qt].bd_nn = __uint_as_float((uint32_t)(a >> 32));
+      q[qt].bj_nn = (uint32_t)a;
+      q[qt].bd_hd = __uint_as_float((uint32_t)(b2 >> 32));
+      q[qt].bj_hd = (uint32_t)b2;
+    }
   };
 
   uint32_t chains = 0, visited = 0;
@@ -1824,18 +1848,21 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               }
             }
             uint32_t m = mn | mh;
-            uint32_t* qu = queues + qi * (kQueueCap * 64);
-            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
-              if (__builtin_amdgcn_ballot_w64((m != 0) & (qcount[qi] == (uint32_t)kQueueCap)) != 0)
-                flush(qi);
+            for (;;) {
+              const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
+              if (have == 0) break;
+              const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
+              if (qn + n_new > (uint32_t)kWaveQueue) flush();
               if (m != 0) {
                 const int p = __builtin_ctz(m);
-                qu[qcount[qi] * 64 + lane] =
-                    tile_row(t, 15 - p, h) | (((mn >> p) & 1u) << 30) | (((mh >> p) & 1u) << 31);
-                ++qcount[qi];
+                const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
+                cand[slot] = make_uint2(tile_row(t, 15 - p, h) | (((mn >> p) & 1u) << 30) | (((mh >> p) & 1u) << 31),
+                                        (uint32_t)(qi * 32 + c));
                 m &= m - 1;
               }
+              qn += n_new;
             }
+            if (qn >= 64u) flush();
           }
           Q.m_nn = new_nn;
           Q.m_hd = new_hd;
@@ -1914,8 +1941,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
       }
     }
-#pragma unroll
-    for (int qt = 0; qt < TQ; ++qt) flush(qt);        // the settle test needs the exact incumbents
+    flush();                                          // the settle test needs the exact incumbents
+    reload();
     if (!(r2_hi <= FLT_MAX) || visited >= U)
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
