@@ -730,7 +730,8 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   const uint32_t T_q = (n_q + 31) / 32;
   if (q_mode != kQueryOwnOrder) {
     // queries in the reference order: only their B form is missing (of the groups of this segment)
-    const uint32_t tq = (uint32_t)tq_of(n_cols);
+    // (query tiles per group: a wave's, or with the shared-operand sweep the workgroup's)
+    const uint32_t tq = (uint32_t)tq_of(n_cols) * (nn_shared_wanted(n_rows, n_cols) ? 4u : 1u);
     const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
     if (tiles_q > 0)
       hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,

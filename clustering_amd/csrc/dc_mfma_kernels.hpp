@@ -2003,6 +2003,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   }
 }
 
+#include "dc_mfma_nn_shared.hpp"
+
 __global__ void nn_merge_fill_kernel(unsigned long long* __restrict__ merge64, uint32_t n_rows) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * n_rows) merge64[i] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | (n_rows + 1);
@@ -2134,6 +2136,29 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                       unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   if (A.n_q == 0) return;
+  if (nn_shared_wanted(n_rows, n_cols)) {
+    // reference operands shared through LDS (dc_mfma_nn_shared.hpp): the workgroup's 4 * TQV tiles are one group
+    const uint32_t groups = seg_groups(((A.n_q + 31) / 32 + 4 * TQV - 1) / (4 * TQV), A.q_seg);
+    if (groups == 0) return;
+    const uint32_t n_chunks = pick_chunks(groups * 4 * TQV, TQV, kNnWaveTarget, T, kNnShareFloor, (size_t)S * 1024 + 128);
+    const size_t smem = (size_t)kRing * (S * 64 + kNnRingExtra) * 16 + sizeof(uint32_t) * 4 * (TQV * kQueueCap * 64 + TQV * 32);
+    if (n_chunks > 1)
+      hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s, A.merge64, n_rows);
+    hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
+    hipLaunchKernelGGL((nn_shared_kernel<S, TQV>), dim3(groups, n_chunks), dim3(256), smem, s, coords, n_rows, n_cols, fe,
+                       A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r, A.fe_c, A.coords_c,
+                       A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg, A.full_range, A.cell2, hdr,
+                       chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2);
+    if (n_chunks > 1 && A.full_range)
+      hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
+                         (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)(4 * TQV), A.q_seg, nn_idx,
+                         nn_d2, hd_idx, hd_d2);
+    else if (n_chunks > 1)
+      hipLaunchKernelGGL(nn_merge_unpack_kernel, dim3((A.n_q + 255) / 256), dim3(256), 0, s,
+                         (const unsigned long long*)A.merge64, A.perm_q, A.n_q, n_rows, (uint32_t)(4 * TQV), A.q_seg, nn_idx,
+                         nn_d2, hd_idx, hd_d2);
+    return;
+  }
   const uint32_t waves = seg_groups(((A.n_q + 31) / 32 + TQV - 1) / TQV, A.q_seg), tiles = waves * TQV;
   if (waves == 0) return;
   const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor, (size_t)S * 1024 + 128);

@@ -559,3 +559,50 @@ def test_shared_operand_population_sweep():
     r = subprocess.run([sys.executable, "-c", SHARED_CHILD, root], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, DC_POP_SHARED="1"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+
+
+NN_SHARED_CHILD = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from clustering_amd import density as dens
+from clustering_amd.synth import gaussian_blobs
+rng = np.random.default_rng(9)
+for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 0.2), (700, 3, 0.1), (4097, 17, 0.35),
+                (33, 30, 0.5), (2, 26, 0.5), (70000, 30, 0.5)]:
+    c = gaussian_blobs(n, d, seed=2 * n + d)
+    if n > 10:
+        c[rng.integers(0, n, n // 5)] = c[rng.integers(0, n, n // 5)]      # duplicates: ties on d2, lowest index wins
+    ct = torch.from_numpy(c).cuda()
+    fe = dens.calculate_free_energies(dens.calculate_populations_partial(ct, [r], variant="direct")[0].contiguous())
+    want = dens.nearest_neighbors_partial(ct, fe, variant="direct")
+    got = dens.nearest_neighbors_partial(ct, fe, variant="pruned")
+    for a, b in zip(got, want):
+        assert bool((a.view(torch.int32) == b.view(torch.int32)).all()), (n, d, "all rows")
+    lo, hi = n // 3, n // 3 + max(1, n // 2)
+    for a, b in zip(dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="pruned"),
+                    dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="direct")):
+        assert bool((a.view(torch.int32) == b.view(torch.int32)).all()), (n, d, "row range")
+    words = None
+    for g in range(3):
+        w = dens.pack_neighbors(*dens.nearest_neighbors_segment(ct, fe, g, 3))
+        words = w if words is None else torch.minimum(words, w)
+    for a, b in zip(dens.unpack_neighbors(words), want):
+        assert bool((a.view(torch.int32) == b.view(torch.int32)).all()), (n, d, "segments")
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_shared_operand_neighbour_sweep():
+    """nn_shared_kernel (workgroup-wide rings and survivor lists, reference operands through an LDS ring; taken by
+    itself only for wide rows and large images, e.g. C5) forced on for small shapes -- all rows, a row range, the
+    segments of a sharded run, duplicates (ties), 1..8 MFMAs per chain, more than one reference share -- against
+    the direct kernels: indices and d2 bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", NN_SHARED_CHILD, root], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, DC_NN_SHARED="1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
