@@ -1199,10 +1199,6 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   }
 }
 
-inline uint32_t env_u32(const char* name, uint32_t dflt) {
-  const char* v = getenv(name);
-  return (v && v[0]) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
-}
 
 #include "dc_mfma_shared.hpp"
 
