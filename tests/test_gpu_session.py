@@ -142,3 +142,26 @@ def test_session_over_rccl(dens, tmp_path):
     rank = np.argsort(np.argsort(want_fe, kind="stable"), kind="stable").astype(np.uint32)
     want_e, _ = dens.radius_forest(c, np.float32(4.0 * want_s2), rank)
     assert got["edges"].tolist() == sorted([int(min(a, b)), int(max(a, b))] for a, b in want_e)
+
+
+def test_bench_starts_its_own_ranks_and_the_sharded_step_agrees(tmp_path):
+    """`bench.py --gpus N` without a launcher spawns its N ranks itself (torch.distributed.run as a child, before
+    anything touches HIP).  On a one-GPU box the ranks share the device and talk over gloo
+    (DC_BENCH_ONE_DEVICE=1: timings mean nothing, the sharded step -- segment sweeps, all-reduce(sum) of the
+    populations, all-reduce(min) of the packed neighbour words -- is the real one): its check values must equal
+    the single-rank run's."""
+    import json
+    env = dict(os.environ, DC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    args = ["--steps", "1", "--warmup", "1", "--n-rows", "150000", "--cpu-sample", "0"]
+    out = {}
+    for n in (1, 4):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + args,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out[n] = json.loads(line)
+        assert out[n]["n_gpus"] == n and out[n]["roofline"]["frac"] <= 1.0
+    assert out[4]["config"]["rccl_ranks"] == 4 and out[4]["config"]["backend"] == "gloo"
+    assert out[1]["check"] == out[4]["check"]        # mean / max population and sigma2 of the merged results
