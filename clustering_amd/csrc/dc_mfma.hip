@@ -133,33 +133,34 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   const bool live = row < n_rows;
   const uint32_t src = live ? (perm ? perm[row] : row) : 0u;
   const float* x = coords + (size_t)src * D;
-  const Scale sc = scale_of(__uint_as_float(hdr[0]));   // (word 0 is final: rowstats_kernel ran before)
-  auto col = [&](uint32_t k) -> float { return (x[k] - means[k]) * sc.s1; };   // x'' = 2^k fl(x - mu)
+  const Scale sc = load_scale(hdr);   // (the sweep's scale: scale_kernel ran before)
+  const float s1 = b_form ? sc.sb : sc.sa;
+  auto col = [&](uint32_t k) -> float { return (x[k] - means[k]) * s1; };   // x'' = 2^k fl(x - mu)
   uint32_t w[4] = {0u, 0u, 0u, 0u};
   if (live) {
     // the 8 consecutive slots of this fragment (slot_value's layout, with ONE division for the first
     // coordinate slot instead of one per slot: the divisions were most of this kernel's time)
     const uint32_t s0 = 16 * m + 8 * h;
-    uint32_t g = 0, k = 0;
+    uint32_t G = 0, k = 0;
     if (s0 >= (uint32_t)kConstSlots) {
-      g = (s0 - kConstSlots) / D;
-      k = (s0 - kConstSlots) - g * D;
+      G = (s0 - kConstSlots) / D;
+      k = (s0 - kConstSlots) - G * D;
     }
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
       uint32_t v;
       if (s0 + j < (uint32_t)kConstSlots) {
-        v = b_form ? 0u : kConstA;
+        v = b_form ? 0u : const_a_bits(sc.a);
       } else {
         v = 0u;
-        if (g < (uint32_t)kPieceGroups) {
-          const Pieces pc = split2(b_form ? -2.0f * col(k) : col(k));
-          const bool mid = b_form ? (g == 2u) : (g == 1u);
-          v = mid ? pc.mid : pc.hi;
+        if (G < (uint32_t)kPieceGroups) {
+          const Pieces pc = split2(b_form ? -2.0f * col(k) : col(k), sc.up, sc.dn);
+          const bool mid = b_form ? (G == 2u) : (G == 1u);
+          v = (G == 0u) ? pc.hi : (mid ? pc.mid : pc.hi_dn);
         }
         if (++k == D) {
           k = 0;
-          ++g;
+          ++G;
         }
       }
       w[j >> 1] |= (v & 0xFFFFu) << (16 * (j & 1));
@@ -172,8 +173,20 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
       const float v = live ? x[k] - means[k] : 0.0f;
       nrm += (double)v * (double)v;
     }
-    norms[row] = live ? (float)nrm * sc.s2 : INFINITY;   // 4^k |x'|^2; pad rows can never be "inside"
+    norms[row] = live ? (float)nrm * sc.s2 : INFINITY;   // S |x'|^2; pad rows can never be "inside"
   }
+}
+
+// the scale of the sweep that follows (dc_mfma_kernels.hpp "scale of a SWEEP") -> header words 20..23, read by
+// the image builder and by the kernels.  r2max < 0: the neighbour rule; otherwise the population rule for
+// a call whose largest squared radius is r2max.
+__global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D) {
+  const float M = __uint_as_float(hdr[0]);   // (final: rowstats_kernel ran before)
+  const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
+  hdr[kHdrScale + 0] = (uint32_t)e.ka;
+  hdr[kHdrScale + 1] = (uint32_t)e.kb;
+  hdr[kHdrScale + 2] = (uint32_t)e.g;
+  hdr[kHdrScale + 3] = (uint32_t)e.a;
 }
 
 // ---- free-energy ordering of the reference frames (neighbour sweep) -----------------------------
@@ -386,7 +399,6 @@ size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
                  bool natural_image, hipStream_t stream) {
-  const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
   if (hipMemsetAsync(p, 0, kHdrBytes, stream) != hipSuccess) return -1;
   const uint32_t blocks = (uint32_t)std::min<size_t>(512, ((size_t)n_rows * n_cols + 255) / 256);
@@ -397,16 +409,7 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
   hipLaunchKernelGGL(rowstats_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 1024u)), dim3(256),
                      sizeof(float) * 256 * (n_cols | 1u), stream, d_coords, n_rows, n_cols,
                      (const float*)(p + kHdrMeans), (uint32_t*)p);
-  // frames in natural order: only the full-sweep kernels read this image
-  if (natural_image) {
-    const dim3 grid_img((uint32_t)(((size_t)L.T * L.NM * 64 + 255) / 256));
-    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                       (uint4*)(p + L.off_img), (float*)(p + L.off_norm), (const uint32_t*)p);
-    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                       (uint4*)(p + L.off_img_b), (float*)nullptr, (const uint32_t*)p);
-  }
+  (void)natural_image;   // (the full sweeps build their natural-order images themselves, at their own scale)
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -422,9 +425,33 @@ static Rad2 single_radius(const Rad2& rad2, int r) {
   return one;
 }
 
+static float max_radius2(const Rad2& rad2, int n_rad) {
+  float m = 0.0f;
+  for (int r = 0; r < n_rad; ++r) m = std::max(m, rad2.v[r]);
+  return m;
+}
+// operand images of the frames in natural order (the full sweeps): A form + norms and / or B form
+static void natural_images(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws, bool a_form,
+                           bool b_form, hipStream_t stream) {
+  const Layout L = make_layout(n_rows, n_cols);
+  char* p = (char*)d_ws;
+  const dim3 grid_img((uint32_t)(((size_t)L.T * L.NM * 64 + 255) / 256));
+  if (a_form)
+    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
+                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
+                       (uint4*)(p + L.off_img), (float*)(p + L.off_norm), (const uint32_t*)p);
+  if (b_form)
+    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
+                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                       (uint4*)(p + L.off_img_b), a_form ? (float*)nullptr : (float*)(p + L.off_norm),
+                       (const uint32_t*)p);
+}
+
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                      hipStream_t stream) {
+  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)d_ws, max_radius2(rad2, n_rad), n_cols);
+  natural_images(d_coords, n_rows, n_cols, d_ws, true, true, stream);
   for (int r = 0; r < n_rad; ++r) {
     const Rad2 one = single_radius(rad2, r);
     uint32_t* out = d_pops + (size_t)r * n_rows;
@@ -461,20 +488,23 @@ static bool pop_multi_radius(uint32_t n_rows, uint32_t n_cols, int n_rad) {
   return n_rad > 1 && nm >= 3 && nm <= 8 && pop_shared_wanted(n_rows, n_cols, n_rad);
 }
 
+// r2_scale: the largest squared radius the prepared images have to serve (the radii of the whole call)
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           const EdgeSink* sink, hipStream_t stream, bool prep = true);
+                           const EdgeSink* sink, hipStream_t stream, float r2_scale, bool prep = true);
 
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                        hipStream_t stream) {
   if (pop_multi_radius(n_rows, n_cols, n_rad)) {
-    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, rad2, n_rad, d_pops, d_ws, nullptr, stream);
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, rad2, n_rad, d_pops, d_ws, nullptr, stream,
+                   max_radius2(rad2, n_rad));
     return;
   }
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, single_radius(rad2, r), 1,
-                   d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, r == 0);   // one preparation for all radii
+                   d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, max_radius2(rad2, n_rad),
+                   r == 0);   // one preparation for all radii
 }
 
 void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
@@ -482,12 +512,13 @@ void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t 
                                uint32_t* d_pops, void* d_ws, hipStream_t stream) {
   if (pop_multi_radius(n_rows, n_cols, n_rad)) {
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments}, rad2, n_rad, d_pops, d_ws,
-                   nullptr, stream);
+                   nullptr, stream, max_radius2(rad2, n_rad));
     return;
   }
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments},
-                   single_radius(rad2, r), 1, d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, r == 0);
+                   single_radius(rad2, r), 1, d_pops + (size_t)r * n_rows, d_ws, nullptr, stream,
+                   max_radius2(rad2, n_rad), r == 0);
 }
 
 // positions of the sweep's spatial order -> frame ids, for the pairs actually written; a flagged
@@ -534,13 +565,13 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
   (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
   if (d_pairs && capacity) {
     const EdgeSink sink{d_pairs, d_count, capacity, nullptr, nullptr, nullptr};
-    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream);
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream, r2);
     hipLaunchKernelGGL(edges_to_frames_kernel, dim3(1024), dim3(256), 0, stream, d_pairs,
                        (const unsigned long long*)d_count, capacity,
                        (const uint32_t*)((char*)d_ws + L.off_perm_p));
   } else {
     // counting only: the plain population sweep knows the answer
-    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, nullptr, stream);
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, nullptr, stream, r2);
     hipLaunchKernelGGL(pairs_from_pops_kernel, dim3(256), dim3(256), 0, stream, (const uint32_t*)d_pops,
                        n_rows, d_count);
     hipLaunchKernelGGL(halve_kernel, dim3(1), dim3(1), 0, stream, d_count);
@@ -559,12 +590,12 @@ void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_c
   // comp / rank arrive per FRAME; pop_pruned_one gathers them into the sweep's order
   const EdgeSink sink{nullptr, nullptr, 0, d_comp, d_rank, d_best};
   pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments}, one, 1, d_pops, d_ws,
-                 &sink, stream);
+                 &sink, stream, r2);
 }
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           const EdgeSink* sink_in, hipStream_t stream, bool prep) {
+                           const EdgeSink* sink_in, hipStream_t stream, float r2_scale, bool prep) {
   // prep == false: the orderings, images and boxes of the previous call (same coordinates, same query
   // selection) are still in the workspace -- the further radii of one populations call
   const uint32_t i_from = qs.i_from, i_to = qs.i_to;
@@ -602,6 +633,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     sink = &sink_local;
   }
   if (prep) {
+    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, fmaxf(r2_scale, 0.0f), n_cols);
     // order all frames by their 2-D cell, build the reference image and the tile boxes
     hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
@@ -698,6 +730,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
       grid_tiles((L.T + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   const size_t tmp_bytes = sort_temp_bytes(n_rows);
+  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols);   // the neighbour scale
   // frames by (cell, free energy): ONE sort on a combined key (cellfe_key_kernel); the pass over the free
   // energies before it finds their range (and raises the flag for NaNs)
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
@@ -777,6 +810,8 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
   uint32_t* perm = (uint32_t*)(p + L.off_perm);
   const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
+  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)p, -1.0f, n_cols);   // the neighbour scale
+  natural_images(d_coords, n_rows, n_cols, d_ws, false, true, stream);   // queries: B form + norms
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, keys_in, vals_in,
                      (uint32_t*)p);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm, n_rows, p + L.fixed_end,

@@ -91,7 +91,9 @@ constexpr int kPieceGroups = 3;        // piece products per column: hi*hi, mid*
 constexpr int nm_for(int n_cols) { return (kPieceGroups * n_cols + kConstSlots + 15) / 16; }
 constexpr int kMaxMfma = nm_for(kMaxCols);   // 13
 constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits, UNSCALED); word 1: non-finite flag;
-                                       // words 8..11: extent of columns 0/1; word 12: ~key of min FE
+                                       // words 2..3 / 4..5: evaluated-chain counters (population / neighbour sweep);
+                                       // words 8..11: extent of columns 0/1; word 12: ~key of min FE, 13: key of
+                                       // max finite FE; words 20..23: the scale of the current sweep (kHdrScale)
 constexpr size_t kHdrSums = 256;       // byte 256..767: column sums (double) for the centring
 constexpr size_t kHdrMeans = 768;      // byte 768..1023: column means as float (what x' = x - mu uses)
 static_assert(kHdrSums + 8 * kMaxCols <= kHdrMeans && kHdrMeans + 4 * kMaxCols <= kHdrBytes,
@@ -230,26 +232,69 @@ __device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// scale of a data set: everything the matrix pipe sees is multiplied by 2^k (coordinates) / 4^k
-// (norms, thresholds, bands) with 4^k M in [2^26, 2^28), M = max |x'|^2 (header word 0)
+// scale of a SWEEP: everything the matrix pipe sees is multiplied by powers of two -- the reference-side
+// coordinates by 2^ka, the query-side ones by 2^kb, norms / thresholds / bands / accumulators by
+// S = 2^(ka + kb).  Two rules (pick_scale_*), chosen per sweep by scale_kernel (dc_mfma.hip), which leaves the
+// exponents in header words 20..23 for the image builder and the kernels:
+//   neighbour sweeps   ka = kb, S M in [2^26, 2^28): the pieces use the top of the fp16 range;
+//   population sweeps  the largest S for which the guard band eps of the launch is <= 1.  The threshold is
+//                      folded as c_q = |x'|^2 - (r^2 - 1), so the accumulator t of a pair says
+//                          t < 0        inside          (sign bit)
+//                          t >= 2       outside         (bit 30: biased exponent >= 128)
+//                          otherwise    band -> exact   (neither bit)
+//                      and the epilogue needs ONE instruction per accumulator register: v_alignbit shifts both
+//                      bits into a string (no minimum over the elements for the band test).  S M is then
+//                      ~2^15 .. 2^17.6 (eps ~ 100 .. 400 u S M), the coordinates ~2^7 .. 2^9: the pieces sit in
+//                      the middle of the fp16 range, and the ones that would fall below its smallest normal are
+//                      kept by scaling the mid-piece products (mid 2^g x hi 2^-g, g = 6).
+// M = max |x'|^2 (header word 0).
 // ---------------------------------------------------------------------------------------------
-struct Scale {
-  float s1;   // 2^k
-  float s2;   // 4^k
+struct ScaleExp {
+  int ka, kb;   // reference side / query side: coordinates times 2^ka, 2^kb (kb in {ka - 1, ka})
+  int g;        // mid pieces are stored as mid 2^g, their partner hi pieces as hi 2^-g
+  int a;        // constant slots: 2^a on the A side, the pieces of c_q / 2^a on the B side
 };
-__device__ __forceinline__ Scale scale_of(float M) {
+struct Scale {
+  float sa, sb, s2;   // 2^ka, 2^kb, 2^(ka + kb)
+  float up, dn;       // 2^g, 2^-g
+  float cinv;         // 2^-a
+  int g, a;
+};
+constexpr uint32_t kHdrScale = 20;      // header words 20..23: ka, kb, g, a
+constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
+constexpr float kThrCapNn = 1610612736.0f;    // 1.5 * 2^30 (neighbour scale: d2 <= 4 S M < 2^30)
+constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
+                                              //  4 S M below 2^19.6; only a radius beyond the clamps of
+                                              //  pick_scale_pop reaches the cap, and then every pair is inside)
+
+__host__ __device__ inline Scale make_scale(const ScaleExp& e) {
+  Scale s;
+  s.sa = ldexpf(1.0f, e.ka);
+  s.sb = ldexpf(1.0f, e.kb);
+  s.s2 = ldexpf(1.0f, e.ka + e.kb);
+  s.up = ldexpf(1.0f, e.g);
+  s.dn = ldexpf(1.0f, -e.g);
+  s.cinv = ldexpf(1.0f, -e.a);
+  s.g = e.g;
+  s.a = e.a;
+  return s;
+}
+__device__ __forceinline__ Scale load_scale(const uint32_t* __restrict__ hdr) {
+  ScaleExp e;
+  e.ka = (int)hdr[kHdrScale + 0];
+  e.kb = (int)hdr[kHdrScale + 1];
+  e.g = (int)hdr[kHdrScale + 2];
+  e.a = (int)hdr[kHdrScale + 3];
+  return make_scale(e);
+}
+
+__host__ __device__ inline ScaleExp pick_scale_nn(float M) {
   int e = 0;
   (void)frexpf(M, &e);                  // M = f 2^e, f in [0.5, 1); M = 0 -> e = 0
   int k = (28 - e) >> 1;                // floor: e + 2k in {27, 28}
   k = k < -62 ? -62 : (k > 62 ? 62 : k);
-  Scale s;
-  s.s1 = ldexpf(1.0f, k);
-  s.s2 = ldexpf(1.0f, 2 * k);
-  return s;
+  return ScaleExp{k, k, 0, kConstShiftNn};
 }
-// thresholds beyond this (scaled) hold every pair (d2 <= 4 M < 2^30) and are clamped to it, so that
-// |c_q| / 2^15 stays below the largest fp16
-constexpr float kThrCap = 1610612736.0f;     // 1.5 * 2^30
 
 // ---------------------------------------------------------------------------------------------
 // guard band (DESIGN.md "guard band"), in SCALED units.  For every pair, with d2 its canonical
@@ -263,7 +308,13 @@ constexpr float kThrCap = 1610612736.0f;     // 1.5 * 2^30
 //                                                     17 addends, each truncated to 2^-24 of the largest
 //       + ns 18 (d2 + thr + 0.004 M) + (d2 + thr)     the ns MFMAs of small products, accumulator ~ d2 - thr
 //       + (D/4 + 9) d2 + 2 M ]                        canonical summation order + centring (as for fp32)
-//   + 2^-12 sqrt(D M) + 2                             pieces below 2^-14 flushed to zero (coordinates, c_q)
+//   + flush                                           values below 2^-14 (the smallest normal fp16) stored as zero:
+//       (2^(-12-g) + [g > 0] 2^(-23+g)) sqrt(D M)       lost piece remainders (|rho| <= max(2^-22 |v|, 2^(-14-g)))
+//                                                       times the other side (sum_k |w_k| <= sqrt(D) |w|, the two
+//                                                       sides' scales differ by at most 2), and hi 2^-g copies
+//                                                       below 2^-14 times their mid partners (<= 2^-11 |v|)
+//       + [g > 0] D 2^(-27+g)                           the same where both factors are tiny
+//       + 2^(-14+a)                                     the remainder of c_q / 2^a
 // with a further factor 1.25 on everything.  nb = ceil((D + 2) / 16), ns = NM - nb.
 // ---------------------------------------------------------------------------------------------
 struct GuardBand {
@@ -271,71 +322,115 @@ struct GuardBand {
   float kappa;   // relative part, per unit of d2
 };
 
-__device__ __forceinline__ float next_up(float f) {   // f >= 0 finite; inf / NaN -> inf
+__host__ __device__ inline float next_up(float f) {   // f >= 0 finite; inf / NaN -> inf
   if (!(f <= FLT_MAX)) return INFINITY;
-  return __uint_as_float(__float_as_uint(f) + 1u);
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f) + 1u);
 }
 
-__device__ __forceinline__ GuardBand guard_band(float M, float thr, int D) {   // M, thr: scaled
+// (doubles: the population rule evaluates these at scales far from the final one)
+__host__ __device__ inline double guard_e0_linear(double M, double thr, int D) {   // M, thr: scaled
   const double u = 5.9604644775390625e-8;
   const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
-  const double t = (thr > 0.0f) ? (double)thr : 0.0;
+  const double t = (thr > 0.0) ? thr : 0.0;
   const double cM = 3.0 + 4.1 + 27.0 + 34.0 + 72.4 * (nb - 1) + 0.072 * ns + 2.0;
   const double cT = 1.0 + 4.1 + 17.0 + 18.0 * (nb - 1) + 18.0 * ns + 1.0;
-  const double cD = 18.0 * ns + 1.0 + 0.25 * D + 9.0;
-  const double flush = 2.44140625e-4 * sqrt((double)D * (double)M) + 2.0;
-  GuardBand g;
-  g.e0 = next_up((float)(1.25 * (u * (cM * (double)M + cT * t) + flush)));
-  g.kappa = next_up((float)(1.25 * u * cD));
-  return g;
+  return 1.25 * u * (cM * M + cT * t);
+}
+__host__ __device__ inline double guard_flush(double M, int D, int g, int a) {
+  const double fl_rel = ldexp(1.0, -12 - g) + (g > 0 ? ldexp(1.0, -23 + g) : 0.0);
+  return 1.25 * (fl_rel * sqrt((double)D * M) + (g > 0 ? (double)D * ldexp(1.0, -27 + g) : 0.0) + ldexp(1.0, -14 + a));
+}
+__host__ __device__ inline double guard_e0(double M, double thr, int D, int g, int a) {
+  return guard_e0_linear(M, thr, D) + guard_flush(M, D, g, a);
+}
+__host__ __device__ inline double guard_kappa(int D) {
+  const double u = 5.9604644775390625e-8;
+  const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
+  return 1.25 * u * (18.0 * ns + 1.0 + 0.25 * D + 9.0);
+}
+__host__ __device__ inline GuardBand guard_band(float M, float thr, int D, int g, int a) {   // M, thr: scaled
+  GuardBand gb;
+  gb.e0 = next_up((float)guard_e0((double)M, (double)thr, D, g, a));
+  gb.kappa = next_up((float)guard_kappa(D));
+  return gb;
 }
 
-// population sweep: one band for all pairs with d2 up to the largest radius of the launch
-__device__ __forceinline__ float guard_eps_pop(float M, float r2max, int D) {
-  const GuardBand g = guard_band(M, r2max, D);
-  const float cap = (r2max > 0.0f) ? r2max : 0.0f;
-  return next_up(g.e0 + g.kappa * cap);
+// population sweep: one band for all pairs with d2 up to the largest radius of the launch (scaled units)
+__host__ __device__ inline double guard_eps_pop(double M, double r2max, int D, int g, int a) {
+  const double cap = (r2max > 0.0) ? r2max : 0.0;
+  return (guard_e0(M, r2max, D, g, a) + guard_kappa(D) * cap) * (1.0 + 1.2e-7);
 }
 
-// ---- fp32 (scaled) -> two fp16 pieces: v = hi + mid + rho, |rho| <= max(2^-22 |v|, 2^-14) --------
+// the population rule: the largest S = 2^K with guard_eps_pop(S M, S r2max) <= 1 (M, r2max unscaled; r2max the
+// largest squared radius of the call, so that the images serve every radius of it)
+__host__ __device__ inline ScaleExp pick_scale_pop(float M_in, float r2_in, int D) {
+  const double M = (M_in > 0.0f) ? (double)M_in : 0.0;
+  const double r2 = (r2_in > 0.0f) ? (double)r2_in : 0.0;   // (+inf allowed)
+  constexpr int kLo = -120, kHi = 120;
+  int K = kHi;
+  // eps(S) >= S * lin: an upper bound for K, lowered until the flush part fits as well (a step or two)
+  const double lin = (guard_e0_linear(M, r2, D) + guard_kappa(D) * r2) * (1.0 + 1.2e-7);
+  if (!(lin <= 1.7e308)) {
+    K = kLo;
+  } else if (lin > 0.0) {
+    int e = 0;
+    (void)frexp(lin, &e);               // lin in [2^(e-1), 2^e): S lin <= 1 needs K <= 1 - e
+    K = 1 - e;
+    K = K < kLo ? kLo : (K > kHi ? kHi : K);
+  }
+  while (K > kLo && !(guard_eps_pop(ldexp(M, K), ldexp(r2, K), D, kMidShiftPop, kConstShiftPop) <= 1.0)) --K;
+  ScaleExp e;
+  e.kb = K >> 1;        // floor
+  e.ka = K - e.kb;
+  e.g = kMidShiftPop;
+  e.a = kConstShiftPop;
+  return e;
+}
+
+// ---- fp32 (scaled) -> two fp16 pieces: v = hi + mid + rho, |rho| <= max(2^-22 |v|, 2^(-14-g)) ----------
+// The mid piece is stored as mid 2^g (exact, and normal down to 2^(-14-g)), the hi piece a second time as
+// hi 2^-g for the products with the other side's mid piece (zero below 2^-14: part of the band).
 constexpr float kF16MinNormal = 6.103515625e-05f;   // 2^-14
-__device__ __forceinline__ uint32_t f16_rne(float f) {   // |f| <= 65504; below 2^-14 -> 0
+__host__ __device__ inline uint32_t f16_rne(float f) {   // |f| <= 65504; below 2^-14 -> 0
   if (!(fabsf(f) >= kF16MinNormal)) return 0u;
   return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);
 }
-__device__ __forceinline__ float f16_val(uint32_t b) {
+__host__ __device__ inline float f16_val(uint32_t b) {
   return (float)__builtin_bit_cast(_Float16, (unsigned short)b);
 }
 struct Pieces {
-  uint32_t hi, mid;   // fp16 bit patterns
+  uint32_t hi, mid;   // fp16 bit patterns: hi, mid 2^g
+  uint32_t hi_dn;     // hi 2^-g
 };
-__device__ __forceinline__ Pieces split2(float v) {
+__host__ __device__ inline Pieces split2(float v, float up = 1.0f, float dn = 1.0f) {
   Pieces p;
   p.hi = f16_rne(v);
-  const float r1 = v - f16_val(p.hi);      // exact
-  p.mid = f16_rne(r1);
+  const float hv = f16_val(p.hi);
+  const float r1 = v - hv;                 // exact
+  p.mid = f16_rne(r1 * up);
+  p.hi_dn = f16_rne(hv * dn);              // (11 significant bits: exact unless it falls below 2^-14)
   return p;
 }
-constexpr uint32_t kConstA = 0x7800u;       // fp16 2^15: the A side of the constant slots
-constexpr float kConstScale = 3.0517578125e-05f;   // 2^-15: c_q / 2^15 on the B side
+__host__ __device__ inline uint32_t const_a_bits(int a) { return (uint32_t)(a + 15) << 10; }   // fp16 2^a, -14 <= a <= 15
 
 // K-slot s of a frame: which piece of which column (or the constant) sits there.
-//   slots 0..1            constant: A side 2^15, B side the pieces (hi, mid) of c_q / 2^15
-//   slots 2 + g*D + k     column k, piece pair g (A piece x B piece), large products first:
-//                         0 hi*hi, 1 mid*hi, 2 hi*mid
+//   slots 0..1            constant: A side 2^a, B side the pieces (hi, mid) of c_q / 2^a
+//   slots 2 + G*D + k     column k, piece pair G (A piece x B piece), large products first:
+//                         0 hi x hi, 1 mid 2^g x hi 2^-g, 2 hi 2^-g x mid 2^g
 //   beyond 2 + 3 D        zero padding
 // Returns the fp16 pattern for the A form (reference side) or the B form (query side, column values
 // are those of -2x'') of a row whose centred, SCALED columns are fetched through `col(k)`.
 template <class ColFn>
-__device__ __forceinline__ uint32_t slot_value(uint32_t s, uint32_t D, bool b_form, ColFn col) {
-  if (s < (uint32_t)kConstSlots) return b_form ? 0u : kConstA;   // (the kernels patch c_q in)
-  const uint32_t sp = s - kConstSlots, g = sp / D, k = sp - g * D;
-  if (g >= (uint32_t)kPieceGroups) return 0u;
+__host__ __device__ inline uint32_t slot_value(uint32_t s, uint32_t D, bool b_form, const Scale& sc, ColFn col) {
+  if (s < (uint32_t)kConstSlots) return b_form ? 0u : const_a_bits(sc.a);   // (the kernels patch c_q in)
+  const uint32_t sp = s - kConstSlots, G = sp / D, k = sp - G * D;
+  if (G >= (uint32_t)kPieceGroups) return 0u;
   const float v = b_form ? -2.0f * col(k) : col(k);
-  const Pieces p = split2(v);
-  // piece index (0 hi, 1 mid) per group: A side 0,1,0 ; B side 0,0,1
-  const bool mid = b_form ? (g == 2u) : (g == 1u);
-  return mid ? p.mid : p.hi;
+  const Pieces p = split2(v, sc.up, sc.dn);
+  if (G == 0u) return p.hi;
+  // mid piece on the A side in group 1, on the B side in group 2; the other side holds hi 2^-g
+  const bool mid = b_form ? (G == 2u) : (G == 1u);
+  return mid ? p.mid : p.hi_dn;
 }
 
 template <int NM>
@@ -373,14 +468,14 @@ __device__ __forceinline__ void refill_frag(const uint4* __restrict__ img,
 // constant c_q (scaled units, |c_q| <= 65504 * 2^15) patched into slots 0..1 (held by the h = 0 half)
 template <int NM>
 __device__ __forceinline__ void load_query(const uint4* __restrict__ img_b, uint32_t tile, int lane,
-                                           int h, float cq, s16x8 (&b)[NM]) {
+                                           int h, float cq, const Scale& sc, s16x8 (&b)[NM]) {
   const uint4* ip = img_b + (size_t)tile * (NM * 64) + lane;
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     const uint4 v = ip[m * 64];
     b[m] = __builtin_bit_cast(s16x8, v);
   }
-  const Pieces p = split2(cq * kConstScale);
+  const Pieces p = split2(cq * sc.cinv);
   if (h == 0) {
     b[0][0] = (short)p.hi;
     b[0][1] = (short)p.mid;
@@ -443,9 +538,10 @@ __device__ __forceinline__ void constexpr_for_pairs(F&& f) {
 template <int NM>
 constexpr bool kSingleBuffer = NM > 4;
 
-// a query lane that owns no live row: the constant (the largest the two slots can carry,
-// 65504 * 2^15 ~ 2^31 > 4 S M) keeps its accumulators above every threshold
-constexpr float kDeadConst = 2146435072.0f;
+// a query lane that owns no live row: the constant (the largest the two slots can carry, 65504 * 2^a:
+// ~2^31 at the neighbour scale, ~2^22 at the population scale -- above 4 S M + 2 in both) keeps its
+// accumulators above every threshold
+__device__ __forceinline__ float dead_const(const Scale& sc) { return ldexpf(65504.0f, sc.a); }
 
 // row of reference tile t held by register r of a lane in half h
 __device__ __forceinline__ uint32_t tile_row(uint32_t t, int r, int h) {
@@ -473,17 +569,20 @@ __device__ __forceinline__ void tile_min(const f32x16& acc, float& m) {
 // =============================================================================================
 // population count
 // =============================================================================================
-// The accumulator of radius 0 is t_0 = acc (threshold folded into c_q); radius r uses
-// t_r = acc - delta_r with delta_r = (r_r^2 - eps) - (r_0^2 - eps), the same for every query.
+// The accumulator of radius 0 is t_0 = acc (threshold folded into c_q: c_q = |x'|^2 - (r_0^2 - 1) at the population
+// scale); radius r uses t_r = acc - delta_r with delta_r = r_r^2 - r_0^2, the same for every query.  Of every t the
+// epilogue keeps two bits: the sign (inside) and bit 30 (t >= 2: outside); neither = band.
 template <int NR>
 struct PopQ {            // per query tile, per lane
   uint32_t cnt[NR];
 };
 
+constexpr uint32_t kSignBits = 0xAAAAAAAAu;   // the sign of element r sits at bit 31 - 2 r of a chain's string
+constexpr uint32_t kBandKey = 0x40000000u;    // bits(2.0f): band <=> bits(t) <u kBandKey
+
 template <int NR>
 struct PopAcc {          // per chain scratch
-  uint32_t bits[NR];     // sign bits of t_r, one per element, shifted in from the right
-  uint32_t tmin;         // unsigned min over elements and radii of bits(t_r)
+  uint32_t bits[NR];     // (sign, bit 30) of t_r, two bits per element, shifted in from the right
 };
 
 template <int NR>
@@ -503,10 +602,9 @@ template <int NR>
 __device__ __forceinline__ void pop_epi_begin(PopAcc<NR>& e) {
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) e.bits[rr] = 0;
-  e.tmin = 0xFFFFFFFFu;
 }
 
-// elements [R0, R1) of one accumulator tile (element r ends up at bit 15 - r of the sign strings)
+// elements [R0, R1) of one accumulator tile (element r ends up at bits 31 - 2 r, 30 - 2 r of the strings)
 template <int NR, int R0, int R1>
 __device__ __forceinline__ void pop_epi(const f32x16& acc, const PopDeltas<NR>& dl, PopAcc<NR>& e) {
 #pragma unroll
@@ -514,11 +612,14 @@ __device__ __forceinline__ void pop_epi(const f32x16& acc, const PopDeltas<NR>& 
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
       const uint32_t tb = __float_as_uint(rr == 0 ? acc[r] : acc[r] - dl.d[rr]);
-      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], tb, 31);   // (bits << 1) | sign(t)
-      e.tmin = min(e.tmin, tb);                                     // negative t: huge unsigned
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], tb, 30);   // (bits << 2) | top two bits of t
     }
   }
 }
+// of a chain's string: elements inside (bit 31 - 2 r) / in the band (the same positions)
+__device__ __forceinline__ uint32_t inside_of(uint32_t bits) { return bits & kSignBits; }
+__device__ __forceinline__ uint32_t band_of(uint32_t bits) { return ~(bits | (bits << 1)) & kSignBits; }
+__device__ __forceinline__ int element_of(int bit) { return (31 - bit) >> 1; }   // bit 31 - 2 r -> r
 
 // MFMA chain into acc_new with the epilogue of acc_old spread between the MFMAs: a wave issues in
 // order, so the VALU work has to sit in the shadow of the matrix pipe in PROGRAM order
@@ -594,30 +695,25 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_fix(const float* __restric
 // thresholds of a population launch, shared by the full and the pruned sweep
 template <int NR>
 struct PopSetup {
-  float eps;             // (all three in the scaled units of the operand images)
-  uint32_t wbits;        // band width 2*eps as an unsigned key, +1 ulp
-  Rad2 rad2e;            // r^2 - eps
+  Scale sc;
+  uint32_t wbits;        // band <=> bits(t) <u wbits: bits(2.0f) (the band is [0, 2) in scaled units)
+  Rad2 rad2e;            // r^2 - 1 (scaled)
   PopDeltas<NR> dl;
 };
 
 template <int NR>
 __device__ __forceinline__ PopSetup<NR> pop_setup(const uint32_t* __restrict__ hdr, const Rad2& rad2,
                                                   uint32_t n_cols) {
+  (void)n_cols;
   PopSetup<NR> P;
-  // everything here is in the scaled units of the operand images (exact powers of two)
-  const float M = __uint_as_float(hdr[0]);
-  const Scale sc = scale_of(M);
-  Rad2 r2s;
+  // everything here is in the scaled units of the operand images (exact powers of two); the scale was chosen
+  // (pick_scale_pop, scale_kernel) so that the guard band of the call's largest radius is at most 1
+  P.sc = load_scale(hdr);
+  P.wbits = kBandKey;
 #pragma unroll
-  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) r2s.v[rr] = fminf(rad2.v[rr] * sc.s2, kThrCap);
-  float r2max = r2s.v[0];
-#pragma unroll
-  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, r2s.v[rr]);
-  P.eps = guard_eps_pop(M * sc.s2, r2max, (int)n_cols);
+  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr)
+    P.rad2e.v[rr] = fminf(rad2.v[rr] * P.sc.s2, kThrCapPop) - 1.0f;
   // (delta_r = fl(rad2e_r - rad2e_0) adds at most u * r2max to the band: inside the 1.25 factor)
-  P.wbits = __float_as_uint(2.0f * P.eps) + 1u;
-#pragma unroll
-  for (int rr = 0; rr < kMaxRadiiPerLaunch; ++rr) P.rad2e.v[rr] = r2s.v[rr] - P.eps;
   P.dl = pop_deltas<NR>(P.rad2e);
   return P;
 }
@@ -647,8 +743,8 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
     const bool live = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
-    const float cq = live ? norms[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
-    load_query<NM>(img_b, tl, lane, h, cq, b[qt]);
+    const float cq = live ? norms[tl * 32 + c] - P.rad2e.v[0] : dead_const(P.sc);
+    load_query<NM>(img_b, tl, lane, h, cq, P.sc, b[qt]);
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] = 0;
   }
@@ -661,9 +757,11 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
   auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<NR>& e, uint32_t t) {
     constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr]);   // (16 shifts from 0: 16 bits)
-    const bool band = e.tmin < P.wbits;
-    if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
+    for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(inside_of(e.bits[rr]));
+    uint32_t band = 0;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) band |= band_of(e.bits[rr]);
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(band != 0) & livemask[qi]) != 0, 0)) {
       const PopDelta<NR> dl =
           pop_fix<NR>(coords, nullptr, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qi], t, h);
 #pragma unroll
@@ -922,8 +1020,8 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const bool live = (tile < TQT) && (pos < n_q);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? perm_q[pos] : 0u;
-    const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
-    load_query<NM>(img_q, tl, lane, h, cq, b[qt]);
+    const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : dead_const(P.sc);
+    load_query<NM>(img_q, tl, lane, h, cq, P.sc, b[qt]);
     if constexpr (MODE == kSinkMinEdge) {   // (all rows, in the reference order: position = pos)
       comp_q[qt] = live ? sink.comp[pos] : 0xFFFFFFFFu;
       rank_q[qt] = live ? sink.rank[pos] : 0u;
@@ -996,28 +1094,28 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     auto finish = [&](const f32x16& acc, auto qi_c, const PopAcc<NR>& e, uint32_t t) {
       constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
-      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(e.bits[rr]);   // (16 shifts from 0: 16 bits)
+      for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(inside_of(e.bits[rr]));
       if constexpr (MODE == kSinkMinEdge) {
-        // partners decided "inside" by the accumulator alone (element r = bit 15 - r of the sign
+        // partners decided "inside" by the accumulator alone (element r = bit 31 - 2 r of the
         // string; the query itself is one of them and belongs to its own component): keep the
         // lightest pair that leaves the component.  Inside elements are sparse (< 1 % at 4 sigma^2).
-        uint32_t inside = e.bits[0] & 0xFFFFu;
+        uint32_t inside = inside_of(e.bits[0]);
         while (inside != 0) {
           const int p = __builtin_ctz(inside);
-          edge_key[qi] = min(edge_key[qi], min_edge_key(sink, comp_q[qi], rank_q[qi], tile_row(t, 15 - p, h)));
+          edge_key[qi] = min(edge_key[qi], min_edge_key(sink, comp_q[qi], rank_q[qi], tile_row(t, element_of(p), h)));
           inside &= inside - 1u;
         }
       }
       if constexpr (MODE == kSinkPairs) {
-        // pairs decided "inside" by the accumulator alone: element r = bit 15 - r of the sign string.
+        // pairs decided "inside" by the accumulator alone: element r = bit 31 - 2 r of the string.
         // Only partners at a smaller position are listed (every pair once); one atomic per chain and
         // wave reserves the slots, then each lane stores its own pairs.
         const uint32_t pos_q = (qt0 + (uint32_t)qi) * 32u + (uint32_t)c;
-        uint32_t inside = e.bits[0] & 0xFFFFu;
+        uint32_t inside = inside_of(e.bits[0]);
         if (32u * t + 31u >= pos_q) {       // (all rows of earlier tiles are smaller: nothing to mask)
           uint32_t keep = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) keep |= (tile_row(t, r, h) < pos_q) ? (0x8000u >> r) : 0u;
+          for (int r = 0; r < 16; ++r) keep |= (tile_row(t, r, h) < pos_q) ? (0x80000000u >> (2 * r)) : 0u;
           inside &= keep;
         }
         const uint32_t k = (uint32_t)__builtin_popcount(inside);
@@ -1035,34 +1133,23 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
           unsigned long long idx = base + (incl - k);
           while (inside != 0) {
             const int p = __builtin_ctz(inside);
-            if (idx < sink.capacity) sink.edges[idx] = make_uint2(pos_q, tile_row(t, 15 - p, h));
+            if (idx < sink.capacity) sink.edges[idx] = make_uint2(pos_q, tile_row(t, element_of(p), h));
             ++idx;
             inside &= inside - 1u;
           }
         }
       }
-      const bool band = e.tmin < P.wbits;
-      if (__builtin_expect((__builtin_amdgcn_ballot_w64(band) & livemask[qi]) != 0, 0)) {
+      uint32_t fl[NR];   // per radius: bit (31 - 2 r) set <=> element r sits in that radius' band
+      uint32_t m = 0;
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        fl[rr] = band_of(e.bits[rr]);
+        m |= fl[rr];
+      }
+      if (__builtin_expect((__builtin_amdgcn_ballot_w64(m != 0) & livemask[qi]) != 0, 0)) {
         if (use_queue) {
-          // park the band elements of this lane: (position, radii whose band holds the element).
-          // Band <=> 0 <= t < w: the sign string of (t - w) minus the sign string of t, both in the
-          // order of the epilogue (element r at bit 15 - r).  Pad rows (acc = +inf) and idle lanes
-          // (acc ~ 1e30) are never in a band, so no further masking is needed.
-          const float w = __uint_as_float(P.wbits);
-          uint32_t fl[NR];   // per radius: bit (15 - r) set <=> element r sits in that radius' band
-#pragma unroll
-          for (int rr = 0; rr < NR; ++rr) {
-            uint32_t below = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float tv = rr == 0 ? acc[r] : acc[r] - P.dl.d[rr];
-              below = __builtin_amdgcn_alignbit(below, __float_as_uint(tv - w), 31);
-            }
-            fl[rr] = below & ~e.bits[rr] & 0xFFFFu;
-          }
-          uint32_t m = 0;
-#pragma unroll
-          for (int rr = 0; rr < NR; ++rr) m |= fl[rr];
+          // park the band elements of this lane: (position, radii whose band holds the element).  Pad rows
+          // (acc = +inf) and idle lanes (acc ~ 2^22) are never in a band, so no further masking is needed.
           if constexpr (kWaveWide) {
             for (;;) {
               const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
@@ -1072,7 +1159,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
               if (m != 0) {
                 const int p = __builtin_ctz(m);
                 const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
-                queues[slot] = tile_row(t, 15 - p, h) | ((uint32_t)(qi * 32 + c) << kPopQueuePosBits);
+                queues[slot] = tile_row(t, element_of(p), h) | ((uint32_t)(qi * 32 + c) << kPopQueuePosBits);
                 m &= m - 1;
               }
               qn += n_new;
@@ -1089,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
               uint32_t flags = 0;
 #pragma unroll
               for (int rr = 0; rr < NR; ++rr) flags |= ((fl[rr] >> p) & 1u) << rr;
-              qu[qcount[qi] * 64 + lane] = tile_row(t, 15 - p, h) | (flags << kPopQueuePosBits);
+              qu[qcount[qi] * 64 + lane] = tile_row(t, element_of(p), h) | (flags << kPopQueuePosBits);
               ++qcount[qi];
               m &= m - 1;
             }
@@ -1324,8 +1411,8 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
   if (qt0 * 32 >= i_to) return;
 
   // (scaled units, like the accumulators and the running minima taken from them)
-  const Scale sc = scale_of(__uint_as_float(hdr[0]));
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols);
+  const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc.g, sc.a);
 
   s16x8 b[TQ][NM];
   NnQ q[TQ];
@@ -1338,7 +1425,7 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const bool live = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
-    load_query<NM>(img_b, tl, lane, h, live ? norms[tl * 32 + c] : kDeadConst, b[qt]);
+    load_query<NM>(img_b, tl, lane, h, live ? norms[tl * 32 + c] : dead_const(sc), sc, b[qt]);
     const uint32_t jl = live ? jq[qt] : (n_rows - 1);
     q[qt].pq = live ? pq_of[jl] : 0u;
     q[qt].spos = live ? invpos[jl] : 0xFFFFFFFFu;
@@ -1601,8 +1688,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   uint32_t qn = 0;   // queued candidates (wave-uniform)
 
   // (scaled units, like the accumulators and the running minima taken from them)
-  const Scale sc = scale_of(__uint_as_float(hdr[0]));
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols);
+  const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc.g, sc.a);
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;
@@ -1623,7 +1710,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const bool live = (tile < TQT) && (pos < n_q);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? perm_q[pos] : 0u;
-    load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : kDeadConst, b[qt]);
+    load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
     if (h == 0)   // original coordinates of this lane's query, for the exact path

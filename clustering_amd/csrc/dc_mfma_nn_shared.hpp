@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   uint32_t qn = 0;   // queued candidates (wave-uniform)
 
   // (scaled units, like the accumulators and the running minima taken from them)
-  const Scale sc = scale_of(__uint_as_float(hdr[0]));
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols);
+  const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc.g, sc.a);
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     const bool live = (tile < TQT) && (pos < n_q);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? perm_q[pos] : 0u;
-    load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : kDeadConst, b[qt]);
+    load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
     if (h == 0) jq_tab[qt * 32 + c] = jq[qt];
@@ -270,17 +270,12 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       // reference tile t -> ring slot, by this wave alone (see pop_shared_kernel): NM fragments of 1 KB, the 32 row
       // norms (lanes 0..7) and the tile's free-energy range (two dwords)
       auto fetch = [&](uint32_t t, uint32_t slot_id) {
-        __attribute__((address_space(3))) uint4* dst =
-            (__attribute__((address_space(3))) uint4*)(ring + slot_id * kUnits);
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + slot_id * kUnits));
         const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) __builtin_amdgcn_global_load_lds(src + m * 64, dst + m * 64, 16, 0, 0);
-        if (lane < 8)
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane,
-                                           dst + NM * 64, 16, 0, 0);
-        if (lane < 2)
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(ferange_r + t) + lane,
-                                           (__attribute__((address_space(3))) float*)(dst + NM * 64 + 8), 4, 0, 0);
+        for (int m = 0; m < NM; ++m) lds_dma16(src + m * 64, dst + (uint32_t)m * 1024u);
+        if (lane < 8) lds_dma16(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane, dst + (uint32_t)NM * 1024u);
+        if (lane < 2) lds_dma4(reinterpret_cast<const float*>(ferange_r + t) + lane, dst + (uint32_t)NM * 1024u + 128u);
       };
       // the rest of an epilogue: free-energy classes, band test, parking of the candidates.
       // (t, fr) describe the reference tile the accumulator belongs to.

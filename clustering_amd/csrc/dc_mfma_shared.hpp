@@ -24,27 +24,38 @@ constexpr size_t shared_wave_words(int tq, int nr) { return 2 * kWaveQueue + (si
 template <int NM>
 constexpr int kTileUnits = NM * 64 + 8;   // 16-byte units of one staged tile: NM fragments + 32 norms
 
+// LDS-DMA: 16 (4) bytes per lane from a per-lane global address straight into LDS at lds + 16 (4) * lane.
+// Written as asm on purpose: issued through __builtin_amdgcn_global_load_lds the compiler orders every later LDS
+// read of the ring behind the load (s_waitcnt vmcnt(0) right after the issue: the fetching wave then sits out
+// the memory latency of the tile it has just asked for, once per window); the loop waits for its DMAs itself,
+// once per window, before the barrier that publishes them.  (Operations the compiler does not count only make its
+// own vmcnt waits stricter: loads return in order.)
+// (M0 carries the LDS address; it is saved and restored, so the compiler's own uses of it are not disturbed.)
+__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* gptr, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // ---- epilogue for NR radii per sweep ---------------------------------------------------------------------
 // With five and more MFMAs per chain the distances are worth more than the compares: ONE sweep serves up to
-// eight radii (C5: eight radii, NM = 6 -- eight single-radius sweeps cost 8 x (4 x 26 + 24 x 6) = 1 984 cycles
-// per tile pair by the issue model of DESIGN.md section 5, one sweep 4 x 8 x 33 + 24 x 6 = 1 200).  Per radius
-// and element: t = acc - delta_r (two elements per v_pk_add_f32), the sign into that radius' bit string
-// (v_alignbit), and the radius' own unsigned minimum (v_min3_u32, two elements per instruction) -- the band
-// test then knows WHICH radii have a pair in their band, and only those build the second sign string.
+// eight radii (C5: eight radii, NM = 6).  Per radius and element: t = acc - delta_r (two elements per
+// v_pk_add_f32) and its top two bits -- sign = inside, bit 30 = outside, neither = band (the band is [0, 2) for
+// every radius: pick_scale_pop sized the scale for the largest of them) -- into that radius' string (v_alignbit):
+// 1.5 instructions per element and radius, one for the first radius.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NR>
-struct MrAcc {
-  uint32_t bits[NR];   // sign bits of t_r, one per element, shifted in from the right
-  uint32_t tmin[NR];   // unsigned minimum over the elements of bits(t_r)
-};
+using MrAcc = PopAcc<NR>;
 template <int NR>
-__device__ __forceinline__ void mr_begin(MrAcc<NR>& e) {
-#pragma unroll
-  for (int rr = 0; rr < NR; ++rr) {
-    e.bits[rr] = 0;
-    e.tmin[rr] = 0xFFFFFFFFu;
-  }
-}
+__device__ __forceinline__ void mr_begin(MrAcc<NR>& e) { pop_epi_begin<NR>(e); }
 template <int NR, int R0, int R1>   // elements [R0, R1), both even
 __device__ __forceinline__ void mr_epi(const f32x16& acc, const PopDeltas<NR>& dl, MrAcc<NR>& e) {
   static_assert(R0 % 2 == 0 && R1 % 2 == 0, "elements are handled in pairs");
@@ -54,10 +65,8 @@ __device__ __forceinline__ void mr_epi(const f32x16& acc, const PopDeltas<NR>& d
     for (int r = R0; r < R1; r += 2) {
       f32x2 t = {acc[r], acc[r + 1]};
       if (rr != 0) t = t - f32x2{dl.d[rr], dl.d[rr]};
-      const uint32_t u0 = __float_as_uint(t.x), u1 = __float_as_uint(t.y);
-      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], u0, 31);
-      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], u1, 31);
-      e.tmin[rr] = min(min(e.tmin[rr], u0), u1);
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.x), 30);
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.y), 30);
     }
   }
 }
@@ -152,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     const bool live = (tile < TQT) && (pos < n_q);
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? perm_q[pos] : 0u;
-    const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : kDeadConst;
-    load_query<NM>(img_q, tl, lane, h, cq, b[qt]);
+    const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : dead_const(P.sc);
+    load_query<NM>(img_q, tl, lane, h, cq, P.sc, b[qt]);
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) cnt_q[qt][rr] = 0;
     if (h == 0) {
@@ -193,34 +202,19 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   // the launcher sends larger problems to pop_pruned_kernel)
   auto finish = [&](const f32x16& acc, auto qi_c, const MrAcc<NR>& e, uint32_t t) {
     constexpr int qi = decltype(qi_c)::value;
-    uint32_t tmin = e.tmin[0];
+    uint32_t decided = 0xFFFFFFFFu;   // bit 31 - 2 r: element r is inside or outside for EVERY radius
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-      cnt_q[qi][rr] += __builtin_popcount(e.bits[rr]);   // (16 shifts from 0: 16 bits)
-      tmin = min(tmin, e.tmin[rr]);
+      cnt_q[qi][rr] += __builtin_popcount(inside_of(e.bits[rr]));
+      decided &= e.bits[rr] | (e.bits[rr] << 1);
     }
-    if (__builtin_expect((__builtin_amdgcn_ballot_w64(tmin < P.wbits) & livemask[qi]) != 0, 0)) {
-      // Band <=> 0 <= t_r < w: the sign string of (t_r - w) minus the sign string of t_r, element r at bit
-      // 15 - r -- built only for the radii whose minimum says that some lane has a pair in the band.  Pad rows
-      // (acc = +inf) and idle lanes (acc ~ 1e30) are never in a band.  (A compare per element into scalar lane
-      // masks instead of the second sign string was measured 20 % slower at C5.)
-      const float w = __uint_as_float(P.wbits);
-      uint32_t fl[NR];
-      uint32_t m = 0;
+    uint32_t m = ~decided & kSignBits;
+    (void)acc;
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(m != 0) & livemask[qi]) != 0, 0)) {
+      // Pad rows (acc = +inf) and idle lanes (acc ~ 2^22) are never in a band.
+      uint32_t fl[NR];   // per radius: bit (31 - 2 r) set <=> element r sits in that radius' band
 #pragma unroll
-      for (int rr = 0; rr < NR; ++rr) {
-        fl[rr] = 0;
-        if (__builtin_amdgcn_ballot_w64(e.tmin[rr] < P.wbits) != 0) {
-          uint32_t below = 0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {   // (t_r with the roundings of mr_epi, then the shift by w)
-            const float tv = rr == 0 ? acc[r] : acc[r] - P.dl.d[rr];
-            below = __builtin_amdgcn_alignbit(below, __float_as_uint(tv - w), 31);
-          }
-          fl[rr] = below & ~e.bits[rr] & 0xFFFFu;
-          m |= fl[rr];
-        }
-      }
+      for (int rr = 0; rr < NR; ++rr) fl[rr] = band_of(e.bits[rr]);
       for (;;) {
         const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
         if (have == 0) break;
@@ -232,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
 #pragma unroll
           for (int rr = 0; rr < NR; ++rr) flags |= ((fl[rr] >> p) & 1u) << rr;
           const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
-          queue[slot] = make_uint2(tile_row(t, 15 - p, h), (uint32_t)(qi * 32 + c) | (flags << 8));
+          queue[slot] = make_uint2(tile_row(t, element_of(p), h), (uint32_t)(qi * 32 + c) | (flags << 8));
           m &= m - 1;
         }
         qn += n_new;
@@ -273,14 +267,11 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
       // reference tile t -> ring slot, by this wave alone: NM fragments of 1 KB (lane l lands at +16 l) and the
       // 32 row norms (lanes 0..7)
       auto fetch = [&](uint32_t t, uint32_t slot_id) {
-        __attribute__((address_space(3))) uint4* dst =
-            (__attribute__((address_space(3))) uint4*)(ring + slot_id * kUnits);
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + slot_id * kUnits));
         const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) __builtin_amdgcn_global_load_lds(src + m * 64, dst + m * 64, 16, 0, 0);
-        if (lane < 8)
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane,
-                                           dst + NM * 64, 16, 0, 0);
+        for (int m = 0; m < NM; ++m) lds_dma16(src + m * 64, dst + (uint32_t)m * 1024u);
+        if (lane < 8) lds_dma16(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane, dst + (uint32_t)NM * 1024u);
       };
       f32x16 accA, accB;   // accB: the chain whose epilogue is pending (+inf everywhere: contributes nothing)
 #pragma unroll

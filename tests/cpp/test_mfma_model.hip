@@ -8,9 +8,12 @@
 //      checked on crafted worst cases and on random products over the exponent range of normal fp16
 //      operands (the image builder flushes smaller pieces to zero: subnormal inputs are not exact);
 //  (2) end to end: the accumulator of the fp16x2 Gram chain (operand images built by the product's
-//      own scale_of / slot_value / split2 / gram_chain) stays within the MFMA + dropped-products +
+//      own pick_scale_* / slot_value / split2 / gram_chain) stays within the MFMA + dropped-products +
 //      flush part of the band of its exact value S (|y'|^2 + c_q - 2 x'.y'), for several dimensions
-//      and data scales (from 1e-3 to 1e3: the power-of-two scale S makes them all alike).
+//      and data scales (from 1e-3 to 1e3: the power-of-two scale S makes them all alike), under both
+//      scale rules: the neighbour sweeps' (pieces at the top of the fp16 range) and the population
+//      sweeps' (band <= 1: pieces in the middle of the range, scaled mid-piece products); for the
+//      latter also that the whole band of the launch is at most 1, as the two-bit epilogue assumes.
 //
 // Prints a summary and exits 0 when both hold, 1 otherwise.  Built by clustering_amd/csrc/Makefile,
 // run by tests/test_gpu_parity.py (pytest -m gpu).
@@ -53,18 +56,18 @@ __global__ void one_mfma(const unsigned short* A, const unsigned short* B, const
 // ---- (2) the product's Gram chain on 32 reference x 32 query rows ---------------------------------
 template <int NM>
 __global__ void gram_tile(const float* ref, const float* qry, uint32_t D, const float* ny,
-                          const float* cq, float M, float* out) {
+                          const float* cq, ScaleExp se, float* out) {
   // ref/qry: [32][D] centred coordinates, ny / cq unscaled; out [32 ref][32 qry] in scaled units
   const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
-  const Scale sc = scale_of(M);
+  const Scale sc = make_scale(se);
   s16x8 a[NM], b[NM];
   for (int m = 0; m < NM; ++m)
     for (int j = 0; j < 8; ++j) {
       const uint32_t s = 16 * m + 8 * h + j;
-      a[m][j] = (short)slot_value(s, D, false, [&](uint32_t k) { return ref[c * D + k] * sc.s1; });
-      b[m][j] = (short)slot_value(s, D, true, [&](uint32_t k) { return qry[c * D + k] * sc.s1; });
+      a[m][j] = (short)slot_value(s, D, false, sc, [&](uint32_t k) { return ref[c * D + k] * sc.sa; });
+      b[m][j] = (short)slot_value(s, D, true, sc, [&](uint32_t k) { return qry[c * D + k] * sc.sb; });
     }
-  const Pieces p = split2(cq[c] * sc.s2 * kConstScale);
+  const Pieces p = split2(cq[c] * sc.s2 * sc.cinv);
   if (h == 0) {
     b[0][0] = (short)p.hi;
     b[0][1] = (short)p.mid;
@@ -86,13 +89,6 @@ static float bf2f(unsigned short b) {
   memcpy(&hv, &b, 2);
   return (float)hv;
 }
-static double host_scale2(float M) {   // scale_of(M).s2 on the host
-  int e = 0;
-  (void)frexpf(M, &e);
-  int k = (28 - e) >> 1;
-  k = k < -62 ? -62 : (k > 62 ? 62 : k);
-  return ldexp(1.0, 2 * k);
-}
 static double ulp_of(long double v) {   // spacing of floats at |v|
   int e;
   frexpl(fabsl(v) > 0 ? v : 1e-300L, &e);   // |v| in [2^(e-1), 2^e)
@@ -105,7 +101,7 @@ static double q_of(long double maxmag) {   // 2^(e_max - 24), 2^e_max <= maxmag
 }
 
 template <int NM>
-static int run_gram(uint32_t D, float scale, float offset, float thr, double* worst_ratio, int trials) {
+static int run_gram(bool pop_rule, uint32_t D, float scale, float offset, float thr, double* worst_ratio, int trials) {
   float *d_ref, *d_qry, *d_ny, *d_cq, *d_out;
   CHECK(hipMalloc((void**)&d_ref, 32 * D * 4));
   CHECK(hipMalloc((void**)&d_qry, 32 * D * 4));
@@ -137,8 +133,14 @@ static int run_gram(uint32_t D, float scale, float offset, float thr, double* wo
     CHECK(hipMemcpy(d_ny, ny.data(), 128, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_cq, cq.data(), 128, hipMemcpyHostToDevice));
     const float Mf = (float)M;
-    const double S = host_scale2(Mf), Ms = S * (double)Mf, thrs = S * (double)thr;
-    gram_tile<NM><<<1, 64>>>(d_ref, d_qry, D, d_ny, d_cq, Mf, d_out);
+    const ScaleExp se = pop_rule ? pick_scale_pop(Mf, thr, (int)D) : pick_scale_nn(Mf);
+    const double S = ldexp(1.0, se.ka + se.kb), Ms = S * (double)Mf, thrs = S * (double)thr;
+    if (pop_rule && !(guard_eps_pop(Ms, thrs, (int)D, se.g, se.a) <= 1.0 && guard_eps_pop(2 * Ms, 2 * thrs, (int)D, se.g, se.a) > 1.0)) {
+      fprintf(stderr, "pick_scale_pop: band %.3f at the chosen scale, %.3f at twice the scale (D = %u)\n",
+              guard_eps_pop(Ms, thrs, (int)D, se.g, se.a), guard_eps_pop(2 * Ms, 2 * thrs, (int)D, se.g, se.a), D);
+      ++bad;
+    }
+    gram_tile<NM><<<1, 64>>>(d_ref, d_qry, D, d_ny, d_cq, se, d_out);
     CHECK(hipMemcpy(out.data(), d_out, 4096, hipMemcpyDeviceToHost));
     for (int i = 0; i < 32; ++i)
       for (int j = 0; j < 32; ++j) {
@@ -150,7 +152,7 @@ static int run_gram(uint32_t D, float scale, float offset, float thr, double* wo
         // factor, no centring / canonical terms)
         const double bound = u * (4.1 * (Ms + thrs) + 27.0 * Ms + 17.0 * (2.0 * Ms + thrs) +
                                   (nb - 1) * 18.0 * (4.02 * Ms + thrs) + ns * 18.0 * (absE + 0.004 * Ms) + absE) +
-                             ldexp(1.0, -12) * sqrt((double)D * Ms) + 2.0;
+                             guard_flush(Ms, (int)D, se.g, se.a) / 1.25;
         const double err = (double)fabsl((long double)out[i * 32 + j] - E);
         if (err / bound > *worst_ratio) *worst_ratio = err / bound;
         if (err > bound) ++bad;
@@ -236,20 +238,28 @@ int main() {
 
   double worst_ratio = 0;
   int bad = 0;
-  bad += run_gram<nm_for(2)>(2, 1.0f, 0.0f, 0.01f, &worst_ratio, 40);
-  bad += run_gram<nm_for(3)>(3, 0.3f, 1.0f, 0.04f, &worst_ratio, 40);
-  bad += run_gram<nm_for(10)>(10, 0.1f, 0.5f, 0.04f, &worst_ratio, 60);
-  bad += run_gram<nm_for(10)>(10, 0.01f, 3.0f, 0.0004f, &worst_ratio, 60);
-  bad += run_gram<nm_for(10)>(10, 100.0f, 1000.0f, 2500.0f, &worst_ratio, 40);
-  bad += run_gram<nm_for(14)>(14, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
-  bad += run_gram<nm_for(15)>(15, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
-  bad += run_gram<nm_for(10)>(10, 1e-3f, 0.0f, 4e-6f, &worst_ratio, 40);
-  bad += run_gram<nm_for(30)>(30, 0.1f, 0.5f, 0.09f, &worst_ratio, 40);
-  bad += run_gram<nm_for(32)>(32, 1e-3f, 1e-2f, 1e-5f, &worst_ratio, 40);
-  bad += run_gram<nm_for(48)>(48, 0.1f, 0.5f, 0.3f, &worst_ratio, 30);
-  bad += run_gram<nm_for(64)>(64, 0.05f, 2.0f, 0.2f, &worst_ratio, 30);
-  printf("fp16x2 gram chain: worst error / (MFMA + dropped-product part of the band) = %.3f, violations %d\n",
-         worst_ratio, bad);
+  for (int rule = 0; rule < 2; ++rule) {
+    const bool pr = rule == 1;
+    bad += run_gram<nm_for(2)>(pr, 2, 1.0f, 0.0f, 0.01f, &worst_ratio, 40);
+    bad += run_gram<nm_for(3)>(pr, 3, 0.3f, 1.0f, 0.04f, &worst_ratio, 40);
+    bad += run_gram<nm_for(10)>(pr, 10, 0.1f, 0.5f, 0.04f, &worst_ratio, 60);
+    bad += run_gram<nm_for(10)>(pr, 10, 0.01f, 3.0f, 0.0004f, &worst_ratio, 60);
+    bad += run_gram<nm_for(10)>(pr, 10, 100.0f, 1000.0f, 2500.0f, &worst_ratio, 40);
+    bad += run_gram<nm_for(14)>(pr, 14, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
+    bad += run_gram<nm_for(15)>(pr, 15, 0.1f, 0.5f, 0.04f, &worst_ratio, 40);
+    bad += run_gram<nm_for(10)>(pr, 10, 1e-3f, 0.0f, 4e-6f, &worst_ratio, 40);
+    bad += run_gram<nm_for(30)>(pr, 30, 0.1f, 0.5f, 0.09f, &worst_ratio, 40);
+    bad += run_gram<nm_for(32)>(pr, 32, 1e-3f, 1e-2f, 1e-5f, &worst_ratio, 40);
+    bad += run_gram<nm_for(48)>(pr, 48, 0.1f, 0.5f, 0.3f, &worst_ratio, 30);
+    bad += run_gram<nm_for(64)>(pr, 64, 0.05f, 2.0f, 0.2f, &worst_ratio, 30);
+    // radius far beyond / far below the extent of the data, tiny and huge coordinates
+    bad += run_gram<nm_for(10)>(pr, 10, 0.1f, 0.5f, 400.0f, &worst_ratio, 20);
+    bad += run_gram<nm_for(10)>(pr, 10, 0.1f, 0.5f, 1e-9f, &worst_ratio, 20);
+    bad += run_gram<nm_for(5)>(pr, 5, 1e-12f, 1e-11f, 1e-24f, &worst_ratio, 20);
+    bad += run_gram<nm_for(5)>(pr, 5, 1e10f, 3e10f, 1e20f, &worst_ratio, 20);
+    printf("fp16x2 gram chain, %s scale: worst error / (MFMA + dropped-product + flush part of the band) = %.3f, violations %d\n",
+           pr ? "population" : "neighbour", worst_ratio, bad);
+  }
   const bool ok = failures == 0 && bad == 0;
   printf("%s\n", ok ? "OK" : "FAILED");
   return ok ? 0 : 1;
