@@ -932,18 +932,85 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queu
 // flushes are a small part there; at C5's radii, in pop_shared_kernel, the same change took 222 -> 204 ms).
 // (A build without any band handling runs the C3 sweep in 18.1 instead of 22.5 ms -- but mostly because the
 // compiler then also drops the 8 v_min3_u32 of the band DETECTION from every chain, not because of this path.)
+// sym_tq > 0 (symmetric sweep): a pair whose reference tile lies outside the wave's own group of sym_tq query tiles
+// is evaluated by this wave alone, so the reference frame is credited as well (pops_pos: counts by position).
 __device__ __attribute__((noinline)) void pop_wave_flush_rows(const uint32_t* queue, uint32_t qn,
                                                               const float* qrows, uint32_t* fix_tab,
                                                               const float* __restrict__ coords_r,
-                                                              uint32_t n_cols, float r2, int lane) {
+                                                              uint32_t n_cols, float r2, int lane,
+                                                              uint32_t* __restrict__ pops_pos = nullptr,
+                                                              uint32_t sym_tq = 0, uint32_t own_group = 0) {
   for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
     if (k0 + lane < qn) {
       const uint32_t ent = queue[k0 + lane];
       const uint32_t pos = ent & (kPopQueueMaxRows - 1u), qidx = ent >> kPopQueuePosBits;
       const float d2c = dist2_canon_rt(qrows + (size_t)qidx * n_cols, 1, coords_r + (size_t)pos * n_cols, 1, (int)n_cols);
-      if (d2c < r2) atomicAdd(&fix_tab[qidx], 1u);
+      if (d2c < r2) {
+        atomicAdd(&fix_tab[qidx], 1u);
+        if (sym_tq != 0u && (pos >> 5) / sym_tq != own_group) atomicAdd(&pops_pos[pos], 1u);
+      }
     }
   }
+}
+
+// ---- symmetric population sweep: the reference side of a chain -------------------------------------------------
+// d2(i, j) = d2(j, i) (the canonical sum squares differences: the same value in either order), so a tile pair
+// needs one chain, not two, if BOTH frames of an inside pair are credited -- the reference's own trick
+// (density_clustering.cpp:170, 179-182).  The query side of a chain is an in-lane popcount; the reference side is
+// a sum ACROSS the 32 query lanes of a half-wave, per reference row.  It is taken once per reference tile, over
+// the TQ chains of the wave's query tiles together (they meet the same 32 reference rows):
+//   in-lane     the sign bits of three strings add up bit-sliced (xor3 / majority: two v_bitop3) into 2-bit fields,
+//               the fields of the groups of three are added in 4-bit slots (even / odd elements apart);
+//   lanes       one step of the lane reduction fits the 4-bit slots (<= 12), then the slots are spread to bytes
+//               (four words, <= 192 = TQ * 32) for the remaining steps: row_shr 2, 4, 8 and row_bcast15 into the
+//               odd rows -- lanes 31 / 63 end up with the sums over the queries of their half;
+//   rows        those two lanes leave their 16 bytes in LDS, lane i < 32 picks the byte of row i and adds it to
+//               the row's count with one 128-byte atomic per tile.
+// ~50 VALU instructions per reference tile, i.e. 8 per chain at TQ = 6 -- against the 21 + 2 MFMAs of the second
+// chain they replace.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t v) {   // v of the source lane, 0 where there is none
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+}
+// byte (of the 32 staged by lanes 31 / 63) that holds the count of reference row i = lane, i < 32
+__device__ __forceinline__ uint32_t ref_credit_byte(int lane) {
+  const int i = lane & 31, hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), f = 15 - r;
+  return (uint32_t)(16 * hh + 4 * (f & 3) + (f >> 2));
+}
+template <int TQ>
+__device__ __forceinline__ void ref_credit(const uint32_t (&sb)[TQ], uint32_t t, uint32_t n_rows,
+                                           uint32_t* __restrict__ pops_pos, uint32_t* stage /* 8 words of LDS */,
+                                           uint32_t my_byte, int lane) {
+  static_assert(TQ <= 6, "4-bit slots hold the sums of two groups of three strings over two lanes");
+  uint32_t A = 0, B = 0;
+#pragma unroll
+  for (int g = 0; g < TQ; g += 3) {
+    const uint32_t a = sb[g], b = (g + 1 < TQ) ? sb[g + 1] : 0u, c = (g + 2 < TQ) ? sb[g + 2] : 0u;
+    const uint32_t lo = a ^ b ^ c, hi = (a & b) | (a & c) | (b & c);   // valid at the sign positions (odd bits)
+    const uint32_t x = ((lo >> 1) & 0x55555555u) | (hi & kSignBits);   // element r: 0..3 at bits 31-2r, 30-2r
+    A += x & 0x33333333u;
+    B += (x >> 2) & 0x33333333u;
+  }
+  A += dpp_take<0x111>(A);   // row_shr:1
+  B += dpp_take<0x111>(B);
+  uint32_t W[4] = {A & 0x0F0F0F0Fu, B & 0x0F0F0F0Fu, (A >> 4) & 0x0F0F0F0Fu, (B >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    W[e] += dpp_take<0x112>(W[e]);         // row_shr:2
+    W[e] += dpp_take<0x114>(W[e]);         // row_shr:4
+    W[e] += dpp_take<0x118>(W[e]);         // row_shr:8
+    W[e] += dpp_take<0x142, 0xA>(W[e]);    // row_bcast15 into rows 1 and 3: lanes 31 / 63 hold their half's sums
+  }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) u32x4 LdsU4;
+  typedef __attribute__((address_space(3))) unsigned char LdsU8;
+  if ((lane & 31) == 31) ((LdsU4*)stage)[lane >> 5] = u32x4{W[0], W[1], W[2], W[3]};
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: its LDS operations execute in order)
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t cnt = ((const volatile LdsU8*)stage)[my_byte];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t row = 32u * t + (uint32_t)lane;
+  if (lane < 32 && cnt != 0u && row < n_rows) atomicAdd(&pops_pos[row], cnt);
 }
 
 __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
@@ -953,7 +1020,10 @@ __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
   return dx * dx + dy * dy;
 }
 
-template <int NM, int NR, int TQ, int MODE = kSinkNone>
+// SYM: the symmetric sweep (all rows as queries, one radius, no sink): a query group meets its own tiles as
+// before and, of the other groups, the half that lies ahead of it on the circle of groups -- every unordered pair
+// of groups once -- crediting both sides (ref_credit); all counts go to pops_pos (by position, zero-filled).
+template <int NM, int NR, int TQ, int MODE = kSinkNone, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
@@ -962,8 +1032,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
-    int n_rad, uint32_t* __restrict__ pops, EdgeSink sink) {
+    int n_rad, uint32_t* __restrict__ pops, EdgeSink sink, uint32_t* __restrict__ pops_pos = nullptr) {
+  static_assert(!SYM || (MODE == kSinkNone && NR == 1), "the symmetric sweep is the plain one-radius sweep");
   __shared__ uint32_t lists[4][kListCap];
+  __shared__ uint32_t credit_stage[4][8];
   // dynamic LDS: [4 waves][TQ*32][n_cols] query rows (original coordinates), then the queues of
   // deferred exact evaluations [4 waves][TQ][kQueueCap][64]
   extern __shared__ __attribute__((aligned(16))) float pop_qrows_all[];
@@ -1040,8 +1112,17 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
 
+  // SYM: groups of TQ tiles on a circle; this wave's group and its count; the strings of the chains on the pending
+  // reference tile and whether that tile is credited (it lies outside the wave's own group)
+  const uint32_t n_groups = (TQT + TQ - 1) / TQ;
+  uint32_t sb[TQ];
+  bool symB = false;
+  const uint32_t my_byte = ref_credit_byte(lane);
   auto flush_wave = [&]() {
-    pop_wave_flush_rows(queues, qn, qrows, fix_tab, coords_r, n_cols, rad2.v[0], lane);
+    if constexpr (SYM)
+      pop_wave_flush_rows(queues, qn, qrows, fix_tab, coords_r, n_cols, rad2.v[0], lane, pops_pos, (uint32_t)TQ, wave);
+    else
+      pop_wave_flush_rows(queues, qn, qrows, fix_tab, coords_r, n_cols, rad2.v[0], lane);
     qn = 0;
   };
   // evaluate and empty the queue of query tile qi (all lanes in parallel per slot)
@@ -1076,7 +1157,13 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       if (k + 64 + lane < lim) rb_next = box_r[tile_of(base + k + 64 + lane)];
       // (one test against the box of the whole query group: per-query-tile masks were measured to
       //  save < 0.5 % of the chains and they keep the chains from being pipelined)
-      const bool ok = (k + lane < lim) && (box_gap2(gbox, rb) < far2);
+      bool ok = (k + lane < lim) && (box_gap2(gbox, rb) < far2);
+      if constexpr (SYM) {
+        // the wave's own group, or a group at most half the circle ahead (exactly half: the lower index takes it)
+        const uint32_t gt = t / (uint32_t)TQ;
+        const uint32_t ahead = (gt >= wave) ? gt - wave : gt + n_groups - wave;
+        ok = ok & ((2u * ahead < n_groups) | ((2u * ahead == n_groups) & (wave < gt)));
+      }
       const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
       if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
       cnt += (uint32_t)__builtin_popcountll(m);
@@ -1095,6 +1182,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(inside_of(e.bits[rr]));
+      if constexpr (SYM) sb[qi] = e.bits[0];
       if constexpr (MODE == kSinkMinEdge) {
         // partners decided "inside" by the accumulator alone (element r = bit 31 - 2 r of the
         // string; the query itself is one of them and belongs to its own component): keep the
@@ -1211,6 +1299,8 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
         pop_epi_begin<NR>(e);
         pop_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
         finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
+        if constexpr (SYM && qt == 0)   // the strings of tile tB are complete now
+          if (symB) ref_credit<TQ>(sb, tB, n_rows, pops_pos, credit_stage[wib], my_byte, lane);
         pop_epi_begin<NR>(e);
         if constexpr (qt + 2 == TQ)   // last chain of the tile
           pop_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e, refill);
@@ -1220,6 +1310,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       });
       keep_alive(c0);
       tB = t;
+      symB = (t / (uint32_t)TQ) != wave;
     };
     if constexpr (kSingleBuffer<NM>) {
       uint32_t e0 = entry(0);
@@ -1250,6 +1341,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       pop_epi_begin<NR>(e);
       pop_epi<NR, 0, 16>(accB, P.dl, e);
       finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
+      if constexpr (SYM) {
+        if (symB) ref_credit<TQ>(sb, tB, n_rows, pops_pos, credit_stage[wib], my_byte, lane);
+        symB = false;
+      }
     }
   }
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
@@ -1277,7 +1372,9 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
           const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
           v += 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
         }
-        if (n_chunks == 1)
+        if constexpr (SYM)
+          atomicAdd(&pops_pos[(qt0 + (uint32_t)qt) * 32u + (uint32_t)c], v);   // (all rows: position = place in the order)
+        else if (n_chunks == 1)
           pops[(size_t)rr * n_rows + jq[qt]] = v;
         else
           atomicAdd(&pops[(size_t)rr * n_rows + jq[qt]], v);   // pops was zero-filled by the caller
@@ -2278,6 +2375,24 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
 
 // pruned population sweep: queries = n_q spatially ordered rows (image/perm/boxes "q"), references =
 // all rows spatially ordered ("p"); full_range: the query set is every row -> the two orders coincide
+// Which calls take the symmetric sweep: all rows as queries in the reference order (not a row range, not one
+// segment of a sharded run: its ranks would credit each other's rows), one radius, no pair sink, positions that
+// fit the queue entries.  DC_POP_SYM = 0 turns it off (tests, measurements).
+inline bool pop_sym_wanted(bool sink, int q_mode, QSeg q_seg, uint32_t n_rows, int n_rad) {
+  static const bool off = [] {
+    const char* v = getenv("DC_POP_SYM");
+    return v && v[0] == '0';
+  }();
+  return !off && !sink && q_mode == kQueryAll && q_seg.stride == 1 && n_rad == 1 && n_rows <= kPopQueueMaxRows;
+}
+// counts by position in the sweep's order -> populations by frame (a flagged data set: the direct kernel writes)
+__global__ void pops_by_frame_kernel(const uint32_t* __restrict__ pops_pos, const uint32_t* __restrict__ perm,
+                                     uint32_t n_rows, const uint32_t* __restrict__ hdr, uint32_t* __restrict__ pops) {
+  if (hdr[1] != 0) return;
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos < n_rows) pops[perm[pos]] = pops_pos[pos];
+}
+
 template <int S, int NRV, int TQV>
 void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
                        uint32_t T, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,
@@ -2309,6 +2424,21 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
                        chain_counter, rad2, n_rad, pops);
     return;
+  }
+  if constexpr (NRV == 1 && TQV <= 6) {
+    if (pop_sym_wanted(sink != nullptr, q_mode, q_seg, n_rows, n_rad)) {
+      // symmetric sweep: counts by position (the pq region of the workspace: only the full neighbour sweep uses
+      // it), then to the frames
+      uint32_t* pops_pos = const_cast<uint32_t*>(P.pq);
+      (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T, s);
+      hipLaunchKernelGGL((pop_pruned_kernel<S, 1, TQV, kSinkNone, true>), grid, block, smem, s, coords, n_rows,
+                         n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
+                         perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
+                         EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, pops_pos);
+      hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), block, 0, s, (const uint32_t*)pops_pos,
+                         P.perm_p, n_rows, P.hdr, pops);
+      return;
+    }
   }
   // radius-graph variants: all rows only (query positions = reference positions)
   if (sink && sink->best)
