@@ -2375,15 +2375,18 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
 
 // pruned population sweep: queries = n_q spatially ordered rows (image/perm/boxes "q"), references =
 // all rows spatially ordered ("p"); full_range: the query set is every row -> the two orders coincide
-// Which calls take the symmetric sweep: all rows as queries in the reference order (not a row range, not one
-// segment of a sharded run: its ranks would credit each other's rows), one radius, no pair sink, positions that
-// fit the queue entries.  DC_POP_SYM = 0 turns it off (tests, measurements).
+// Which calls take the symmetric sweep: all rows as queries in the reference order -- every query group, or the
+// groups of one segment of a sharded run (a group owns the same pairs of groups whichever rank runs it, so the
+// ranks' counts are PARTIAL counts of all rows and merge by summation like the one-sided ones) -- but not a row
+// range; one radius, no pair sink, positions that fit the queue entries.  DC_POP_SYM = 0 turns it off (tests,
+// measurements).
 inline bool pop_sym_wanted(bool sink, int q_mode, QSeg q_seg, uint32_t n_rows, int n_rad) {
   static const bool off = [] {
     const char* v = getenv("DC_POP_SYM");
     return v && v[0] == '0';
   }();
-  return !off && !sink && q_mode == kQueryAll && q_seg.stride == 1 && n_rad == 1 && n_rows <= kPopQueueMaxRows;
+  (void)q_seg;
+  return !off && !sink && q_mode == kQueryAll && n_rad == 1 && n_rows <= kPopQueueMaxRows;
 }
 // counts by position in the sweep's order -> populations by frame (a flagged data set: the direct kernel writes)
 __global__ void pops_by_frame_kernel(const uint32_t* __restrict__ pops_pos, const uint32_t* __restrict__ perm,

@@ -90,8 +90,9 @@ def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="a
 
 def calculate_populations_segment(coords, radii, segment, n_segments, variant="auto", out=None):
     """Populations of one segment of a sharded run (dc_hip_populations_segment_dev): with the pruned
-    sweep a run of whole query groups of the spatial order, else the reference's row block.  Zeros for
-    the rows of other segments (partials merge by summation)."""
+    sweep every n_segments-th query group of the spatial order, else the reference's row block.  PARTIAL counts
+    that merge by summation over the segments (a one-radius pruned sweep is symmetric -- it credits both frames
+    of a pair -- so a segment's counts cover all rows; the other sweeps leave zeros outside the segment)."""
     n_rows, n_cols = _check_coords(coords)
     rad = np.ascontiguousarray(radii, dtype=np.float32).reshape(-1)
     if out is None:

@@ -18,7 +18,7 @@ pruning loses a third of its effect (measured: 29 % instead of 20 % of the tile 
 A backend that offers ``*_segment`` methods (the HIP backend does) is therefore asked for SEGMENT
 g of G instead: every G-th query group of the sweep's spatial order (groups are dealt out cyclically, so
 every rank gets the same mix of dense and sparse regions).  Populations merge exactly
-as before (zeros outside the segment, all-reduce(sum)); the neighbour rows of a segment are scattered
+as before (partial counts, all-reduce(sum)); the neighbour rows of a segment are scattered
 over the trajectory, so they merge by ONE all-reduce(min) of [2][N] int64 words
 (d2 bits << 32 | index): every row has exactly one owner, and the "none" value (N+1, FLT_MAX) that
 all the other ranks hold for it is larger than anything the owner can report.

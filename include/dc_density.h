@@ -115,8 +115,12 @@ DC_API int dc_hip_populations_dev(const float* d_coords, size_t n_rows, size_t n
  * rows of a trajectory is spread over the whole conformational space), and dealing the groups out
  * cyclically gives every rank the same mix of dense and sparse regions; with every other variant,
  * n_cols > 64 or non-finite data the
- * segment is the reference's row block.  d_pops as above: zeros for the rows of other segments, so
- * that the partials merge by summation. */
+ * segment is the reference's row block.  d_pops: PARTIAL populations that merge by summation over the
+ * segments (the reference merges its per-GPU partials the same way, density_clustering_cuda.cu:171-180).
+ * A one-radius pruned sweep evaluates every pair of query groups once and credits both frames
+ * (d2(i,j) = d2(j,i), the reference's own i < j loop, density_clustering.cpp:170-182), so a segment's
+ * counts cover all rows; the other sweeps write the final counts of the segment's own rows and zeros
+ * elsewhere.  Only the sum over all segments is a population. */
 DC_API int dc_hip_populations_segment_dev(const float* d_coords, size_t n_rows, size_t n_cols,
                                           const float* radii, size_t n_radii, size_t segment,
                                           size_t n_segments, uint32_t* d_pops, void* d_workspace,

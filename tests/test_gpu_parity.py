@@ -480,8 +480,9 @@ def test_chunked_launches_match_direct(dens, rows):
 @pytest.mark.parametrize("n_rows,n_cols,n_seg", [(5000, 10, 2), (70000, 4, 8), (1000, 30, 3), (37, 2, 5), (4000, 40, 2), (3000, 70, 2)])
 def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols, n_seg):
     """dc_hip_*_segment_dev: the segments of a sharded run (every n_seg-th query group of the spatial order
-    with the pruned sweep, row blocks otherwise -- n_cols = 70 has no matrix-core kernel) partition the rows: summed
-    populations and min-merged (d2, index) words equal the single-device result bit for bit."""
+    with the pruned sweep, row blocks otherwise -- n_cols = 70 has no matrix-core kernel) partition the rows (of the
+    neighbour sweep: every row is answered by exactly one segment): summed populations and min-merged (d2, index)
+    words equal the single-device result bit for bit."""
     import torch
     c = gaussian_blobs(n_rows, n_cols, seed=5 + n_seg)
     ct = torch.from_numpy(c).cuda()
@@ -493,10 +494,10 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
     words = None
     owned = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
     for g in range(n_seg):
-        p = dens.calculate_populations_segment(ct, radii, g, n_seg)
+        p = dens.calculate_populations_segment(ct, radii, g, n_seg)   # partial counts (the symmetric sweep: of all rows)
         acc_p += p
-        owned += (p[0] != 0).to(torch.int32)
         a, b, cc, d = dens.nearest_neighbors_segment(ct, fe, g, n_seg)
+        owned += (a <= n_rows).to(torch.int32) if n_rows > 1 else 1    # rows of other segments hold (n_rows + 1, FLT_MAX)
         w = torch.stack([(b.view(torch.int32).to(torch.int64) << 32) | (a.to(torch.int64) & 0xFFFFFFFF),
                          (d.view(torch.int32).to(torch.int64) << 32) | (cc.to(torch.int64) & 0xFFFFFFFF)])
         assert bool((dens.pack_neighbors(a, b, cc, d) == w).all())      # dc_hip_neighbors_pack_dev
