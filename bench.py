@@ -60,7 +60,7 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-PMC_PROFILES = ("r2_c3_pmc.json", "r1_pruned_pmc.json")   # newest first
+PMC_PROFILES = ("r2b_c3_pmc.json", "r2_c3_pmc.json", "r1_pruned_pmc.json")   # newest first
 
 
 def measured_counters(kernel, n, d, radii, variant):
