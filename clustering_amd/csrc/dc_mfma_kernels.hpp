@@ -27,16 +27,17 @@
 //     -2 x.y  ~  sum_k  yh*xh + ym*xh + yh*xm                               (x pieces of -2x')
 // (the dropped ym*xm, yh*rho, rho*xh are <= 3 * 2^-22 |x_k y_k|: 27 u max|x'|^2 in the band, against
 // 34 u for the accumulation itself).  That is 3 D "slots" of the K axis, plus two slots
-// (2^15 * pieces of c_q / 2^15, c_q a per-query constant) that fold the query norm and the threshold
+// (2^a * pieces of c_q / 2^a, c_q a per-query constant) that fold the query norm and the threshold
 // into the accumulator:
-//     acc = |y'|^2 + c_q - 2 x'.y'   with  c_q = |x'|^2 - (r^2 - eps)   (populations: inside <=> acc < 0)
+//     acc = |y'|^2 + c_q - 2 x'.y'   with  c_q = |x'|^2 - (r^2 - 1)     (populations: inside <=> acc < 0)
 //                                          c_q = |x'|^2                 (neighbours:  acc ~ d2)
 // NM = ceil((3 D + 2) / 16) MFMAs per tile: 2 for D = 10 (the first, exact bf16x3 version of these
 // kernels -- git tag bf16x3-r1 -- needed 4; the fp32 MFMA 5 of 4x the cycles), 7 for D = 32, 13 for D = 64 (kMaxCols).
-// fp16 has a narrow exponent range, so everything the matrix pipe sees is SCALED by a power of two
-// chosen per data set (exact): x'' = 2^k x', S = 4^k with S max|x'|^2 in [2^26, 2^28).  Then
-// |x''_k| < 2^14, |-2 x''_k| < 2^15 and |c_q| / 2^15 < 65504 all fit, and pieces below the smallest
-// normal fp16 (2^-14, i.e. 2^-27 of the largest coordinate) are flushed to zero by the image
+// fp16 has a narrow exponent range, so everything the matrix pipe sees is SCALED by powers of two
+// chosen per SWEEP (exact; "scale of a SWEEP" below): the neighbour sweeps put S max|x'|^2 into
+// [2^26, 2^28) (|x''_k| < 2^14, |-2 x''_k| < 2^15, |c_q| / 2^15 < 65504), the population sweeps take
+// the largest S at which the guard band is <= 1, which turns the band test into a test of bit 30.
+// Values below the smallest normal fp16 (2^-14) are stored as zero by the image
 // builder (subnormal MFMA inputs are not exact on this hardware: scratch/mfma_probe_f16.hip); the
 // flush is part of the band.  Norms, thresholds and bands live in the same scaled units; the exact
 // path works on the original coordinates and never sees the scale.
@@ -57,9 +58,11 @@
 // half-waves (h = 0/1) see disjoint reference rows of the same 32 queries and are merged by one
 // __shfl_xor(.., 32) at the very end.
 //
-// The epilogues use no compare masks at all (no SGPR hand-offs between VALU and SALU):
-//     inside  <=>  sign bit of acc             -> shifted into a bit string (v_alignbit), v_bcnt
-//     in band <=>  bits(acc) <u bits(2 eps)    -> unsigned min (v_min3_u32), one test per chain
+// The epilogues use no compare masks at all (no SGPR hand-offs between VALU and SALU).  Populations
+// (threshold folded as c_q = |x'|^2 - (r^2 - 1), band <= 1):
+//     inside  <=>  sign bit of acc             -\  both shifted into a bit string (one v_alignbit per
+//     outside <=>  bit 30 (acc >= 2)           -/  element), v_bcnt of the sign positions
+//     in band <=>  neither                     -> one v_bitop3 + compare per chain
 // which is valid because the MFMA kernels only run on finite data (the header pass raises a flag
 // for non-finite or overflow-prone rows; the flagged case runs the direct kernels instead, both
 // launches are gated on the device so no host synchronisation is needed).
