@@ -1037,15 +1037,18 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
     int n_rad, uint32_t* __restrict__ pops, EdgeSink sink, uint32_t* __restrict__ pops_pos = nullptr) {
   static_assert(!SYM || (MODE == kSinkNone && NR == 1), "the symmetric sweep is the plain one-radius sweep");
-  __shared__ uint32_t lists[4][kListCap];
   __shared__ uint32_t credit_stage[4][8];
-  // dynamic LDS: [4 waves][TQ*32][n_cols] query rows (original coordinates), then the queues of
-  // deferred exact evaluations [4 waves][TQ][kQueueCap][64]
-  extern __shared__ __attribute__((aligned(16))) float pop_qrows_all[];
+  // dynamic LDS, per wave of the workgroup (one wave, see nn_pruned_kernel): the survivor list of a scan round
+  // [kListCap], then [TQ*32][n_cols] query rows (original coordinates), then the queues of deferred exact
+  // evaluations [TQ][kQueueCap][64]
+  extern __shared__ __attribute__((aligned(16))) float pop_dyn_lds[];
   if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
-  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib) * q_seg.stride + q_seg.offset;
+  const uint32_t wpb = blockDim.x >> 6;
+  uint32_t* lists_all = reinterpret_cast<uint32_t*>(pop_dyn_lds);
+  float* pop_qrows_all = pop_dyn_lds + (size_t)wpb * kListCap;
+  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * wpb + wib) * q_seg.stride + q_seg.offset;
   // gridDim.y > 1: the reference tiles are dealt round-robin to gridDim.y waves per query group and
   // the partial counts are merged with atomics (keeps small launches, e.g. one rank of an 8-GPU
   // run, at >= 2 waves per SIMD without giving up the operand reuse of TQ query tiles per wave)
@@ -1053,9 +1056,9 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
-  uint32_t* list = lists[wib];
+  uint32_t* list = lists_all + (size_t)wib * kListCap;
   float* qrows = pop_qrows_all + (size_t)wib * (TQ * 32) * n_cols;
-  uint32_t* queues = reinterpret_cast<uint32_t*>(pop_qrows_all + (size_t)4 * (TQ * 32) * n_cols) +
+  uint32_t* queues = reinterpret_cast<uint32_t*>(pop_qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
                      (size_t)wib * TQ * kQueueCap * 64;
   const bool use_queue = n_rows <= kPopQueueMaxRows;   // positions fit the queue entries
   // plain sweep of one radius: ONE compact list per wave (carved out of the same LDS region: 128 entries and a
@@ -1764,21 +1767,26 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
     unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx,
     float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
-  __shared__ uint32_t lists[4][kListCap];
-  // dynamic LDS: [4 waves][TQ*32][n_cols] query rows (original coordinates), then the candidate
-  // queues [4 waves][TQ][kQueueCap][64]
-  extern __shared__ __attribute__((aligned(16))) float qrows_all[];
+  // dynamic LDS, per wave of the workgroup: the survivor list of a scan round [kListCap], then [TQ*32][n_cols] query
+  // rows (original coordinates), then the candidate queues [TQ][kQueueCap][64]
+  extern __shared__ __attribute__((aligned(16))) float nn_dyn_lds[];
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
-  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wib) * q_seg.stride + q_seg.offset;
+  // waves per workgroup (kWavesPerGroup): the waves share nothing, and a workgroup holds its LDS until its LAST
+  // wave is done -- with four waves of unequal cost a fifth of the wave slots sat idle (SQ_WAVE_CYCLES: 1.57 of 2
+  // per SIMD at C3), with one wave per workgroup a finished wave is replaced at once (C3: 16.3 -> 15.2 ms)
+  const uint32_t wpb = blockDim.x >> 6;
+  uint32_t* lists_all = reinterpret_cast<uint32_t*>(nn_dyn_lds);
+  float* qrows_all = nn_dyn_lds + (size_t)wpb * kListCap;
+  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * wpb + wib) * q_seg.stride + q_seg.offset;
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;
-  uint32_t* list = lists[wib];
+  uint32_t* list = lists_all + (size_t)wib * kListCap;
   float* qrows = qrows_all + (size_t)wib * (TQ * 32) * n_cols;
-  uint32_t* queues = reinterpret_cast<uint32_t*>(qrows_all + (size_t)4 * (TQ * 32) * n_cols) +
+  uint32_t* queues = reinterpret_cast<uint32_t*>(qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
                      (size_t)wib * TQ * kQueueCap * 64;
   // the wave's LDS behind the query rows (TQ * kQueueCap * 64 words): the compact candidate list (kWaveQueue
   // entries of 8 B) and the packed exact incumbents [2][TQ*32] of 8 B
@@ -1830,6 +1838,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       if (g_nn[qt] < FLT_MAX) q[qt].m_nn = s_nn + (gb.e0 + gb.kappa * s_nn);
       if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
     }
+    q[qt].m_nn = fminf(q[qt].m_nn, q[qt].m_hd);   // (two reads of merge64 a moment apart: keep m_nn <= m_hd)
     q[qt].bn = nn_band(gb, q[qt].m_nn);
     q[qt].bh = nn_band(gb, q[qt].m_hd);
     q[qt].bd_nn = FLT_MAX;
@@ -1971,8 +1980,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         // per-element treatment ends up in the rare path.  The running minima can only change there
         // too (a value below the minimum is below its band).  ONE wave-level test: the scalar
         // hand-off (v_cmp -> s_cbranch) is a pipeline bubble at two waves per SIMD.
-        const float hcons = (fr.x < Q.feq) ? tmin : INFINITY;
-        const bool rare = (tmin < Q.bn) | (hcons < Q.bh);
+        // (bh >= bn always -- the minimum over the lower-free-energy frames cannot undercut the minimum over all
+        //  frames -- so a tile that has lower frames is tested against bh alone, any other against bn)
+        const float thr = (fr.x < Q.feq) ? Q.bh : Q.bn;
+        const bool rare = tmin < thr;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
           const bool all_lower = fr.y < Q.feq;
           const bool mixed = (fr.x < Q.feq) & !all_lower;
@@ -2303,6 +2314,21 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
 constexpr uint32_t kPopWaveTarget = 98304, kNnWaveTarget = 98304;
 constexpr uint32_t kPopShareFloor = 512, kNnShareFloor = 900;
+// waves per workgroup of the per-wave sweeps (pop_pruned_kernel, nn_pruned_kernel; see nn_pruned_kernel): ONE while a
+// chain has at most two MFMAs -- no slot waits for the slowest wave of a workgroup (1M x 10: neighbours 16.1 -> 15.0 ms,
+// 1M x 3: 5.7 -> 5.3 / populations 6.3 -> 6.05 ms) -- and four beyond that: the four waves of a workgroup sit on one CU
+// and walk nearly the same reference tiles at nearly the same time, so three of them find the operands in its L1
+// (populations 600k x 12: 8.0 ms with four waves per workgroup, 10.4 ms with one; 300k x 40: 6.1 / 7.9 ms; the neighbour
+// sweep does not care).  DC_WAVES_PER_GROUP = 1 / 2 / 4 for measurements.
+inline uint32_t waves_per_group(int nm) {
+  static const int forced = [] {
+    const char* v = getenv("DC_WAVES_PER_GROUP");
+    const int k = (v && v[0]) ? atoi(v) : 0;
+    return (k == 1 || k == 2 || k == 4) ? k : 0;
+  }();
+  if (forced) return (uint32_t)forced;
+  return nm <= 2 ? 1u : 4u;
+}
 inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles,
                             uint32_t share_floor, size_t /*tile_bytes*/) {
   const uint32_t waves = (tiles + tq - 1) / tq;
@@ -2346,13 +2372,14 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
   if (waves == 0) return;
   const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor, (size_t)S * 1024 + 128);
   // query rows (original coordinates) + candidate queues, per wave
-  const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
-                      sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
+  const uint32_t wpb = waves_per_group(S);
+  const size_t smem = wpb * (sizeof(uint32_t) * kListCap + sizeof(float) * TQV * 32 * (size_t)n_cols +
+                             sizeof(uint32_t) * TQV * kQueueCap * 64);
   if (n_chunks > 1)
     hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s,
                        A.merge64, n_rows);
   hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
-  hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + 3) / 4, n_chunks), dim3(256), smem, s,
+  hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + wpb - 1) / wpb, n_chunks), dim3(64 * wpb), smem, s,
                      coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
@@ -2408,7 +2435,9 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // the query groups of this launch: all of them, or one segment's share
   const uint32_t waves = seg_groups(((n_q + 31) / 32 + TQV - 1) / TQV, q_seg), tiles = waves * TQV;
   if (waves == 0) return;
-  const dim3 grid((waves + 3) / 4, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128)), block(256);
+  const uint32_t wpb = waves_per_group(S);
+  const dim3 grid((waves + wpb - 1) / wpb, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128)),
+      block(64 * wpb);
   // B form of the query rows: its own image for a row range, else the B form of the rows in the
   // reference order (img_q)
   const bool own = q_mode == kQueryOwnOrder;
@@ -2416,9 +2445,9 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   const float* norms_q = own ? P.norms_q : P.norms_p;
   const uint32_t* perm_q = own ? P.perm_q : P.perm_p;
   const float4* box_q = own ? P.box_q : P.box_p;
-  // query rows (original coordinates) + queues of deferred exact evaluations, per wave
-  const size_t smem = sizeof(float) * 4 * TQV * 32 * (size_t)n_cols +
-                      sizeof(uint32_t) * 4 * TQV * kQueueCap * 64;
+  // survivor list + query rows (original coordinates) + queues of deferred exact evaluations, per wave
+  const size_t smem = wpb * (sizeof(uint32_t) * kListCap + sizeof(float) * TQV * 32 * (size_t)n_cols +
+                             sizeof(uint32_t) * TQV * kQueueCap * 64);
   if (!sink && pop_shared_wanted(n_rows, n_cols, n_rad)) {
     // reference operands shared through LDS (dc_mfma_shared.hpp); NRV radii in this one sweep
     constexpr int kTQS = tq_shared_for<S, NRV>;
@@ -2426,7 +2455,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
     if (groups == 0) return;
     const dim3 grid_s(groups, pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
     const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * shared_wave_words(kTQS, NRV);
-    hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, block, smem_s, s, coords, n_rows, n_cols, P.img_p,
+    hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols, P.img_p,
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
                        chain_counter, rad2, n_rad, pops);
     return;
@@ -2441,7 +2470,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
                          n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                          perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
                          EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, pops_pos);
-      hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), block, 0, s, (const uint32_t*)pops_pos,
+      hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, (const uint32_t*)pops_pos,
                          P.perm_p, n_rows, P.hdr, pops);
       return;
     }

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       if (g_nn[qt] < FLT_MAX) q[qt].m_nn = s_nn + (gb.e0 + gb.kappa * s_nn);
       if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
     }
+    q[qt].m_nn = fminf(q[qt].m_nn, q[qt].m_hd);   // (two reads of merge64 a moment apart: keep m_nn <= m_hd)
     q[qt].bn = nn_band(gb, q[qt].m_nn);
     q[qt].bh = nn_band(gb, q[qt].m_hd);
     q[qt].bd_nn = FLT_MAX;
@@ -288,8 +289,10 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
         // per-element treatment ends up in the rare path.  The running minima can only change there
         // too (a value below the minimum is below its band).  ONE wave-level test: the scalar
         // hand-off (v_cmp -> s_cbranch) is a pipeline bubble at two waves per SIMD.
-        const float hcons = (fr.x < Q.feq) ? tmin : INFINITY;
-        const bool rare = (tmin < Q.bn) | (hcons < Q.bh);
+        // (bh >= bn always -- the minimum over the lower-free-energy frames cannot undercut the minimum over all
+        //  frames -- so a tile that has lower frames is tested against bh alone, any other against bn)
+        const float thr = (fr.x < Q.feq) ? Q.bh : Q.bn;
+        const bool rare = tmin < thr;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
           const bool all_lower = fr.y < Q.feq;
           const bool mixed = (fr.x < Q.feq) & !all_lower;
