@@ -71,3 +71,15 @@ def test_sessions_without_a_device_fail_with_a_status():
     assert capi.lib.dc_hip_session_populations(None, r.ctypes.data_as(C.c_void_p), 1, pops.ctypes.data_as(C.c_void_p)) == -1
     assert capi.lib.dc_hip_density_all(c.ctypes.data_as(C.c_void_p), 8, 3, r.ctypes.data_as(C.c_void_p), 1, 0, 0,
                                        pops.ctypes.data_as(C.c_void_p), None, None, None, None, None) == -2
+
+
+def test_population_scale_rule_on_the_host():
+    """tests/cpp/test_scale_host.hip (built with the library, no device code runs): the population sweeps' scale is
+    the largest power of two with a guard band <= 1 for extents and radii over 60 orders of magnitude, everything
+    fits fp16 at that scale, and the two fp16 pieces reproduce a value to 2^-22 (2^-20 absolute)."""
+    import subprocess
+    exe = os.path.join(ROOT, "clustering_amd", "bin", "test_scale_host")
+    if not os.path.exists(exe):
+        pytest.skip("clustering_amd/bin/test_scale_host not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
