@@ -2418,6 +2418,18 @@ inline bool pop_sym_wanted(bool sink, int q_mode, QSeg q_seg, uint32_t n_rows, i
   (void)q_seg;
   return !off && !sink && q_mode == kQueryAll && n_rad == 1 && n_rows <= kPopQueueMaxRows;
 }
+// the shared-operand sweeps in their symmetric form: with ONE radius (5M x 30, all rows: 1 482 -> 932 ms; 1M x 30:
+// 56.3 -> 35.8 ms).  With several radii per sweep the reference side costs one 128-byte atomic per reference tile,
+// wave and RADIUS into count arrays far larger than the L2 (C5: 8 x 20 MB): four radii at 1M x 16 still gain 9 %, but
+// the eight radii of C5's segment sweep went from 797 to 2 062 ms -- about 10^9 such atomics per second is what the
+// memory side takes.  DC_POP_SHARED_SYM = 0 / 1 / 2: never / one radius only (default) / always.
+inline bool pop_shared_sym_wanted(int nr) {
+  static const int mode = [] {
+    const char* v = getenv("DC_POP_SHARED_SYM");
+    return (v && v[0]) ? atoi(v) : 1;
+  }();
+  return mode >= 2 || (mode == 1 && nr == 1);
+}
 // counts by position in the sweep's order -> populations by frame (a flagged data set: the direct kernel writes)
 __global__ void pops_by_frame_kernel(const uint32_t* __restrict__ pops_pos, const uint32_t* __restrict__ perm,
                                      uint32_t n_rows, const uint32_t* __restrict__ hdr, uint32_t* __restrict__ pops) {
@@ -2455,6 +2467,20 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
     if (groups == 0) return;
     const dim3 grid_s(groups, pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
     const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * shared_wave_words(kTQS, NRV);
+    if (pop_sym_wanted(false, q_mode, q_seg, n_rows, 1) && pop_shared_sym_wanted(NRV)) {
+      // symmetric form: counts by position, one array of 32 T words per radius (the regions from norms_s to
+      // vals_in of the workspace: the population sweeps leave them alone once the orders are built)
+      uint32_t* pops_pos = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(P.norms_s));
+      (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T * NRV, s);
+      hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV, true>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols,
+                         P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
+                         chain_counter, rad2, n_rad, pops, pops_pos);
+      for (int rr = 0; rr < n_rad; ++rr)
+        hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
+                           (const uint32_t*)(pops_pos + (size_t)rr * 32 * T), P.perm_p, n_rows, P.hdr,
+                           pops + (size_t)rr * n_rows);
+      return;
+    }
     hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols, P.img_p,
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
                        chain_counter, rad2, n_rad, pops);

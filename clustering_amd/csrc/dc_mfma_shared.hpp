@@ -88,26 +88,37 @@ __device__ __forceinline__ void mr_chain(const s16x8 (&a)[NM], const s16x8 (&b)[
 // queries through their LDS counters (fix_tab[radius][query]).  Entry: x = reference position, y = query
 // (tile * 32 + column) | radii whose band holds the pair << 8.  Out of line: the hot loop calls it once
 // every few hundred chains.
+// sym_tiles > 0 (symmetric sweep, dc_mfma_kernels.hpp "symmetric population sweep"): a pair whose reference tile
+// lies outside the workgroup's own group of sym_tiles query tiles is evaluated here alone, so the reference frame is
+// credited too (pops_pos: [NR][pos_stride] counts by position).
 template <int NR>
 __device__ __attribute__((noinline)) void pop_wave_flush(const uint2* queue, uint32_t qn,
                                                          const uint32_t* jq_tab, uint32_t* fix_tab,
                                                          uint32_t n_queries, const float* __restrict__ coords,
                                                          const float* __restrict__ coords_r, uint32_t n_cols,
-                                                         Rad2 rad2, int lane) {
+                                                         Rad2 rad2, int lane, uint32_t* __restrict__ pops_pos = nullptr,
+                                                         uint32_t pos_stride = 0, uint32_t sym_tiles = 0,
+                                                         uint32_t own_group = 0) {
   for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
     if (k0 + lane < qn) {
       const uint2 ent = queue[k0 + lane];
       const uint32_t qidx = ent.y & 0xFFu, flags = ent.y >> 8;
       const float d2c = dist2_canon_rt(coords + (size_t)jq_tab[qidx] * n_cols, 1, coords_r + (size_t)ent.x * n_cols, 1,
                                        (int)n_cols);
+      const bool both = sym_tiles != 0u && (ent.x >> 5) / sym_tiles != own_group;
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
-        if (((flags >> rr) & 1u) && d2c < rad2.v[rr]) atomicAdd(&fix_tab[rr * n_queries + qidx], 1u);
+        if (((flags >> rr) & 1u) && d2c < rad2.v[rr]) {
+          atomicAdd(&fix_tab[rr * n_queries + qidx], 1u);
+          if (both) atomicAdd(&pops_pos[(size_t)rr * pos_stride + ent.x], 1u);
+        }
     }
   }
 }
 
-template <int NM, int TQ, int NR>
+// SYM: every unordered pair of query GROUPS (here: the 4 * TQ tiles of a workgroup) once, both frames credited --
+// pop_pruned_kernel's symmetric form; the strings of the NR radii on the pending reference tile are kept per wave.
+template <int NM, int TQ, int NR, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
@@ -115,10 +126,11 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2, int n_rad,
-    uint32_t* __restrict__ pops) {
+    uint32_t* __restrict__ pops, uint32_t* __restrict__ pops_pos = nullptr) {
   static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
   static_assert(NR >= 1 && NR <= 8 && TQ * 32 <= 256, "queue entries: 8 radius flags, 8 bits of query index");
   __shared__ uint32_t lists[4][kShareSub];
+  __shared__ uint32_t credit_stage[4][8];
   __shared__ uint32_t list_cnt[4];
   __shared__ float4 wave_box[4];
   // dynamic LDS: operand ring [kRing][kTileUnits] x 16 B, then per wave the compact queue of deferred exact
@@ -194,8 +206,24 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   // distance per lane and batch.  The owner of the query is credited through an LDS counter.  At C5's radii
   // (r^2 near the typical pair distance: a band pair every five chains) the per-lane scheme cost 30 - 40 %
   // of the sweep.
+  // SYM: the groups on their circle, the strings of the chains on the pending reference tile (per radius and query
+  // tile), whether that tile is credited (it lies outside the workgroup's own group), stride of a radius in pops_pos
+  const uint32_t n_groups = (TQT + 4u * TQ - 1u) / (4u * TQ);
+  const uint32_t pos_stride = 32u * T;
+  uint32_t sb[NR][TQ];
+  bool symB = false;
+  const uint32_t my_byte = ref_credit_byte(lane);
+  auto credit = [&](uint32_t t) {
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+      if (rr < n_rad) ref_credit<TQ>(sb[rr], t, n_rows, pops_pos + (size_t)rr * pos_stride, credit_stage[wib], my_byte, lane);
+  };
   auto flush = [&]() {
-    pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords, coords_r, n_cols, rad2, lane);
+    if constexpr (SYM)
+      pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords, coords_r, n_cols, rad2, lane, pops_pos, pos_stride,
+                         4u * TQ, group);
+    else
+      pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords, coords_r, n_cols, rad2, lane);
     qn = 0;
   };
   // the rest of an epilogue: counts, band test, parking of the band pairs (positions fit the queue entries:
@@ -207,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     for (int rr = 0; rr < NR; ++rr) {
       cnt_q[qi][rr] += __builtin_popcount(inside_of(e.bits[rr]));
       decided &= e.bits[rr] | (e.bits[rr] << 1);
+      if constexpr (SYM) sb[rr][qi] = e.bits[rr];
     }
     uint32_t m = ~decided & kSignBits;
     (void)acc;
@@ -249,6 +278,12 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
       if (u < U) {
         t = tile_of(u);
         ok = box_gap2(gbox, box_r[t]) < far2;
+        if constexpr (SYM) {
+          // the workgroup's own group, or a group at most half the circle ahead (exactly half: the lower index)
+          const uint32_t gt = t / (4u * TQ);
+          const uint32_t ahead = (gt >= group) ? gt - group : gt + n_groups - group;
+          ok = ok & ((2u * ahead < n_groups) | ((2u * ahead == n_groups) & (group < gt)));
+        }
       }
       const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
       if (ok) lists[wib][cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
@@ -303,12 +338,15 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
             mr_begin<NR>(e);
             mr_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
             finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
+            if constexpr (SYM && qt == 0)   // the strings of tile tB are complete now
+              if (symB) credit(tB);
             mr_begin<NR>(e);
             mr_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e);
             finish(accA, std::integral_constant<int, qt>{}, e, t);
           });
           keep_alive(c0);
           tB = t;
+          symB = (t / (4u * TQ)) != group;
         }
       }
       if (wave_live) {  // drain: epilogue of the last pending chain of this round
@@ -316,6 +354,10 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
         mr_begin<NR>(e);
         mr_epi<NR, 0, 16>(accB, P.dl, e);
         finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
+        if constexpr (SYM) {
+          if (symB) credit(tB);
+          symB = false;
+        }
       }
     }
     __syncthreads();   // lists and ring are free for the next round
@@ -338,7 +380,9 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
           const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
           v += 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
         }
-        if (n_chunks == 1)
+        if constexpr (SYM)
+          atomicAdd(&pops_pos[(size_t)rr * pos_stride + (qt0 + (uint32_t)qt) * 32u + (uint32_t)c], v);   // (position = place in the order)
+        else if (n_chunks == 1)
           pops[(size_t)rr * n_rows + jq[qt]] = v;
         else
           atomicAdd(&pops[(size_t)rr * n_rows + jq[qt]], v);   // pops was zero-filled by the caller
