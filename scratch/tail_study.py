@@ -37,3 +37,8 @@ for frac in (0.01, 0.03, 0.1):
     hit = len(set(top_area.tolist()) & set(top_cost.tolist())) / k
     print(f"top {frac:.0%} by box area: mean cost {cost[top_area].mean():.0f} (all: {cost.mean():.0f}); overlap with the top {frac:.0%} by cost {hit:.2f}")
 print("correlation(cost, area) %.3f   correlation(cost, need) %.3f" % (torch.corrcoef(torch.stack([cost, area]))[0, 1], torch.corrcoef(torch.stack([cost, need]))[0, 1]))
+ra = area / (cell * cell)
+print("group box area / cell^2 quantiles 50/90/97/99/99.9 %:", [round(v, 2) for v in torch.quantile(ra, torch.tensor([0.5, 0.9, 0.97, 0.99, 0.999], device=ra.device)).tolist()])
+for k in (1.0, 2.0, 4.0, 8.0):
+    sel = ra > k
+    print(f"area > {k} cell^2: {sel.float().mean().item():.4f} of the groups, mean cost {cost[sel].mean().item():.0f}, they hold {(cost[sel].sum() / cost.sum()).item():.3f} of the work; heaviest 0.5 % by cost inside: {(sel[idx[:G // 200]]).float().mean().item():.2f}")
