@@ -121,4 +121,39 @@ __device__ __forceinline__ float dist2_canon_rt(const float* x, int sx, const fl
   return s;
 }
 
+// the same for two CONTIGUOUS rows in memory (the deferred exact evaluations of the matrix-core sweeps: one lane per
+// pair, a row of the original coordinates each): four columns per load.  Every lane reads another row, so a load
+// instruction touches 64 cache lines whatever its width -- a quarter of the instructions is a quarter of the tag
+// look-ups (the flushes of the band pairs were 30 % of C5's multi-radius sweep).  Rows are only 4-byte aligned.
+// Same order of operations as dist2_canon_rt, bit for bit.
+typedef float f32x4_row __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float dist2_canon_rows(const float* x, const float* y, int D) {
+  if (D <= 3) return dist2_canon_rt(x, 1, y, 1, D);
+  const int V = 4 * (D / 4);
+  f32x4_row xv = *reinterpret_cast<const f32x4_row*>(x), yv = *reinterpret_cast<const f32x4_row*>(y);
+  float c0 = xv.x - yv.x, c1 = xv.y - yv.y, c2 = xv.z - yv.z, c3 = xv.w - yv.w;
+  float a0 = c0 * c0, a1 = c1 * c1, a2 = c2 * c2, a3 = c3 * c3;
+  for (int k0 = 4; k0 < V; k0 += 4) {
+    xv = *reinterpret_cast<const f32x4_row*>(x + k0);
+    yv = *reinterpret_cast<const f32x4_row*>(y + k0);
+    c0 = xv.x - yv.x, c1 = xv.y - yv.y, c2 = xv.z - yv.z, c3 = xv.w - yv.w;
+    a0 = a0 + c0 * c0;
+    a1 = a1 + c1 * c1;
+    a2 = a2 + c2 * c2;
+    a3 = a3 + c3 * c3;
+  }
+  float s = (a0 + a2) + (a1 + a3);
+  auto sq = [&](int k) {
+    const float c = x[k] - y[k];
+    return c * c;
+  };
+  int k = V;
+  if (D - k >= 2) {
+    s = s + (sq(k) + sq(k + 1));
+    k += 2;
+  }
+  if (D - k == 1) s = s + sq(k);
+  return s;
+}
+
 }  // namespace dc

@@ -916,7 +916,7 @@ __device__ __attribute__((noinline)) PopDelta<NR> pop_flush(const uint32_t* queu
     if ((uint32_t)k < count) {
       const uint32_t ent = queue[k * 64 + lane];
       const uint32_t pos = ent & (kPopQueueMaxRows - 1u), flags = ent >> kPopQueuePosBits;
-      const float d2c = dist2_canon_rt(qrow, 1, coords_r + (size_t)pos * n_cols, 1, (int)n_cols);
+      const float d2c = dist2_canon_rows(qrow, coords_r + (size_t)pos * n_cols, (int)n_cols);
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
         out.d[rr] += ((((flags >> rr) & 1u) != 0u) & (d2c < rad2.v[rr])) ? 1u : 0u;
@@ -947,7 +947,7 @@ __device__ __attribute__((noinline)) void pop_wave_flush_rows(const uint32_t* qu
     if (k0 + lane < qn) {
       const uint32_t ent = queue[k0 + lane];
       const uint32_t pos = ent & (kPopQueueMaxRows - 1u), qidx = ent >> kPopQueuePosBits;
-      const float d2c = dist2_canon_rt(qrows + (size_t)qidx * n_cols, 1, coords_r + (size_t)pos * n_cols, 1, (int)n_cols);
+      const float d2c = dist2_canon_rows(qrows + (size_t)qidx * n_cols, coords_r + (size_t)pos * n_cols, (int)n_cols);
       if (d2c < r2) {
         atomicAdd(&fix_tab[qidx], 1u);
         if (sym_tq != 0u && (pos >> 5) / sym_tq != own_group) atomicAdd(&pops_pos[pos], 1u);
@@ -1701,7 +1701,7 @@ __device__ __attribute__((noinline)) NnBest nn_fix_fe(const float* __restrict__ 
       const int r = __builtin_ctz(m);
       const uint32_t pos = tile_row(t, r, h);
       const uint32_t j = perm[pos];
-      const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)pos * n_cols, 1, (int)n_cols);
+      const float d2c = dist2_canon_rows(qrow, coords_c + (size_t)pos * n_cols, (int)n_cols);
       lexi_update((mn >> r) & 1u, best.bd_nn, best.bj_nn, d2c, j, n_rows);
       lexi_update((mh >> r) & 1u, best.bd_hd, best.bj_hd, d2c, j, n_rows);
       m &= m - 1;
@@ -1733,7 +1733,7 @@ __device__ __attribute__((noinline)) void nn_wave_flush(const uint2* queue, uint
       const uint2 ent = queue[k0 + lane];
       const uint32_t pos = ent.x & kQueuePosMask, qidx = ent.y;
       const uint32_t j = perm[pos];
-      const float d2c = dist2_canon_rt(qrows + (size_t)qidx * n_cols, 1, coords_c + (size_t)pos * n_cols, 1, (int)n_cols);
+      const float d2c = dist2_canon_rows(qrows + (size_t)qidx * n_cols, coords_c + (size_t)pos * n_cols, (int)n_cols);
       const unsigned long long key = ((unsigned long long)__float_as_uint(d2c) << 32) | j;
       if ((ent.x >> 30) & 1u) atomicMin(&best[qidx], key);
       if ((ent.x >> 31) & 1u) atomicMin(&best[n_queries + qidx], key);
@@ -2474,7 +2474,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
       (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T * NRV, s);
       hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV, true>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols,
                          P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                         chain_counter, rad2, n_rad, pops, pops_pos);
+                         chain_counter, rad2, n_rad, pops, own ? 0 : 1, pops_pos);
       for (int rr = 0; rr < n_rad; ++rr)
         hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                            (const uint32_t*)(pops_pos + (size_t)rr * 32 * T), P.perm_p, n_rows, P.hdr,
@@ -2483,7 +2483,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
     }
     hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols, P.img_p,
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                       chain_counter, rad2, n_rad, pops);
+                       chain_counter, rad2, n_rad, pops, own ? 0 : 1);
     return;
   }
   if constexpr (NRV == 1 && TQV <= 6) {

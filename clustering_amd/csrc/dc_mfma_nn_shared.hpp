@@ -22,7 +22,7 @@ __device__ __attribute__((noinline)) void nn_wave_flush_rows(const uint2* queue,
       const uint2 ent = queue[k0 + lane];
       const uint32_t pos = ent.x & kQueuePosMask, qidx = ent.y;
       const uint32_t j = perm[pos];
-      const float d2c = dist2_canon_rt(coords + (size_t)jq_tab[qidx] * n_cols, 1, coords_c + (size_t)pos * n_cols, 1,
+      const float d2c = dist2_canon_rows(coords + (size_t)jq_tab[qidx] * n_cols, coords_c + (size_t)pos * n_cols,
                                        (int)n_cols);
       const unsigned long long key = ((unsigned long long)__float_as_uint(d2c) << 32) | j;
       if ((ent.x >> 30) & 1u) atomicMin(&best[qidx], key);
