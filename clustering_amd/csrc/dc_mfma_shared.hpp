@@ -103,8 +103,7 @@ __device__ __attribute__((noinline)) void pop_wave_flush(const uint2* queue, uin
     if (k0 + lane < qn) {
       const uint2 ent = queue[k0 + lane];
       const uint32_t qidx = ent.y & 0xFFu, flags = ent.y >> 8;
-      const float d2c = dist2_canon_rt(coords + (size_t)jq_tab[qidx] * n_cols, 1, coords_r + (size_t)ent.x * n_cols, 1,
-                                       (int)n_cols);
+      const float d2c = dist2_canon_rows(coords + (size_t)jq_tab[qidx] * n_cols, coords_r + (size_t)ent.x * n_cols, (int)n_cols);
       const bool both = sym_tiles != 0u && (ent.x >> 5) / sym_tiles != own_group;
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr)
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2, int n_rad,
-    uint32_t* __restrict__ pops, uint32_t* __restrict__ pops_pos = nullptr) {
+    uint32_t* __restrict__ pops, int q_in_ref_order, uint32_t* __restrict__ pops_pos = nullptr) {
   static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
   static_assert(NR >= 1 && NR <= 8 && TQ * 32 <= 256, "queue entries: 8 radius flags, 8 bits of query index");
   __shared__ uint32_t lists[4][kShareSub];
@@ -178,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) cnt_q[qt][rr] = 0;
     if (h == 0) {
-      jq_tab[qt * 32 + c] = jq[qt];
+      // row of the query for the exact path: its place in the reference order when the queries are the reference
+      // rows (their original coordinates then sit next to each other in coords_r: the wave's TQ * 32 rows stay in
+      // the caches from one flush to the next), else its frame id in the caller's matrix
+      jq_tab[qt * 32 + c] = q_in_ref_order ? pos : jq[qt];
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) fix_tab[rr * (TQ * 32) + qt * 32 + c] = 0;
     }
@@ -218,12 +220,13 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     for (int rr = 0; rr < NR; ++rr)
       if (rr < n_rad) ref_credit<TQ>(sb[rr], t, n_rows, pops_pos + (size_t)rr * pos_stride, credit_stage[wib], my_byte, lane);
   };
+  const float* q_rows = q_in_ref_order ? coords_r : coords;
   auto flush = [&]() {
     if constexpr (SYM)
-      pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords, coords_r, n_cols, rad2, lane, pops_pos, pos_stride,
+      pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, q_rows, coords_r, n_cols, rad2, lane, pops_pos, pos_stride,
                          4u * TQ, group);
     else
-      pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords, coords_r, n_cols, rad2, lane);
+      pop_wave_flush<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, q_rows, coords_r, n_cols, rad2, lane);
     qn = 0;
   };
   // the rest of an epilogue: counts, band test, parking of the band pairs (positions fit the queue entries:
