@@ -168,25 +168,27 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   }
   img[((size_t)t * NM + m) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);   // pad rows: all zero
   if (norms && m == 0 && h == 0) {
+    // |x''|^2 of the SCALED coordinates (double accumulate, rounded once); a power-of-two scale commutes with it
     double nrm = 0.0;
     for (uint32_t k = 0; k < D; ++k) {
-      const float v = live ? x[k] - means[k] : 0.0f;
+      const float v = live ? col(k) : 0.0f;
       nrm += (double)v * (double)v;
     }
-    norms[row] = live ? (float)nrm * sc.s2 : INFINITY;   // S |x'|^2; pad rows can never be "inside"
+    norms[row] = live ? (float)nrm : INFINITY;   // pad rows can never be "inside"
   }
 }
 
-// the scale of the sweep that follows (dc_mfma_kernels.hpp "scale of a SWEEP") -> header words 20..23, read by
+// the scale of the sweep that follows (dc_mfma_kernels.hpp "scale of a SWEEP") -> header words 20..24, read by
 // the image builder and by the kernels.  r2max < 0: the neighbour rule; otherwise the population rule for
 // a call whose largest squared radius is r2max.
 __global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D) {
   const float M = __uint_as_float(hdr[0]);   // (final: rowstats_kernel ran before)
   const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
-  hdr[kHdrScale + 0] = (uint32_t)e.ka;
-  hdr[kHdrScale + 1] = (uint32_t)e.kb;
+  hdr[kHdrScale + 0] = __float_as_uint(e.c);
+  hdr[kHdrScale + 1] = __float_as_uint(e.s2);
   hdr[kHdrScale + 2] = (uint32_t)e.g;
   hdr[kHdrScale + 3] = (uint32_t)e.a;
+  hdr[kHdrScale + 4] = (uint32_t)e.rounded;
 }
 
 // ---- free-energy ordering of the reference frames (neighbour sweep) -----------------------------

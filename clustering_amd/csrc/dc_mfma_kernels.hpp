@@ -96,7 +96,7 @@ constexpr int kMaxMfma = nm_for(kMaxCols);   // 13
 constexpr size_t kHdrBytes = 1024;     // word 0: max |x'|^2 (float bits, UNSCALED); word 1: non-finite flag;
                                        // words 2..3 / 4..5: evaluated-chain counters (population / neighbour sweep);
                                        // words 8..11: extent of columns 0/1; word 12: ~key of min FE, 13: key of
-                                       // max finite FE; words 20..23: the scale of the current sweep (kHdrScale)
+                                       // max finite FE; words 20..24: the scale of the current sweep (kHdrScale)
 constexpr size_t kHdrSums = 256;       // byte 256..767: column sums (double) for the centring
 constexpr size_t kHdrMeans = 768;      // byte 768..1023: column means as float (what x' = x - mu uses)
 static_assert(kHdrSums + 8 * kMaxCols <= kHdrMeans && kHdrMeans + 4 * kMaxCols <= kHdrBytes,
@@ -235,35 +235,41 @@ __device__ __forceinline__ float auto_cell(const uint32_t* __restrict__ hdr, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// scale of a SWEEP: everything the matrix pipe sees is multiplied by powers of two -- the reference-side
-// coordinates by 2^ka, the query-side ones by 2^kb, norms / thresholds / bands / accumulators by
-// S = 2^(ka + kb).  Two rules (pick_scale_*), chosen per sweep by scale_kernel (dc_mfma.hip), which leaves the
-// exponents in header words 20..23 for the image builder and the kernels:
-//   neighbour sweeps   ka = kb, S M in [2^26, 2^28): the pieces use the top of the fp16 range;
-//   population sweeps  the largest S for which the guard band eps of the launch is <= 1.  The threshold is
-//                      folded as c_q = |x'|^2 - (r^2 - 1), so the accumulator t of a pair says
+// scale of a SWEEP: everything the matrix pipe sees is multiplied by a factor chosen per sweep -- the centred
+// coordinates by c (x'' = fl(c x')), thresholds / distances by S = fl(c c); norms are taken from the scaled
+// coordinates.  Two rules (pick_scale_*), applied by scale_kernel (dc_mfma.hip), which leaves the factors in header
+// words 20..24 for the image builder and the kernels:
+//   neighbour sweeps   c a power of two, S M in [2^26, 2^28): exact, the pieces use the top of the fp16 range;
+//   population sweeps  the largest S for which the guard band eps of the launch is <= 1 -- c is then NOT a power of
+//                      two, which costs one rounding per coordinate (a few percent on the band's constants, see
+//                      guard_e0_linear) and buys a band that is exactly as wide as eps: with a power of two it
+//                      was up to twice that, and band pairs are most of a wide multi-radius sweep (C5: eps = 0.65
+//                      of the band it paid for, 1.7 band pairs per chain).  The threshold is folded as
+//                      c_q = |x''|^2 - (S r^2 - 1), so the accumulator t of a pair says
 //                          t < 0        inside          (sign bit)
 //                          t >= 2       outside         (bit 30: biased exponent >= 128)
 //                          otherwise    band -> exact   (neither bit)
 //                      and the epilogue needs ONE instruction per accumulator register: v_alignbit shifts both
 //                      bits into a string (no minimum over the elements for the band test).  S M is then
-//                      ~2^15 .. 2^17.6 (eps ~ 100 .. 400 u S M), the coordinates ~2^7 .. 2^9: the pieces sit in
+//                      ~2^16 .. 2^17.6 (eps ~ 100 .. 400 u S M), the coordinates ~2^8 .. 2^9: the pieces sit in
 //                      the middle of the fp16 range, and the ones that would fall below its smallest normal are
 //                      kept by scaling the mid-piece products (mid 2^g x hi 2^-g, g = 6).
 // M = max |x'|^2 (header word 0).
 // ---------------------------------------------------------------------------------------------
 struct ScaleExp {
-  int ka, kb;   // reference side / query side: coordinates times 2^ka, 2^kb (kb in {ka - 1, ka})
+  float c;      // coordinates (both sides) times c
+  float s2;     // fl(c * c): thresholds, exact distances -> scaled units
   int g;        // mid pieces are stored as mid 2^g, their partner hi pieces as hi 2^-g
   int a;        // constant slots: 2^a on the A side, the pieces of c_q / 2^a on the B side
+  int rounded;  // c is not a power of two: the scaled coordinates carry one more rounding
 };
 struct Scale {
-  float sa, sb, s2;   // 2^ka, 2^kb, 2^(ka + kb)
+  float sa, sb, s2;   // c (reference side), c (query side), fl(c c)
   float up, dn;       // 2^g, 2^-g
   float cinv;         // 2^-a
-  int g, a;
+  int g, a, rounded;
 };
-constexpr uint32_t kHdrScale = 20;      // header words 20..23: ka, kb, g, a
+constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapNn = 1610612736.0f;    // 1.5 * 2^30 (neighbour scale: d2 <= 4 S M < 2^30)
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
@@ -272,22 +278,24 @@ constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 
 
 __host__ __device__ inline Scale make_scale(const ScaleExp& e) {
   Scale s;
-  s.sa = ldexpf(1.0f, e.ka);
-  s.sb = ldexpf(1.0f, e.kb);
-  s.s2 = ldexpf(1.0f, e.ka + e.kb);
+  s.sa = e.c;
+  s.sb = e.c;
+  s.s2 = e.s2;
   s.up = ldexpf(1.0f, e.g);
   s.dn = ldexpf(1.0f, -e.g);
   s.cinv = ldexpf(1.0f, -e.a);
   s.g = e.g;
   s.a = e.a;
+  s.rounded = e.rounded;
   return s;
 }
 __device__ __forceinline__ Scale load_scale(const uint32_t* __restrict__ hdr) {
   ScaleExp e;
-  e.ka = (int)hdr[kHdrScale + 0];
-  e.kb = (int)hdr[kHdrScale + 1];
+  e.c = __uint_as_float(hdr[kHdrScale + 0]);
+  e.s2 = __uint_as_float(hdr[kHdrScale + 1]);
   e.g = (int)hdr[kHdrScale + 2];
   e.a = (int)hdr[kHdrScale + 3];
+  e.rounded = (int)hdr[kHdrScale + 4];
   return make_scale(e);
 }
 
@@ -296,7 +304,7 @@ __host__ __device__ inline ScaleExp pick_scale_nn(float M) {
   (void)frexpf(M, &e);                  // M = f 2^e, f in [0.5, 1); M = 0 -> e = 0
   int k = (28 - e) >> 1;                // floor: e + 2k in {27, 28}
   k = k < -62 ? -62 : (k > 62 ? 62 : k);
-  return ScaleExp{k, k, 0, kConstShiftNn};
+  return ScaleExp{ldexpf(1.0f, k), ldexpf(1.0f, 2 * k), 0, kConstShiftNn, 0};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,12 +318,15 @@ __host__ __device__ inline ScaleExp pick_scale_nn(float M) {
 //       + 17 (2 M + thr) + (nb-1) 18 (4.02 M + thr)   the nb MFMAs that hold c_q and the hi*hi products:
 //                                                     17 addends, each truncated to 2^-24 of the largest
 //       + ns 18 (d2 + thr + 0.004 M) + (d2 + thr)     the ns MFMAs of small products, accumulator ~ d2 - thr
-//       + (D/4 + 9) d2 + 2 M ]                        canonical summation order + centring (as for fp32)
+//       + (D/4 + 9) d2 + 2 M                          canonical summation order + centring (as for fp32)
+//       + [rounded] 2.1 (M + thr + d2) ]              x'' = fl(c x'): |x'' - y''|^2 differs from c^2 |x' - y'|^2 by
+//                                                     <= 4 u c^2 |x' - y'| sqrt(M) <= 2 u S (d2 + M); the threshold
+//                                                     fl(fl(c c) r^2) from c^2 r^2 by 2 u S r^2
 //   + flush                                           values below 2^-14 (the smallest normal fp16) stored as zero:
 //       (2^(-12-g) + [g > 0] 2^(-23+g)) sqrt(D M)       lost piece remainders (|rho| <= max(2^-22 |v|, 2^(-14-g)))
-//                                                       times the other side (sum_k |w_k| <= sqrt(D) |w|, the two
-//                                                       sides' scales differ by at most 2), and hi 2^-g copies
-//                                                       below 2^-14 times their mid partners (<= 2^-11 |v|)
+//                                                       times the other side (sum_k |w_k| <= sqrt(D) |w|), and
+//                                                       hi 2^-g copies below 2^-14 times their mid partners
+//                                                       (<= 2^-11 |v|)
 //       + [g > 0] D 2^(-27+g)                           the same where both factors are tiny
 //       + 2^(-14+a)                                     the remainder of c_q / 2^a
 // with a further factor 1.25 on everything.  nb = ceil((D + 2) / 16), ns = NM - nb.
@@ -331,48 +342,51 @@ __host__ __device__ inline float next_up(float f) {   // f >= 0 finite; inf / Na
 }
 
 // (doubles: the population rule evaluates these at scales far from the final one)
-__host__ __device__ inline double guard_e0_linear(double M, double thr, int D) {   // M, thr: scaled
+__host__ __device__ inline double guard_e0_linear(double M, double thr, int D, int rounded) {   // M, thr: scaled
   const double u = 5.9604644775390625e-8;
   const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
   const double t = (thr > 0.0) ? thr : 0.0;
-  const double cM = 3.0 + 4.1 + 27.0 + 34.0 + 72.4 * (nb - 1) + 0.072 * ns + 2.0;
-  const double cT = 1.0 + 4.1 + 17.0 + 18.0 * (nb - 1) + 18.0 * ns + 1.0;
+  const double cR = rounded ? 2.1 : 0.0;
+  const double cM = 3.0 + 4.1 + 27.0 + 34.0 + 72.4 * (nb - 1) + 0.072 * ns + 2.0 + cR;
+  const double cT = 1.0 + 4.1 + 17.0 + 18.0 * (nb - 1) + 18.0 * ns + 1.0 + cR;
   return 1.25 * u * (cM * M + cT * t);
 }
 __host__ __device__ inline double guard_flush(double M, int D, int g, int a) {
   const double fl_rel = ldexp(1.0, -12 - g) + (g > 0 ? ldexp(1.0, -23 + g) : 0.0);
   return 1.25 * (fl_rel * sqrt((double)D * M) + (g > 0 ? (double)D * ldexp(1.0, -27 + g) : 0.0) + ldexp(1.0, -14 + a));
 }
-__host__ __device__ inline double guard_e0(double M, double thr, int D, int g, int a) {
-  return guard_e0_linear(M, thr, D) + guard_flush(M, D, g, a);
+__host__ __device__ inline double guard_e0(double M, double thr, int D, int g, int a, int rounded) {
+  return guard_e0_linear(M, thr, D, rounded) + guard_flush(M, D, g, a);
 }
-__host__ __device__ inline double guard_kappa(int D) {
+__host__ __device__ inline double guard_kappa(int D, int rounded) {
   const double u = 5.9604644775390625e-8;
   const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
-  return 1.25 * u * (18.0 * ns + 1.0 + 0.25 * D + 9.0);
+  return 1.25 * u * (18.0 * ns + 1.0 + 0.25 * D + 9.0 + (rounded ? 2.1 : 0.0));
 }
-__host__ __device__ inline GuardBand guard_band(float M, float thr, int D, int g, int a) {   // M, thr: scaled
+__host__ __device__ inline GuardBand guard_band(float M, float thr, int D, const Scale& sc) {   // M, thr: scaled
   GuardBand gb;
-  gb.e0 = next_up((float)guard_e0((double)M, (double)thr, D, g, a));
-  gb.kappa = next_up((float)guard_kappa(D));
+  gb.e0 = next_up((float)guard_e0((double)M, (double)thr, D, sc.g, sc.a, sc.rounded));
+  gb.kappa = next_up((float)guard_kappa(D, sc.rounded));
   return gb;
 }
 
 // population sweep: one band for all pairs with d2 up to the largest radius of the launch (scaled units)
-__host__ __device__ inline double guard_eps_pop(double M, double r2max, int D, int g, int a) {
+__host__ __device__ inline double guard_eps_pop(double M, double r2max, int D, int g, int a, int rounded) {
   const double cap = (r2max > 0.0) ? r2max : 0.0;
-  return (guard_e0(M, r2max, D, g, a) + guard_kappa(D) * cap) * (1.0 + 1.2e-7);
+  return (guard_e0(M, r2max, D, g, a, rounded) + guard_kappa(D, rounded) * cap) * (1.0 + 1.2e-7);
 }
 
-// the population rule: the largest S = 2^K with guard_eps_pop(S M, S r2max) <= 1 (M, r2max unscaled; r2max the
-// largest squared radius of the call, so that the images serve every radius of it)
+// the population rule: the largest S with guard_eps_pop(S M, S r2max) <= 1 (M, r2max unscaled; r2max the largest
+// squared radius of the call, so that the images serve every radius of it).  Every term of the band grows at most
+// linearly with S, so S = 2^K / eps(2^K) is admissible when 2^K is; c = sqrt(S) rounded down, s2 = fl(c c).
 __host__ __device__ inline ScaleExp pick_scale_pop(float M_in, float r2_in, int D) {
   const double M = (M_in > 0.0f) ? (double)M_in : 0.0;
   const double r2 = (r2_in > 0.0f) ? (double)r2_in : 0.0;   // (+inf allowed)
   constexpr int kLo = -120, kHi = 120;
+  auto eps_at = [&](double S) { return guard_eps_pop(S * M, S * r2, D, kMidShiftPop, kConstShiftPop, 1); };
   int K = kHi;
   // eps(S) >= S * lin: an upper bound for K, lowered until the flush part fits as well (a step or two)
-  const double lin = (guard_e0_linear(M, r2, D) + guard_kappa(D) * r2) * (1.0 + 1.2e-7);
+  const double lin = (guard_e0_linear(M, r2, D, 1) + guard_kappa(D, 1) * r2) * (1.0 + 1.2e-7);
   if (!(lin <= 1.7e308)) {
     K = kLo;
   } else if (lin > 0.0) {
@@ -381,12 +395,24 @@ __host__ __device__ inline ScaleExp pick_scale_pop(float M_in, float r2_in, int 
     K = 1 - e;
     K = K < kLo ? kLo : (K > kHi ? kHi : K);
   }
-  while (K > kLo && !(guard_eps_pop(ldexp(M, K), ldexp(r2, K), D, kMidShiftPop, kConstShiftPop) <= 1.0)) --K;
+  while (K > kLo && !(eps_at(ldexp(1.0, K)) <= 1.0)) --K;
   ScaleExp e;
-  e.kb = K >> 1;        // floor
-  e.ka = K - e.kb;
   e.g = kMidShiftPop;
   e.a = kConstShiftPop;
+  const double epsK = eps_at(ldexp(1.0, K));
+  if (K <= kLo || K >= kHi || !(epsK > 0.0) || !(epsK <= 1.0)) {
+    // the clamps (degenerate data, a radius beyond everything): an even power of two, exact scaling
+    K &= ~1;
+    e.c = ldexpf(1.0f, K / 2);
+    e.s2 = ldexpf(1.0f, K);
+    e.rounded = 0;
+    return e;
+  }
+  float c = (float)sqrt(ldexp(1.0, K) / epsK * (1.0 - 1e-6));
+  while (!(eps_at((double)c * (double)c) <= 1.0)) c = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, c) - 1u);
+  e.c = c;
+  e.s2 = (float)((double)c * (double)c);
+  e.rounded = 1;
   return e;
 }
 
@@ -1515,7 +1541,7 @@ __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc.g, sc.a);
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc);
 
   s16x8 b[TQ][NM];
   NnQ q[TQ];
@@ -1797,7 +1823,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc.g, sc.a);
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc);
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;

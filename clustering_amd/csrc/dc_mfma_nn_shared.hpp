@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc.g, sc.a);
+  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc);
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;

@@ -57,23 +57,24 @@ __global__ void one_mfma(const unsigned short* A, const unsigned short* B, const
 template <int NM>
 __global__ void gram_tile(const float* ref, const float* qry, uint32_t D, const float* ny,
                           const float* cq, ScaleExp se, float* out) {
-  // ref/qry: [32][D] centred coordinates, ny / cq unscaled; out [32 ref][32 qry] in scaled units
+  // ref/qry: [32][D] centred and SCALED coordinates (x'' = fl(c x'), what the image builder splits), ny / cq in
+  // scaled units; se carries the piece shifts of the rule under test; out [32 ref][32 qry] in scaled units
   const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
   const Scale sc = make_scale(se);
   s16x8 a[NM], b[NM];
   for (int m = 0; m < NM; ++m)
     for (int j = 0; j < 8; ++j) {
       const uint32_t s = 16 * m + 8 * h + j;
-      a[m][j] = (short)slot_value(s, D, false, sc, [&](uint32_t k) { return ref[c * D + k] * sc.sa; });
-      b[m][j] = (short)slot_value(s, D, true, sc, [&](uint32_t k) { return qry[c * D + k] * sc.sb; });
+      a[m][j] = (short)slot_value(s, D, false, sc, [&](uint32_t k) { return ref[c * D + k]; });
+      b[m][j] = (short)slot_value(s, D, true, sc, [&](uint32_t k) { return qry[c * D + k]; });
     }
-  const Pieces p = split2(cq[c] * sc.s2 * sc.cinv);
+  const Pieces p = split2(cq[c] * sc.cinv);
   if (h == 0) {
     b[0][0] = (short)p.hi;
     b[0][1] = (short)p.mid;
   }
   f32x16 c0;
-  for (int g = 0; g < 16; ++g) c0[g] = ny[(g & 3) + 8 * (g >> 2) + 4 * h] * sc.s2;
+  for (int g = 0; g < 16; ++g) c0[g] = ny[(g & 3) + 8 * (g >> 2) + 4 * h];
   const f32x16 acc = gram_chain<NM>(a, b, c0);
   for (int g = 0; g < 16; ++g) out[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + c] = acc[g];
 }
@@ -124,32 +125,48 @@ static int run_gram(bool pop_rule, uint32_t D, float scale, float offset, float 
         n1 += (double)ref[i * D + k] * ref[i * D + k];
         n2 += (double)qry[i * D + k] * qry[i * D + k];
       }
-      ny[i] = (float)n1;
-      cq[i] = (float)n2 - thr;
       M = fmax(M, fmax(n1, n2));
     }
+    const float Mf = (float)M;
+    const ScaleExp se = pop_rule ? pick_scale_pop(Mf, thr, (int)D) : pick_scale_nn(Mf);
+    const double S = (double)se.c * (double)se.c;
+    if (pop_rule) {
+      const double eps = guard_eps_pop(S * (double)Mf, S * (double)thr, (int)D, se.g, se.a, se.rounded);
+      if (!(eps <= 1.0) || (se.rounded && !(eps > 0.95))) {
+        fprintf(stderr, "pick_scale_pop: band %.4f at the chosen scale (D = %u)\n", eps, D);
+        ++bad;
+      }
+    }
+    // the scaled data, as the image builder forms it: x'' = fl(c x'), |x''|^2 in double rounded once,
+    // thresholds times fl(c c); everything below is in those units
+    double Ms = 0;
+    for (int i = 0; i < 32; ++i) {
+      double n1 = 0, n2 = 0;
+      for (uint32_t k = 0; k < D; ++k) {
+        ref[i * D + k] = ref[i * D + k] * se.c;
+        qry[i * D + k] = qry[i * D + k] * se.c;
+        n1 += (double)ref[i * D + k] * ref[i * D + k];
+        n2 += (double)qry[i * D + k] * qry[i * D + k];
+      }
+      ny[i] = (float)n1;
+      cq[i] = (float)n2 - thr * se.s2;
+      Ms = fmax(Ms, fmax(n1, n2));
+    }
+    const double thrs = (double)(thr * se.s2);
     CHECK(hipMemcpy(d_ref, ref.data(), 32 * D * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_qry, qry.data(), 32 * D * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_ny, ny.data(), 128, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_cq, cq.data(), 128, hipMemcpyHostToDevice));
-    const float Mf = (float)M;
-    const ScaleExp se = pop_rule ? pick_scale_pop(Mf, thr, (int)D) : pick_scale_nn(Mf);
-    const double S = ldexp(1.0, se.ka + se.kb), Ms = S * (double)Mf, thrs = S * (double)thr;
-    if (pop_rule && !(guard_eps_pop(Ms, thrs, (int)D, se.g, se.a) <= 1.0 && guard_eps_pop(2 * Ms, 2 * thrs, (int)D, se.g, se.a) > 1.0)) {
-      fprintf(stderr, "pick_scale_pop: band %.3f at the chosen scale, %.3f at twice the scale (D = %u)\n",
-              guard_eps_pop(Ms, thrs, (int)D, se.g, se.a), guard_eps_pop(2 * Ms, 2 * thrs, (int)D, se.g, se.a), D);
-      ++bad;
-    }
     gram_tile<NM><<<1, 64>>>(d_ref, d_qry, D, d_ny, d_cq, se, d_out);
     CHECK(hipMemcpy(out.data(), d_out, 4096, hipMemcpyDeviceToHost));
     for (int i = 0; i < 32; ++i)
       for (int j = 0; j < 32; ++j) {
         long double dot = 0;
         for (uint32_t k = 0; k < D; ++k) dot += (long double)ref[i * D + k] * (long double)qry[j * D + k];
-        const long double E = (long double)S * ((long double)ny[i] + (long double)cq[j] - 2.0L * dot);
+        const long double E = (long double)ny[i] + (long double)cq[j] - 2.0L * dot;
         const double absE = (double)fabsl(E);
         // MFMA + c_q pieces + dropped products + flush part of the band, in scaled units (no 1.25
-        // factor, no centring / canonical terms)
+        // factor, no centring / canonical / scaling-rounding terms)
         const double bound = u * (4.1 * (Ms + thrs) + 27.0 * Ms + 17.0 * (2.0 * Ms + thrs) +
                                   (nb - 1) * 18.0 * (4.02 * Ms + thrs) + ns * 18.0 * (absE + 0.004 * Ms) + absE) +
                              guard_flush(Ms, (int)D, se.g, se.a) / 1.25;

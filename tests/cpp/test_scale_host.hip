@@ -18,26 +18,32 @@ int main() {
       for (float r2 : r2s) {
         ++cases;
         const ScaleExp e = pick_scale_pop(M, r2, D);
-        const int K = e.ka + e.kb;
-        const double Msc = ldexp((double)M, K), r2sc = ldexp((double)r2, K);
-        const double eps = guard_eps_pop(Msc, r2sc, D, e.g, e.a), eps2 = guard_eps_pop(2 * Msc, 2 * r2sc, D, e.g, e.a);
-        const bool clamped = (K == -120 || K == 120);
-        bool ok = (e.ka - e.kb == 0 || e.ka - e.kb == 1) && e.g == kMidShiftPop && e.a == kConstShiftPop;
-        if (!clamped) ok = ok && eps <= 1.0 && eps2 > 1.0;          // the largest power of two with a band <= 1
-        if (K == 120) ok = ok && eps <= 1.0;                        // (tiny data: any scale will do)
+        const double S = (double)e.c * (double)e.c;
+        const double eps = guard_eps_pop(S * (double)M, S * (double)r2, D, e.g, e.a, e.rounded);
+        bool ok = e.g == kMidShiftPop && e.a == kConstShiftPop && e.c > 0.0f && e.s2 == (float)S;
+        if (e.rounded) {
+          // the regular case: the band is at most 1 and the scale within a few percent of the largest such
+          // (the sub-linear flush terms are the difference)
+          ok = ok && eps <= 1.0 && eps > 0.95;
+        } else {
+          // the clamps: a power of two; admissible unless the radius is beyond every scale (then thr is capped)
+          int ex = 0;
+          ok = ok && frexpf(e.c, &ex) == 0.5f;
+          if (r2 < INFINITY && M > 0.0f) ok = ok && eps <= 1.0;
+        }
         if (eps <= 1.0) {
-          // coordinates (A form x 2^ka, B form -2x 2^kb) and c_q / 2^a fit the fp16 range
-          const double xa = sqrt(ldexp((double)M, 2 * e.ka)), xb = 2.0 * sqrt(ldexp((double)M, 2 * e.kb));
-          const double cq = Msc + fmin(r2sc, (double)kThrCapPop) + 1.0;
-          ok = ok && xa < 32768.0 && xb < 32768.0 && ldexp(cq, -e.a) < 65504.0 && ldexp(65504.0, e.a) > 4.0 * Msc + 2.0;
+          // coordinates (A form, and -2x in the B form) and c_q / 2^a fit the fp16 range
+          const double xa = sqrt(S * (double)M);
+          const double cq = S * (double)M + fmin(S * (double)r2, (double)kThrCapPop) + 1.0;
+          ok = ok && 2.0 * xa < 32768.0 && ldexp(cq, -e.a) < 65504.0 && ldexp(65504.0, e.a) > 4.0 * S * (double)M + 2.0;
         }
         if (!ok) {
           ++bad;
-          fprintf(stderr, "D %d M %g r2 %g: ka %d kb %d eps %g (twice the scale: %g)\n", D, M, r2, e.ka, e.kb, eps, eps2);
+          fprintf(stderr, "D %d M %g r2 %g: c %g rounded %d eps %g\n", D, M, r2, e.c, e.rounded, eps);
         }
       }
   // pieces: v = hi + mid 2^-g + rho with |rho| <= max(2^-22 |v|, 2^(-14-g)); the hi 2^-g copy is exact or zero
-  const Scale sc = make_scale(ScaleExp{7, 7, kMidShiftPop, kConstShiftPop});
+  const Scale sc = make_scale(ScaleExp{181.0f, 32761.0f, kMidShiftPop, kConstShiftPop, 1});
   uint32_t seed = 12345u;
   for (int i = 0; i < 200000; ++i) {
     seed = seed * 1664525u + 1013904223u;
