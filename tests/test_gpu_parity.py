@@ -607,3 +607,55 @@ def test_shared_operand_neighbour_sweep():
     r = subprocess.run([sys.executable, "-c", NN_SHARED_CHILD, root], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, DC_NN_SHARED="1"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+
+
+_SWEEP_FORMS_CHILD = r"""
+import sys, json
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from clustering_amd import density as dens
+from clustering_amd.synth import gaussian_blobs
+out = {{}}
+for n, d, radii in {cases!r}:
+    c = gaussian_blobs(n, d, seed=11)
+    c[: n // 7] = c[n // 3: n // 3 + n // 7]          # duplicates: band pairs at distance 0 and ties
+    ct = torch.from_numpy(c).cuda()
+    p = dens.calculate_populations_partial(ct, radii)
+    acc = torch.zeros_like(p)
+    for g in range(3):
+        acc += dens.calculate_populations_segment(ct, radii, g, 3)
+    fe = dens.calculate_free_energies(p[0].contiguous())
+    nn = dens.nearest_neighbors_partial(ct, fe)
+    out[f"{{n}}x{{d}}"] = [int(p.to(torch.int64).sum()), int((p.to(torch.int64) * torch.arange(1, p.numel() + 1, device=p.device).view_as(p)).sum() % (1 << 61)),
+                          bool((acc == p).all()), int(nn[0].to(torch.int64).sum()), int(nn[2].to(torch.int64).sum()),
+                          int(nn[1].view(torch.int32).to(torch.int64).sum()), int(nn[3].view(torch.int32).to(torch.int64).sum())]
+print("FORMS " + json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_sweep_forms_agree():
+    """The population sweep has a symmetric form (every pair of query groups once, both frames credited) and a
+    one-sided one, workgroups of one or four waves, and a symmetric shared-operand sweep for one or several radii:
+    every combination, in its own process (the switches are read once), gives the same populations (plain and
+    position-weighted checksums), the same sums over three segments, and the same neighbours -- on shapes with an even
+    and an odd number of query groups, more than one reference share, 1 to 6 MFMAs per chain, and duplicated rows."""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(1152, 10, [0.2]), (1344, 10, [0.3, 0.15]), (40000, 10, [0.2]), (9000, 3, [0.05]), (20000, 16, [0.4, 0.3, 0.5]),
+             (12000, 30, [0.6])]
+    envs = [{}, {"DC_POP_SYM": "0"}, {"DC_WAVES_PER_GROUP": "4"}, {"DC_WAVES_PER_GROUP": "1"},
+            {"DC_POP_SHARED": "1", "DC_POP_SHARED_SYM": "2"}, {"DC_POP_SHARED": "1", "DC_POP_SHARED_SYM": "0", "DC_NN_SHARED": "1"}]
+    results = []
+    for extra in envs:
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _SWEEP_FORMS_CHILD.format(root=ROOT, cases=cases)], capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert r.returncode == 0, (extra, r.stderr[-2000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("FORMS ")][-1]
+        results.append(json.loads(line[6:]))
+    for extra, got in zip(envs[1:], results[1:]):
+        assert got == results[0], (extra, got, results[0])
+    assert all(v[2] for v in results[0].values()), "segments sum to the full populations"
