@@ -318,6 +318,9 @@ def main():
             "pairs_per_launch_unpruned": full_pairs,
             "launch_ms": 1e3 * dom_t,
             "evaluated_fraction": {"pop": pop_pairs / full_pairs, "nn": nn_pairs / full_pairs},
+            "evaluated_fraction_note": "tile pairs the kernels COMPUTED (their own counters) x 1024 / N^2; the one-radius "
+                                       "population sweep computes every unordered pair of query groups once and credits "
+                                       "both frames (d2 is symmetric), so its figure covers about twice as many ordered pairs",
         })
         line = {
             "metric": "frame-pairs/s (density pop+nn)" if want_nn else "frame-pairs/s (density pop)",
