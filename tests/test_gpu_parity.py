@@ -659,3 +659,40 @@ def test_sweep_forms_agree():
     for extra, got in zip(envs[1:], results[1:]):
         assert got == results[0], (extra, got, results[0])
     assert all(v[2] for v in results[0].values()), "segments sum to the full populations"
+
+
+@pytest.mark.gpu
+def test_degenerate_inputs_pruned_equals_direct(dens):
+    """Inputs at the edges of the scale rule of the matrix-core sweeps -- all rows identical (M = 0: every pair in the
+    band), two far points with a tiny radius, a radius beyond everything / of 1e-30 / infinite, coordinates of 1e15 and
+    1e-15, a constant and a huge column, lattices (exact ties), n = 1 and 2, 64 columns: pruned sweeps = direct kernels."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, d = 5000, 10
+    two = np.concatenate([np.zeros((n // 2, d)), np.ones((n - n // 2, d)) * 1e3])
+    lattice = np.stack(np.meshgrid(np.arange(20), np.arange(20), np.arange(10)), -1).reshape(-1, 3) * 0.25
+    cases = [
+        ("identical rows", np.full((n, d), 0.37), [0.0, 1e-3, 1.0]),
+        ("all zero", np.zeros((n, d)), [0.5]),
+        ("two far points, tiny radius", two, [1e-6, 10.0]),
+        ("radius beyond everything", two, [1e9]),
+        ("1e15", rng.normal(size=(n, d)) * 1e15, [2e15, 5e15]),
+        ("1e-15", rng.normal(size=(n, d)) * 1e-15, [2e-15, 5e-15]),
+        ("constant and huge column", np.concatenate([rng.normal(size=(n, d - 2)), np.full((n, 1), 7.0),
+                                                     rng.normal(size=(n, 1)) * 1e6], 1), [3.0, 1e6]),
+        ("radius 1e-30", rng.normal(size=(n, d)), [1e-30, 3.0]),
+        ("radius inf", rng.normal(size=(300, 3)), [float("inf")]),
+        ("n = 1", rng.normal(size=(1, 7)), [1.0]),
+        ("n = 2 identical", np.ones((2, 40)), [0.0, 1.0]),
+        ("64 columns", rng.normal(size=(3000, 64)), [8.0, 11.0, 12.5]),
+        ("lattice", lattice, [0.25, 0.5, 0.3535534]),
+    ]
+    for name, c, radii in cases:
+        ct = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).cuda()
+        a = dens.calculate_populations_partial(ct, radii, variant="pruned")
+        b = dens.calculate_populations_partial(ct, radii, variant="direct")
+        assert bool((a == b).all()), name
+        fe = dens.calculate_free_energies(b[0].contiguous())
+        for p, q in zip(dens.nearest_neighbors_partial(ct, fe, variant="pruned"),
+                        dens.nearest_neighbors_partial(ct, fe, variant="direct")):
+            assert bool((p.view(torch.int32) == q.view(torch.int32)).all()), name
