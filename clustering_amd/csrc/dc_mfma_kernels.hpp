@@ -271,7 +271,6 @@ struct Scale {
 };
 constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
-constexpr float kThrCapNn = 1610612736.0f;    // 1.5 * 2^30 (neighbour scale: d2 <= 4 S M < 2^30)
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
                                               //  4 S M below 2^19.6; only a radius beyond the clamps of
                                               //  pick_scale_pop reaches the cap, and then every pair is inside)
