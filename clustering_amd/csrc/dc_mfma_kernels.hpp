@@ -1213,7 +1213,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       constexpr int qi = decltype(qi_c)::value;
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += __builtin_popcount(inside_of(e.bits[rr]));
-      if constexpr (SYM) sb[qi] = e.bits[0];
+      if constexpr (SYM) {   // (the band of a whole reference tile is looked at once, from the kept strings: park_tile)
+        sb[qi] = e.bits[0];
+        return;
+      }
       if constexpr (MODE == kSinkMinEdge) {
         // partners decided "inside" by the accumulator alone (element r = bit 31 - 2 r of the
         // string; the query itself is one of them and belongs to its own component): keep the
@@ -1308,6 +1311,33 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
         }
       }
     };
+    // SYM: the band pairs of reference tile t, from the strings of its TQ chains -- one test per tile instead of one
+    // per chain (a compare and a scalar branch less in every chain)
+    auto park_tile = [&](uint32_t t) {
+      uint32_t decided = 0xFFFFFFFFu;
+#pragma unroll
+      for (int qi = 0; qi < TQ; ++qi) decided &= sb[qi] | (sb[qi] << 1);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64((~decided & kSignBits) != 0u) == 0, 1)) return;
+#pragma unroll
+      for (int qi = 0; qi < TQ; ++qi) {
+        uint32_t m = band_of(sb[qi]);
+        for (;;) {
+          const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
+          if (have == 0) break;
+          const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
+          if (qn + n_new > (uint32_t)kWaveQueue) flush_wave();
+          if (m != 0) {
+            const int p = __builtin_ctz(m);
+            const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
+            queues[slot] = tile_row(t, element_of(p), h) | ((uint32_t)(qi * 32 + c) << kPopQueuePosBits);
+            m &= m - 1;
+          }
+          qn += n_new;
+        }
+      }
+      if (qn >= 64u) flush_wave();
+    };
+    bool pendB = false;   // SYM: sb[] holds the strings of a real reference tile (tB)
     // accB always holds the chain whose epilogue is still pending: query tile TQ-1 of reference
     // tile tB (or +inf everywhere = contributes nothing)
     f32x16 accA, accB;
@@ -1330,8 +1360,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
         pop_epi_begin<NR>(e);
         pop_chain<NM, NR>(a, b[qt], c0, accA, accB, P.dl, e);
         finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
-        if constexpr (SYM && qt == 0)   // the strings of tile tB are complete now
+        if constexpr (SYM && qt == 0) {   // the strings of tile tB are complete now
+          if (pendB) park_tile(tB);
           if (symB) ref_credit<TQ>(sb, tB, n_rows, pops_pos, credit_stage[wib], my_byte, lane);
+        }
         pop_epi_begin<NR>(e);
         if constexpr (qt + 2 == TQ)   // last chain of the tile
           pop_chain<NM, NR>(a, b[qt + 1], c0, accB, accA, P.dl, e, refill);
@@ -1342,6 +1374,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       keep_alive(c0);
       tB = t;
       symB = (t / (uint32_t)TQ) != wave;
+      pendB = true;
     };
     if constexpr (kSingleBuffer<NM>) {
       uint32_t e0 = entry(0);
@@ -1373,8 +1406,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       pop_epi<NR, 0, 16>(accB, P.dl, e);
       finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
       if constexpr (SYM) {
+        if (pendB) park_tile(tB);
         if (symB) ref_credit<TQ>(sb, tB, n_rows, pops_pos, credit_stage[wib], my_byte, lane);
         symB = false;
+        pendB = false;
       }
     }
   }
