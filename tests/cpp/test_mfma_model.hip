@@ -15,7 +15,9 @@
 //      sweeps' (band <= 1: pieces in the middle of the range, scaled mid-piece products); for the
 //      latter also that the whole band of the launch is at most 1, as the two-bit epilogue assumes.
 //
-// Prints a summary and exits 0 when both hold, 1 otherwise.  Built by clustering_amd/csrc/Makefile,
+//  (3) ref_credit (the cross-lane reduction of the symmetric population sweep) against a host count on random strings.
+//
+// Prints a summary and exits 0 when all hold, 1 otherwise.  Built by clustering_amd/csrc/Makefile,
 // run by tests/test_gpu_parity.py (pytest -m gpu).
 #include "../../clustering_amd/csrc/dc_mfma_kernels.hpp"
 
@@ -179,6 +181,53 @@ static int run_gram(bool pop_rule, uint32_t D, float scale, float offset, float 
   return bad;
 }
 
+// ---- (3) the reference-side reduction of the symmetric population sweep ---------------------------------------
+// ref_credit on random strings: row i of the tile must be credited with the number of (query tile, lane of the
+// row's half-wave) whose string has the sign bit of the row's element set.
+template <int TQ>
+__global__ void credit_probe(const uint32_t* strings /* [TQ][64] */, uint32_t* counts /* [32] */) {
+  __shared__ uint32_t stage[8];
+  const int lane = threadIdx.x;
+  uint32_t sb[TQ];
+  for (int q = 0; q < TQ; ++q) sb[q] = strings[q * 64 + lane];
+  ref_credit<TQ>(sb, 0u, 32u, counts, stage, ref_credit_byte(lane), lane);
+}
+template <int TQ>
+static int run_credit(int trials) {
+  uint32_t *d_s, *d_c;
+  CHECK(hipMalloc((void**)&d_s, TQ * 64 * 4));
+  CHECK(hipMalloc((void**)&d_c, 128));
+  std::vector<uint32_t> st(TQ * 64), got(32);
+  int bad = 0;
+  for (int t = 0; t < trials; ++t) {
+    // dense, sparse and all-ones strings; the flag bits (even positions) are noise the reduction must ignore
+    const int density = t % 4;
+    for (auto& v : st) {
+      uint32_t w = 0;
+      for (int b = 0; b < 32; ++b) {
+        const int r = rand() & 255;
+        const bool on = density == 0 ? (r < 128) : density == 1 ? (r < 8) : density == 2 ? true : (r < 250);
+        w |= (uint32_t)on << b;
+      }
+      v = w;
+    }
+    CHECK(hipMemcpy(d_s, st.data(), TQ * 64 * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemset(d_c, 0, 128));
+    credit_probe<TQ><<<1, 64>>>(d_s, d_c);
+    CHECK(hipMemcpy(got.data(), d_c, 128, hipMemcpyDeviceToHost));
+    for (int row = 0; row < 32; ++row) {
+      // element r of half h is row (r & 3) + 8 (r >> 2) + 4 h; its sign sits at bit 31 - 2 r
+      const int hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+      uint32_t want = 0;
+      for (int q = 0; q < TQ; ++q)
+        for (int l = 32 * hh; l < 32 * hh + 32; ++l) want += (st[q * 64 + l] >> (31 - 2 * r)) & 1u;
+      if (got[row] != want) ++bad;
+    }
+  }
+  (void)hipFree(d_s); (void)hipFree(d_c);
+  return bad;
+}
+
 int main() {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
@@ -277,6 +326,9 @@ int main() {
     printf("fp16x2 gram chain, %s scale: worst error / (MFMA + dropped-product + flush part of the band) = %.3f, violations %d\n",
            pr ? "population" : "neighbour", worst_ratio, bad);
   }
+  const int bad_credit = run_credit<2>(40) + run_credit<4>(40) + run_credit<6>(40);
+  printf("reference-side reduction of the symmetric sweep (2, 4, 6 strings): violations %d\n", bad_credit);
+  bad += bad_credit;
   const bool ok = failures == 0 && bad == 0;
   printf("%s\n", ok ? "OK" : "FAILED");
   return ok ? 0 : 1;
