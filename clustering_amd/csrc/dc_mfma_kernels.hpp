@@ -1010,6 +1010,12 @@ __device__ __forceinline__ void ref_credit(const uint32_t (&sb)[TQ], uint32_t t,
                                            uint32_t* __restrict__ pops_pos, uint32_t* stage /* 8 words of LDS */,
                                            uint32_t my_byte, int lane) {
   static_assert(TQ <= 6, "4-bit slots hold the sums of two groups of three strings over two lanes");
+  {  // nothing inside in the whole tile (tiles at the edge of the pruning radius): nothing to credit
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) any |= sb[q];
+    if (__builtin_amdgcn_ballot_w64((any & kSignBits) != 0u) == 0) return;
+  }
   uint32_t A = 0, B = 0;
 #pragma unroll
   for (int g = 0; g < TQ; g += 3) {
