@@ -116,7 +116,7 @@ extern "C" {
 
 const char* dc_hip_last_error(void) { return g_last_error.c_str(); }
 
-int dc_hip_abi_version(void) { return 1; }
+int dc_hip_abi_version(void) { return DC_HIP_ABI_VERSION; }
 
 int dc_hip_device_count(void) {
   int n = 0;
@@ -135,6 +135,17 @@ int dc_hip_device_count(void) {
 size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radii) {
   (void)n_radii;
   return dc::mfma_workspace_bytes(n_rows, n_cols);
+}
+
+int dc_hip_sweep_timing(int enable) {
+  dc::sweep_timer_enable(enable != 0);
+  return DC_OK;
+}
+
+int dc_hip_last_sweep_ms(int kind, float* ms) {
+  if (!ms || (kind != 0 && kind != 1)) return fail(DC_ERR_INVALID_ARGUMENT, "kind 0 (population) or 1 (neighbour), ms != NULL");
+  if (dc::sweep_timer_read(kind, ms) != 0) return fail(DC_ERR_INVALID_ARGUMENT, "no timed sweep of kind %d on this device", kind);
+  return DC_OK;
 }
 
 int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles, uint64_t* nn_tiles,
@@ -167,6 +178,8 @@ int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const 
                      size_t n_radii, size_t i_from, size_t i_to, size_t segment, size_t n_segments,
                      uint32_t* d_pops, void* d_workspace, size_t workspace_bytes, int variant,
                      void* stream) {
+  const bool stats_valid = (variant & DC_FLAG_STATS_VALID) != 0;
+  variant &= DC_VARIANT_MASK;
   if (n_segments > 0) {
     if (segment >= n_segments) return fail(DC_ERR_INVALID_ARGUMENT, "segment %zu of %zu", segment, n_segments);
     shard_rows(n_rows, n_segments, segment, &i_from, &i_to);
@@ -185,7 +198,7 @@ int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const 
       return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                   dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
     if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
-                                  variant == DC_VARIANT_MFMA, s))
+                                  variant == DC_VARIANT_MFMA, s, stats_valid))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
   }
   for (size_t r0 = 0; r0 < n_radii; r0 += dc::kMaxRadiiPerLaunch) {
@@ -345,6 +358,8 @@ int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, 
                            size_t i_from, size_t i_to, size_t segment, size_t n_segments,
                            uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
                            void* d_workspace, size_t workspace_bytes, int variant, void* stream) {
+  const bool stats_valid = (variant & DC_FLAG_STATS_VALID) != 0;
+  variant &= DC_VARIANT_MASK;
   if (n_segments > 0) {
     if (segment >= n_segments) return fail(DC_ERR_INVALID_ARGUMENT, "segment %zu of %zu", segment, n_segments);
     shard_rows(n_rows, n_segments, segment, &i_from, &i_to);
@@ -367,7 +382,7 @@ int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, 
     // (the pruned sweep packs reference positions into 30 bits of its candidate queue entries)
     const bool full_sweep = variant == DC_VARIANT_MFMA || n_rows >= ((size_t)1 << 30);
     if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
-                                  full_sweep, s))
+                                  full_sweep, s, stats_valid))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
     if (full_sweep)
       dc::launch_nn_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,

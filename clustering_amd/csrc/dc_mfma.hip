@@ -3,6 +3,8 @@
 #include "dc_mfma_kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 #ifndef DC_STEP_MASK
 #define DC_STEP_MASK 0xFFFFu   // bit (n-1) set <=> dc_mfma_step.hip was built with -DDC_STEP=n
@@ -66,7 +68,7 @@ __device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v, uint32_t
 // so word 0 bounds every norm of every operand image built from these coordinates.
 // 256 rows per block staged through LDS (coalesced reads; odd row stride against bank conflicts).
 __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
-                                const float* __restrict__ means, uint32_t* __restrict__ hdr) {
+                                const float* __restrict__ means, uint32_t* __restrict__ hdr, uint32_t cookie) {
   extern __shared__ float rs_tile[];
   __shared__ uint32_t wave_max[4];
   const uint32_t Dp = D | 1u;
@@ -103,11 +105,21 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
     m3 = max(m3, fin ? fkey(c1) : 0u);
   }
   if (bad) atomicOr(hdr + 1, 1u);
+  if (threadIdx.x == 0) hdr[kHdrCookie] = cookie;   // whose statistics these are (DC_FLAG_STATS_VALID is checked against it)
   publish_max(hdr, m_norm, wave_max);
   publish_max(hdr + 8, m0, wave_max);
   publish_max(hdr + 9, m1, wave_max);
   publish_max(hdr + 10, m2, wave_max);
   publish_max(hdr + 11, m3, wave_max);
+}
+
+// DC_FLAG_STATS_VALID: the caller says the header still holds the statistics of these coordinates.  If the cookie
+// says otherwise (the previous call on this workspace was not a matrix-core sweep over the same array and shape) the
+// data is flagged: the matrix-core kernels stand down and the gated direct kernels answer -- slow, never wrong.
+// Flag word 1: bit 0 = non-finite / overflow-prone coordinates (a statistic: it stays), bit 1 = cookie mismatch,
+// bit 2 = NaN free energies (belongs to one neighbour sweep: cleared here).
+__global__ void stats_guard_kernel(uint32_t* __restrict__ hdr, uint32_t cookie) {
+  hdr[1] = (hdr[1] & 1u) | ((hdr[kHdrCookie] != cookie) ? 2u : 0u);
 }
 
 // operand image of the (centred, scaled) coordinates in the fp16x2 slot layout (dc_mfma_kernels.hpp), rows
@@ -212,7 +224,7 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
     inv = max(inv, ~key);
     top = max(top, (fabsf(f) <= FLT_MAX) ? key : 0u);
   }
-  if (nan) atomicOr(hdr + 1, 1u);
+  if (nan) atomicOr(hdr + 1, 4u);
   // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax), largest FINITE
   // one -> word 13 (as key); at most one atomic per block and word
   publish_max(hdr + 12, inv, wave_max);
@@ -227,7 +239,7 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
 __global__ void cellfe_key_kernel(const float* __restrict__ coords, uint32_t D,
                                   const float* __restrict__ fe, const uint32_t* __restrict__ hdr,
                                   float frames_per_cell, uint32_t n_rows, uint32_t* __restrict__ keys,
-                                  uint32_t* __restrict__ vals) {
+                                  uint32_t* __restrict__ vals, uint32_t key_bits) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
   vals[i] = i;
@@ -247,14 +259,15 @@ __global__ void cellfe_key_kernel(const float* __restrict__ coords, uint32_t D,
   const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 4001.0f) + 1u;
   const uint32_t cells = nbx * nby;                               // <= 4002^2 < 2^24
   const uint32_t cell_bits = 32u - (uint32_t)__builtin_clz(cells | 1u);
-  const uint32_t fe_bits = 32u - cell_bits;                       // >= 8
+  // key_bits: what the sort will look at (cellfe_key_bits: the host's bound of the cell bits + >= 10, whole passes)
+  const uint32_t fe_bits = key_bits > cell_bits ? key_bits - cell_bits : 0u;
   const float fe_lo = fkey_inv(~hdr[12]), fe_hi = fkey_inv(hdr[13]);
   const float span = fe_hi - fe_lo;
   float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
   u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
   const uint32_t levels = (fe_bits >= 32u) ? 0xFFFFFFFFu : ((1u << fe_bits) - 1u);
   const uint32_t q = (uint32_t)((double)u * (double)levels);
-  keys[i] = ((bx * nby + by) << fe_bits) | q;
+  keys[i] = (fe_bits >= 32u) ? q : (((bx * nby + by) << fe_bits) | q);
 }
 
 __global__ void fe_scatter_kernel(const uint32_t* __restrict__ perm, const float* __restrict__ fe,
@@ -285,6 +298,27 @@ __global__ void fe_rank_kernel(const float* __restrict__ fe, const float* __rest
   pq[i] = lo;
 }
 
+
+// Upper bound, known on the host, of the bits a cell key needs: the grid has about K = n / frames_per_cell cells
+// (auto_cell), at most 4002 per dimension; (x + 1)(y + 1) with x y <= K and x, y <= 4001 is at most
+// K + 4001 + K / 4001 + 1.  The Onesweep sort costs one pass (~35 us at 10^6 frames) per 8 key bits: C3's population
+// ordering needs 15 bits, not kCellKeyBits = 24.  (Should a data set ever exceed the bound, the sort would ignore the
+// top bits of its keys: a worse ordering, i.e. less pruning -- never a different result.)
+static unsigned cell_key_bits(uint32_t n_rows, float frames_per_cell) {
+  const double K = (double)n_rows / (double)frames_per_cell;
+  const double bound = K + 4002.0 + K / 4001.0 + 8.0;
+  unsigned bits = 1;
+  while (bits < kCellKeyBits && (double)(1u << bits) < bound) ++bits;
+  return bits;
+}
+// ... and of the combined (cell, free energy) key of the neighbour sweep: the cell bits + at least kFeKeyBits of
+// quantised free energy, rounded up to whole sort passes
+constexpr unsigned kFeKeyBits = 10;
+static unsigned cellfe_key_bits(uint32_t n_rows, float frames_per_cell) {
+  const unsigned want = cell_key_bits(n_rows, frames_per_cell) + kFeKeyBits;
+  const unsigned rounded = (want + 7u) & ~7u;
+  return rounded > 32u ? 32u : rounded;
+}
 
 // ---- spatial ordering of the frames (pruned sweeps) ----------------------------------------------
 // key = row-major index of the frame's cell in a 2-D grid on columns 0/1 (like compute_box_grid,
@@ -390,6 +424,47 @@ __global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
 #define DC_FOR_EACH_S(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 DC_FOR_EACH_S(DC_DECLARE_STEP)
 
+// ---- sweep timers (see dc_mfma.hpp) -------------------------------------------------------------------
+namespace {
+struct SweepTimer {
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool started = false;
+};
+std::atomic<bool> g_timing{false};
+SweepTimer g_timers[16][2];   // [device & 15][kind]
+std::mutex g_timer_mutex;
+}  // namespace
+
+void sweep_timer_enable(bool on) { g_timing.store(on); }
+
+void sweep_timer_mark(int kind, bool begin, hipStream_t s) {
+  if (!g_timing.load(std::memory_order_relaxed)) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_timer_mutex);
+  SweepTimer& t = g_timers[dev & 15][kind & 1];
+  if (!t.ev[0]) {
+    if (hipEventCreate(&t.ev[0]) != hipSuccess || hipEventCreate(&t.ev[1]) != hipSuccess) return;
+  }
+  if (begin) {
+    if (!t.started) (void)hipEventRecord(t.ev[0], s);
+    t.started = true;
+  } else {
+    (void)hipEventRecord(t.ev[1], s);
+  }
+}
+
+int sweep_timer_read(int kind, float* ms) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lock(g_timer_mutex);
+  SweepTimer& t = g_timers[dev & 15][kind & 1];
+  if (!t.started || !t.ev[0]) return -1;
+  t.started = false;
+  if (hipEventSynchronize(t.ev[1]) != hipSuccess) return -1;
+  return hipEventElapsedTime(ms, t.ev[0], t.ev[1]) == hipSuccess ? 0 : -1;
+}
+
 bool mfma_supports(size_t n_cols) {
   if (n_cols < 1 || n_cols > (size_t)kMaxCols) return false;
   return ((DC_STEP_MASK >> (nm_for((int)n_cols) - 1)) & 1u) != 0;
@@ -400,8 +475,18 @@ size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
 }
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
-                 bool natural_image, hipStream_t stream) {
+                 bool natural_image, hipStream_t stream, bool stats_valid) {
   char* p = (char*)d_ws;
+  const uint32_t cookie = (0x5354A7u ^ (n_rows * 2654435761u) ^ (n_cols * 40503u) ^
+                           (uint32_t)((uintptr_t)d_coords >> 4)) | 1u;
+  if (stats_valid) {
+    // DC_FLAG_STATS_VALID: means, max norm, flag and bounding box of an earlier sweep over the same coordinates
+    // stay; only the per-sweep words start over (evaluated-tile counters: words 2..5; free-energy range: 12..13)
+    if (hipMemsetAsync(p + 8, 0, 16, stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(p + 48, 0, 8, stream) != hipSuccess) return -1;
+    hipLaunchKernelGGL(stats_guard_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)p, cookie);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   if (hipMemsetAsync(p, 0, kHdrBytes, stream) != hipSuccess) return -1;
   const uint32_t blocks = (uint32_t)std::min<size_t>(512, ((size_t)n_rows * n_cols + 255) / 256);
   hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, d_coords, n_rows, n_cols,
@@ -410,7 +495,7 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
                      n_cols, (float*)(p + kHdrMeans));
   hipLaunchKernelGGL(rowstats_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 1024u)), dim3(256),
                      sizeof(float) * 256 * (n_cols | 1u), stream, d_coords, n_rows, n_cols,
-                     (const float*)(p + kHdrMeans), (uint32_t*)p);
+                     (const float*)(p + kHdrMeans), (uint32_t*)p, cookie);
   (void)natural_image;   // (the full sweeps build their natural-order images themselves, at their own scale)
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -639,7 +724,8 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     // order all frames by their 2-D cell, build the reference image and the tile boxes
     hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream,
+                       cell_key_bits(n_rows, kPopCellFrames)))
       return;
     // original rows in the reference order: the deferred exact path reads them without a
     // permutation look-up, and the operand images are built from them with coalesced reads
@@ -672,7 +758,8 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
       // query rows of this call: the same ordering restricted to [i_from, i_to)
       hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
                          (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
-      if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
+      if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream,
+                         cell_key_bits(n_q, kCellFramesHere)))
         return;
       hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
                          L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
@@ -737,9 +824,10 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   // energies before it finds their range (and raises the flag for NaNs)
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
                      (uint32_t*)nullptr, hdr);
+  const unsigned key_bits = cellfe_key_bits(n_rows, kNnCellFrames);
   hipLaunchKernelGGL(cellfe_key_kernel, grid_n, blk, 0, stream, d_coords, n_cols, d_fe,
-                     (const uint32_t*)hdr, kNnCellFrames, n_rows, keys_in, vals_in);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream))
+                     (const uint32_t*)hdr, kNnCellFrames, n_rows, keys_in, vals_in, key_bits);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits))
     return;
   hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
                      L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
@@ -777,7 +865,8 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
     hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, kCellKeyBits))
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream,
+                       cell_key_bits(n_q, kCellFramesHere)))
       return;
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,

@@ -29,7 +29,7 @@ size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols);
 // builds the operand images of d_coords in the workspace; returns 0 on success
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
                  bool natural_image,
-                 hipStream_t stream);
+                 hipStream_t stream, bool stats_valid = false);
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
                      void* d_ws, hipStream_t stream);
@@ -78,6 +78,14 @@ void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
+
+// Optional timing of the MAIN sweep kernels (bench.py's roofline entry wants the kernel's own duration, not the call's:
+// the orderings and operand images are "prep").  When enabled the launchers bracket every main-kernel launch with HIP
+// events on the launch stream: the first launch of a kind (0 population, 1 neighbour) since the last read sets the
+// start, every launch moves the end.  sweep_timer_read synchronises on the end event.
+void sweep_timer_enable(bool on);
+void sweep_timer_mark(int kind, bool begin, hipStream_t s);
+int sweep_timer_read(int kind, float* ms);   // 0 ok, -1 nothing recorded / error
 
 // dc_sort.hip: stable key/value radix sort (rocPRIM Onesweep) on the low key_bits bits of the keys
 size_t sort_temp_bytes(size_t n);

@@ -270,6 +270,7 @@ struct Scale {
   int g, a, rounded;
 };
 constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
+constexpr uint32_t kHdrCookie = 28;     // whose statistics the header holds (array, shape); 0 after a reset
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
                                               //  4 S M below 2^19.6; only a radius beyond the clamps of
@@ -2334,8 +2335,8 @@ void pop_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const P
   constexpr int kTQ = tq_full_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
   // one radius per sweep (dc_mfma.hip loops over the radii of a call)
-  hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
-                     P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops);
+  { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_mfma_kernel<S, 1, kTQ>), grid, block, 0, s, coords, n_rows, n_cols, P.img,
+                     P.img_b, P.norms, P.hdr, T, i_from, i_to, rad2, n_rad, pops); sweep_timer_mark(0, false, s); }
 }
 
 // tile boxes regrouped by reference share: share c holds the tiles c, c + n, c + 2n, ... at
@@ -2420,10 +2421,10 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
     if (n_chunks > 1)
       hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s, A.merge64, n_rows);
     hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
-    hipLaunchKernelGGL((nn_shared_kernel<S, TQV>), dim3(groups, n_chunks), dim3(256), smem, s, coords, n_rows, n_cols, fe,
+    { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_shared_kernel<S, TQV>), dim3(groups, n_chunks), dim3(256), smem, s, coords, n_rows, n_cols, fe,
                        A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r, A.fe_c, A.coords_c,
                        A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg, A.full_range, A.cell2, hdr,
-                       chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2);
+                       chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2); sweep_timer_mark(1, false, s); }
     if (n_chunks > 1 && A.full_range)
       hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                          (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)(4 * TQV), A.q_seg, nn_idx,
@@ -2445,11 +2446,11 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
     hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s,
                        A.merge64, n_rows);
   hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
-  hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + wpb - 1) / wpb, n_chunks), dim3(64 * wpb), smem, s,
+  { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + wpb - 1) / wpb, n_chunks), dim3(64 * wpb), smem, s,
                      coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
-                     hd_d2);
+                     hd_d2); sweep_timer_mark(1, false, s); }
   if (n_chunks > 1 && A.full_range)
     hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                        (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)TQV, A.q_seg,
@@ -2538,18 +2539,18 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
       // vals_in of the workspace: the population sweeps leave them alone once the orders are built)
       uint32_t* pops_pos = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(P.norms_s));
       (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T * NRV, s);
-      hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV, true>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols,
+      { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV, true>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols,
                          P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                         chain_counter, rad2, n_rad, pops, own ? 0 : 1, pops_pos);
+                         chain_counter, rad2, n_rad, pops, own ? 0 : 1, pops_pos); sweep_timer_mark(0, false, s); }
       for (int rr = 0; rr < n_rad; ++rr)
         hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                            (const uint32_t*)(pops_pos + (size_t)rr * 32 * T), P.perm_p, n_rows, P.hdr,
                            pops + (size_t)rr * n_rows);
       return;
     }
-    hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols, P.img_p,
+    { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols, P.img_p,
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                       chain_counter, rad2, n_rad, pops, own ? 0 : 1);
+                       chain_counter, rad2, n_rad, pops, own ? 0 : 1); sweep_timer_mark(0, false, s); }
     return;
   }
   if constexpr (NRV == 1 && TQV <= 6) {
@@ -2558,10 +2559,10 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
       // it), then to the frames
       uint32_t* pops_pos = const_cast<uint32_t*>(P.pq);
       (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T, s);
-      hipLaunchKernelGGL((pop_pruned_kernel<S, 1, TQV, kSinkNone, true>), grid, block, smem, s, coords, n_rows,
+      { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, 1, TQV, kSinkNone, true>), grid, block, smem, s, coords, n_rows,
                          n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                          perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
-                         EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, pops_pos);
+                         EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, pops_pos); sweep_timer_mark(0, false, s); }
       hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, (const uint32_t*)pops_pos,
                          P.perm_p, n_rows, P.hdr, pops);
       return;
@@ -2569,18 +2570,18 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   }
   // radius-graph variants: all rows only (query positions = reference positions)
   if (sink && sink->best)
-    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkMinEdge>), grid, block, smem, s, coords,
+    { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkMinEdge>), grid, block, smem, s, coords,
                        n_rows, n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q,
-                       norms_q, perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
+                       norms_q, perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink); sweep_timer_mark(0, false, s); }
   else if (sink)
-    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkPairs>), grid, block, smem, s, coords, n_rows,
+    { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkPairs>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
-                       perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink);
+                       perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink); sweep_timer_mark(0, false, s); }
   else
-    hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkNone>), grid, block, smem, s, coords, n_rows,
+    { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkNone>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                        perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
-                       EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr});
+                       EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}); sweep_timer_mark(0, false, s); }
 }
 
 template <int S, int NRV>
@@ -2618,9 +2619,9 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                  float* hd_d2, hipStream_t s) {
   constexpr int kTQnn = tq_full_for<S>;
   const dim3 grid(grid_for(i_from, i_to, kTQnn)), block(256);
-  hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img_b,
+  { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_mfma_kernel<S, kTQnn>), grid, block, 0, s, coords, n_rows, n_cols, P.img_b,
                      P.norms, P.img_s, P.norms_s, P.perm, P.invpos, P.pq, P.hdr, T, i_from, i_to, nn_idx,
-                     nn_d2, hd_idx, hd_d2);
+                     nn_d2, hd_idx, hd_d2); sweep_timer_mark(1, false, s); }
 }
 
 }  // namespace

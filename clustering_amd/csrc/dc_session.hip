@@ -13,7 +13,10 @@
 // RCCL is bound at run time (dlopen of librccl.so.1 on the first session that spans more than one
 // device): a single-GPU process -- the common case of the command line, and every python process that
 // already carries torch's copy of the library -- neither pays for loading the 570 MB library nor ends
-// up with two copies of it.  A session that needs it and cannot load it FAILS (no host-merge fallback).
+// up with two copies of it.  A session that needs it and cannot load it, or whose communicator cannot be
+// built, falls back to the reference's own merge: every partial is copied to the host, summed / minimised
+// there and written back to every device (density_clustering_cuda.cu:171-180, :311-326) -- slower, same
+// results.  DC_SESSION_MERGE=host / rccl forces one or the other (rccl: failing to get it is an error).
 #include "../../include/dc_density.h"
 #include "dc_common.hpp"
 #include "dc_mfma.hpp"
@@ -102,20 +105,41 @@ struct DevState {
   uint32_t* d_comp = nullptr;   // forest: component ids, ranks
   uint32_t* d_rank = nullptr;
   ncclComm_t comm = nullptr;
+  bool stats_ready = false;     // a sweep has left the statistics of the resident coordinates in the workspace header
+  int variant() const { return DC_VARIANT_AUTO | (stats_ready ? DC_FLAG_STATS_VALID : 0); }
 };
 
 }  // namespace
 
+enum MergeMode { kMergeNone = 0, kMergeRccl = 1, kMergeHost = 2 };
+
 struct dc_hip_session {
   size_t n_rows = 0, n_cols = 0;
   std::vector<DevState> dev;
-  bool use_rccl = false;
+  bool use_rccl = false;         // partials merge with RCCL collectives
+  bool host_merge = false;       // ... or through the host (RCCL unavailable, or forced)
   bool have_fe = false;
   size_t n_radii = 0;            // of the populations currently resident
   uint64_t tiles_pop = 0, tiles_nn = 0;
+  std::string merge_note;        // why RCCL is not used although there are several devices
 };
 
 namespace {
+
+// every entry point leaves the calling thread's current device as it found it (a torch host, or a caller
+// of the _dev entry points, relies on it)
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) {
+      (void)hipGetLastError();
+      prev = -1;
+    }
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 
 // fn(g) on one host thread per device (density_clustering_cuda.cu:152-157, :295-299 do the same with
 // OpenMP); the first failure wins and its message becomes the caller's last error
@@ -151,21 +175,56 @@ int on_every_device(dc_hip_session* s, const std::function<int(int)>& fn) {
       return failf(DC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
-// in-place all-reduce of one buffer per device, all devices in one group call from this thread
-int all_reduce(dc_hip_session* s, const std::function<void*(DevState&)>& buf, size_t count,
-               ncclDataType_t type, ncclRedOp_t op, const char* what) {
-  if (!s->use_rccl) return DC_OK;
-  Rccl* r = rccl();
-  ncclResult_t e = r->GroupStart();
-  for (auto& d : s->dev) {
-    if (e != ncclSuccess) break;
-    void* p = buf(d);
-    e = r->AllReduce(p, p, count, type, op, d.comm, d.stream);
+// Merge of one buffer per device, in place, every device ends up with the merged array: uint32 sum (partial
+// populations, density_clustering_cuda.cu:171-180) or uint64 min (packed neighbour words, :311-326; Boruvka
+// candidates).  RCCL: one grouped all-reduce from this thread.  Host merge: every device's partial to the
+// host (one thread per device), reduced there, the result back to every device.
+int merge_partials(dc_hip_session* s, const std::function<void*(DevState&)>& buf, size_t count,
+                   ncclDataType_t type, ncclRedOp_t op, const char* what) {
+  const size_t G = s->dev.size();
+  if (s->use_rccl) {
+    Rccl* r = rccl();
+    ncclResult_t e = r->GroupStart();
+    for (auto& d : s->dev) {
+      if (e != ncclSuccess) break;
+      void* p = buf(d);
+      e = r->AllReduce(p, p, count, type, op, d.comm, d.stream);
+    }
+    const ncclResult_t e2 = r->GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return failf(DC_ERR_HIP, "RCCL all-reduce (%s): %s", what, r->GetErrorString(e));
+    return DC_OK;
   }
-  const ncclResult_t e2 = r->GroupEnd();
-  if (e == ncclSuccess) e = e2;
-  if (e != ncclSuccess) return failf(DC_ERR_HIP, "RCCL all-reduce (%s): %s", what, r->GetErrorString(e));
-  return DC_OK;
+  if (!s->host_merge || G < 2) return DC_OK;
+  const size_t esz = (type == ncclUint64) ? 8 : 4;
+  std::vector<std::vector<unsigned char>> part(G);
+  int rc = on_every_device(s, [&](int g) -> int {
+    DevState& d = s->dev[g];
+    part[g].resize(count * esz);
+    SESSION_HIP_TRY(hipMemcpyAsync(part[g].data(), buf(d), count * esz, hipMemcpyDeviceToHost, d.stream));
+    SESSION_HIP_TRY(hipStreamSynchronize(d.stream));
+    return DC_OK;
+  });
+  if (rc != DC_OK) return rc;
+  if (type == ncclUint64) {
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(part[0].data());
+    for (size_t g = 1; g < G; ++g) {
+      const unsigned long long* p = reinterpret_cast<const unsigned long long*>(part[g].data());
+      for (size_t i = 0; i < count; ++i) acc[i] = (op == ncclMin) ? std::min(acc[i], p[i]) : acc[i] + p[i];
+    }
+  } else {
+    uint32_t* acc = reinterpret_cast<uint32_t*>(part[0].data());
+    for (size_t g = 1; g < G; ++g) {
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(part[g].data());
+      for (size_t i = 0; i < count; ++i) acc[i] = (op == ncclMin) ? std::min(acc[i], p[i]) : acc[i] + p[i];
+    }
+  }
+  return on_every_device(s, [&](int g) -> int {
+    DevState& d = s->dev[g];
+    SESSION_HIP_TRY(hipMemcpyAsync(buf(d), part[0].data(), count * esz, hipMemcpyHostToDevice, d.stream));
+    SESSION_HIP_TRY(hipStreamSynchronize(d.stream));
+    return DC_OK;
+  });
 }
 
 int sync_all(dc_hip_session* s, const char* what) {
@@ -197,6 +256,7 @@ extern "C" {
 
 void dc_hip_session_close(dc_hip_session* s) {
   if (!s) return;
+  DeviceGuard guard;
   for (auto& d : s->dev) {
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
@@ -226,6 +286,8 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
     devices = nullptr;
   }
   if (n_devices > avail) return failf(DC_ERR_INVALID_ARGUMENT, "%d devices requested, %d present", n_devices, avail);
+  DeviceGuard guard;
+  bool duplicates = false;
   dc_hip_session* s = new dc_hip_session();
   s->n_rows = n_rows;
   s->n_cols = n_cols;
@@ -237,8 +299,16 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
       delete s;
       return failf(DC_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", bad, avail);
     }
+    // DC_SESSION_ALLOW_DUPLICATE_DEVICES=1 (tests): one physical device may carry several of the session's
+    // "devices" -- own stream, buffers, host thread and segment each -- so that the multi-device flow and
+    // the host merge run on a one-GPU box (RCCL refuses duplicate devices: such a session merges on the host)
     for (int k = 0; k < g; ++k)
       if (s->dev[k].device == s->dev[g].device) {
+        const char* dup = getenv("DC_SESSION_ALLOW_DUPLICATE_DEVICES");
+        if (dup && dup[0] == '1') {
+          duplicates = true;
+          continue;
+        }
         delete s;
         return failf(DC_ERR_INVALID_ARGUMENT, "device %d listed twice", devices[g]);
       }
@@ -261,25 +331,34 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
   });
   if (pinned) (void)hipHostUnregister((void*)coords);
   // DC_SESSION_FORCE_RCCL=1: build the communicator and run the collectives on a single device as well
-  // (a one-rank all-reduce is a copy onto itself): exercises the RCCL call path on a one-GPU box
+  // (a one-rank all-reduce is a copy onto itself): exercises the RCCL call path on a one-GPU box.
+  // DC_SESSION_MERGE=host: merge through the host even where RCCL is available; =rccl: RCCL or fail.
   const char* force = getenv("DC_SESSION_FORCE_RCCL");
-  if (rc == DC_OK && (n_devices > 1 || (force && force[0] == '1'))) {
+  const char* mode = getenv("DC_SESSION_MERGE");
+  const bool want_host = (mode && strcmp(mode, "host") == 0) || duplicates;
+  const bool must_rccl = mode && strcmp(mode, "rccl") == 0;
+  if (rc == DC_OK && !want_host && (n_devices > 1 || (force && force[0] == '1'))) {
     Rccl* r = rccl();
+    std::string why;
     if (!r->error.empty()) {
-      rc = failf(DC_ERR_HIP, "%d devices need RCCL: %s", n_devices, r->error.c_str());
+      why = r->error;
     } else {
       std::vector<ncclComm_t> comms(n_devices);
       std::vector<int> devs(n_devices);
       for (int g = 0; g < n_devices; ++g) devs[g] = s->dev[g].device;
       const ncclResult_t e = r->CommInitAll(comms.data(), n_devices, devs.data());
       if (e != ncclSuccess) {
-        rc = failf(DC_ERR_HIP, "ncclCommInitAll over %d devices: %s", n_devices, r->GetErrorString(e));
+        why = std::string("ncclCommInitAll: ") + r->GetErrorString(e);
       } else {
         for (int g = 0; g < n_devices; ++g) s->dev[g].comm = comms[g];
         s->use_rccl = true;
       }
     }
+    if (!s->use_rccl && must_rccl)
+      rc = failf(DC_ERR_HIP, "%d devices, DC_SESSION_MERGE=rccl: %s", n_devices, why.c_str());
+    s->merge_note = why;   // (empty: RCCL is up; else why the session merges on the host)
   }
+  if (rc == DC_OK && n_devices > 1 && !s->use_rccl) s->host_merge = true;
   if (rc != DC_OK) {
     const std::string keep = dc_hip_last_error();
     dc_hip_session_close(s);
@@ -291,6 +370,10 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
 
 int dc_hip_session_devices(const dc_hip_session* s) { return s ? (int)s->dev.size() : 0; }
 int dc_hip_session_uses_rccl(const dc_hip_session* s) { return (s && s->use_rccl) ? 1 : 0; }
+int dc_hip_session_merge_mode(const dc_hip_session* s) {
+  if (!s) return kMergeNone;
+  return s->use_rccl ? kMergeRccl : (s->host_merge ? kMergeHost : kMergeNone);
+}
 
 int dc_hip_session_counters(const dc_hip_session* s, uint64_t* pop_tiles, uint64_t* nn_tiles) {
   if (!s) return failf(DC_ERR_INVALID_ARGUMENT, "null session");
@@ -300,6 +383,7 @@ int dc_hip_session_counters(const dc_hip_session* s, uint64_t* pop_tiles, uint64
 }
 
 int dc_hip_session_populations(dc_hip_session* s, const float* radii, size_t n_radii, uint32_t* pops) {
+  DeviceGuard guard;
   if (!s || (!radii && n_radii)) return failf(DC_ERR_INVALID_ARGUMENT, "null argument");
   if (n_radii == 0 || s->n_rows == 0) return DC_OK;
   const size_t n = s->n_rows, G = s->dev.size();
@@ -312,17 +396,20 @@ int dc_hip_session_populations(dc_hip_session* s, const float* radii, size_t n_r
       SESSION_HIP_TRY(hipMalloc((void**)&d.d_pops, sizeof(uint32_t) * n_radii * n));
       d.pops_cap = n_radii;
     }
-    if (G == 1)
-      return dc_hip_populations_dev(d.d_coords, n, s->n_cols, radii, n_radii, 0, n, d.d_pops, d.d_ws,
-                                    d.ws_bytes, DC_VARIANT_AUTO, d.stream);
-    return dc_hip_populations_segment_dev(d.d_coords, n, s->n_cols, radii, n_radii, (size_t)g, G, d.d_pops,
-                                          d.d_ws, d.ws_bytes, DC_VARIANT_AUTO, d.stream);
+    // (the coordinates of a session never change: after the first sweep the header statistics stay valid)
+    const int r = (G == 1) ? dc_hip_populations_dev(d.d_coords, n, s->n_cols, radii, n_radii, 0, n, d.d_pops, d.d_ws,
+                                                    d.ws_bytes, d.variant(), d.stream)
+                           : dc_hip_populations_segment_dev(d.d_coords, n, s->n_cols, radii, n_radii, (size_t)g, G,
+                                                            d.d_pops, d.d_ws, d.ws_bytes, d.variant(), d.stream);
+    d.stats_ready = (r == DC_OK);
+    return r;
   });
-  if (rc != DC_OK) return rc;
-  s->n_radii = n_radii;
+  // (whatever was resident is gone; the new populations count as resident only once merged and synchronised)
+  s->n_radii = 0;
   s->have_fe = false;
-  // merge = sum of the zero-padded partials (density_clustering_cuda.cu:171-180), on the devices
-  if ((rc = all_reduce(s, [](DevState& d) { return (void*)d.d_pops; }, n_radii * n, ncclUint32, ncclSum,
+  if (rc != DC_OK) return rc;
+  // merge = sum of the partials (density_clustering_cuda.cu:171-180), on the devices
+  if ((rc = merge_partials(s, [](DevState& d) { return (void*)d.d_pops; }, n_radii * n, ncclUint32, ncclSum,
                        "populations")) != DC_OK)
     return rc;
   if (pops) {
@@ -331,10 +418,12 @@ int dc_hip_session_populations(dc_hip_session* s, const float* radii, size_t n_r
                                    s->dev[0].stream));
   }
   if ((rc = sync_all(s, "population sweep")) != DC_OK) return rc;
+  s->n_radii = n_radii;
   return read_counters(s, true);
 }
 
 int dc_hip_session_free_energies(dc_hip_session* s, size_t radius_index, float* fe, uint32_t* max_pop) {
+  DeviceGuard guard;
   if (!s) return failf(DC_ERR_INVALID_ARGUMENT, "null session");
   if (s->n_rows == 0) return DC_OK;
   if (radius_index >= s->n_radii)
@@ -347,8 +436,9 @@ int dc_hip_session_free_energies(dc_hip_session* s, size_t radius_index, float* 
     if (!d.d_fe) SESSION_HIP_TRY(hipMalloc((void**)&d.d_fe, sizeof(float) * n));
     return dc_hip_free_energies_dev(d.d_pops + radius_index * n, n, d.d_fe, &mx[g], d.stream);
   });
+  s->have_fe = false;
   if (rc != DC_OK) return rc;
-  s->have_fe = true;
+  s->have_fe = true;   // (dc_hip_free_energies_dev synchronises its stream: the values are there)
   if (max_pop) *max_pop = mx[0];
   if (fe) {
     SESSION_HIP_TRY(hipSetDevice(s->dev[0].device));
@@ -359,6 +449,7 @@ int dc_hip_session_free_energies(dc_hip_session* s, size_t radius_index, float* 
 }
 
 int dc_hip_session_set_free_energies(dc_hip_session* s, const float* fe) {
+  DeviceGuard guard;
   if (!s || !fe) return failf(DC_ERR_INVALID_ARGUMENT, "null argument");
   if (s->n_rows == 0) return DC_OK;
   const size_t n = s->n_rows;
@@ -369,12 +460,13 @@ int dc_hip_session_set_free_energies(dc_hip_session* s, const float* fe) {
     SESSION_HIP_TRY(hipStreamSynchronize(d.stream));
     return DC_OK;
   });
-  if (rc == DC_OK) s->have_fe = true;
+  s->have_fe = (rc == DC_OK);
   return rc;
 }
 
 int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx,
                                      float* hd_d2, double* sigma2) {
+  DeviceGuard guard;
   if (!s) return failf(DC_ERR_INVALID_ARGUMENT, "null session");
   const size_t n = s->n_rows, G = s->dev.size();
   if (n == 0) {
@@ -387,20 +479,24 @@ int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float*
     if (!d.d_idx) SESSION_HIP_TRY(hipMalloc((void**)&d.d_idx, sizeof(uint32_t) * 2 * n));
     if (!d.d_d2) SESSION_HIP_TRY(hipMalloc((void**)&d.d_d2, sizeof(float) * 2 * n));
     int r;
-    if (G == 1 && !s->use_rccl)
-      return dc_hip_nearest_neighbors_dev(d.d_coords, n, s->n_cols, d.d_fe, 0, n, d.d_idx, d.d_d2, d.d_idx + n,
-                                          d.d_d2 + n, d.d_ws, d.ws_bytes, DC_VARIANT_AUTO, d.stream);
+    if (G == 1 && !s->use_rccl) {
+      r = dc_hip_nearest_neighbors_dev(d.d_coords, n, s->n_cols, d.d_fe, 0, n, d.d_idx, d.d_d2, d.d_idx + n,
+                                       d.d_d2 + n, d.d_ws, d.ws_bytes, d.variant(), d.stream);
+      d.stats_ready = (r == DC_OK);
+      return r;
+    }
     if (!d.d_words) SESSION_HIP_TRY(hipMalloc((void**)&d.d_words, sizeof(unsigned long long) * 2 * n));
     r = dc_hip_nearest_neighbors_segment_dev(d.d_coords, n, s->n_cols, d.d_fe, (size_t)g, G, d.d_idx, d.d_d2,
-                                             d.d_idx + n, d.d_d2 + n, d.d_ws, d.ws_bytes, DC_VARIANT_AUTO, d.stream);
+                                             d.d_idx + n, d.d_d2 + n, d.d_ws, d.ws_bytes, d.variant(), d.stream);
+    d.stats_ready = (r == DC_OK);
     if (r != DC_OK) return r;
     return dc_hip_neighbors_pack_dev(d.d_idx, d.d_d2, d.d_idx + n, d.d_d2 + n, n, d.d_words, d.stream);
   });
   if (rc != DC_OK) return rc;
-  if (s->use_rccl) {
+  if (s->use_rccl || s->host_merge) {
     // every row has one owner; all other devices hold the larger "none" word (density_clustering_cuda.cu:311-326
     // copies row blocks on the host)
-    if ((rc = all_reduce(s, [](DevState& d) { return (void*)d.d_words; }, 2 * n, ncclUint64, ncclMin,
+    if ((rc = merge_partials(s, [](DevState& d) { return (void*)d.d_words; }, 2 * n, ncclUint64, ncclMin,
                          "neighbours")) != DC_OK)
       return rc;
     rc = on_every_device(s, [&](int g) -> int {
@@ -432,6 +528,7 @@ int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float*
 
 int dc_hip_session_radius_pairs(dc_hip_session* s, float r2, uint32_t* pairs, size_t capacity,
                                 unsigned long long* count) {
+  DeviceGuard guard;
   if (!s || !count) return failf(DC_ERR_INVALID_ARGUMENT, "null argument");
   *count = 0;
   const size_t n = s->n_rows;
@@ -471,6 +568,7 @@ int dc_hip_session_radius_pairs(dc_hip_session* s, float r2, uint32_t* pairs, si
 
 int dc_hip_session_radius_forest(dc_hip_session* s, float r2, const uint32_t* rank, uint32_t* edges,
                                  size_t* n_edges, uint32_t* n_rounds) {
+  DeviceGuard guard;
   if (!s || !n_edges) return failf(DC_ERR_INVALID_ARGUMENT, "null argument");
   *n_edges = 0;
   if (n_rounds) *n_rounds = 0;
@@ -526,7 +624,7 @@ int dc_hip_session_radius_forest(dc_hip_session* s, float r2, const uint32_t* ra
                                                 G > 1 ? G : 0, d.d_words, d.d_pops, d.d_ws, d.ws_bytes, d.stream);
     });
     if (rc != DC_OK) return rc;
-    if ((rc = all_reduce(s, [](DevState& d) { return (void*)d.d_words; }, n, ncclUint64, ncclMin,
+    if ((rc = merge_partials(s, [](DevState& d) { return (void*)d.d_words; }, n, ncclUint64, ncclMin,
                          "lightest outgoing pairs")) != DC_OK)
       return rc;
     DevState& d0 = s->dev[0];
@@ -556,7 +654,9 @@ int dc_hip_session_radius_forest(dc_hip_session* s, float r2, const uint32_t* ra
     for (size_t i = 0; i < n; ++i) comp[i] = find((uint32_t)i);
   }
   *n_edges = found;
-  if (n_rounds) *n_rounds = rounds + 1;
+  if (n_rounds) *n_rounds = rounds + (rounds < 64 ? 1 : 0);
+  if (rounds >= 64)   // (every round at least halves the joinable components: 64 rounds cannot be needed)
+    return failf(DC_ERR_HIP, "radius forest: components still merging after %u rounds (incomplete forest)", rounds);
   return DC_OK;
 }
 

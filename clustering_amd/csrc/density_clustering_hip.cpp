@@ -35,8 +35,9 @@ void must(int status, const char* what) {
 // again inside every call (density_clustering_cuda.cu:65-81, 201-225).  Here the first call opens a
 // session on all GPUs (dc_hip_session_open) and the later ones find the coordinates -- and whatever the
 // previous phase left in HBM -- still resident.  The session is keyed on the pointer, the shape and a
-// sampled fingerprint of the data; HIP::release_resident() drops it (a caller that rewrites the same
-// buffer in place between calls must do that; the reference's caller never does).
+// fingerprint of the WHOLE buffer, so a caller that rewrites the buffer in place gets a fresh upload;
+// HIP::release_resident() drops the session and frees the device memory (screening does that itself once
+// a scan is over -- see release_resident's note).
 struct Resident {
   dc_hip_session* session = nullptr;
   const float* coords = nullptr;
@@ -45,17 +46,39 @@ struct Resident {
 };
 Resident* g_resident = nullptr;   // (heap object, never destroyed: no HIP calls during static destruction)
 
-std::uint64_t sampled_fingerprint(const float* coords, std::size_t n) {
-  std::uint64_t h = 1469598103934665603ull ^ n;
+// fingerprint of the WHOLE buffer (every word enters; four interleaved multiply-xor lanes, one pass at memory
+// bandwidth: ~10 ms for the 40 MB of C3, against the sweeps' 30 ms and the upload's 5): an in-place change of
+// any element, or another trajectory at the same address, is seen and the stale device copy is dropped
+std::uint64_t full_fingerprint(const float* coords, std::size_t n) {
   const std::uint32_t* w = reinterpret_cast<const std::uint32_t*>(coords);
-  const std::size_t step = n > 65536 ? n / 65536 : 1;
-  for (std::size_t k = 0; k < n; k += step) h = (h ^ w[k]) * 1099511628211ull;
-  if (n) h = (h ^ w[n - 1]) * 1099511628211ull;
-  return h;
+  std::uint64_t h[4] = {1469598103934665603ull ^ n, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
+  std::size_t k = 0;
+  for (; k + 4 <= n; k += 4)
+    for (int l = 0; l < 4; ++l) {
+      h[l] = (h[l] ^ w[k + l]) * 0x100000001B3ull;
+      h[l] ^= h[l] >> 29;
+    }
+  for (; k < n; ++k) h[k & 3] = (h[k & 3] ^ w[k]) * 0x100000001B3ull;
+  std::uint64_t out = h[0];
+  for (int l = 1; l < 4; ++l) out = (out ^ (h[l] + 0x9E3779B97F4A7C15ull + (out << 6) + (out >> 2))) * 0x100000001B3ull;
+  return out;
+}
+
+void check_abi_once() {
+  static const bool ok = [] {
+    if (dc_hip_abi_version() != DC_HIP_ABI_VERSION) {
+      std::cerr << "HIP error: libdcdensity.so has ABI version " << dc_hip_abi_version() << ", this host was built "
+                << "against " << DC_HIP_ABI_VERSION << std::endl;
+      exit(EXIT_FAILURE);
+    }
+    return true;
+  }();
+  (void)ok;
 }
 
 dc_hip_session* resident_session(const float* coords, std::size_t n_rows, std::size_t n_cols) {
-  const std::uint64_t fp = sampled_fingerprint(coords, n_rows * n_cols);
+  check_abi_once();
+  const std::uint64_t fp = full_fingerprint(coords, n_rows * n_cols);
   if (!g_resident) g_resident = new Resident();
   Resident& r = *g_resident;
   if (r.session && r.coords == coords && r.n_rows == n_rows && r.n_cols == n_cols && r.fingerprint == fp)
@@ -76,6 +99,7 @@ void check_error(std::string msg) {
 }
 
 int get_num_gpus() {
+  check_abi_once();
   int n_gpus = dc_hip_device_count();
   if (n_gpus < 0) fail_now("trying to get number of available GPUs");
   if (n_gpus == 0) {
@@ -237,6 +261,65 @@ std::vector<std::size_t> screening(const std::vector<float>& free_energy, const 
   cache.last_result = result;
   cache.last_threshold = free_energy_threshold;
   return result;
+}
+
+std::vector<std::size_t> sanitize_state_names(std::vector<std::size_t> clustering) {
+  // Declared in density_clustering_cuda.hpp:44-45 and defined nowhere in the reference.  What the name and
+  // the screening code around it (normalized_cluster_names, density_clustering.cpp:437-456) suggest: states
+  // renumbered 1..K in ascending order of their old names, 0 (= no state) kept.
+  std::vector<std::size_t> names(clustering);
+  std::sort(names.begin(), names.end());
+  names.erase(std::unique(names.begin(), names.end()), names.end());
+  std::size_t shift = (!names.empty() && names[0] == 0) ? 0 : 1;
+  for (std::size_t& c : clustering)
+    c = (std::size_t)(std::lower_bound(names.begin(), names.end(), c) - names.begin()) + shift;
+  return clustering;
+}
+
+std::set<std::size_t> high_density_neighborhood(const float* coords, const std::size_t n_cols,
+                                                const std::vector<FreeEnergy>& sorted_fe,
+                                                const std::size_t i_frame, const std::size_t limit,
+                                                const float max_dist) {
+  // CPU semantics: density_clustering.cpp:292-332 -- the positions j < limit (in order of free energy) of
+  // the frames whose squared distance to frame sorted_fe[i_frame] is < max_dist, plus i_frame itself.  The
+  // partner lists of ALL frames come from one GPU sweep (radius graph), cached per (coords, max_dist).
+  namespace H = Clustering::Density::HIP;
+  const std::size_t n_rows = sorted_fe.size();
+  struct Cache {
+    const float* coords = nullptr;
+    std::size_t n_rows = 0, n_cols = 0;
+    float max_dist = 0.0f;
+    std::uint64_t order_fp = 0;
+    H::RadiusGraph graph;
+    std::vector<std::uint32_t> pos_of;   // frame -> position in sorted_fe
+  };
+  static Cache cache;
+  std::uint64_t order_fp = 1469598103934665603ull;
+  for (const auto& e : sorted_fe) order_fp = (order_fp ^ e.first) * 1099511628211ull;
+  if (cache.coords != coords || cache.n_rows != n_rows || cache.n_cols != n_cols || cache.max_dist != max_dist ||
+      cache.order_fp != order_fp) {
+    cache = Cache();
+    std::string err;
+    if (!H::build_radius_graph(resident_session(coords, n_rows, n_cols), n_rows, max_dist, &cache.graph, &err)) {
+      std::cerr << "error in high_density_neighborhood (radius graph)\n" << err << std::endl;
+      exit(EXIT_FAILURE);
+    }
+    cache.coords = coords;
+    cache.n_rows = n_rows;
+    cache.n_cols = n_cols;
+    cache.max_dist = max_dist;
+    cache.order_fp = order_fp;
+    cache.pos_of.resize(n_rows);
+    for (std::size_t p = 0; p < n_rows; ++p) cache.pos_of[sorted_fe[p].first] = (std::uint32_t)p;
+  }
+  std::set<std::size_t> nh;
+  const std::size_t frame = sorted_fe[i_frame].first;
+  for (std::uint64_t k = cache.graph.offset[frame]; k < cache.graph.offset[frame + 1]; ++k) {
+    const std::size_t j = cache.pos_of[cache.graph.neighbor[k]];
+    if (j < limit) nh.insert(j);
+  }
+  nh.insert(i_frame);
+  return nh;
 }
 
 }  // namespace CUDA

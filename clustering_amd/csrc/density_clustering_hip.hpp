@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <utility>
@@ -25,6 +26,8 @@ using Neighborhood = std::map<std::size_t, Clustering::Tools::Neighbor>;
 namespace Density {
 //! radius -> populations                              (density_clustering_common.hpp:39)
 typedef std::map<float, std::vector<std::size_t>> Pops;
+//! (frame id, free energy)                            (density_clustering.hpp:54)   
+using FreeEnergy = std::pair<std::size_t, float>;
 
 namespace CUDA {   // the reference's namespace name is kept so that call sites compile unchanged
 
@@ -81,6 +84,18 @@ std::vector<std::size_t> screening(const std::vector<float>& free_energy, const 
                                    const std::size_t n_rows, const std::size_t n_cols,
                                    const std::vector<std::size_t> initial_clusters);
 
+//! declared in density_clustering_cuda.hpp:44-45, defined nowhere in the reference: states renumbered
+//! 1..K in ascending order of their old names, 0 kept (normalized_cluster_names' numbering rule)
+std::vector<std::size_t> sanitize_state_names(std::vector<std::size_t> clustering);
+
+//! declared in density_clustering_cuda.hpp:56-62, defined nowhere in the reference's CUDA sources; CPU
+//! semantics density_clustering.cpp:292-332.  All ids are positions in sorted_fe.  Served from the GPU
+//! radius graph of the resident trajectory (n_rows = sorted_fe.size()), cached per (coords, max_dist).
+std::set<std::size_t> high_density_neighborhood(const float* coords, const std::size_t n_cols,
+                                                const std::vector<FreeEnergy>& sorted_fe,
+                                                const std::size_t i_frame, const std::size_t limit,
+                                                const float max_dist);
+
 }  // namespace CUDA
 
 // ---- flat-array helpers for hosts that do not want the node-based containers -------------------
@@ -93,9 +108,9 @@ struct DensityResult {
   double sigma2 = 0.0;                          // mean nn d2 (compute_sigma2, density_clustering.cpp:334-343)
 };
 //! The CUDA:: entry points above keep the trajectory they were last called with resident on the GPUs
-//! (one upload for populations, neighbours and screening; keyed on pointer, shape and a sampled
-//! fingerprint).  This drops it: frees the device memory, and is REQUIRED before re-using the same host
-//! buffer for different coordinates of the same shape.
+//! (one upload for populations, neighbours and screening; keyed on pointer, shape and a fingerprint of
+//! the whole buffer, so re-using a host buffer for other coordinates is detected).  This drops it and frees
+//! the device memory and the RCCL communicators of all GPUs; call it when the density phase is over.
 void release_resident();
 //! whole path (pop -> FE -> NN) with coordinates kept resident on the devices between the phases
 DensityResult density_all(const float* coords, std::size_t n_rows, std::size_t n_cols,

@@ -58,6 +58,12 @@ def _workspace(device):
     return _workspaces[key]
 
 
+def _variant(variant, stats_valid):
+    """the C ABI's `variant` argument: kernel family | DC_FLAG_STATS_VALID (the workspace header still holds the
+    statistics of an earlier sweep over the SAME coordinates: the second call of a populations -> neighbours pair)"""
+    return capi.VARIANTS[variant] | (capi.FLAG_STATS_VALID if stats_valid else 0)
+
+
 def _check_coords(coords):
     if not (isinstance(coords, torch.Tensor) and coords.is_cuda and coords.dtype == torch.float32
             and coords.dim() == 2 and coords.is_contiguous()):
@@ -65,7 +71,7 @@ def _check_coords(coords):
     return coords.shape[0], coords.shape[1]
 
 
-def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="auto", out=None):
+def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="auto", out=None, stats_valid=False):
     """Per-GPU partial of calculate_populations (density_clustering_cuda.cu:45-137).
 
     coords: float32 CUDA tensor [n_rows, n_cols]; radii: sequence of float.
@@ -83,12 +89,12 @@ def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="a
         ws, ws_bytes = _workspace(coords.device).get(n_rows, n_cols, rad.size)
         rc = capi.lib.dc_hip_populations_dev(
             _dev(coords), n_rows, n_cols, rad.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
-            i_from, i_to, _dev(out), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+            i_from, i_to, _dev(out), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
     capi.check(rc, "dc_hip_populations_dev")
     return out
 
 
-def calculate_populations_segment(coords, radii, segment, n_segments, variant="auto", out=None):
+def calculate_populations_segment(coords, radii, segment, n_segments, variant="auto", out=None, stats_valid=False):
     """Populations of one segment of a sharded run (dc_hip_populations_segment_dev): with the pruned
     sweep every n_segments-th query group of the spatial order, else the reference's row block.  PARTIAL counts
     that merge by summation over the segments (a one-radius pruned sweep is symmetric -- it credits both frames
@@ -102,12 +108,12 @@ def calculate_populations_segment(coords, radii, segment, n_segments, variant="a
         ws, ws_bytes = _workspace(coords.device).get(n_rows, n_cols, rad.size)
         rc = capi.lib.dc_hip_populations_segment_dev(
             _dev(coords), n_rows, n_cols, rad.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
-            segment, n_segments, _dev(out), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+            segment, n_segments, _dev(out), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
     capi.check(rc, "dc_hip_populations_segment_dev")
     return out
 
 
-def nearest_neighbors_segment(coords, fe, segment, n_segments, variant="auto"):
+def nearest_neighbors_segment(coords, fe, segment, n_segments, variant="auto", stats_valid=False):
     """Neighbours of one segment of a sharded run (dc_hip_nearest_neighbors_segment_dev); the rows of
     other segments hold (n_rows+1, FLT_MAX)."""
     n_rows, n_cols = _check_coords(coords)
@@ -121,7 +127,7 @@ def nearest_neighbors_segment(coords, fe, segment, n_segments, variant="auto"):
         ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
         rc = capi.lib.dc_hip_nearest_neighbors_segment_dev(
             _dev(coords), n_rows, n_cols, _dev(fe), segment, n_segments, _dev(nn_idx), _dev(nn_d2),
-            _dev(hd_idx), _dev(hd_d2), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+            _dev(hd_idx), _dev(hd_d2), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
     capi.check(rc, "dc_hip_nearest_neighbors_segment_dev")
     return nn_idx, nn_d2, hd_idx, hd_d2
 
@@ -138,7 +144,7 @@ def calculate_free_energies(pops):
     return fe
 
 
-def nearest_neighbors_partial(coords, fe, i_from=0, i_to=None, variant="auto"):
+def nearest_neighbors_partial(coords, fe, i_from=0, i_to=None, variant="auto", stats_valid=False):
     """Per-GPU partial of nearest_neighbors (density_clustering_cuda.cu:184-284).
 
     -> (nn_idx int32, nn_d2 float32, hd_idx int32, hd_d2 float32), each [n_rows]; rows outside the
@@ -155,7 +161,7 @@ def nearest_neighbors_partial(coords, fe, i_from=0, i_to=None, variant="auto"):
         ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
         rc = capi.lib.dc_hip_nearest_neighbors_dev(
             _dev(coords), n_rows, n_cols, _dev(fe), i_from, i_to, _dev(nn_idx), _dev(nn_d2),
-            _dev(hd_idx), _dev(hd_d2), ws, ws_bytes, capi.VARIANTS[variant], _stream_ptr())
+            _dev(hd_idx), _dev(hd_d2), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
     capi.check(rc, "dc_hip_nearest_neighbors_dev")
     return nn_idx, nn_d2, hd_idx, hd_d2
 
@@ -172,6 +178,19 @@ def evaluated_tiles(device):
         rc = capi.lib.dc_hip_workspace_counters_dev(_dev(ws.buf), C.byref(a), C.byref(b), _stream_ptr())
     capi.check(rc, "dc_hip_workspace_counters_dev")
     return int(a.value), int(b.value)
+
+
+def sweep_timing(enable):
+    """dc_hip_sweep_timing: bracket the main sweep kernels with HIP events (measurement aid of bench.py)"""
+    capi.check(capi.lib.dc_hip_sweep_timing(1 if enable else 0), "dc_hip_sweep_timing")
+
+
+def last_sweep_ms(kind, device):
+    """duration in ms of the main sweep kernel(s) of one kind ("pop" / "nn") since the last read (synchronises)"""
+    ms = C.c_float(0.0)
+    with torch.cuda.device(device):
+        capi.check(capi.lib.dc_hip_last_sweep_ms(0 if kind == "pop" else 1, C.byref(ms)), "dc_hip_last_sweep_ms")
+    return float(ms.value)
 
 
 def radius_pairs(coords, r2, capacity=None):
@@ -317,6 +336,11 @@ class Session:
     @property
     def uses_rccl(self):
         return bool(capi.lib.dc_hip_session_uses_rccl(self._h))
+
+    @property
+    def merge_mode(self):
+        """0: one device; 1: RCCL collectives on the devices; 2: through the host (the reference's own merge)"""
+        return int(capi.lib.dc_hip_session_merge_mode(self._h))
 
     def counters(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

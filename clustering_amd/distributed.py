@@ -43,14 +43,15 @@ class HipBackend:
     def free_energies(self, pops_row):
         return self._d.calculate_free_energies(pops_row)
 
-    def nearest_neighbors_partial(self, coords, fe, lo, hi):
-        return self._d.nearest_neighbors_partial(coords, fe, lo, hi, variant=self.variant)
+    def nearest_neighbors_partial(self, coords, fe, lo, hi, stats_valid=False):
+        return self._d.nearest_neighbors_partial(coords, fe, lo, hi, variant=self.variant, stats_valid=stats_valid)
 
     def populations_segment(self, coords, radii, segment, n_segments):
         return self._d.calculate_populations_segment(coords, radii, segment, n_segments, variant=self.variant)
 
-    def nearest_neighbors_segment(self, coords, fe, segment, n_segments):
-        return self._d.nearest_neighbors_segment(coords, fe, segment, n_segments, variant=self.variant)
+    def nearest_neighbors_segment(self, coords, fe, segment, n_segments, stats_valid=False):
+        return self._d.nearest_neighbors_segment(coords, fe, segment, n_segments, variant=self.variant,
+                                                 stats_valid=stats_valid)
 
     def pack_neighbors(self, nn_idx, nn_d2, hd_idx, hd_d2):
         return self._d.pack_neighbors(nn_idx, nn_d2, hd_idx, hd_d2)

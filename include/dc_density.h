@@ -69,11 +69,24 @@ typedef enum dc_variant {
                                  the radius (the GPU counterpart of the reference's box grid,
                                  density_clustering.cpp:41-89); identical results */
 } dc_variant;
+/* may be OR-ed into the `variant` argument of the _dev sweeps: the column means, max |x - mean|^2, the
+ * non-finite flag and the bounding box in this workspace's header were computed by an earlier sweep over
+ * the SAME d_coords (same contents) and are still valid -- the sweep skips its three statistics passes.
+ * The reference runs populations and then neighbours over one coordinate array
+ * (density_clustering.cpp:616-621, 659-663): the second call of such a pair may set it. */
+#define DC_FLAG_STATS_VALID 0x100
+#define DC_VARIANT_MASK 0xFF
 
 /* message of the last failing call on this thread ("" if none). */
 DC_API const char* dc_hip_last_error(void);
 
-/* library/ABI version, bumped on any signature change. */
+/* library/ABI version, bumped on any change of a signature or of a documented contract.  Hosts check it at
+ * load time (clustering_amd/capi.py, density_clustering_hip.cpp).
+ *   1  rounds 1-2 up to the sessions
+ *   2  sessions (dc_hip_session_*), segment entry points whose populations are PARTIAL counts of ALL rows
+ *      (symmetric one-radius sweeps credit both frames of a pair), dc_hip_session_merge_mode, host-merge
+ *      fallback, DC_FLAG_STATS_VALID */
+#define DC_HIP_ABI_VERSION 2
 DC_API int dc_hip_abi_version(void);
 
 /* replaces Clustering::Density::CUDA::get_num_gpus() (density_clustering_cuda.hpp:16-17,
@@ -95,6 +108,15 @@ DC_API size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radi
  * DC_VARIANT_MFMA do not count and report 0).  Synchronises the stream. */
 DC_API int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles,
                                          uint64_t* nn_tiles, void* stream);
+
+/* measurement aid (bench.py's roofline entry): with timing enabled the library brackets its MAIN sweep
+ * kernels (population_count / nearest_neighbor_search counterparts) with HIP events on the launch stream;
+ * dc_hip_last_sweep_ms returns the duration of the kernels of one kind (0 population, 1 neighbour) launched on
+ * the calling thread's current device since the previous read -- the sweep kernel alone, without the ordering /
+ * operand-image passes of the call.  Synchronises on the kernel's end.  Returns DC_ERR_INVALID_ARGUMENT if no
+ * sweep of that kind was recorded. */
+DC_API int dc_hip_sweep_timing(int enable);
+DC_API int dc_hip_last_sweep_ms(int kind, float* ms);
 
 /* replaces the kernel loop of calculate_populations_per_gpu (density_clustering_cuda.cu:45-137;
  * kernel population_count, density_clustering_cuda_kernels.cu:9-56): ONE launch sweeps all
@@ -275,12 +297,18 @@ typedef struct dc_hip_session dc_hip_session;
 
 /* devices: n_devices device ordinals, or NULL for 0..n_devices-1; n_devices <= 0: all devices.
  * coords: HOST, read during the call only.  RCCL (librccl.so.1) is loaded on first need, i.e. when a
- * session spans more than one device; failing to load it is an error (there is no host-merge path). */
+ * session spans more than one device; if it cannot be loaded or its communicator cannot be built the
+ * session merges its partials through the HOST instead, exactly like the reference
+ * (density_clustering_cuda.cu:171-180, :311-326): same results, PCIe instead of xGMI.
+ * Environment: DC_SESSION_MERGE=host forces the host merge, =rccl makes a missing RCCL an error.
+ * The calling thread's current device is restored by every session entry point. */
 DC_API int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const int* devices,
                                int n_devices, dc_hip_session** session);
 DC_API void dc_hip_session_close(dc_hip_session* session);
 DC_API int dc_hip_session_devices(const dc_hip_session* session);      /* number of devices */
 DC_API int dc_hip_session_uses_rccl(const dc_hip_session* session);    /* 1 if partials merge over RCCL */
+/* 0: one device, nothing to merge; 1: RCCL collectives on the devices; 2: through the host */
+DC_API int dc_hip_session_merge_mode(const dc_hip_session* session);
 /* 32x32 frame-pair tiles the last population call / neighbour call evaluated, summed over devices */
 DC_API int dc_hip_session_counters(const dc_hip_session* session, uint64_t* pop_tiles, uint64_t* nn_tiles);
 

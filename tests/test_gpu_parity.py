@@ -518,7 +518,11 @@ import numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from clustering_amd import density as dens
 from clustering_amd.synth import gaussian_blobs
+from oracle.oracle import Oracle
+oracle = Oracle()
 rng = np.random.default_rng(7)
+def equals_oracle(t, want_u64, what):
+    assert (t.cpu().numpy().astype(np.uint32).astype(np.uint64) == want_u64).all(), what
 for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 0.2), (700, 3, 0.1), (4097, 17, 0.35),
                 (33, 30, 0.5), (1, 26, 0.5)]:
     c = gaussian_blobs(n, d, seed=n + d)
@@ -527,6 +531,9 @@ for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 
     want = dens.calculate_populations_partial(ct, [r, 0.8 * r], variant="direct")
     got = dens.calculate_populations_partial(ct, [r, 0.8 * r], variant="pruned")
     assert bool((got == want).all()), (n, d, "all rows")
+    # ... and against the ORACLE itself (not only the direct kernels): every form of this child on every shape
+    want_o = oracle.populations(c, [r, 0.8 * r])
+    equals_oracle(got, want_o, (n, d, "all rows vs oracle"))
     lo, hi = n // 3, n // 3 + max(1, n // 2)
     assert bool((dens.calculate_populations_partial(ct, [r], lo, hi, variant="pruned")
                  == dens.calculate_populations_partial(ct, [r], lo, hi, variant="direct")).all()), (n, d, "row range")
@@ -534,11 +541,15 @@ for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 
     for g in range(3):
         acc += dens.calculate_populations_segment(ct, [r], g, 3)
     assert bool((acc == want[:1]).all()), (n, d, "segments")
+    equals_oracle(acc, want_o[:1], (n, d, "segments vs oracle"))
     # several radii in ONE sweep (wide rows only: 5..8 MFMAs per chain), 2..17 radii in any order
     for n_rad in (2, 4, 5, 8, 9, 17):
         radii = [float(x) for x in r * rng.uniform(0.5, 1.3, n_rad)]
         want_m = dens.calculate_populations_partial(ct, radii, variant="direct")
-        assert bool((dens.calculate_populations_partial(ct, radii, variant="pruned") == want_m).all()), (n, d, n_rad)
+        got_m = dens.calculate_populations_partial(ct, radii, variant="pruned")
+        assert bool((got_m == want_m).all()), (n, d, n_rad)
+        if n_rad in (4, 8, 17):
+            equals_oracle(got_m, oracle.populations(c, radii), (n, d, n_rad, "multi-radius sweep vs oracle"))
         acc = torch.zeros_like(want_m)
         for g in range(2):
             acc += dens.calculate_populations_segment(ct, radii, g, 2)
@@ -552,14 +563,17 @@ def test_shared_operand_population_sweep():
     """pop_shared_kernel (reference operands shared through LDS by the workgroup; taken by itself only for wide
     rows and large images, e.g. C5) forced on for small shapes of every kind -- all rows, a row range, the
     segments of a sharded run, duplicates, 1..8 MFMAs per chain, and (wide rows) up to eight radii per sweep --
-    against the direct kernels, bit for bit."""
+    against the direct kernels AND against the oracle (all rows, the segment sums and the 4 / 8 / 17-radius sweeps of
+    every shape), bit for bit; a second run with the symmetric form forced for several radii too
+    (DC_POP_SHARED_SYM=2)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", SHARED_CHILD, root], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, DC_POP_SHARED="1"))
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+    for extra in ({}, {"DC_POP_SHARED_SYM": "2"}):
+        r = subprocess.run([sys.executable, "-c", SHARED_CHILD, root], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, DC_POP_SHARED="1", **extra))
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stderr[-3000:])
 
 
 NN_SHARED_CHILD = r"""
@@ -568,6 +582,8 @@ import numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from clustering_amd import density as dens
 from clustering_amd.synth import gaussian_blobs
+from oracle.oracle import Oracle
+oracle = Oracle()
 rng = np.random.default_rng(9)
 for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 0.2), (700, 3, 0.1), (4097, 17, 0.35),
                 (33, 30, 0.5), (2, 26, 0.5), (70000, 30, 0.5)]:
@@ -580,6 +596,11 @@ for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 
     got = dens.nearest_neighbors_partial(ct, fe, variant="pruned")
     for a, b in zip(got, want):
         assert bool((a.view(torch.int32) == b.view(torch.int32)).all()), (n, d, "all rows")
+    if n <= 20000:   # ... and against the ORACLE itself: indices and d2 bits
+        exp = oracle.nearest_neighbors(c, fe.cpu().numpy())
+        g = [t.cpu().numpy() for t in got]
+        assert (g[0].astype(np.uint32).astype(np.uint64) == exp[0]).all() and (g[2].astype(np.uint32).astype(np.uint64) == exp[2]).all(), (n, d, "idx vs oracle")
+        assert (g[1].view(np.uint32) == exp[1].view(np.uint32)).all() and (g[3].view(np.uint32) == exp[3].view(np.uint32)).all(), (n, d, "d2 vs oracle")
     lo, hi = n // 3, n // 3 + max(1, n // 2)
     for a, b in zip(dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="pruned"),
                     dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="direct")):
@@ -599,7 +620,7 @@ def test_shared_operand_neighbour_sweep():
     """nn_shared_kernel (workgroup-wide rings and survivor lists, reference operands through an LDS ring; taken by
     itself only for wide rows and large images, e.g. C5) forced on for small shapes -- all rows, a row range, the
     segments of a sharded run, duplicates (ties), 1..8 MFMAs per chain, more than one reference share -- against
-    the direct kernels: indices and d2 bits."""
+    the direct kernels and (shapes up to 20 000 rows) against the oracle: indices and d2 bits."""
     import os
     import subprocess
     import sys
@@ -615,17 +636,27 @@ import numpy as np, torch
 sys.path.insert(0, {root!r})
 from clustering_amd import density as dens
 from clustering_amd.synth import gaussian_blobs
+from oracle.oracle import Oracle
+oracle = Oracle()
 out = {{}}
 for n, d, radii in {cases!r}:
     c = gaussian_blobs(n, d, seed=11)
     c[: n // 7] = c[n // 3: n // 3 + n // 7]          # duplicates: band pairs at distance 0 and ties
     ct = torch.from_numpy(c).cuda()
     p = dens.calculate_populations_partial(ct, radii)
+    if n <= 20000:    # every form against the ORACLE (not only against each other)
+        want = oracle.populations(c, radii)
+        assert (p.cpu().numpy().astype(np.uint32).astype(np.uint64) == want).all(), (n, d, "pops vs oracle")
     acc = torch.zeros_like(p)
     for g in range(3):
         acc += dens.calculate_populations_segment(ct, radii, g, 3)
     fe = dens.calculate_free_energies(p[0].contiguous())
     nn = dens.nearest_neighbors_partial(ct, fe)
+    if n <= 20000:
+        exp = oracle.nearest_neighbors(c, oracle.free_energies(want[0]))
+        g = [t.cpu().numpy() for t in nn]
+        assert (g[0].astype(np.uint32).astype(np.uint64) == exp[0]).all() and (g[2].astype(np.uint32).astype(np.uint64) == exp[2]).all(), (n, d, "nn idx vs oracle")
+        assert (g[1].view(np.uint32) == exp[1].view(np.uint32)).all() and (g[3].view(np.uint32) == exp[3].view(np.uint32)).all(), (n, d, "nn d2 vs oracle")
     out[f"{{n}}x{{d}}"] = [int(p.to(torch.int64).sum()), int((p.to(torch.int64) * torch.arange(1, p.numel() + 1, device=p.device).view_as(p)).sum() % (1 << 61)),
                           bool((acc == p).all()), int(nn[0].to(torch.int64).sum()), int(nn[2].to(torch.int64).sum()),
                           int(nn[1].view(torch.int32).to(torch.int64).sum()), int(nn[3].view(torch.int32).to(torch.int64).sum())]
@@ -637,7 +668,8 @@ print("FORMS " + json.dumps(out))
 def test_sweep_forms_agree():
     """The population sweep has a symmetric form (every pair of query groups once, both frames credited) and a
     one-sided one, workgroups of one or four waves, and a symmetric shared-operand sweep for one or several radii:
-    every combination, in its own process (the switches are read once), gives the same populations (plain and
+    every combination, in its own process (the switches are read once), reproduces the ORACLE on the shapes up to
+    20 000 rows (populations of every radius, neighbour indices and d2 bits) and gives the same populations (plain and
     position-weighted checksums), the same sums over three segments, and the same neighbours -- on shapes with an even
     and an odd number of query groups, more than one reference share, 1 to 6 MFMAs per chain, and duplicated rows."""
     import json

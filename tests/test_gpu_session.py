@@ -1,7 +1,12 @@
 """Resident sessions (dc_hip_session_*, -m gpu): the fused pop -> FE -> NN -> sigma2 -> forest flow on
-coordinates uploaded once must equal the call-by-call path bit for bit; the multi-device code path (one
-host thread per device, RCCL all-reduce of the partials) is driven with as many devices as the box has
-(min(avail, 2)) and, on a one-GPU box, through a one-rank RCCL communicator (DC_SESSION_FORCE_RCCL=1)."""
+coordinates uploaded once must equal the call-by-call path bit for bit.  The multi-device code path (one
+host thread per device, one segment each, partials merged) runs
+  - with two REAL devices over RCCL wherever the box has two (the tests then REQUIRE two devices and RCCL:
+    no silent degradation to one rank),
+  - on a one-GPU box through a one-rank RCCL communicator (DC_SESSION_FORCE_RCCL=1), and
+  - on ANY box as two / three "devices" that share the one GPU (DC_SESSION_ALLOW_DUPLICATE_DEVICES=1: own
+    host thread, stream, buffers and segment each) merged through the host like the reference does
+    (density_clustering_cuda.cu:171-180, :311-326) -- the fallback of a session whose RCCL is missing."""
 import os
 import subprocess
 import sys
@@ -93,6 +98,10 @@ def test_density_all_on_two_devices_equals_one(dens):
                                                p(hd_idx), p(hd_d2)), "dc_hip_density_all")
         return pops, fe, nn_idx, nn_d2, hd_idx, hd_d2
 
+    if avail >= 2:   # two devices exist: the two-device session must really be one (and merge over RCCL)
+        with dens.Session(c[:256], n_devices=2) as s2:
+            assert s2.n_devices == 2 and s2.merge_mode in (1, 2), "a 2-device session degraded to one rank"
+            assert s2.uses_rccl, "two devices, but the session merges on the host: RCCL did not come up"
     one = run(1)
     two = run(min(avail, 2))
     for a, b in zip(one, two):
@@ -110,7 +119,8 @@ from clustering_amd import density as dens
 from clustering_amd.synth import gaussian_blobs
 c = gaussian_blobs(12000, 10, seed=21)
 with dens.Session(c, n_devices=int(sys.argv[2])) as s:
-    assert s.uses_rccl, "the session did not build an RCCL communicator"
+    assert s.uses_rccl and s.merge_mode == 1, "the session did not build an RCCL communicator"
+    assert s.n_devices == int(sys.argv[2]), "fewer devices than asked for"
     print("devices", s.n_devices)
     pops = s.populations([0.2, 0.3])
     fe = s.free_energies(0)
@@ -165,3 +175,60 @@ def test_bench_starts_its_own_ranks_and_the_sharded_step_agrees(tmp_path):
         assert out[n]["n_gpus"] == n and out[n]["roofline"]["frac"] <= 1.0
     assert out[4]["config"]["rccl_ranks"] == 4 and out[4]["config"]["backend"] == "gloo"
     assert out[1]["check"] == out[4]["check"]        # mean / max population and sigma2 of the merged results
+
+
+HOST_MERGE_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+from clustering_amd import density as dens
+from clustering_amd.synth import gaussian_blobs
+n_dev = int(sys.argv[2])
+c = gaussian_blobs(12000, 10, seed=21)
+torch.cuda.set_device(0)
+with dens.Session(c, devices=[0] * n_dev) as s:
+    assert s.n_devices == n_dev and s.merge_mode == 2 and not s.uses_rccl
+    pops = s.populations([0.2, 0.3])
+    fe = s.free_energies(0)
+    nn = s.nearest_neighbors()
+    rank = np.argsort(np.argsort(fe, kind="stable"), kind="stable").astype(np.uint32)
+    edges, rounds = s.radius_forest(4.0 * nn[4], rank)
+    assert torch.cuda.current_device() == 0          # every entry point restores the caller's device
+np.savez(sys.argv[3], pops=pops, fe=fe, nn_idx=nn[0], nn_d2=nn[1], hd_idx=nn[2], hd_d2=nn[3], sigma2=nn[4],
+         edges=np.array(sorted((int(min(a, b)), int(max(a, b))) for a, b in edges)))
+"""
+
+
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_session_host_merge_of_several_segments(dens, tmp_path, n_dev):
+    """The multi-device flow with its HOST merge (what a session falls back to when RCCL cannot be loaded or its
+    communicator cannot be built; the reference's own merge, density_clustering_cuda.cu:171-180, :311-326): n_dev
+    "devices" on the one physical GPU -- one host thread, stream, workspace and segment each, sweeping concurrently --
+    partial populations summed and packed neighbour words minimised on the host, results and forest equal to the
+    single-device call-by-call path bit for bit."""
+    out = str(tmp_path / "h.npz")
+    env = dict(os.environ, DC_SESSION_ALLOW_DUPLICATE_DEVICES="1")
+    r = subprocess.run([sys.executable, "-c", HOST_MERGE_CHILD, ROOT, str(n_dev), out], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    c = gaussian_blobs(12000, 10, seed=21)
+    want_p, want_fe, want_nn, want_s2 = call_by_call(dens, c, [0.2, 0.3], 0)
+    assert (got["pops"] == want_p).all() and (bits(got["fe"]) == bits(want_fe)).all()
+    assert (got["nn_idx"] == want_nn[0].astype(np.uint32)).all() and (got["hd_idx"] == want_nn[2].astype(np.uint32)).all()
+    assert (bits(got["nn_d2"]) == bits(want_nn[1])).all() and (bits(got["hd_d2"]) == bits(want_nn[3])).all()
+    assert float(got["sigma2"]) == want_s2
+    rank = np.argsort(np.argsort(want_fe, kind="stable"), kind="stable").astype(np.uint32)
+    want_e, _ = dens.radius_forest(c, np.float32(4.0 * want_s2), rank)
+    assert got["edges"].tolist() == sorted([int(min(a, b)), int(max(a, b))] for a, b in want_e)
+
+
+def test_duplicate_devices_need_the_test_switch(dens):
+    """without DC_SESSION_ALLOW_DUPLICATE_DEVICES a device listed twice is an argument error"""
+    from clustering_amd import capi
+    c = gaussian_blobs(256, 5, seed=1)
+    if os.environ.get("DC_SESSION_ALLOW_DUPLICATE_DEVICES") == "1":
+        pytest.skip("switch set in the environment")
+    with pytest.raises(capi.DensityLibraryError):
+        dens.Session(c, devices=[0, 0])
