@@ -11,13 +11,16 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one
     1 000 000 frames x 10 dims, 3-Gaussian-blob generator of SURVEY.md 8(d) (seed 20240), r = 0.2.
 Metric: frame-pairs/s (density pop+nn) = 2*N^2 / t_step  (ordered pairs of both sweeps per second).
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-    "roofline":     dominant kernel against the pipe it runs on: the sweeps execute the distance contraction on
-                    two fp16 pieces per coordinate on the f16 MFMA pipe (NM 32x32x16 MFMAs = 32*NM flop per
-                    EVALUATED frame pair, dense peak 2.5 PFLOP/s): "achieved" = executed flop/s, "frac" <= 1.
-                    Beside it "frac_algorithmic" (SURVEY.md 8(d)'s 2*D flop per evaluated pair against the same
-                    peak) and "fp32_equivalent" (the same flops against the fp32 MFMA peak 157.3 TFLOP/s, the
-                    figure BASELINE.json's ">= 60 % of the fp32 MFMA roofline" refers to; it exceeds 1 because
-                    the contraction does not run on the fp32 pipe); pruned-away pairs earn no credit anywhere
+    "roofline":     the dominant sweep kernel against the pipe it runs on (the f16 MFMA pipe, dense peak
+                    2.5 PFLOP/s).  "frac" is SURVEY.md 8(d)'s ALGORITHMIC figure: 2*D flop per EVALUATED frame
+                    pair / the kernel's own duration (HIP events around the kernel launch, on its stream) / peak.
+                    "frac_executed" counts what the pipe executes (NM 32x32x16 MFMAs = 32*NM flop per pair, zero
+                    padded K slots and the three piece products included); "fp32_equivalent" prices the
+                    algorithmic flops against the fp32 MFMA peak 157.3 TFLOP/s (BASELINE.json's target figure; it
+                    exceeds 1 because the contraction does not run on that pipe).  Pruned-away pairs earn no
+                    credit anywhere.  "roofline_by_kernel" carries the same for BOTH sweeps.
+    "phases_ms":    the step split into pop_prep / pop_kernel / pops_allreduce / fe / nn_prep / nn_kernel /
+                    nn_merge, max and min over the ranks (measured in separate instrumented steps).
     "cpu_baseline": the CPU restatement (oracle, fast build, all host threads) on a bounded sample.
 """
 import argparse
@@ -60,14 +63,15 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-PMC_PROFILES = ("r2b_c3_pmc.json", "r2_c3_pmc.json", "r1_pruned_pmc.json")   # newest first
+PMC_PROFILES = ("r3_c3_pmc.json", "r2b_c3_pmc.json", "r2_c3_pmc.json", "r1_pruned_pmc.json")   # newest first
 
 
 def measured_counters(kernel, n, d, radii, variant):
-    """Counter figures of the dominant kernel (memory-side bytes per launch, matrix-pipe busy, VALU
+    """Counter figures of a sweep kernel (memory-side bytes per launch, matrix-pipe busy, VALU
     instructions per tile pair): not measurable from inside the timed run (PMC counters need their own
     rocprofv3 passes), so they come from the committed counter summary of the SAME workload
-    (profiles/r*_pmc.json, produced with scratch/pmc_summary.py); {} for any other workload or variant."""
+    (profiles/r*_pmc.json, produced with scratch/pmc_summary.py / make_pmc_profile.py, which records the
+    commit of the kernels it measured); {} for any other workload or variant."""
     if variant not in ("auto", "pruned"):
         return {}
     for fname in PMC_PROFILES:
@@ -83,8 +87,18 @@ def measured_counters(kernel, n, d, radii, variant):
             if tag in name:
                 return {"traffic": e.get("traffic_bytes"), "mfma_busy": e.get("matrix_pipe_utilisation"),
                         "valu_insts_per_tile_pair": e.get("valu_insts_per_32x32_tile_pair"),
-                        "source": "profiles/" + fname}
+                        "source": "profiles/" + fname, "source_commit": prof.get("commit")}
     return {}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def parse_args():
@@ -99,6 +113,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="rows of the workload the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-nn", action="store_true", help="populations + free energies only (C2-style)")
+    ap.add_argument("--no-full-sweep", action="store_true", help="skip the unpruned reference sweeps (roofline_full_sweep)")
     return ap.parse_args()
 
 
@@ -124,12 +139,16 @@ def cpu_baseline(coords_np, radii, sample_rows, want_nn):
         "value": sweeps * float(n) * n / (t3 - t0),
         "unit": "frame-pairs/s",
         "cores": o.threads,
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"first {n} rows of the workload ({n}x{c.shape[1]}, radii {list(radii)}): "
                   f"pops {t1 - t0:.2f}s (box grid, i<j) + fe {t2 - t1:.3f}s"
                   + (f" + nn {t3 - t2:.2f}s (brute force)" if want_nn else "")
                   + "; rate = sweeps*n^2/t at THIS n (the pruned pop sweep gets relatively cheaper as n grows)",
     }
+
+
+PHASES = ("pop_prep", "pop_kernel", "pops_allreduce", "fe", "nn_prep", "nn_kernel", "nn_merge")
 
 
 def main():
@@ -179,32 +198,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # per-kernel HIP events (torch events record on the current stream, which is the stream the
-    # C ABI launches on: clustering_amd.density passes torch.cuda.current_stream()).
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    pop_ms, nn_ms = [], []
-
-    def step(timed):
-        if timed:
-            ev[0].record()
-        # (the same calls ShardedDensity makes: every world-th query group of the spatial order when sharded)
-        pops = (backend.populations_segment(coords, args.radii, rank, world) if world > 1
-                else backend.populations_partial(coords, args.radii, lo, hi))
-        if timed:
-            ev[1].record()
-        if world > 1:
-            dist.all_reduce(pops, op=dist.ReduceOp.SUM)
-        fe = backend.free_energies(pops[0].contiguous())
-        res = None
-        if want_nn:
-            if timed:
-                ev[2].record()
-            res = (backend.nearest_neighbors_segment(coords, fe, rank, world) if world > 1
-                   else backend.nearest_neighbors_partial(coords, fe, lo, hi))
-            if timed:
-                ev[3].record()
-        return pops, fe, res
-
     for _ in range(args.warmup):
         job.run(coords, args.radii, 0, want_nn)
     barrier()
@@ -218,13 +211,43 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
-    # kernel durations for the roofline entry: same calls, outside the whole-job timed region
-    for _ in range(max(1, min(args.steps, 3))):
-        step(True)
+    # ---- instrumented steps (outside the whole-job timed region): the SAME ShardedDensity.run with phase marks
+    # (torch events on the current stream, which is the stream the C ABI launches on) and the library's own event
+    # pair around the main sweep kernels (dc_hip_sweep_timing) -- prep = call - kernel
+    density.sweep_timing(True)
+    reps = max(1, min(args.steps, 3))
+    acc = {k: [] for k in PHASES}
+    for _ in range(reps):
+        marks = []
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+        job.run(coords, args.radii, 0, want_nn, mark=mark)
         torch.cuda.synchronize()
-        pop_ms.append(ev[0].elapsed_time(ev[1]))
+        span = {}
+        for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            span[name] = a.elapsed_time(b)
+        pop_k = density.last_sweep_ms("pop", dev) if args.variant != "direct" and d <= 64 else span.get("pop", 0.0)
+        nn_k = 0.0
         if want_nn:
-            nn_ms.append(ev[2].elapsed_time(ev[3]))
+            nn_k = density.last_sweep_ms("nn", dev) if args.variant != "direct" and d <= 64 else span.get("nn", 0.0)
+        acc["pop_kernel"].append(pop_k)
+        acc["pop_prep"].append(max(0.0, span.get("pop", 0.0) - pop_k))
+        acc["pops_allreduce"].append(span.get("pops_allreduce", 0.0))
+        acc["fe"].append(span.get("fe", 0.0))
+        acc["nn_kernel"].append(nn_k)
+        acc["nn_prep"].append(max(0.0, span.get("nn", 0.0) - nn_k))
+        acc["nn_merge"].append(span.get("nn_merge", 0.0))
+    density.sweep_timing(False)
+    mine = torch.tensor([float(np.mean(acc[k])) for k in PHASES], dtype=torch.float64, device=dev)
+    ph_max, ph_min = mine.clone(), mine.clone()
+    if world > 1:
+        dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ph_min, op=dist.ReduceOp.MIN)
+    pop_t, nn_t = float(mine[PHASES.index("pop_kernel")]) * 1e-3, float(mine[PHASES.index("nn_kernel")]) * 1e-3
+
     # pairs actually evaluated (the pruned variants skip tile pairs that are provably too far apart):
     # each sweep leaves its 32x32-tile count in the workspace header
     pops_c = (backend.populations_segment(coords, args.radii, rank, world) if world > 1
@@ -242,7 +265,7 @@ def main():
         nn_tiles = density.evaluated_tiles(dev)[1]
     # reference point for the roofline: the same sweeps with EVERY pair evaluated (DC_VARIANT_MFMA)
     full_ms = None
-    if args.variant in ("auto", "pruned") and rank == 0:
+    if args.variant in ("auto", "pruned") and rank == 0 and not args.no_full_sweep:
         fb = HipBackend("mfma")
         e0, e1, e2, e3 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         fb.populations_partial(coords, args.radii, lo, hi)          # warm-up (workspace, code)
@@ -271,57 +294,66 @@ def main():
     tiles_all = [int(v) for v in tiles_all.tolist()]
 
     if rank == 0:
-        pop_t = float(np.mean(pop_ms)) * 1e-3
-        nn_t = float(np.mean(nn_ms)) * 1e-3 if want_nn else 0.0
-        # dominant kernel = the longer of the two sweeps on this rank.  Work = ordered (query, reference)
-        # pairs the kernel EVALUATED: the 32x32 tile pairs it counted itself (all pairs of the rank's rows
-        # for the variants that do not prune); pruned-away pairs earn no roofline credit.
+        # Work = ordered (query, reference) pairs the kernel EVALUATED: the 32x32 tile pairs it counted itself (all pairs
+        # of the rank's rows for the variants that do not prune); pruned-away pairs earn no roofline credit.
         full_pairs = float(n) * n / world          # this rank's share of the N^2 ordered pairs
         pop_pairs = pop_tiles * 1024.0 if pop_tiles else full_pairs
         nn_pairs = nn_tiles * 1024.0 if nn_tiles else full_pairs
-        if nn_t > pop_t:
-            dom, dom_t, dom_pairs = "nearest_neighbor_search", nn_t, nn_pairs
-        else:
-            dom, dom_t, dom_pairs = "population_count", pop_t, pop_pairs
         matrix = args.variant != "direct" and d <= 64
-        algorithmic = dom_pairs * 2.0 * d / dom_t / 1e12                     # 2*D flop per pair
-        executed = dom_pairs * executed_flop_per_pair(d) / dom_t / 1e12      # what the f16 pipe does
-        pmc = measured_counters(dom, n, d, args.radii, args.variant) if world == 1 else {}
+
+        def roof_of(kernel, pairs, t):
+            if t <= 0.0:
+                return None
+            algorithmic = pairs * 2.0 * d / t / 1e12                     # 2*D flop per pair
+            executed = pairs * executed_flop_per_pair(d) / t / 1e12      # what the f16 pipe does
+            pmc = measured_counters(kernel, n, d, args.radii, args.variant) if world == 1 else {}
+            if matrix:
+                r = {"bound": "mfma", "pipe": "f16 (v_mfma_f32_32x32x16_f16, dense)", "kernel": kernel,
+                     "achieved": algorithmic, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": algorithmic / PEAK_BF16_TFLOPS,
+                     "frac_definition": "SURVEY.md 8(d): 2*D fp32 flop per EVALUATED ordered frame pair (one multiply-add per "
+                                        "dimension) / the kernel's launch duration / the dense peak of the pipe it runs on",
+                     "flop_per_pair_algorithmic": 2 * d,
+                     "achieved_executed": executed, "frac_executed": executed / PEAK_BF16_TFLOPS,
+                     "flop_per_pair_executed": executed_flop_per_pair(d),
+                     "fp32_equivalent": {"achieved": algorithmic, "peak": PEAK_FP32_TFLOPS,
+                                         "frac": algorithmic / PEAK_FP32_TFLOPS,
+                                         "what": "the algorithmic flops against the fp32 MFMA/VALU peak (BASELINE.json's "
+                                                 "target figure); > 1 is possible because the contraction runs on the f16 pipe"}}
+            else:
+                r = {"bound": "mfma", "pipe": "fp32 VALU (direct kernels)", "kernel": kernel,
+                     "achieved": algorithmic, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": algorithmic / PEAK_FP32_TFLOPS, "flop_per_pair_algorithmic": 2 * d}
+            r.update({
+                "traffic": pmc.get("traffic"),
+                "traffic_note": "bytes per launch at the L2's memory side (TCC_EA0 read requests x 128 B + write requests x "
+                                "64 B, separate rocprofv3 --pmc pass, Infinity-Cache hits included) from "
+                                + str(pmc.get("source")) + " (kernels of commit " + str(pmc.get("source_commit"))
+                                + "); algorithmic bytes per launch = N*D*4 + outputs = "
+                                f"{n * d * 4 + n * 16} B: the kernel is compute-bound and re-streams its operand image through L2",
+                "mfma_busy": pmc.get("mfma_busy"),
+                "valu_insts_per_tile_pair": pmc.get("valu_insts_per_tile_pair"),
+                "pairs_per_launch": pairs,
+                "pairs_per_launch_unpruned": full_pairs,
+                "launch_ms": 1e3 * t,
+                "launch_ms_source": "HIP events recorded by the library around the kernel launch, on its stream "
+                                    "(dc_hip_sweep_timing / dc_hip_last_sweep_ms)",
+            })
+            return r
+        by_kernel = {"population_count": roof_of("population_count", pop_pairs, pop_t)}
+        if want_nn:
+            by_kernel["nearest_neighbor_search"] = roof_of("nearest_neighbor_search", nn_pairs, nn_t)
+        dom = "nearest_neighbor_search" if (want_nn and nn_t > pop_t) else "population_count"
+        roof = dict(by_kernel[dom])
+        roof["evaluated_fraction"] = {"pop": pop_pairs / full_pairs, "nn": nn_pairs / full_pairs}
+        roof["evaluated_fraction_note"] = ("tile pairs the kernels COMPUTED (their own counters) x 1024 / N^2; the one-radius "
+                                           "population sweep computes every unordered pair of query groups once and credits "
+                                           "both frames (d2 is symmetric), so its figure covers about twice as many ordered pairs")
         pop_sum = int(out["pops"][0].sum(dtype=torch.int64).item())
         evaluated_all = (tiles_all[0] + tiles_all[1]) * 1024.0 if tiles_all[0] else pairs_per_step
-        if matrix:
-            roof = {
-                "bound": "mfma", "pipe": "f16 (v_mfma_f32_32x32x16_f16, dense)", "kernel": dom,
-                "achieved": executed, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": executed / PEAK_BF16_TFLOPS,
-                "flop_per_pair_executed": executed_flop_per_pair(d),
-                "frac_algorithmic": algorithmic / PEAK_BF16_TFLOPS, "flop_per_pair_algorithmic": 2 * d,
-                "fp32_equivalent": {"achieved": algorithmic, "peak": PEAK_FP32_TFLOPS,
-                                    "frac": algorithmic / PEAK_FP32_TFLOPS,
-                                    "what": "2*D flop per evaluated pair against the fp32 MFMA/VALU peak "
-                                            "(BASELINE.json's target figure); > 1 is possible because the "
-                                            "contraction runs on the f16 pipe"},
-            }
-        else:
-            roof = {"bound": "mfma", "pipe": "fp32 VALU (direct kernels)", "kernel": dom,
-                    "achieved": algorithmic, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": algorithmic / PEAK_FP32_TFLOPS, "flop_per_pair_algorithmic": 2 * d}
-        roof.update({
-            "traffic": pmc.get("traffic"),
-            "traffic_note": "bytes per launch at the L2's memory side (TCC_EA0 read requests x 128 B + write "
-                            "requests x 64 B, separate rocprofv3 --pmc pass, Infinity-Cache hits included) from "
-                            + str(pmc.get("source")) + "; algorithmic bytes per launch = N*D*4 + outputs = "
-                            f"{n * d * 4 + n * 16} B: the kernel is compute-bound and re-streams its operand image through L2",
-            "mfma_busy": pmc.get("mfma_busy"),
-            "valu_insts_per_tile_pair": pmc.get("valu_insts_per_tile_pair"),
-            "pairs_per_launch": dom_pairs,
-            "pairs_per_launch_unpruned": full_pairs,
-            "launch_ms": 1e3 * dom_t,
-            "evaluated_fraction": {"pop": pop_pairs / full_pairs, "nn": nn_pairs / full_pairs},
-            "evaluated_fraction_note": "tile pairs the kernels COMPUTED (their own counters) x 1024 / N^2; the one-radius "
-                                       "population sweep computes every unordered pair of query groups once and credits "
-                                       "both frames (d2 is symmetric), so its figure covers about twice as many ordered pairs",
-        })
+        phases = {k: float(ph_max[i]) for i, k in enumerate(PHASES)}
+        phases["sum_of_phases"] = float(sum(phases[k] for k in PHASES))
+        phases["unaccounted (host gaps between launches)"] = ms_per_step - phases["sum_of_phases"]
         line = {
             "metric": "frame-pairs/s (density pop+nn)" if want_nn else "frame-pairs/s (density pop)",
             "value": value,
@@ -341,7 +373,7 @@ def main():
                             + ("pop + free energy + nn/nn_hd" if want_nn else "pop + free energy"),
                 "n_rows": n, "n_cols": d, "radii": args.radii, "variant": args.variant,
                 "parallelism": f"rows sharded over {world} GPU(s) (every {world}-th query group of the spatial order), coords replicated; "
-                               "all-reduce(sum) of the populations + all-reduce(min) of the packed (d2, index) neighbour words",
+                               "all-reduce(sum) of the populations + " + job.neighbour_merge_name(),
                 "backend": (dist.get_backend() if world > 1 else "none (single process)"),
                 "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
             },
@@ -349,12 +381,17 @@ def main():
                           "spatial ordering count, like the reference's box grid skips them); "
                           "evaluated_pairs_per_s = pairs the kernels actually evaluated per second",
             "evaluated_pairs_per_s": evaluated_all / (elapsed / args.steps),
-            "phases_ms": {"pop_kernel": 1e3 * pop_t, "nn_kernel": 1e3 * nn_t,
-                          "other (fe, collectives, host)": max(0.0, ms_per_step - 1e3 * (pop_t + nn_t))},
+            "phases_ms": phases,
+            "phases_ms_min_over_ranks": {k: float(ph_min[i]) for i, k in enumerate(PHASES)},
+            "phases_note": "max over the ranks (min beside it) of each phase of instrumented steps run after the timed region: "
+                           "*_kernel = the sweep kernel alone (library event pair), *_prep = the rest of the call (statistics, "
+                           "orderings, operand images, boxes, unpack), pops_allreduce / nn_merge = the collectives with their "
+                           "pack / unpack kernels, fe = free energies (device log + host referee, one stream synchronisation)",
             "check": {"mean_pop_r0": pop_sum / n, "max_pop_r0": int(out["pops"][0].max().item()),
                       "sigma2": (density.compute_sigma2(out["nn_d2"]) if want_nn else None),
                       "reference_run": "BASELINE.md: mean 7233.1, max 65950, sigma2 0.00704766 at C3"},
             "roofline": roof,
+            "roofline_by_kernel": by_kernel,
         }
         if full_ms is not None:
             # the unpruned sweeps (every ordered pair evaluated) for comparison
@@ -362,11 +399,11 @@ def main():
             fl32 = float(n) * n / world * 2.0 * d
 
             def full(ms):
-                return {"launch_ms": ms, "frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                        "frac_algorithmic": fl32 / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                return {"launch_ms": ms, "frac": fl32 / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "frac_executed": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                         "fp32_equivalent_frac": fl32 / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
             line["roofline_full_sweep"] = {
-                "variant": "mfma (no pruning)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "variant": "mfma (no pruning; launch_ms = whole call)", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "pop": full(full_ms["pop_kernel"]),
                 "nn": None if full_ms["nn_kernel"] is None else full(full_ms["nn_kernel"]),
                 "frame_pairs_per_s": (sweeps * float(n) * n / world

@@ -24,7 +24,8 @@ SYMBOLS = (
     "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_sweep_timing", "dc_hip_last_sweep_ms", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs", "dc_hip_radius_min_edge_dev", "dc_hip_radius_forest",
     "dc_hip_populations_segment_dev", "dc_hip_nearest_neighbors_segment_dev",
-    "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev", "dc_hip_radius_min_edge_segment_dev",
+    "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev", "dc_hip_neighbors_block_rows",
+    "dc_hip_neighbors_block_pack_dev", "dc_hip_neighbors_block_unpack_dev", "dc_hip_radius_min_edge_segment_dev",
     "dc_hip_session_open", "dc_hip_session_close", "dc_hip_session_devices", "dc_hip_session_uses_rccl",
     "dc_hip_session_merge_mode",
     "dc_hip_session_counters", "dc_hip_session_populations", "dc_hip_session_free_energies",
@@ -89,6 +90,12 @@ def _load():
     lib.dc_hip_neighbors_pack_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.dc_hip_neighbors_unpack_dev.restype = i32
     lib.dc_hip_neighbors_unpack_dev.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+    lib.dc_hip_neighbors_block_rows.restype = sz
+    lib.dc_hip_neighbors_block_rows.argtypes = [sz, sz, sz]
+    lib.dc_hip_neighbors_block_pack_dev.restype = i32
+    lib.dc_hip_neighbors_block_pack_dev.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz, vp, sz, i32, vp, vp]
+    lib.dc_hip_neighbors_block_unpack_dev.restype = i32
+    lib.dc_hip_neighbors_block_unpack_dev.argtypes = [vp, sz, sz, sz, vp, sz, i32, vp, vp, vp, vp, vp]
     lib.dc_hip_radius_min_edge_dev.restype = i32
     lib.dc_hip_radius_min_edge_dev.argtypes = [vp, sz, sz, C.c_float, vp, vp, vp, vp, vp, sz, vp]
     lib.dc_hip_radius_min_edge_segment_dev.restype = i32

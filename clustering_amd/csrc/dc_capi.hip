@@ -446,6 +446,50 @@ int dc_hip_neighbors_unpack_dev(const unsigned long long* d_words, size_t n_rows
   return check_launch("neighbour unpack launch");
 }
 
+size_t dc_hip_neighbors_block_rows(size_t n_rows, size_t n_cols, size_t n_segments) {
+  return dc::nn_block_rows(n_rows, n_cols, n_segments);
+}
+
+namespace {
+// did dc_hip_nearest_neighbors_segment_dev(variant) run the pruned matrix-core sweep (segments of the spatial order)?
+bool segment_sweep_is_pruned(int variant, size_t n_rows, size_t n_cols) {
+  variant &= DC_VARIANT_MASK;
+  return want_mfma(variant, n_cols) && variant != DC_VARIANT_MFMA && n_rows < ((size_t)1 << 30);
+}
+}  // namespace
+
+int dc_hip_neighbors_block_pack_dev(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
+                                    const float* d_hd_d2, size_t n_rows, size_t n_cols, size_t segment,
+                                    size_t n_segments, const void* d_workspace, size_t workspace_bytes, int variant,
+                                    uint32_t* d_block, void* stream) {
+  if (n_segments == 0 || segment >= n_segments) return fail(DC_ERR_INVALID_ARGUMENT, "segment %zu of %zu", segment, n_segments);
+  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
+  if (n_rows == 0) return DC_OK;
+  if (!d_nn_idx || !d_nn_d2 || !d_hd_idx || !d_hd_d2 || !d_block) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  const bool pruned = segment_sweep_is_pruned(variant, n_rows, n_cols);
+  if (pruned && (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols)))
+    return fail(DC_ERR_WORKSPACE, "the workspace of the segment sweep is needed (its ordering)");
+  dc::launch_nn_block_pack(d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)segment,
+                           (uint32_t)n_segments, pruned, d_workspace, d_block, (hipStream_t)stream);
+  return check_launch("neighbour block pack launch");
+}
+
+int dc_hip_neighbors_block_unpack_dev(const uint32_t* d_blocks, size_t n_rows, size_t n_cols, size_t n_segments,
+                                      const void* d_workspace, size_t workspace_bytes, int variant,
+                                      uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
+                                      void* stream) {
+  if (n_segments == 0) return fail(DC_ERR_INVALID_ARGUMENT, "n_segments must be positive");
+  if (int rc = check_sizes(n_rows, n_cols, 0, n_rows)) return rc;
+  if (n_rows == 0) return DC_OK;
+  if (!d_nn_idx || !d_nn_d2 || !d_hd_idx || !d_hd_d2 || !d_blocks) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  const bool pruned = segment_sweep_is_pruned(variant, n_rows, n_cols);
+  if (pruned && (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols)))
+    return fail(DC_ERR_WORKSPACE, "the workspace of the segment sweep is needed (its ordering)");
+  dc::launch_nn_block_unpack(d_blocks, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)n_segments, pruned, d_workspace,
+                             d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, (hipStream_t)stream);
+  return check_launch("neighbour block unpack launch");
+}
+
 int dc_hip_sigma2_dev(const float* d_nn_d2, size_t n_rows, double* sigma2_out, void* stream) {
   if (!sigma2_out) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
   if (n_rows == 0) {

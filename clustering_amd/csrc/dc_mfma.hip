@@ -889,6 +889,97 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   }
 }
 
+// ---- blocks of a sharded neighbour sweep (all-gather merge) ---------------------------------------------------
+// A segment's rows are scattered over the trajectory (every G-th query group of the sweep's order); compacted by
+// LOCAL POSITION they form a dense block that an all-gather can move -- half the bytes of the all-reduce(min) of packed
+// words, and no reduction.  Local position l of segment g: group l / (32 tq) of the segment = group (l / (32 tq)) G + g
+// of the order, i.e. position p(l); frame perm[p].  A flagged data set (the direct kernels answered for the row block
+// of the segment) uses the row block: the choice is made on the device from the same flag the sweeps looked at.
+__device__ __forceinline__ uint32_t block_none(uint32_t c, uint32_t n_rows) {
+  return (c & 1u) ? __float_as_uint(FLT_MAX) : n_rows + 1u;
+}
+__global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const float* __restrict__ nn_d2,
+                                     const uint32_t* __restrict__ hd_idx, const float* __restrict__ hd_d2,
+                                     uint32_t n_rows, uint32_t gsize /* 32 tq, 0: row blocks only */, uint32_t seg,
+                                     uint32_t G, uint32_t block_rows, const uint32_t* __restrict__ perm,
+                                     const uint32_t* __restrict__ hdr, uint32_t* __restrict__ block) {
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= block_rows) return;
+  const bool by_position = gsize != 0u && hdr[1] == 0u;
+  uint32_t i = 0xFFFFFFFFu;
+  if (by_position) {
+    const unsigned long long p = ((unsigned long long)(l / gsize) * G + seg) * gsize + l % gsize;
+    if (p < n_rows) i = perm[p];
+  } else {
+    const uint32_t rng = n_rows / G, lo = seg * rng, hi = (seg == G - 1u) ? n_rows : lo + rng;
+    if (lo + l < hi) i = lo + l;
+  }
+  const bool live = i != 0xFFFFFFFFu;
+  block[0 * (size_t)block_rows + l] = live ? nn_idx[i] : block_none(0, n_rows);
+  block[1 * (size_t)block_rows + l] = live ? __float_as_uint(nn_d2[i]) : block_none(1, n_rows);
+  block[2 * (size_t)block_rows + l] = live ? hd_idx[i] : block_none(2, n_rows);
+  block[3 * (size_t)block_rows + l] = live ? __float_as_uint(hd_d2[i]) : block_none(3, n_rows);
+}
+__global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G][4][block_rows] */, uint32_t n_rows,
+                                       uint32_t gsize, uint32_t G, uint32_t block_rows,
+                                       const uint32_t* __restrict__ perm, const uint32_t* __restrict__ hdr,
+                                       uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
+                                       uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_rows) return;
+  const bool by_position = gsize != 0u && hdr[1] == 0u;
+  uint32_t i, r, l;
+  if (by_position) {
+    const uint32_t grp = p / gsize;
+    r = grp % G;
+    l = (grp / G) * gsize + p % gsize;
+    i = perm[p];
+  } else {
+    const uint32_t rng = n_rows / G;
+    i = p;
+    r = rng ? min(p / rng, G - 1u) : G - 1u;
+    l = p - r * rng;
+  }
+  const uint32_t* b = blocks + (size_t)r * 4u * block_rows;
+  nn_idx[i] = b[l];
+  nn_d2[i] = __uint_as_float(b[(size_t)block_rows + l]);
+  hd_idx[i] = b[2 * (size_t)block_rows + l];
+  hd_d2[i] = __uint_as_float(b[3 * (size_t)block_rows + l]);
+}
+
+static uint32_t nn_group_rows(uint32_t n_rows, uint32_t n_cols) {
+  return 32u * (uint32_t)tq_of(n_cols) * (nn_shared_wanted(n_rows, n_cols) ? 4u : 1u);
+}
+size_t nn_block_rows(size_t n_rows, size_t n_cols, size_t n_segments) {
+  if (n_segments == 0 || n_rows == 0) return 0;
+  const size_t row_block = n_rows - (n_segments - 1) * (n_rows / n_segments);   // the last (largest) row block
+  if (!mfma_supports(n_cols)) return row_block;
+  const size_t gs = nn_group_rows((uint32_t)n_rows, (uint32_t)n_cols);
+  const size_t groups = (n_rows + gs - 1) / gs;
+  return std::max(row_block, ((groups + n_segments - 1) / n_segments) * gs);
+}
+void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
+                          const float* d_hd_d2, uint32_t n_rows, uint32_t n_cols, uint32_t segment,
+                          uint32_t n_segments, bool pruned, const void* d_ws, uint32_t* d_block, hipStream_t stream) {
+  const uint32_t rows = (uint32_t)nn_block_rows(n_rows, n_cols, n_segments);
+  const Layout L = make_layout(n_rows, n_cols);
+  const char* p = (const char*)d_ws;
+  hipLaunchKernelGGL(nn_block_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2, d_hd_idx,
+                     d_hd_d2, n_rows, pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, rows,
+                     pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block);
+}
+void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t n_cols, uint32_t n_segments,
+                            bool pruned, const void* d_ws, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                            float* d_hd_d2, hipStream_t stream) {
+  const uint32_t rows = (uint32_t)nn_block_rows(n_rows, n_cols, n_segments);
+  const Layout L = make_layout(n_rows, n_cols);
+  const char* p = (const char*)d_ws;
+  hipLaunchKernelGGL(nn_block_unpack_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_blocks, n_rows,
+                     pruned ? nn_group_rows(n_rows, n_cols) : 0u, n_segments, rows,
+                     pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr,
+                     d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
+}
+
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream) {

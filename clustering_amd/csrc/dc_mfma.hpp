@@ -79,6 +79,18 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
 
+// The rows of one segment of a sharded neighbour sweep compacted into a dense block [4][nn_block_rows] (nn_idx,
+// nn_d2 bits, hd_idx, hd_d2 bits by local position), and the gathered blocks of all segments back to the four
+// arrays by frame.  pruned: the segment sweep that ran was the pruned matrix-core sweep (its ordering is still in the
+// workspace); otherwise, and for flagged data, the segments are the reference's row blocks.
+size_t nn_block_rows(size_t n_rows, size_t n_cols, size_t n_segments);
+void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
+                          const float* d_hd_d2, uint32_t n_rows, uint32_t n_cols, uint32_t segment,
+                          uint32_t n_segments, bool pruned, const void* d_ws, uint32_t* d_block, hipStream_t stream);
+void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t n_cols, uint32_t n_segments,
+                            bool pruned, const void* d_ws, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
+                            float* d_hd_d2, hipStream_t stream);
+
 // Optional timing of the MAIN sweep kernels (bench.py's roofline entry wants the kernel's own duration, not the call's:
 // the orderings and operand images are "prep").  When enabled the launchers bracket every main-kernel launch with HIP
 // events on the launch stream: the first launch of a kind (0 population, 1 neighbour) since the last read sets the

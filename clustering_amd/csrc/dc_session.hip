@@ -285,7 +285,11 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
     n_devices = avail;
     devices = nullptr;
   }
-  if (n_devices > avail) return failf(DC_ERR_INVALID_ARGUMENT, "%d devices requested, %d present", n_devices, avail);
+  {
+    const char* dup = getenv("DC_SESSION_ALLOW_DUPLICATE_DEVICES");
+    if (n_devices > avail && !(devices && dup && dup[0] == '1'))
+      return failf(DC_ERR_INVALID_ARGUMENT, "%d devices requested, %d present", n_devices, avail);
+  }
   DeviceGuard guard;
   bool duplicates = false;
   dc_hip_session* s = new dc_hip_session();

@@ -288,6 +288,47 @@ def unpack_neighbors(words, out=None):
     return out
 
 
+def neighbor_block_rows(n_rows, n_cols, n_segments):
+    """rows of one rank's block in the all-gather merge of the neighbour partials (dc_hip_neighbors_block_rows)"""
+    return int(capi.lib.dc_hip_neighbors_block_rows(n_rows, n_cols, n_segments))
+
+
+def pack_neighbor_block(coords, nn_idx, nn_d2, hd_idx, hd_d2, segment, n_segments, variant="auto", out=None):
+    """The results of this segment's own rows as a dense block int32 [4, block_rows] (dc_hip_neighbors_block_pack_dev);
+    call right after nearest_neighbors_segment on the same device (its ordering is read from the workspace)."""
+    n_rows, n_cols = _check_coords(coords)
+    rows = neighbor_block_rows(n_rows, n_cols, n_segments)
+    if out is None:
+        out = torch.empty((4, rows), dtype=torch.int32, device=coords.device)
+    assert out.shape == (4, rows) and out.dtype == torch.int32 and out.is_contiguous()
+    with torch.cuda.device(coords.device):
+        ws, ws_bytes = _workspace(coords.device).get(n_rows, n_cols, 1)
+        rc = capi.lib.dc_hip_neighbors_block_pack_dev(_dev(nn_idx), _dev(nn_d2), _dev(hd_idx), _dev(hd_d2), n_rows, n_cols,
+                                                      segment, n_segments, ws, ws_bytes, capi.VARIANTS[variant],
+                                                      _dev(out), _stream_ptr())
+    capi.check(rc, "dc_hip_neighbors_block_pack_dev")
+    return out
+
+
+def unpack_neighbor_blocks(coords, blocks, n_segments, variant="auto", out=None):
+    """blocks int32 [n_segments, 4, block_rows] gathered from all ranks -> (nn_idx, nn_d2, hd_idx, hd_d2) by frame
+    (dc_hip_neighbors_block_unpack_dev)"""
+    n_rows, n_cols = _check_coords(coords)
+    dev = coords.device
+    rows = neighbor_block_rows(n_rows, n_cols, n_segments)
+    assert blocks.is_contiguous() and blocks.dtype == torch.int32 and blocks.numel() == n_segments * 4 * rows
+    if out is None:
+        out = (torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev),
+               torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev))
+    with torch.cuda.device(dev):
+        ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
+        rc = capi.lib.dc_hip_neighbors_block_unpack_dev(_dev(blocks), n_rows, n_cols, n_segments, ws, ws_bytes,
+                                                        capi.VARIANTS[variant], _dev(out[0]), _dev(out[1]), _dev(out[2]),
+                                                        _dev(out[3]), _stream_ptr())
+    capi.check(rc, "dc_hip_neighbors_block_unpack_dev")
+    return out
+
+
 def compute_sigma2(nn_d2):
     """compute_sigma2 (density_clustering.cpp:334-343)."""
     out = C.c_double(0.0)

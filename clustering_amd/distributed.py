@@ -12,6 +12,12 @@ Sharding and merging follow the reference's multi-GPU host code:
     ONE all-gather of per-rank blocks [4][block] (nn_idx, nn_d2 bits, hd_idx, hd_d2 bits), blocks
     padded to the largest (= last) shard.
 
+Neighbour merge of the segments (default since round 3): an ALL-GATHER of position-ordered blocks.  Every
+rank compacts the results of its own segment's rows into a dense block [4][block_rows] (by local position in the
+sweep's spatial order, which all ranks derive identically from the replicated inputs), one
+all_gather_into_tensor moves the blocks, one kernel scatters them back to frame order: half the bytes of the
+all-reduce(min) below and no reduction.  DC_NN_MERGE=allreduce selects the older merge.
+
 Spatial segments.  A block of consecutive trajectory rows is spread over the whole conformational
 space, so a rank's query groups are far less compact than those of a full sweep and the tile-pair
 pruning loses a third of its effect (measured: 29 % instead of 20 % of the tile pairs at 1/8 of C3).
@@ -53,6 +59,14 @@ class HipBackend:
         return self._d.nearest_neighbors_segment(coords, fe, segment, n_segments, variant=self.variant,
                                                  stats_valid=stats_valid)
 
+    accepts_stats_valid = True      # ShardedDensity may tell the neighbour call that the header statistics are valid
+
+    def pack_neighbor_block(self, coords, nn, segment, n_segments):
+        return self._d.pack_neighbor_block(coords, nn[0], nn[1], nn[2], nn[3], segment, n_segments, variant=self.variant)
+
+    def unpack_neighbor_blocks(self, coords, blocks, n_segments):
+        return self._d.unpack_neighbor_blocks(coords, blocks, n_segments, variant=self.variant)
+
     def pack_neighbors(self, nn_idx, nn_d2, hd_idx, hd_d2):
         return self._d.pack_neighbors(nn_idx, nn_d2, hd_idx, hd_d2)
 
@@ -75,32 +89,62 @@ class ShardedDensity:
             return dist.get_rank(self.group), dist.get_world_size(self.group)
         return 0, 1
 
-    def run(self, coords, radii, fe_radius_index=0, want_nn=True):
+    def neighbour_merge(self):
+        """"allgather" (position-ordered blocks; needs a backend with pack_neighbor_block) or "allreduce" (packed
+        (d2, index) words, minimum); DC_NN_MERGE overrides"""
+        import os
+        want = os.environ.get("DC_NN_MERGE", "allgather")
+        if want == "allgather" and hasattr(self.backend, "pack_neighbor_block"):
+            return "allgather"
+        return "allreduce"
+
+    def neighbour_merge_name(self):
+        if self.neighbour_merge() == "allgather":
+            return "all-gather of position-ordered neighbour blocks [4][block_rows] per rank"
+        return "all-reduce(min) of the packed (d2, index) neighbour words"
+
+    def run(self, coords, radii, fe_radius_index=0, want_nn=True, mark=None):
         """coords: [N, D] float32 on this rank's device (replicated).  Returns a dict of tensors on
         that device: pops int32 [n_radii, N], fe float32 [N], and if want_nn nn_idx/hd_idx int32 [N],
-        nn_d2/hd_d2 float32 [N] -- identical on every rank."""
+        nn_d2/hd_d2 float32 [N] -- identical on every rank.  mark(name), if given, is called at the start and
+        after every phase: "start", "pop", "pops_allreduce", "fe", "nn", "nn_merge" (bench.py records events)."""
+        mark = mark or (lambda name: None)
         rank, world = self._world()
         n_rows = coords.shape[0]
         lo, hi = shard_rows(n_rows, world, rank)
         segments = world > 1 and hasattr(self.backend, "populations_segment")
+        mark("start")
         if segments:
             pops = self.backend.populations_segment(coords, radii, rank, world)
         else:
             pops = self.backend.populations_partial(coords, radii, lo, hi)
+        mark("pop")
         if world > 1:
             dist.all_reduce(pops, op=dist.ReduceOp.SUM, group=self.group)
+        mark("pops_allreduce")
         fe = self.backend.free_energies(pops[fe_radius_index].contiguous())
+        mark("fe")
         out = {"pops": pops, "fe": fe}
         if not want_nn:
             return out
+        # the neighbour sweep runs over the coordinates the population sweep just went through: its statistics
+        # passes (column means, max norm, bounding box) are skipped (DC_FLAG_STATS_VALID)
+        kw = {"stats_valid": True} if getattr(self.backend, "accepts_stats_valid", False) else {}
         if segments:
-            nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.nearest_neighbors_segment(coords, fe, rank, world)
-            # (d2 bits << 32 | index): d2 >= 0, so the words order like (d2, index); one owner per row
-            if hasattr(self.backend, "pack_neighbors"):     # two library kernels instead of a dozen torch ops
-                packed = self.backend.pack_neighbors(nn_idx, nn_d2, hd_idx, hd_d2)
+            nn = self.backend.nearest_neighbors_segment(coords, fe, rank, world, **kw)
+            mark("nn")
+            if self.neighbour_merge() == "allgather":
+                block = self.backend.pack_neighbor_block(coords, nn, rank, world)
+                gathered = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
+                dist.all_gather_into_tensor(gathered.view(-1), block.view(-1), group=self.group)
+                nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.unpack_neighbor_blocks(coords, gathered, world)
+            elif hasattr(self.backend, "pack_neighbors"):     # two library kernels instead of a dozen torch ops
+                # (d2 bits << 32 | index): d2 >= 0, so the words order like (d2, index); one owner per row
+                packed = self.backend.pack_neighbors(*nn)
                 dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=self.group)
                 nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.unpack_neighbors(packed)
             else:
+                nn_idx, nn_d2, hd_idx, hd_d2 = nn
                 packed = torch.empty((2, n_rows), dtype=torch.int64, device=coords.device)
                 packed[0] = (nn_d2.view(torch.int32).to(torch.int64) << 32) | (nn_idx.to(torch.int64) & 0xFFFFFFFF)
                 packed[1] = (hd_d2.view(torch.int32).to(torch.int64) << 32) | (hd_idx.to(torch.int64) & 0xFFFFFFFF)
@@ -109,9 +153,11 @@ class ShardedDensity:
                 hd_idx = (packed[1] & 0xFFFFFFFF).to(torch.int32)
                 nn_d2 = (packed[0] >> 32).to(torch.int32).view(torch.float32)
                 hd_d2 = (packed[1] >> 32).to(torch.int32).view(torch.float32)
+            mark("nn_merge")
             out.update(nn_idx=nn_idx, nn_d2=nn_d2, hd_idx=hd_idx, hd_d2=hd_d2)
             return out
-        nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.nearest_neighbors_partial(coords, fe, lo, hi)
+        nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.nearest_neighbors_partial(coords, fe, lo, hi, **kw)
+        mark("nn")
         if world > 1:
             block = n_rows - (world - 1) * (n_rows // world)        # largest shard (the last one)
             send = torch.zeros((4, block), dtype=torch.int32, device=coords.device)
@@ -127,6 +173,7 @@ class ShardedDensity:
                 nn_d2[glo:ghi] = recv[g, 1, :ghi - glo].view(torch.float32)
                 hd_idx[glo:ghi] = recv[g, 2, :ghi - glo]
                 hd_d2[glo:ghi] = recv[g, 3, :ghi - glo].view(torch.float32)
+        mark("nn_merge")
         out.update(nn_idx=nn_idx, nn_d2=nn_d2, hd_idx=hd_idx, hd_d2=hd_d2)
         return out
 

@@ -191,6 +191,26 @@ DC_API int dc_hip_neighbors_unpack_dev(const unsigned long long* d_words, size_t
                                        uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
                                        float* d_hd_d2, void* stream);
 
+/* The same merge as an ALL-GATHER (half the bytes, no reduction): every rank compacts the results of its own
+ * segment's rows into a dense block [4][block_rows] uint32 (nn_idx, nn_d2 bits, hd_idx, hd_d2 bits, by local
+ * position in the segment; pad entries hold the "none" value), the blocks of all ranks are gathered into
+ * [n_segments][4][block_rows], and the gathered blocks are scattered back to the four arrays by frame.
+ * With the pruned matrix-core sweep a segment is every n_segments-th query group of the sweep's spatial order,
+ * which every rank derives identically from the replicated coordinates and free energies: pack and unpack read
+ * the ordering that dc_hip_nearest_neighbors_segment_dev left in THIS rank's workspace (same n_rows, n_cols,
+ * variant; no other sweep in between).  Otherwise (other variants, n_cols > 64, flagged data) the blocks are the
+ * reference's row blocks (density_clustering_cuda.cu:293, 305-308, 311-326). */
+DC_API size_t dc_hip_neighbors_block_rows(size_t n_rows, size_t n_cols, size_t n_segments);
+DC_API int dc_hip_neighbors_block_pack_dev(const uint32_t* d_nn_idx, const float* d_nn_d2,
+                                           const uint32_t* d_hd_idx, const float* d_hd_d2, size_t n_rows,
+                                           size_t n_cols, size_t segment, size_t n_segments,
+                                           const void* d_workspace, size_t workspace_bytes, int variant,
+                                           uint32_t* d_block, void* stream);
+DC_API int dc_hip_neighbors_block_unpack_dev(const uint32_t* d_blocks, size_t n_rows, size_t n_cols,
+                                             size_t n_segments, const void* d_workspace,
+                                             size_t workspace_bytes, int variant, uint32_t* d_nn_idx,
+                                             float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2, void* stream);
+
 /* replaces Clustering::Density::compute_sigma2 (density_clustering.cpp:334-343): mean of the nearest-
  * neighbour d2 accumulated in double IN FRAME ORDER (bit-stable), on the device (one block, fixed
  * reduction tree would change bits -- so this is a single ordered pass over a device->host copy).

@@ -53,6 +53,34 @@ class SegmentOracleBackend(OracleBackend):
                 torch.where(mask, c, none_i), torch.where(mask, d, none_d))
 
 
+class BlockSegmentOracleBackend(SegmentOracleBackend):
+    """... and the block interface of the HIP backend, so that ShardedDensity takes its all-gather merge: the rows of
+    segment g compacted into a dense block [4][ceil(N/G)] by LOCAL position (local l of segment g = frame l*G + g --
+    the stand-in for "position in the sweep's spatial order"), gathered, scattered back to frame order."""
+
+    @staticmethod
+    def _rows(n, n_segments):
+        return (n + n_segments - 1) // n_segments
+
+    def pack_neighbor_block(self, coords, nn, segment, n_segments):
+        n = coords.shape[0]
+        rows = self._rows(n, n_segments)
+        block = torch.empty((4, rows), dtype=torch.int32)
+        block[0::2] = n + 1
+        block[1::2] = torch.tensor(np.float32(np.finfo(np.float32).max)).view(torch.int32)
+        own = torch.arange(segment, n, n_segments)
+        for c, t in enumerate(nn):
+            block[c, :own.numel()] = t[own].view(torch.int32)
+        return block
+
+    def unpack_neighbor_blocks(self, coords, blocks, n_segments):
+        n = coords.shape[0]
+        frames = torch.arange(n)
+        g, l = frames % n_segments, frames // n_segments
+        cols = [blocks[g, c, l] for c in range(4)]
+        return cols[0], cols[1].view(torch.float32), cols[2], cols[3].view(torch.float32)
+
+
 class MinEdgeOracleBackend:
     """dc_hip_radius_min_edge_segment_dev restated with the oracle's pairwise d2: segment g of G sees the
     pairs from the query rows i with i % G == g."""
@@ -149,18 +177,25 @@ def _worker(rank, world, port, n_rows, out_dir, segments=False):
     try:
         from clustering_amd.distributed import ShardedDensity
         coords = torch.from_numpy(gaussian_blobs(n_rows, 5, seed=99))
-        backend = SegmentOracleBackend() if segments else OracleBackend()
-        out = ShardedDensity(backend).run(coords, [0.1, 0.2], fe_radius_index=1, want_nn=True)
+        backend = {False: OracleBackend, True: SegmentOracleBackend, "blocks": BlockSegmentOracleBackend}[segments]()
+        job = ShardedDensity(backend)
+        if world > 1:
+            assert job.neighbour_merge() == ("allgather" if segments == "blocks" else "allreduce")
+        phases = []
+        out = job.run(coords, [0.1, 0.2], fe_radius_index=1, want_nn=True, mark=phases.append)
+        assert phases == ["start", "pop", "pops_allreduce", "fe", "nn", "nn_merge"]
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,n_rows,segments", [(2, 1001, False), (2, 64, False), (3, 500, False),
-                                                   (2, 777, True), (3, 500, True)])
+                                                   (2, 777, True), (3, 500, True), (2, 777, "blocks"),
+                                                   (3, 500, "blocks"), (3, 2, "blocks")])
 def test_sharded_density_matches_single_process(tmp_path, oracle, world, n_rows, segments):
-    """row blocks + all-gather (segments=False) and scattered segments + all-reduce(min) of the packed
-    (d2, index) words (segments=True: the path the HIP backend takes)"""
+    """row blocks + all-gather (segments=False), scattered segments + all-reduce(min) of the packed (d2, index)
+    words (segments=True) and scattered segments + all-gather of position-ordered blocks (segments="blocks": the
+    path the HIP backend takes)"""
     mp.spawn(_worker, args=(world, _free_port(), n_rows, str(tmp_path), segments), nprocs=world, join=True)
     c = gaussian_blobs(n_rows, 5, seed=99)
     pops = oracle.populations(c, [0.1, 0.2])

@@ -493,10 +493,13 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
     acc_p = torch.zeros_like(full_p)
     words = None
     owned = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+    blocks = []
     for g in range(n_seg):
         p = dens.calculate_populations_segment(ct, radii, g, n_seg)   # partial counts (the symmetric sweep: of all rows)
         acc_p += p
-        a, b, cc, d = dens.nearest_neighbors_segment(ct, fe, g, n_seg)
+        # (the second call of a populations -> neighbours pair over one array: DC_FLAG_STATS_VALID)
+        a, b, cc, d = dens.nearest_neighbors_segment(ct, fe, g, n_seg, stats_valid=True)
+        blocks.append(dens.pack_neighbor_block(ct, a, b, cc, d, g, n_seg))    # dc_hip_neighbors_block_pack_dev
         owned += (a <= n_rows).to(torch.int32) if n_rows > 1 else 1    # rows of other segments hold (n_rows + 1, FLT_MAX)
         w = torch.stack([(b.view(torch.int32).to(torch.int64) << 32) | (a.to(torch.int64) & 0xFFFFFFFF),
                          (d.view(torch.int32).to(torch.int64) << 32) | (cc.to(torch.int64) & 0xFFFFFFFF)])
@@ -510,6 +513,13 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
     assert bool(((words[1] >> 32).to(torch.int32) == full_n[3].view(torch.int32)).all())
     for got, want in zip(dens.unpack_neighbors(words.contiguous()), full_n):   # dc_hip_neighbors_unpack_dev
         assert bool((got.view(torch.int32) == want.view(torch.int32)).all())
+    # the all-gather merge: the segments' dense blocks, stacked as an all_gather_into_tensor would, scattered back
+    rows = dens.neighbor_block_rows(n_rows, n_cols, n_seg)
+    assert all(tuple(b.shape) == (4, rows) for b in blocks) and n_seg * rows >= n_rows
+    live = sum(int((b[0] <= n_rows).sum()) for b in blocks) if n_rows > 1 else n_rows
+    assert live == n_rows, "every row sits in exactly one block"
+    for got, want in zip(dens.unpack_neighbor_blocks(ct, torch.stack(blocks).contiguous(), n_seg), full_n):
+        assert bool((got.view(torch.int32) == want.view(torch.int32)).all())   # dc_hip_neighbors_block_unpack_dev
 
 
 SHARED_CHILD = r"""
@@ -728,3 +738,43 @@ def test_degenerate_inputs_pruned_equals_direct(dens):
         for p, q in zip(dens.nearest_neighbors_partial(ct, fe, variant="pruned"),
                         dens.nearest_neighbors_partial(ct, fe, variant="direct")):
             assert bool((p.view(torch.int32) == q.view(torch.int32)).all()), name
+
+
+@pytest.mark.gpu
+def test_stats_valid_flag_is_checked_on_the_device(dens, oracle):
+    """DC_FLAG_STATS_VALID: the neighbour call of a populations -> neighbours pair over ONE array skips the three
+    statistics passes and gives the same bits; claimed for an array whose statistics the workspace does NOT hold
+    (another array of the same shape went through last, or a direct-variant call that left no statistics) the cookie
+    check on the device flags the sweep and the direct kernels answer: slower, never different."""
+    import torch
+    n, d = 6000, 10
+    c1 = gaussian_blobs(n, d, seed=41)
+    c2 = (gaussian_blobs(n, d, seed=42) * 37.0 + 5.0).astype(np.float32)     # other scale: stale statistics would hurt
+    t1, t2 = torch.from_numpy(c1).cuda(), torch.from_numpy(c2).cuda()
+
+    def reference(c):
+        pops = oracle.populations(c, [0.2 if c is c1 else 7.0])
+        fe = oracle.free_energies(pops[0])
+        return pops, fe, oracle.nearest_neighbors(c, fe)
+
+    def same(nn, exp):
+        g = [t.cpu().numpy() for t in nn]
+        return ((g[0].astype(np.uint32).astype(np.uint64) == exp[0]).all() and (g[2].astype(np.uint32).astype(np.uint64) == exp[2]).all()
+                and (bits(g[1]) == bits(exp[1])).all() and (bits(g[3]) == bits(exp[3])).all())
+
+    p1, fe1, nn1 = reference(c1)
+    p2, fe2, nn2 = reference(c2)
+    f1, f2 = torch.from_numpy(fe1).cuda(), torch.from_numpy(fe2).cuda()
+    # the legitimate pair
+    got = dens.calculate_populations_partial(t1, [0.2])
+    assert (got.cpu().numpy().astype(np.uint32).astype(np.uint64) == p1).all()
+    assert same(dens.nearest_neighbors_partial(t1, f1, stats_valid=True), nn1)
+    assert dens.evaluated_tiles(t1.device)[1] > 0                      # the pruned matrix-core sweep ran
+    # a false claim: the workspace holds the statistics of c1, the call is about c2
+    assert same(dens.nearest_neighbors_partial(t2, f2, stats_valid=True), nn2)
+    assert dens.evaluated_tiles(t2.device)[1] == 0                     # flagged on the device: the direct kernel answered
+    assert (dens.calculate_populations_partial(t2, [7.0], stats_valid=True).cpu().numpy().astype(np.uint32).astype(np.uint64) == p2).all()
+    # ... and after a direct-variant call (no statistics at all in the header)
+    dens.calculate_populations_partial(t2, [7.0])                      # (fresh statistics of c2)
+    assert same(dens.nearest_neighbors_partial(t2, f2, stats_valid=True), nn2)
+    assert dens.evaluated_tiles(t2.device)[1] > 0
