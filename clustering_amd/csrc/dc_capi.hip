@@ -137,6 +137,17 @@ size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radii) {
   return dc::mfma_workspace_bytes(n_rows, n_cols);
 }
 
+int dc_hip_workspace_components_dev(const void* d_workspace, size_t n_rows, size_t n_cols, uint32_t* n_components,
+                                    float* extent2_global, float* extent2_local, float* scale, void* stream) {
+  if (!d_workspace || !n_components || !extent2_global || !extent2_local || !scale)
+    return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  if (!dc::mfma_supports(n_cols)) return fail(DC_ERR_INVALID_ARGUMENT, "no matrix-core sweep for n_cols=%zu", n_cols);
+  if (dc::components_info(d_workspace, n_rows, n_cols, n_components, extent2_global, extent2_local, scale,
+                          (hipStream_t)stream) != 0)
+    return fail(DC_ERR_HIP, "reading the workspace header failed");
+  return DC_OK;
+}
+
 int dc_hip_sweep_timing(int enable) {
   dc::sweep_timer_enable(enable != 0);
   return DC_OK;

@@ -3,6 +3,7 @@
 #include "dc_mfma_kernels.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <mutex>
 
@@ -74,7 +75,7 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   const uint32_t Dp = D | 1u;
   const size_t total = (size_t)n_rows * D;
   const uint32_t n_chunks = (n_rows + 255) / 256;
-  uint32_t m_norm = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  uint32_t m_norm = 0, m_rest = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
   bool bad = false;
   // chunks of 256 rows, grid-stride: the block publishes its five extrema once at the end
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -93,10 +94,17 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
       const float v = x[k] - means[k];
       nrm += (double)v * (double)v;
     }
+    double rest = nrm;   // (columns >= 2: the exact sum minus the exact squares of the first two)
+    for (uint32_t k = 0; k < min(D, 2u); ++k) {
+      const float v = x[k] - means[k];
+      rest -= (double)v * (double)v;
+    }
+    rest = fmax(rest, 0.0);
     const float nf = (float)nrm;
     const bool ok = live && (nf <= kNormLimit);
     bad = bad | (live && !ok);   // NaN / inf / overflow-prone row: MFMA kernels stand down
     m_norm = max(m_norm, ok ? __float_as_uint(nf) : 0u);
+    m_rest = max(m_rest, ok ? __float_as_uint(next_up(next_up((float)rest))) : 0u);   // (columns >= 2: the part no component origin moves)
     const float c0 = x[0], c1 = (D > 1) ? x[1] : 0.0f;
     const bool fin = live && (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
     m0 = max(m0, fin ? ~fkey(c0) : 0u);
@@ -107,6 +115,7 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   if (bad) atomicOr(hdr + 1, 1u);
   if (threadIdx.x == 0) hdr[kHdrCookie] = cookie;   // whose statistics these are (DC_FLAG_STATS_VALID is checked against it)
   publish_max(hdr, m_norm, wave_max);
+  publish_max(hdr + kHdrMrest, m_rest, wave_max);
   publish_max(hdr + 8, m0, wave_max);
   publish_max(hdr + 9, m1, wave_max);
   publish_max(hdr + 10, m2, wave_max);
@@ -130,7 +139,12 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
                              uint32_t D, uint32_t NM, uint32_t T, const float* __restrict__ means,
                              const uint32_t* __restrict__ perm, int b_form, uint4* __restrict__ img,
                              float* __restrict__ norms, const uint32_t* __restrict__ hdr,
-                             uint32_t grp_tq = 1, QSeg grp = QSeg{1u, 0u}) {
+                             uint32_t grp_tq = 1, QSeg grp = QSeg{1u, 0u},
+                             const uint32_t* __restrict__ tile_comp = nullptr,
+                             const float* __restrict__ origins = nullptr,
+                             const uint32_t* __restrict__ valid = nullptr) {
+  // tile_comp / origins: the origin of tile t is origins[tile_comp[t]][.] instead of the column means (the components
+  // of the pruned population sweeps); valid: frame of every row of the order, kInvalidFrame for its pad rows
   // n_total: frames in the data set (divisor of the centring mean); n_rows: rows of this image.
   // (A variant that decodes the 16 slots of a block once into LDS was measured slower: the column
   //  loads then hang on the table look-ups instead of being issued together.)
@@ -142,8 +156,12 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   const uint32_t t = ((tc / grp_tq) * grp.stride + grp.offset) * grp_tq + tc % grp_tq;
   if (t >= T) return;
   const uint32_t row = 32 * t + (lane & 31), h = lane >> 5;
-  const bool live = row < n_rows;
-  const uint32_t src = live ? (perm ? perm[row] : row) : 0u;
+  bool live = row < n_rows;
+  uint32_t src = live ? (perm ? perm[row] : row) : 0u;
+  if (live && perm && src == kInvalidFrame) live = false;
+  if (live && valid && valid[row] == kInvalidFrame) live = false;
+  src = live ? src : 0u;
+  if (tile_comp) means = origins + (size_t)tile_comp[t] * kMaxCols;
   const float* x = coords + (size_t)src * D;
   const Scale sc = load_scale(hdr);   // (the sweep's scale: scale_kernel ran before)
   const float s1 = b_form ? sc.sb : sc.sa;
@@ -193,8 +211,15 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
 // the scale of the sweep that follows (dc_mfma_kernels.hpp "scale of a SWEEP") -> header words 20..24, read by
 // the image builder and by the kernels.  r2max < 0: the neighbour rule; otherwise the population rule for
 // a call whose largest squared radius is r2max.
-__global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D) {
-  const float M = __uint_as_float(hdr[0]);   // (final: rowstats_kernel ran before)
+__global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D,
+                             const uint32_t* __restrict__ comp = nullptr) {
+  float M = __uint_as_float(hdr[0]);   // (final: rowstats_kernel ran before)
+  // several components (pruned population sweeps): every row is measured from its component's origin -- the far
+  // corner of its tile's box in columns 0/1 (box_rows_kernel) plus the bound of the other columns (rowstats_kernel)
+  if (comp && comp[kCompGrid + 5] > 1u) {
+    const float a = __uint_as_float(hdr[kHdrMloc]), b = __uint_as_float(hdr[kHdrMrest]);
+    M = fminf(next_up(a + b), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);   // (never more than the triangle bound on the global extent)
+  }
   const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
   hdr[kHdrScale + 0] = __float_as_uint(e.c);
   hdr[kHdrScale + 1] = __float_as_uint(e.s2);
@@ -350,6 +375,339 @@ __global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t D,
   keys[j] = bx * nby + by;   // < 4002 * 4003 < 2^24
 }
 
+
+// ---- components of the pruned population sweeps (dc_mfma_kernels.hpp "components") -------------------------------
+struct CoarseGrid {
+  float gc, min0, min1;
+  uint32_t ncx, ncy;
+};
+// coarse occupancy grid over the bounding box of columns 0/1: cells of a quarter of the largest radius, at most
+// kCoarseDim per dimension
+__device__ __forceinline__ CoarseGrid coarse_grid(const uint32_t* __restrict__ hdr, float r_max) {
+  CoarseGrid g;
+  g.min0 = fkey_inv(~hdr[8]);
+  g.min1 = fkey_inv(~hdr[10]);
+  float e0 = fkey_inv(hdr[9]) - g.min0, e1 = fkey_inv(hdr[11]) - g.min1;
+  if (!(e0 >= 0.0f) || !(e0 <= FLT_MAX)) e0 = 0.0f;
+  if (!(e1 >= 0.0f) || !(e1 <= FLT_MAX)) e1 = 0.0f;
+  if (!(fabsf(g.min0) <= FLT_MAX)) g.min0 = 0.0f;
+  if (!(fabsf(g.min1) <= FLT_MAX)) g.min1 = 0.0f;
+  const float quarter = (r_max <= FLT_MAX) ? 0.25f * r_max : FLT_MAX;
+  g.gc = fmaxf(quarter, fmaxf(e0, e1) / (float)(kCoarseDim - 1));
+  if (!(g.gc > 0.0f)) g.gc = 1.0f;
+  g.ncx = min((uint32_t)fminf(e0 / g.gc, (float)kCoarseDim) + 1u, (uint32_t)kCoarseDim);
+  g.ncy = min((uint32_t)fminf(e1 / g.gc, (float)kCoarseDim) + 1u, (uint32_t)kCoarseDim);
+  return g;
+}
+__device__ __forceinline__ uint32_t coarse_cell(const CoarseGrid& g, float x, float y) {
+  // (NaN: fminf / fmaxf return the other operand -> cell 0)
+  const uint32_t cx = (uint32_t)fminf(fmaxf((x - g.min0) / g.gc, 0.0f), (float)(g.ncx - 1));
+  const uint32_t cy = (uint32_t)fminf(fmaxf((y - g.min1) / g.gc, 0.0f), (float)(g.ncy - 1));
+  return cx * g.ncy + cy;
+}
+
+// occupancy bitmap of the sub-cells (kFineSub x kFineSub per coarse cell): plain byte stores, no atomics
+__global__ void fine_mark_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
+                                 const uint32_t* __restrict__ hdr, float r_max, uint32_t* __restrict__ comp) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
+  if (!(fabsf(x) <= FLT_MAX) || !(fabsf(y) <= FLT_MAX)) return;   // (flagged data: the sweep stands down anyway)
+  const CoarseGrid g = coarse_grid(hdr, r_max);
+  const float gf = g.gc / (float)kFineSub;
+  const uint32_t fx = (uint32_t)fminf(fmaxf((x - g.min0) / gf, 0.0f), (float)(g.ncx * kFineSub - 1));
+  const uint32_t fy = (uint32_t)fminf(fmaxf((y - g.min1) / gf, 0.0f), (float)(g.ncy * kFineSub - 1));
+  reinterpret_cast<unsigned char*>(comp + kCompBitmap)[(size_t)fx * (kCoarseDim * kFineSub) + fy] = 1;
+}
+
+// box of the occupied sub-cells of every coarse cell (a little wider than the sub-cells: every frame of the cell lies
+// inside whatever the rounding of its sub-cell index did); lo0 > hi0 marks an empty cell.  NB: a frame is assigned to
+// the COARSE cell of its sub-cell (fx / kFineSub), see comp_of_point.
+__global__ void coarse_box_kernel(const uint32_t* __restrict__ hdr, float r_max, uint32_t* __restrict__ comp) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const CoarseGrid g = coarse_grid(hdr, r_max);
+  if (c >= g.ncx * g.ncy) return;
+  const uint32_t cx = c / g.ncy, cy = c % g.ncy;
+  const unsigned char* bm = reinterpret_cast<const unsigned char*>(comp + kCompBitmap);
+  int x0 = kFineSub, x1 = -1, y0 = kFineSub, y1 = -1;
+  for (int sx = 0; sx < kFineSub; ++sx)
+    for (int sy = 0; sy < kFineSub; ++sy)
+      if (bm[(size_t)(cx * kFineSub + sx) * (kCoarseDim * kFineSub) + (cy * kFineSub + sy)]) {
+        x0 = min(x0, sx);
+        x1 = max(x1, sx);
+        y0 = min(y0, sy);
+        y1 = max(y1, sy);
+      }
+  float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+  if (x1 >= 0) {
+    const float gf = g.gc / (float)kFineSub, slack = 1.0e-3f * gf;
+    box.x = g.min0 + (float)(cx * kFineSub + x0) * gf - slack;
+    box.y = g.min0 + (float)(cx * kFineSub + x1 + 1) * gf + slack;
+    box.z = g.min1 + (float)(cy * kFineSub + y0) * gf - slack;
+    box.w = g.min1 + (float)(cy * kFineSub + y1 + 1) * gf + slack;
+  }
+  reinterpret_cast<float4*>(comp + kCompCellBox)[c] = box;
+}
+
+__device__ __forceinline__ float4 cell_box(const uint32_t* __restrict__ comp, uint32_t cell) {
+  return reinterpret_cast<const float4*>(comp + kCompCellBox)[cell];
+}
+// coarse cell of a point, through its sub-cell (the same arithmetic as fine_mark_kernel)
+__device__ __forceinline__ uint32_t coarse_cell_of_point(const CoarseGrid& g, float x, float y) {
+  const float gf = g.gc / (float)kFineSub;
+  const uint32_t fx = (uint32_t)fminf(fmaxf((x - g.min0) / gf, 0.0f), (float)(g.ncx * kFineSub - 1));
+  const uint32_t fy = (uint32_t)fminf(fmaxf((y - g.min1) / gf, 0.0f), (float)(g.ncy * kFineSub - 1));
+  return (fx / kFineSub) * g.ncy + (fy / kFineSub);
+}
+
+// Labels the occupied coarse cells (one workgroup): cells whose point boxes are closer than r_max are connected --
+// two frames closer than r_max in the (col 0, col 1) plane then always share a component, so frames of DIFFERENT
+// components are at least r_max apart in full dimension as well.  Minimum-label propagation over the (2R + 1)^2
+// neighbourhood with pointer jumping; labels are cell indices (the result does not depend on the order in which the
+// cells were listed).  Writes the component of every cell, the components' origins and fine cell grids.
+__global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __restrict__ hdr,
+                                                          const float* __restrict__ means, uint32_t D,
+                                                          float r_max, uint32_t n_rows, float frames_per_cell,
+                                                          uint32_t fine_bits, uint32_t* __restrict__ comp,
+                                                          int force_single) {
+  __shared__ uint32_t occ[kMaxOccupied], label[kMaxOccupied];
+  __shared__ float4 obox[kMaxOccupied];
+  __shared__ uint32_t n_occ_s, changed_s, n_comp_s;
+  __shared__ uint32_t root_cell[kMaxComp];
+  __shared__ uint32_t cbox[kMaxComp][4];
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const CoarseGrid g = coarse_grid(hdr, r_max);
+  const uint32_t n_cells = g.ncx * g.ncy;
+  uint32_t* cell_comp = comp + kCompCellComp;   // during the labelling: cell -> index in occ[] (0xFFFFFFFF: empty)
+  if (tid == 0) {
+    n_occ_s = 0;
+    n_comp_s = 0;
+  }
+  __syncthreads();
+  for (uint32_t c = tid; c < n_cells; c += nt) {
+    uint32_t idx = 0xFFFFFFFFu;
+    const float4 bx = cell_box(comp, c);
+    if (bx.x <= bx.y) {
+      idx = atomicAdd(&n_occ_s, 1u);
+      if (idx < (uint32_t)kMaxOccupied) {
+        occ[idx] = c;
+        obox[idx] = bx;
+      }
+    }
+    cell_comp[c] = idx;
+  }
+  __syncthreads();
+  const uint32_t n_occ = n_occ_s;
+  bool single = force_single != 0 || n_occ > (uint32_t)kMaxOccupied || n_occ <= 1u || !(r_max <= FLT_MAX);
+  const float r2c = r_max * r_max * 1.0002f;
+  if (!single) {
+    const int R = min((int)ceilf(r_max / g.gc) + 1, kCoarseDim);
+    for (uint32_t i = tid; i < n_occ; i += nt) label[i] = occ[i];
+    __syncthreads();
+    int iter = 0;
+    for (;; ++iter) {
+      if (tid == 0) changed_s = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < n_occ; i += nt) {
+        const uint32_t c = occ[i];
+        const int cx = (int)(c / g.ncy), cy = (int)(c % g.ncy);
+        const float4 bi = obox[i];
+        uint32_t m = label[i];
+        for (int dx = -R; dx <= R; ++dx) {
+          const int nx = cx + dx;
+          if (nx < 0 || nx >= (int)g.ncx) continue;
+          for (int dy = -R; dy <= R; ++dy) {
+            const int ny = cy + dy;
+            if (ny < 0 || ny >= (int)g.ncy) continue;
+            const uint32_t nc = (uint32_t)nx * g.ncy + (uint32_t)ny;
+            const uint32_t j = cell_comp[nc];
+            if (j == 0xFFFFFFFFu || j >= n_occ) continue;
+            if (box_gap2(bi, obox[j]) <= r2c) m = min(m, label[j]);
+          }
+        }
+        if (m < label[i]) {
+          atomicMin(&label[i], m);
+          changed_s = 1;
+        }
+      }
+      __syncthreads();
+      // pointer jumping: the label of my label's cell
+      for (int hop = 0; hop < 4; ++hop) {
+        for (uint32_t i = tid; i < n_occ; i += nt) {
+          const uint32_t l = label[cell_comp[label[i]]];
+          if (l < label[i]) {
+            atomicMin(&label[i], l);
+            changed_s = 1;
+          }
+        }
+        __syncthreads();
+      }
+      const uint32_t ch = changed_s;
+      __syncthreads();
+      if (ch == 0 || iter >= 128) break;
+    }
+    if (iter >= 128) single = true;   // (not settled: one component is always right)
+  }
+  if (!single) {
+    // roots = cells that are their own label; component id = rank of the root's cell index
+    for (uint32_t i = tid; i < n_occ; i += nt)
+      if (label[i] == occ[i]) {
+        const uint32_t k = atomicAdd(&n_comp_s, 1u);
+        if (k < (uint32_t)kMaxComp) root_cell[k] = occ[i];
+      }
+    __syncthreads();
+    if (n_comp_s > (uint32_t)kMaxComp || n_comp_s <= 1u) single = true;
+  }
+  __syncthreads();
+  uint32_t n_comp = single ? 1u : n_comp_s;
+  if (tid < (uint32_t)kMaxComp) {
+    cbox[tid][0] = 0;
+    cbox[tid][1] = 0;
+    cbox[tid][2] = 0;
+    cbox[tid][3] = 0;
+  }
+  __syncthreads();
+  if (single) {
+    for (uint32_t c = tid; c < n_cells; c += nt) cell_comp[c] = 0u;
+  } else {
+    // (sort the few roots by cell index: id = number of roots with a smaller index)
+    for (uint32_t i = tid; i < n_occ; i += nt) {
+      const uint32_t root = label[i];
+      uint32_t id = 0;
+      for (uint32_t k = 0; k < n_comp; ++k) id += (root_cell[k] < root) ? 1u : 0u;
+      label[i] = id;
+      const float4 bx = obox[i];
+      atomicMax(&cbox[id][0], ~fkey(bx.x));
+      atomicMax(&cbox[id][1], fkey(bx.y));
+      atomicMax(&cbox[id][2], ~fkey(bx.z));
+      atomicMax(&cbox[id][3], fkey(bx.w));
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < n_cells; c += nt) cell_comp[c] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < n_occ; i += nt) cell_comp[occ[i]] = label[i];
+  }
+  __syncthreads();
+  // origins and fine grids
+  const float gmin0 = fkey_inv(~hdr[8]), gmax0 = fkey_inv(hdr[9]), gmin1 = fkey_inv(~hdr[10]), gmax1 = fkey_inv(hdr[11]);
+  float cell = auto_cell(hdr, n_rows, frames_per_cell);
+  if (!single) {
+    // sparse data: the frames cover a small part of the bounding box -- size the fine cells by the occupied area (x 8:
+    // what the blobs of the reference workload cover of theirs), so that the cells do not grow with the empty space
+    const double a_box = (double)fmaxf(gmax0 - gmin0, 0.0f) * (double)fmaxf(gmax1 - gmin1, 0.0f);
+    const double a_occ = 8.0 * (double)n_occ * (double)g.gc * (double)g.gc;
+    if (a_occ > 0.0 && a_occ < a_box)
+      cell = (float)sqrt(a_occ * (double)frames_per_cell / (double)(n_rows ? n_rows : 1u));
+  }
+  const float cells_max = ldexpf(1.0f, (int)fine_bits) * 0.5f;   // (x + 1)(y + 1) must stay below 2^fine_bits
+  if (tid < n_comp) {
+    const float lo0 = single ? gmin0 : fkey_inv(~cbox[tid][0]), hi0 = single ? gmax0 : fkey_inv(cbox[tid][1]);
+    const float lo1 = single ? gmin1 : fkey_inv(~cbox[tid][2]), hi1 = single ? gmax1 : fkey_inv(cbox[tid][3]);
+    float* a = reinterpret_cast<float*>(comp + kCompOrigin) + (size_t)tid * kMaxCols;
+    for (uint32_t k = 0; k < D; ++k) a[k] = means[k];
+    if (!single) {
+      a[0] = 0.5f * lo0 + 0.5f * hi0;
+      if (D > 1) a[1] = 0.5f * lo1 + 0.5f * hi1;
+    }
+    const float e0 = fmaxf(hi0 - lo0, 0.0f), e1 = fmaxf(hi1 - lo1, 0.0f);
+    float c0 = fmaxf(cell, e0 / 4000.0f), c1 = fmaxf(cell, e1 / 4000.0f);
+    if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
+    if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
+    // (a long thin component inside a sparse data set: never more cells than the key has bits for)
+    float nx = fminf(e0 / c0, 4001.0f) + 1.0f, ny = fminf(e1 / c1, 4001.0f) + 1.0f;
+    if (nx * ny > cells_max) {
+      const float f = sqrtf(nx * ny / cells_max) * 1.01f;
+      c0 *= f;
+      c1 *= f;
+      nx = fminf(e0 / c0, 4001.0f) + 1.0f;
+      ny = fminf(e1 / c1, 4001.0f) + 1.0f;
+    }
+    uint32_t* f = comp + kCompFine + 4 * (size_t)tid;
+    f[0] = __float_as_uint((fabsf(lo0) <= FLT_MAX) ? lo0 : 0.0f);
+    f[1] = __float_as_uint((fabsf(lo1) <= FLT_MAX) ? lo1 : 0.0f);
+    f[2] = __float_as_uint(c0);
+    f[3] = __float_as_uint(c1);
+    comp[kCompNby + tid] = (uint32_t)ny;
+  }
+  if (tid == 0) {
+    comp[kCompGrid + 0] = __float_as_uint(g.gc);
+    comp[kCompGrid + 3] = g.ncx;
+    comp[kCompGrid + 4] = g.ncy;
+    comp[kCompGrid + 5] = n_comp;
+  }
+}
+
+// ordering key of the pruned population sweeps: (component, cell of the component's fine grid on columns 0/1) for
+// the rows [i_from, i_to): keys[j], vals[j] = key, id of row i_from + j
+__global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ hdr,
+                               float r_max, const uint32_t* __restrict__ comp, uint32_t fine_bits, uint32_t i_from,
+                               uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = i_from + j;
+  if (i >= i_to) return;
+  const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
+  const CoarseGrid g = coarse_grid(hdr, r_max);
+  uint32_t c = 0, bx = 0, by = 0, nby = 1;
+  if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
+    c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
+    const uint32_t* f = comp + kCompFine + 4 * (size_t)c;
+    const float lo0 = __uint_as_float(f[0]), lo1 = __uint_as_float(f[1]);
+    const float c0 = __uint_as_float(f[2]), c1 = __uint_as_float(f[3]);
+    nby = comp[kCompNby + c];
+    bx = (uint32_t)fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f);
+    by = min((uint32_t)fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f), nby - 1u);
+  }
+  const uint32_t fine = min(bx * nby + by, (1u << fine_bits) - 1u);
+  keys[j] = (c << fine_bits) | fine;
+  vals[j] = i;
+}
+
+// After the sort: where each component starts in the sorted list (a component without frames starts where the next
+// one does) ...
+__global__ void comp_start_kernel(const uint32_t* __restrict__ keys_sorted, uint32_t n, uint32_t fine_bits,
+                                  uint32_t* __restrict__ start /* [kMaxComp + 1], preset to n */) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = keys_sorted[i] >> fine_bits;
+  const uint32_t prev = (i == 0) ? 0xFFFFFFFFu : (keys_sorted[i - 1] >> fine_bits);
+  if (c != prev && c < (uint32_t)kMaxComp) start[c] = i;
+}
+// ... the tile range of every component once each is padded to whole query groups (group_rows positions) ...
+__global__ void comp_ranges_kernel(uint32_t* __restrict__ start, uint32_t n, uint32_t group_rows,
+                                   uint32_t* __restrict__ range /* [kMaxComp + 1][2] */) {
+  if (threadIdx.x != 0) return;
+  // (empty components: their start was never written -- take the next one's)
+  uint32_t next = n;
+  for (int c = kMaxComp - 1; c >= 0; --c) {
+    if (start[c] > next) start[c] = next;   // (preset n; a real start is never beyond the next component's)
+    next = start[c];
+  }
+  start[kMaxComp] = n;
+  uint32_t s = 0;
+  for (int c = 0; c < kMaxComp; ++c) {
+    const uint32_t cnt = start[c + 1] - start[c];
+    const uint32_t padded = ((cnt + group_rows - 1) / group_rows) * group_rows;
+    range[2 * c] = s / 32;
+    range[2 * c + 1] = (s + padded) / 32;
+    s += padded;
+  }
+  range[2 * kMaxComp] = 0;
+  range[2 * kMaxComp + 1] = 0;
+}
+// ... and the padded order itself: sorted entry i of component c goes to position 32 range[c].lo + (i - start[c]);
+// every other position keeps kInvalidFrame, every tile gets its component (preset: kMaxComp, the all-pad tiles)
+__global__ void pad_scatter_kernel(const uint32_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted,
+                                   uint32_t n, uint32_t fine_bits, const uint32_t* __restrict__ start,
+                                   const uint32_t* __restrict__ range, uint32_t* __restrict__ perm,
+                                   uint32_t* __restrict__ tile_comp) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = min(keys_sorted[i] >> fine_bits, (uint32_t)kMaxComp - 1u);
+  const uint32_t pos = 32u * range[2 * c] + (i - start[c]);
+  perm[pos] = vals_sorted[i];
+  if ((pos & 31u) == 0) tile_comp[pos >> 5] = c;
+}
+
 // bounding box (lo0, hi0, lo1, hi1) of the frames of each tile of an ordered frame list
 __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
                            const uint32_t* __restrict__ perm, uint32_t n_used, uint32_t T,
@@ -363,6 +721,7 @@ __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
     const uint32_t pos = t * 32 + r;
     if (pos >= n_used) break;
     const uint32_t i = perm[pos];
+    if (i == kInvalidFrame) continue;   // (a pad position of the order)
     const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
     lo0 = fminf(lo0, x);
     hi0 = fmaxf(hi0, x);
@@ -381,11 +740,16 @@ __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
 // lane per row, a half-wave per tile (box_kernel's one thread per tile is latency-bound: 27 - 40 us at C3)
 __global__ void box_rows_kernel(const float* __restrict__ coords_o, uint32_t D, uint32_t n_used,
                                 uint32_t T, float4* __restrict__ boxes, const float* __restrict__ fe_o,
-                                float2* __restrict__ ferange) {
+                                float2* __restrict__ ferange, const uint32_t* __restrict__ valid = nullptr,
+                                const uint32_t* __restrict__ tile_comp = nullptr,
+                                const float* __restrict__ origins = nullptr, uint32_t* __restrict__ hdr = nullptr) {
+  // valid: frame of every row of the order (kInvalidFrame: a pad row).  tile_comp / origins / hdr: the squared distance
+  // from the tile's origin to the far corner of its box bounds |x - origin|^2 in columns 0/1 for all its rows; the
+  // maximum over the tiles goes to hdr[kHdrMloc] (scale_kernel adds the bound of the other columns)
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;   // 32 consecutive lanes = one tile
   const uint32_t t = pos >> 5;
   if (t >= T) return;                                           // (whole half-waves leave together)
-  const bool live = pos < n_used;
+  const bool live = pos < n_used && (!valid || valid[pos] != kInvalidFrame);
   const float x = live ? coords_o[(size_t)pos * D] : 0.0f;
   const float y = (live && D > 1) ? coords_o[(size_t)pos * D + 1] : 0.0f;
   float lo0 = live ? x : INFINITY, hi0 = live ? x : -INFINITY;
@@ -404,6 +768,16 @@ __global__ void box_rows_kernel(const float* __restrict__ coords_o, uint32_t D, 
   if ((pos & 31u) == 0) {
     boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
     if (ferange) ferange[t] = make_float2(flo, fhi);
+    if (tile_comp && lo0 <= hi0) {
+      const float* a = origins + (size_t)tile_comp[t] * kMaxCols;
+      const float dx = fmaxf(fabsf(lo0 - a[0]), fabsf(hi0 - a[0]));
+      const float dy = (D > 1) ? fmaxf(fabsf(lo1 - a[1]), fabsf(hi1 - a[1])) : 0.0f;
+      const float m = next_up(next_up(dx * dx + dy * dy));
+      if (m <= FLT_MAX) {
+        const uint32_t bits = __float_as_uint(m);
+        if (bits > __atomic_load_n(hdr + kHdrMloc, __ATOMIC_RELAXED)) atomicMax(hdr + kHdrMloc, bits);
+      }
+    }
   }
 }
 
@@ -415,7 +789,8 @@ __global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)n * D) return;
   const uint32_t pos = (uint32_t)(e / D), k = (uint32_t)(e - (size_t)pos * D);
-  out[e] = coords[(size_t)perm[pos] * D + k];
+  const uint32_t i = perm[pos];
+  out[e] = (i != kInvalidFrame) ? coords[(size_t)i * D + k] : 0.0f;   // (pad positions of a padded order)
 }
 
 
@@ -465,13 +840,30 @@ int sweep_timer_read(int kind, float* ms) {
   return hipEventElapsedTime(ms, t.ev[0], t.ev[1]) == hipSuccess ? 0 : -1;
 }
 
+// diagnostics of the last pruned population sweep in a workspace: components, global and component-wise extent
+int components_info(const void* d_ws, size_t n_rows, size_t n_cols, uint32_t* n_comp, float* m_global, float* m_local,
+                    float* scale, hipStream_t stream) {
+  const Layout L = make_layout(n_rows, n_cols);
+  const char* p = (const char*)d_ws;
+  uint32_t hdr[32], grid[8];
+  if (hipMemcpyAsync(hdr, p, sizeof(hdr), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+  if (hipMemcpyAsync(grid, p + L.off_comp, sizeof(grid), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+  *n_comp = grid[5];
+  memcpy(m_global, &hdr[0], 4);
+  const float a = __builtin_bit_cast(float, hdr[kHdrMloc]), b = __builtin_bit_cast(float, hdr[kHdrMrest]);
+  *m_local = (grid[5] > 1u) ? a + b : *m_global;
+  memcpy(scale, &hdr[kHdrScale + 1], 4);
+  return 0;
+}
+
 bool mfma_supports(size_t n_cols) {
   if (n_cols < 1 || n_cols > (size_t)kMaxCols) return false;
   return ((DC_STEP_MASK >> (nm_for((int)n_cols) - 1)) & 1u) != 0;
 }
 size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
   if (!mfma_supports(n_cols) || n_rows == 0) return 0;
-  return make_layout(n_rows, n_cols).fixed_end + sort_temp_bytes(n_rows);
+  return make_layout(n_rows, n_cols).fixed_end + sort_temp_bytes(n_rows + kOrderPadRows);   // (the padded orders)
 }
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
@@ -627,7 +1019,7 @@ __global__ void edges_flag_kernel(const uint32_t* __restrict__ hdr, unsigned lon
 __global__ void gather_u32_kernel(const uint32_t* __restrict__ by_frame, const uint32_t* __restrict__ perm,
                                   uint32_t n, uint32_t* __restrict__ by_pos) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) by_pos[p] = by_frame[perm[p]];
+  if (p < n) by_pos[p] = (perm[p] != kInvalidFrame) ? by_frame[perm[p]] : 0xFFFFFFFFu;   // (pad positions of the order)
 }
 
 // number of unordered pairs from the populations: sum(pop - 1) / 2 (every pair is counted at both ends)
@@ -680,6 +1072,29 @@ void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_c
                  &sink, stream, r2);
 }
 
+// the padded order of a sorted (component, fine cell) list: perm[position] = frame or kInvalidFrame, tile_comp[tile]
+static void pad_order(const uint32_t* keys_sorted, const uint32_t* vals_sorted, uint32_t n, unsigned fine_bits,
+                      uint32_t group_rows, uint32_t* start, uint32_t* range, uint32_t* perm, uint32_t* tile_comp,
+                      uint32_t T_used, hipStream_t stream) {
+  (void)hipMemsetD32Async((hipDeviceptr_t)start, (int)n, kMaxComp + 1, stream);
+  (void)hipMemsetAsync(perm, 0xFF, sizeof(uint32_t) * 32 * (size_t)T_used, stream);
+  (void)hipMemsetD32Async((hipDeviceptr_t)tile_comp, kMaxComp, T_used, stream);
+  const dim3 blk(256), grid((n + 255) / 256);
+  hipLaunchKernelGGL(comp_start_kernel, grid, blk, 0, stream, keys_sorted, n, (uint32_t)fine_bits, start);
+  hipLaunchKernelGGL(comp_ranges_kernel, dim3(1), dim3(64), 0, stream, start, n, group_rows, range);
+  hipLaunchKernelGGL(pad_scatter_kernel, grid, blk, 0, stream, keys_sorted, vals_sorted, n, (uint32_t)fine_bits,
+                     (const uint32_t*)start, (const uint32_t*)range, perm, tile_comp);
+}
+
+// DC_POP_COMPONENTS=0: one component whatever the data looks like (measurements, tests)
+static bool components_off() {
+  static const bool off = [] {
+    const char* v = getenv("DC_POP_COMPONENTS");
+    return v && v[0] == '0';
+  }();
+  return off;
+}
+
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
                            const EdgeSink* sink_in, hipStream_t stream, float r2_scale, bool prep) {
@@ -694,12 +1109,14 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
   uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
   uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
-  (void)n_rad;
+  uint32_t* comp = (uint32_t*)(p + L.off_comp);
+  uint32_t* tile_comp = (uint32_t*)(p + L.off_tile_comp);
+  uint32_t* tile_comp_q = (uint32_t*)(p + L.off_tile_comp_q);
+  uint32_t* vals_sorted = (uint32_t*)(p + L.off_invpos);   // (a region of the full neighbour sweep: free here)
+  const float* origins = (const float*)(comp + kCompOrigin);
   constexpr float kCellFramesHere = kPopCellFrames;
-  const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
-      grid_tiles((L.T + 255) / 256);
+  const dim3 blk(256), grid_n((n_rows + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
-  const size_t tmp_bytes = sort_temp_bytes(n_rows);
   const float* coords_p = (const float*)(p + L.off_coords_p);
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
@@ -710,7 +1127,16 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     n_q = n_rows;
     q_seg = QSeg{qs.n_segments, qs.segment};
   }
-  const uint32_t T_q = (n_q + 31) / 32;
+  // The orders are PADDED: every component of the frames (dc_mfma_kernels.hpp "components") starts at a whole query
+  // group; the sort's input carries kMaxComp * (group_rows - 1) extra (key, kInvalidFrame) entries for that.
+  const uint32_t tq = pop_group_tiles(n_rows, n_cols, sink_in != nullptr, n_rad), group_rows = 32u * tq;
+  const uint32_t T_r = (n_rows + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
+  const uint32_t T_q = (n_q + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
+  const size_t tmp_bytes = sort_temp_bytes(n_rows + kOrderPadRows);
+  const float r_max = sqrtf(fmaxf(r2_scale, 0.0f)) * 1.0001f;
+  const unsigned fine_bits = cell_key_bits(n_rows, kPopCellFrames) + 1u;
+  const unsigned key_bits = fine_bits + 6u;   // kMaxComp = 64 components
+  static_assert(kMaxComp == 64, "six component bits in the ordering keys");
   EdgeSink sink_local;
   const EdgeSink* sink = sink_in;
   if (sink_in && sink_in->best) {   // (component ids and ranks in the sweep's order: gathered below)
@@ -720,60 +1146,78 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     sink = &sink_local;
   }
   if (prep) {
-    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, fmaxf(r2_scale, 0.0f), n_cols);
-    // order all frames by their 2-D cell, build the reference image and the tile boxes
-    hipLaunchKernelGGL(cellkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)hdr, kPopCellFrames, 0u, n_rows, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream,
-                       cell_key_bits(n_rows, kPopCellFrames)))
+    // components of the frames for this call's largest radius, their origins and fine grids
+    (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
+    (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_max,
+                       comp);
+    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_max, comp);
+    hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
+                       (const float*)(p + kHdrMeans), n_cols, r_max, n_rows, kPopCellFrames, fine_bits, comp,
+                       components_off() ? 1 : 0);
+    // order all frames by (component, fine cell); every component then moves to a whole query group of the padded order
+    hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_max,
+                       (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in);
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits))
       return;
+    pad_order(keys_out, vals_sorted, n_rows, fine_bits, group_rows, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
+              T_r, stream);
     // original rows in the reference order: the deferred exact path reads them without a
     // permutation look-up, and the operand images are built from them with coalesced reads
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
-                       0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)32 * T_r * n_cols + 255) / 256)), blk,
+                       0, stream, d_coords, n_cols, (const uint32_t*)perm_p, 32u * T_r,
                        (float*)(p + L.off_coords_p));
-    hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
-                       L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                       (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
-    hipLaunchKernelGGL(box_rows_kernel, grid_t, blk, 0, stream, coords_p, n_cols, n_rows, L.T,
-                       (float4*)(p + L.off_box_p), (const float*)nullptr, (float2*)nullptr);
+    hipLaunchKernelGGL(box_rows_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, coords_p, n_cols, 32u * T_r, T_r,
+                       (float4*)(p + L.off_box_p), (const float*)nullptr, (float2*)nullptr, (const uint32_t*)perm_p,
+                       (const uint32_t*)tile_comp, origins, hdr);
+    // the scale follows the components' extents
+    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, fmaxf(r2_scale, 0.0f), n_cols,
+                       (const uint32_t*)comp);
+    hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+                       L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
+                       (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                       (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
     // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
     // buffers are free again)
     if (sink_in && sink_in->best) {
-      hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->comp, (const uint32_t*)perm_p,
-                         n_rows, keys_in);
-      hipLaunchKernelGGL(gather_u32_kernel, grid_n, blk, 0, stream, sink_in->rank, (const uint32_t*)perm_p,
-                         n_rows, keys_out);
+      hipLaunchKernelGGL(gather_u32_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, sink_in->comp,
+                         (const uint32_t*)perm_p, 32u * T_r, keys_in);
+      hipLaunchKernelGGL(gather_u32_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, sink_in->rank,
+                         (const uint32_t*)perm_p, 32u * T_r, keys_out);
     }
     if (q_mode != kQueryOwnOrder) {
       // queries in the reference order: only their B form is missing (of the groups of this segment)
-      const uint32_t tq = pop_group_tiles(n_rows, n_cols, sink_in != nullptr, n_rad);
-      const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
+      const uint32_t tiles_q = seg_groups((T_r + tq - 1) / tq, q_seg) * tq;
       if (tiles_q > 0)
-        hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
-                           L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                           (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg);
+        hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+                           L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                           (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg,
+                           (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
     }
     if (q_mode == kQueryOwnOrder) {
       // query rows of this call: the same ordering restricted to [i_from, i_to)
-      hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
-                         (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
-      if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream,
-                         cell_key_bits(n_q, kCellFramesHere)))
+      hipLaunchKernelGGL(compkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr,
+                         r_max, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in);
+      if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_q, p + L.fixed_end, tmp_bytes, stream, key_bits))
         return;
-      hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
+      pad_order(keys_out, vals_sorted, n_q, fine_bits, group_rows, comp + kCompStart + (kMaxComp + 1),
+                comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
+      hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, 32u * T_q, n_cols,
                          L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                         (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p);
-      hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                         (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
+                         (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                         (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
+      hipLaunchKernelGGL(box_kernel, dim3((T_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
+                         (const uint32_t*)perm_q, 32u * T_q, T_q, (float4*)(p + L.off_box_q),
                          (const float*)nullptr, (float2*)nullptr);
     }
   }
+  (void)kCellFramesHere;
+  const uint32_t n_pos_q = 32u * ((q_mode == kQueryOwnOrder) ? T_q : T_r);
   switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                 \
   case SV:                                                                                    \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
-      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, n_q, q_mode, q_seg, rad2, n_rad,   \
+      pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, T_r, n_pos_q, q_mode, q_seg, rad2, n_rad, \
                            d_pops, sink, stream);                                             \
     break;
     DC_FOR_EACH_S(X)

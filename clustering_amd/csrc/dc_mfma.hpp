@@ -50,10 +50,13 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
 struct QSeg {
   uint32_t stride, offset;
 };
-inline uint32_t seg_groups(uint32_t n_groups, QSeg q) {
+__host__ __device__ inline uint32_t seg_groups(uint32_t n_groups, QSeg q) {
   return n_groups > q.offset ? (n_groups - q.offset + q.stride - 1) / q.stride : 0u;
 }
-constexpr size_t kMinEdgeMaxRows = (size_t)1 << 24;   // (the sweep's deferred-evaluation queue holds 24-bit positions)
+// positions the padded orders of the pruned population sweeps add (dc_mfma_kernels.hpp: components padded to whole
+// query groups: kMaxComp x kMaxGroupRows)
+constexpr size_t kOrderPadRows = 64 * 512;
+constexpr size_t kMinEdgeMaxRows = ((size_t)1 << 24) - kOrderPadRows;   // (the sweep's deferred-evaluation queue holds 24-bit positions)
 // one Boruvka round on the radius graph (d2 < r2): for every component (d_comp[frame] = its id, any
 // frame id) the lightest pair that leaves it, by (max(rank), min(rank)) with d_rank[frame] a
 // permutation; d_best[id] = (max << 32 | min) or ~0.  d_pops: [n_rows] scratch (populations).
@@ -90,6 +93,11 @@ void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const 
 void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t n_cols, uint32_t n_segments,
                             bool pruned, const void* d_ws, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
                             float* d_hd_d2, hipStream_t stream);
+
+// diagnostics of the last pruned population sweep that ran in a workspace (synchronises): number of components, the
+// global max |x - mean|^2, the bound of max |x - origin(component)|^2 the scale was chosen for, and that scale S
+int components_info(const void* d_ws, size_t n_rows, size_t n_cols, uint32_t* n_comp, float* m_global, float* m_local,
+                    float* scale, hipStream_t stream);
 
 // Optional timing of the MAIN sweep kernels (bench.py's roofline entry wants the kernel's own duration, not the call's:
 // the orderings and operand images are "prep").  When enabled the launchers bracket every main-kernel launch with HIP

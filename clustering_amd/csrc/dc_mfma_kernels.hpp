@@ -103,6 +103,38 @@ static_assert(kHdrSums + 8 * kMaxCols <= kHdrMeans && kHdrMeans + 4 * kMaxCols <
               "header regions sized for kMaxCols columns");
 constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram form -> flagged
 
+// ---- components (pruned population sweeps) ------------------------------------------------------------------
+// The Gram form's guard band grows with max |x - origin|^2 (DESIGN.md "guard band"), so ONE origin for a data set
+// whose clusters lie far apart makes every chain wade through band pairs.  The population sweeps therefore cut the
+// frames into COMPONENTS: sets that are at least r_max apart in the (col 0, col 1) plane -- connected components of
+// a coarse occupancy grid under "point boxes closer than r_max" -- so that no pair of different components can be
+// inside any radius.  Each component gets its own origin (centre of its box in columns 0/1, the column means
+// elsewhere), its own fine cell grid, and a contiguous, group-aligned range of the sweep's order (pad positions
+// carry kInvalidFrame); a query group only ever scans the tiles of its own component.  One component (dense data,
+// more than kMaxComp components, a grid too busy to label) is exactly the old single-origin sweep.
+constexpr uint32_t kInvalidFrame = 0xFFFFFFFFu;
+constexpr int kMaxComp = 64;                 // components with an origin of their own
+constexpr int kCoarseDim = 128;              // coarse occupancy grid: at most kCoarseDim^2 cells
+constexpr int kCoarseCells = kCoarseDim * kCoarseDim;
+constexpr int kMaxOccupied = 2048;           // occupied coarse cells the labelling takes (more: one component)
+constexpr int kFineSub = 4;                  // the occupancy bitmap resolves a coarse cell into kFineSub^2 sub-cells
+constexpr int kMaxGroupRows = 512;           // largest query group (pop_shared_kernel: 4 waves x 4 tiles x 32 rows)
+constexpr uint32_t kPadTiles = (uint32_t)kMaxComp * kMaxGroupRows / 32;   // pad positions of the order, in tiles
+// layout of the component region (L.off_comp), 32-bit words
+constexpr size_t kCompGrid = 0;                                        // [8]: bits(gc), -, -, ncx, ncy, n_comp
+constexpr size_t kCompCellBox = 64;                                    // [cells] float4: box of the occupied sub-cells (lo0 > hi0: empty)
+constexpr size_t kCompCellComp = kCompCellBox + 4 * (size_t)kCoarseCells;   // [cells]: component of the cell
+constexpr size_t kCompOrigin = kCompCellComp + (size_t)kCoarseCells;   // [kMaxComp][kMaxCols] floats
+constexpr size_t kCompFine = kCompOrigin + (size_t)kMaxComp * kMaxCols;      // [kMaxComp][4]: bits(min0), bits(min1), bits(cell edge 0), bits(cell edge 1)
+constexpr size_t kCompNby = kCompFine + 4 * (size_t)kMaxComp;          // [kMaxComp]: cells along column 1 of the component's fine grid
+constexpr size_t kCompStart = kCompNby + (size_t)kMaxComp;             // [2][kMaxComp + 1]: first sorted index of a component (reference / query order)
+constexpr size_t kCompRange = kCompStart + 2 * ((size_t)kMaxComp + 1); // [2][kMaxComp + 1][2]: tile range [lo, hi) of a component (reference / query
+                                                                       // order); entry kMaxComp is the empty range of the all-pad tiles at the end
+constexpr size_t kCompRangeStride = 2 * ((size_t)kMaxComp + 1);
+constexpr size_t kCompBitmap = kCompRange + 2 * kCompRangeStride;      // occupancy of the sub-cells, one byte each
+constexpr size_t kCompBitmapWords = (size_t)kCoarseCells * kFineSub * kFineSub / 4;
+constexpr size_t kCompWords = kCompBitmap + kCompBitmapWords;
+
 // Workspace layout.  Regions used by the population sweep: hdr, img, norms.  The neighbour sweep
 // adds a second operand image with the reference frames ORDERED BY FREE ENERGY (img_s, norms_s),
 // the permutation (perm: sorted position -> frame id, invpos: frame id -> sorted position), the
@@ -111,6 +143,7 @@ constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram 
 // own temp storage sits after `fixed_end` and is sized by dc_mfma.hip).
 struct Layout {
   uint32_t T, NM;
+  uint32_t Tp;          // tiles of a padded order (pruned population sweeps): T + kPadTiles
   // img: A form, natural order; img_b: B form, natural order (queries of the full sweeps);
   // img_s: A form, frames ordered by free energy (full neighbour sweep)
   size_t off_img, off_img_b, off_norm, off_img_s, off_norm_s, off_fe_s, off_perm, off_invpos, off_pq,
@@ -123,6 +156,8 @@ struct Layout {
       off_coords_p,    // ORIGINAL coordinates gathered into the reference order (exact path reads)
       off_merge64,     // [2][n_rows] packed (d2, id) for merging reference chunks (neighbour sweep)
       off_box_t,       // tile boxes regrouped by reference share (neighbour sweep: contiguous scans)
+      off_comp,        // component region (kComp* words) + per-tile component of the reference / query order
+      off_tile_comp, off_tile_comp_q,
       fixed_end;
 };
 
@@ -132,8 +167,10 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   Layout L;
   L.T = (uint32_t)((n_rows + 31) / 32);
   L.NM = (uint32_t)nm_for((int)n_cols);
-  const size_t img_bytes = (size_t)16 * 64 * (size_t)L.T * L.NM;
-  const size_t row_bytes = align256(sizeof(float) * 32 * (size_t)L.T);
+  L.Tp = L.T + kPadTiles;
+  // (every per-position region is sized for the padded orders)
+  const size_t img_bytes = (size_t)16 * 64 * (size_t)L.Tp * L.NM;
+  const size_t row_bytes = align256(sizeof(float) * 32 * (size_t)L.Tp);
   L.off_img = kHdrBytes;
   L.off_img_b = align256(L.off_img + img_bytes);
   L.off_norm = align256(L.off_img_b + img_bytes);
@@ -150,15 +187,18 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_norm_p = align256(L.off_img_p + img_bytes);
   L.off_perm_p = L.off_norm_p + row_bytes;
   L.off_box_p = L.off_perm_p + row_bytes;
-  L.off_img_q = align256(L.off_box_p + sizeof(float) * 4 * (size_t)L.T);
+  L.off_img_q = align256(L.off_box_p + sizeof(float) * 4 * (size_t)L.Tp);
   L.off_norm_q = align256(L.off_img_q + img_bytes);
   L.off_perm_q = L.off_norm_q + row_bytes;
   L.off_box_q = L.off_perm_q + row_bytes;
-  L.off_ferange_p = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.T);
-  L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.T);
-  L.off_merge64 = align256(L.off_coords_p + sizeof(float) * n_rows * n_cols);
+  L.off_ferange_p = align256(L.off_box_q + sizeof(float) * 4 * (size_t)L.Tp);
+  L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.Tp);
+  L.off_merge64 = align256(L.off_coords_p + sizeof(float) * 32 * (size_t)L.Tp * n_cols);
   L.off_box_t = align256(L.off_merge64 + sizeof(unsigned long long) * 2 * n_rows);
-  L.fixed_end = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.T + L.T / 32 + 64));   // (+ one pad box per share)
+  L.off_comp = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.T + L.T / 32 + 64));   // (+ one pad box per share)
+  L.off_tile_comp = align256(L.off_comp + sizeof(uint32_t) * kCompWords);
+  L.off_tile_comp_q = align256(L.off_tile_comp + sizeof(uint32_t) * (size_t)L.Tp);
+  L.fixed_end = align256(L.off_tile_comp_q + sizeof(uint32_t) * (size_t)L.Tp);
   return L;
 }
 
@@ -183,6 +223,9 @@ struct Ptrs {
   const uint32_t* perm_q;
   const float4* box_q;
   const float* coords_p;   // original coordinates gathered into the reference order
+  const uint32_t* comp;        // component region (kComp* words)
+  const uint32_t* tile_comp;   // component of every tile of the reference order
+  const uint32_t* tile_comp_q; // ... of the query order (row ranges)
 };
 
 inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
@@ -206,7 +249,10 @@ inline Ptrs ws_ptrs(void* d_ws, const Layout& L) {
               (const float*)(p + L.off_norm_q),
               (const uint32_t*)(p + L.off_perm_q),
               (const float4*)(p + L.off_box_q),
-              (const float*)(p + L.off_coords_p)};
+              (const float*)(p + L.off_coords_p),
+              (const uint32_t*)(p + L.off_comp),
+              (const uint32_t*)(p + L.off_tile_comp),
+              (const uint32_t*)(p + L.off_tile_comp_q)};
 }
 
 // ordered-integer image of a float (ascending) and back; header words 8..11 hold the bounding box of
@@ -271,6 +317,8 @@ struct Scale {
 };
 constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
 constexpr uint32_t kHdrCookie = 28;     // whose statistics the header holds (array, shape); 0 after a reset
+constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: bound of max |x - origin(component of x)|^2 (float bits)
+constexpr uint32_t kHdrMrest = 30;      // max over the rows of sum_{k >= 2} (x_k - mean_k)^2 (float bits; a statistic)
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
                                               //  4 S M below 2^19.6; only a radius beyond the clamps of
@@ -870,14 +918,25 @@ __global__ __launch_bounds__(256, 2) void pop_mfma_kernel(
 // and runs the usual Gram-chain + epilogue on them; per chain one more box test against the single
 // query tile.  Counting, guard band and exact re-check are those of pop_mfma_kernel.
 // ---------------------------------------------------------------------------------------------
-// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.
-// Query groups are numbered along the spatial ordering, and neighbouring groups walk nearly the same
-// reference tiles: this remap gives every XCD a CONTIGUOUS range of groups, so that the tiles its
-// waves stream are shared through its L2 instead of being fetched by all eight.
-__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n_blocks) {
-  const uint32_t xcd = b & 7u, idx = b >> 3, n_full = n_blocks >> 3, rem = n_blocks & 7u;
-  return xcd * n_full + (xcd < rem ? xcd : rem) + idx;
+// Workgroups are dealt round-robin to the 8 XCDs by their linear id (x fastest), each XCD with its own L2.  Query
+// groups are numbered along the spatial ordering, and neighbouring groups walk nearly the same reference tiles: every
+// XCD gets a CONTIGUOUS eighth of the groups, so that the tiles its waves stream are shared through its L2 instead of
+// being fetched by all eight.  The eighths are ROTATED from one reference share (blockIdx.y) to the next: the work of
+// a group follows the local density and, in the symmetric population sweep, its place in its cluster (the groups at
+// the start of a cluster carry most of its pairs), so an XCD that kept the same eighth for every share would finish
+// long before or after the others.  (Round 2 had this by accident -- its grids were not multiples of 8, which shifted
+// the XCD of a block from share to share; a grid of 5272 = 8 * 659 groups then ran the C3 sweep in 18 instead of 12.4
+// ms with a third of the chip idle in the tail.)  The launchers round gridDim.x up to a multiple of 8, so block (x, y)
+// runs on XCD x & 7; n_blocks: the real number of block-sized units.  Returns the unit of this block, 0xFFFFFFFF for a
+// pad block.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t n_blocks) {
+  const uint32_t b = blockIdx.x, phys = b & 7u, idx = b >> 3;
+  const uint32_t eighth = (phys + blockIdx.y) & 7u;
+  const uint32_t n_full = n_blocks >> 3, rem = n_blocks & 7u;
+  if (idx >= n_full + (eighth < rem ? 1u : 0u)) return 0xFFFFFFFFu;
+  return eighth * n_full + min(eighth, rem) + idx;
 }
+inline uint32_t grid_x8(uint32_t n_blocks) { return (n_blocks + 7u) & ~7u; }
 
 // which rows a pruned sweep answers for, and where their operands live:
 //   kQueryOwnOrder  a row range [i_from, i_to): its own spatial ordering (img_q / norms_q / perm_q / box_q)
@@ -901,7 +960,8 @@ constexpr int kSeedNeighbours = 4;   // neighbour sweep: frames on either side o
 // reference row from a copy of the ORIGINAL coordinates gathered into the reference order.
 constexpr uint32_t kPopQueuePosBits = 24;    // entry = position | radius flags << 24
 constexpr uint32_t kPopQueueMaxRows = 1u << kPopQueuePosBits;
-static_assert(kMinEdgeMaxRows == kPopQueueMaxRows, "min-edge sweeps take the queue path only");
+static_assert(kMinEdgeMaxRows + kOrderPadRows == kPopQueueMaxRows, "min-edge sweeps take the queue path only");
+static_assert(kOrderPadRows == (size_t)32 * kPadTiles, "pad positions of the orders");
 
 // wave-aggregated append: lanes with `have` add one pair each
 __device__ __forceinline__ void emit_edge(const EdgeSink& sink, bool have, uint32_t pos_q, uint32_t pos_r) {
@@ -1055,6 +1115,14 @@ __device__ __forceinline__ float box_gap2(const float4& a, const float4& b) {
   return dx * dx + dy * dy;
 }
 
+// what a pruned population sweep needs to know about the components (file header of this section): the component of
+// every QUERY tile, the tile range of every component in the REFERENCE order, and the number of positions of that order
+struct CompView {
+  const uint32_t* tile_comp_q;
+  const uint32_t* range_r;   // [kMaxComp][2]
+  uint32_t n_pos;
+};
+
 // SYM: the symmetric sweep (all rows as queries, one radius, no sink): a query group meets its own tiles as
 // before and, of the other groups, the half that lies ahead of it on the circle of groups -- every unordered pair
 // of groups once -- crediting both sides (ref_credit); all counts go to pops_pos (by position, zero-filled).
@@ -1067,7 +1135,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2,
-    int n_rad, uint32_t* __restrict__ pops, EdgeSink sink, uint32_t* __restrict__ pops_pos = nullptr) {
+    int n_rad, uint32_t* __restrict__ pops, EdgeSink sink, CompView CV, uint32_t* __restrict__ pops_pos = nullptr) {
   static_assert(!SYM || (MODE == kSinkNone && NR == 1), "the symmetric sweep is the plain one-radius sweep");
   __shared__ uint32_t credit_stage[4][8];
   // dynamic LDS, per wave of the workgroup (one wave, see nn_pruned_kernel): the survivor list of a scan round
@@ -1080,19 +1148,21 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const uint32_t wpb = blockDim.x >> 6;
   uint32_t* lists_all = reinterpret_cast<uint32_t*>(pop_dyn_lds);
   float* pop_qrows_all = pop_dyn_lds + (size_t)wpb * kListCap;
-  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * wpb + wib) * q_seg.stride + q_seg.offset;
+  const uint32_t TQT = (n_q + 31) / 32;
+  const uint32_t blk_unit = xcd_block((seg_groups((TQT + TQ - 1) / TQ, q_seg) + wpb - 1) / wpb);
+  if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid)
+  const uint32_t wave = (blk_unit * wpb + wib) * q_seg.stride + q_seg.offset;
   // gridDim.y > 1: the reference tiles are dealt round-robin to gridDim.y waves per query group and
   // the partial counts are merged with atomics (keeps small launches, e.g. one rank of an 8-GPU
   // run, at >= 2 waves per SIMD without giving up the operand reuse of TQ query tiles per wave)
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
-  const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
   uint32_t* list = lists_all + (size_t)wib * kListCap;
   float* qrows = pop_qrows_all + (size_t)wib * (TQ * 32) * n_cols;
   uint32_t* queues = reinterpret_cast<uint32_t*>(pop_qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
                      (size_t)wib * TQ * kQueueCap * 64;
-  const bool use_queue = n_rows <= kPopQueueMaxRows;   // positions fit the queue entries
+  const bool use_queue = CV.n_pos <= kPopQueueMaxRows;   // positions fit the queue entries
   // plain sweep of one radius: ONE compact list per wave (carved out of the same LDS region: 128 entries and a
   // counter per query instead of TQ x kQueueCap x 64 entries)
   constexpr bool kWaveWide = (MODE == kSinkNone) && (NR == 1) && (TQ * 32 <= 256) && (TQ * kQueueCap * 64 >= kWaveQueue + TQ * 32);
@@ -1127,9 +1197,11 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const uint32_t tile = qt0 + qt;
     const uint32_t tl = tile < TQT ? tile : TQT - 1;
     const uint32_t pos = tile * 32 + c;
-    const bool live = (tile < TQT) && (pos < n_q);
+    // (pad positions of the order -- the components are padded to whole query groups -- carry kInvalidFrame)
+    const uint32_t frame = ((tile < TQT) && (pos < n_q)) ? perm_q[pos] : kInvalidFrame;
+    const bool live = frame != kInvalidFrame;
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
-    jq[qt] = live ? perm_q[pos] : 0u;
+    jq[qt] = live ? frame : 0u;
     const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : dead_const(P.sc);
     load_query<NM>(img_q, tl, lane, h, cq, P.sc, b[qt]);
     if constexpr (MODE == kSinkMinEdge) {   // (all rows, in the reference order: position = pos)
@@ -1180,8 +1252,12 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   uint32_t chains = 0;
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scan only touches its own boxes)
-  const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
-  for (uint32_t base = 0; base < U; base += kListCap) {
+  // ... of the tiles of the group's own COMPONENT: every other frame is at least r_max away (CompView)
+  const uint32_t my_comp = CV.tile_comp_q[qt0];
+  const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
+  const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
+  const uint32_t U = (t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u;
+  for (uint32_t base = u_lo; base < U; base += kListCap) {
     // ---- scan: which reference tiles of this round can hold a pair within r_max of the group?
     uint32_t cnt = 0;
     const uint32_t lim = min(U - base, (uint32_t)kListCap);
@@ -1312,7 +1388,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
           }
         } else {
           const PopDelta<NR> dl =
-              pop_fix<NR>(coords, perm_r, n_rows, n_cols, rad2, P.dl, acc, P.wbits, jq[qi], t, h);
+              pop_fix<NR>(coords, perm_r, CV.n_pos, n_cols, rad2, P.dl, acc, P.wbits, jq[qi], t, h);
 #pragma unroll
           for (int rr = 0; rr < NR; ++rr) q[qi].cnt[rr] += ((livemask[qi] >> lane) & 1) ? dl.d[rr] : 0u;
         }
@@ -1369,7 +1445,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
         finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
         if constexpr (SYM && qt == 0) {   // the strings of tile tB are complete now
           if (pendB) park_tile(tB);
-          if (symB) ref_credit<TQ>(sb, tB, n_rows, pops_pos, credit_stage[wib], my_byte, lane);
+          if (symB) ref_credit<TQ>(sb, tB, CV.n_pos, pops_pos, credit_stage[wib], my_byte, lane);
         }
         pop_epi_begin<NR>(e);
         if constexpr (qt + 2 == TQ)   // last chain of the tile
@@ -1414,7 +1490,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
       if constexpr (SYM) {
         if (pendB) park_tile(tB);
-        if (symB) ref_credit<TQ>(sb, tB, n_rows, pops_pos, credit_stage[wib], my_byte, lane);
+        if (symB) ref_credit<TQ>(sb, tB, CV.n_pos, pops_pos, credit_stage[wib], my_byte, lane);
         symB = false;
         pendB = false;
       }
@@ -1846,9 +1922,11 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const uint32_t wpb = blockDim.x >> 6;
   uint32_t* lists_all = reinterpret_cast<uint32_t*>(nn_dyn_lds);
   float* qrows_all = nn_dyn_lds + (size_t)wpb * kListCap;
-  const uint32_t wave = (xcd_contiguous(blockIdx.x, gridDim.x) * wpb + wib) * q_seg.stride + q_seg.offset;
-  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t TQT = (n_q + 31) / 32;
+  const uint32_t blk_unit = xcd_block((seg_groups((TQT + TQ - 1) / TQ, q_seg) + wpb - 1) / wpb);
+  if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid)
+  const uint32_t wave = (blk_unit * wpb + wib) * q_seg.stride + q_seg.offset;
+  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;
   uint32_t* list = lists_all + (size_t)wib * kListCap;
@@ -2421,7 +2499,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
     if (n_chunks > 1)
       hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s, A.merge64, n_rows);
     hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
-    { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_shared_kernel<S, TQV>), dim3(groups, n_chunks), dim3(256), smem, s, coords, n_rows, n_cols, fe,
+    { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_shared_kernel<S, TQV>), dim3(grid_x8(groups), n_chunks), dim3(256), smem, s, coords, n_rows, n_cols, fe,
                        A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r, A.fe_c, A.coords_c,
                        A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg, A.full_range, A.cell2, hdr,
                        chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2); sweep_timer_mark(1, false, s); }
@@ -2446,7 +2524,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
     hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s,
                        A.merge64, n_rows);
   hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
-  { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3((waves + wpb - 1) / wpb, n_chunks), dim3(64 * wpb), smem, s,
+  { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_pruned_kernel<S, TQV>), dim3(grid_x8((waves + wpb - 1) / wpb), n_chunks), dim3(64 * wpb), smem, s,
                      coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
@@ -2483,7 +2561,7 @@ inline bool pop_sym_wanted(bool sink, int q_mode, QSeg q_seg, uint32_t n_rows, i
     return v && v[0] == '0';
   }();
   (void)q_seg;
-  return !off && !sink && q_mode == kQueryAll && n_rad == 1 && n_rows <= kPopQueueMaxRows;
+  return !off && !sink && q_mode == kQueryAll && n_rad == 1 && n_rows + 32u * kPadTiles <= kPopQueueMaxRows;
 }
 // the shared-operand sweeps in their symmetric form: with ONE radius (5M x 30, all rows: 1 482 -> 932 ms; 1M x 30:
 // 56.3 -> 35.8 ms).  With several radii per sweep the reference side costs one 128-byte atomic per reference tile,
@@ -2501,8 +2579,8 @@ inline bool pop_shared_sym_wanted(int nr) {
 __global__ void pops_by_frame_kernel(const uint32_t* __restrict__ pops_pos, const uint32_t* __restrict__ perm,
                                      uint32_t n_rows, const uint32_t* __restrict__ hdr, uint32_t* __restrict__ pops) {
   if (hdr[1] != 0) return;
-  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pos < n_rows) pops[perm[pos]] = pops_pos[pos];
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;   // n_rows here: positions of the (padded) order
+  if (pos < n_rows && perm[pos] != kInvalidFrame) pops[perm[pos]] = pops_pos[pos];
 }
 
 template <int S, int NRV, int TQV>
@@ -2515,11 +2593,13 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   const uint32_t waves = seg_groups(((n_q + 31) / 32 + TQV - 1) / TQV, q_seg), tiles = waves * TQV;
   if (waves == 0) return;
   const uint32_t wpb = waves_per_group(S);
-  const dim3 grid((waves + wpb - 1) / wpb, pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128)),
+  const dim3 grid(grid_x8((waves + wpb - 1) / wpb), pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128)),
       block(64 * wpb);
   // B form of the query rows: its own image for a row range, else the B form of the rows in the
   // reference order (img_q)
   const bool own = q_mode == kQueryOwnOrder;
+  // T: tiles of the (padded) reference order; n_q: positions of the query order
+  const CompView CV{own ? P.tile_comp_q : P.tile_comp, P.comp + kCompRange, 32u * T};
   const uint4* img_q = P.img_q;
   const float* norms_q = own ? P.norms_q : P.norms_p;
   const uint32_t* perm_q = own ? P.perm_q : P.perm_p;
@@ -2532,7 +2612,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
     constexpr int kTQS = tq_shared_for<S, NRV>;
     const uint32_t groups = seg_groups(((n_q + 31) / 32 + 4 * kTQS - 1) / (4 * kTQS), q_seg);
     if (groups == 0) return;
-    const dim3 grid_s(groups, pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
+    const dim3 grid_s(grid_x8(groups), pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
     const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * shared_wave_words(kTQS, NRV);
     if (pop_sym_wanted(false, q_mode, q_seg, n_rows, 1) && pop_shared_sym_wanted(NRV)) {
       // symmetric form: counts by position, one array of 32 T words per radius (the regions from norms_s to
@@ -2541,16 +2621,16 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
       (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T * NRV, s);
       { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV, true>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols,
                          P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                         chain_counter, rad2, n_rad, pops, own ? 0 : 1, pops_pos); sweep_timer_mark(0, false, s); }
+                         chain_counter, rad2, n_rad, pops, own ? 0 : 1, CV, pops_pos); sweep_timer_mark(0, false, s); }
       for (int rr = 0; rr < n_rad; ++rr)
-        hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
-                           (const uint32_t*)(pops_pos + (size_t)rr * 32 * T), P.perm_p, n_rows, P.hdr,
+        hipLaunchKernelGGL(pops_by_frame_kernel, dim3((32 * T + 255) / 256), dim3(256), 0, s,
+                           (const uint32_t*)(pops_pos + (size_t)rr * 32 * T), P.perm_p, 32u * T, P.hdr,
                            pops + (size_t)rr * n_rows);
       return;
     }
     { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols, P.img_p,
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                       chain_counter, rad2, n_rad, pops, own ? 0 : 1); sweep_timer_mark(0, false, s); }
+                       chain_counter, rad2, n_rad, pops, own ? 0 : 1, CV); sweep_timer_mark(0, false, s); }
     return;
   }
   if constexpr (NRV == 1 && TQV <= 6) {
@@ -2562,9 +2642,9 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
       { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, 1, TQV, kSinkNone, true>), grid, block, smem, s, coords, n_rows,
                          n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                          perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
-                         EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, pops_pos); sweep_timer_mark(0, false, s); }
-      hipLaunchKernelGGL(pops_by_frame_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, (const uint32_t*)pops_pos,
-                         P.perm_p, n_rows, P.hdr, pops);
+                         EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, CV, pops_pos); sweep_timer_mark(0, false, s); }
+      hipLaunchKernelGGL(pops_by_frame_kernel, dim3((32 * T + 255) / 256), dim3(256), 0, s, (const uint32_t*)pops_pos,
+                         P.perm_p, 32u * T, P.hdr, pops);
       return;
     }
   }
@@ -2572,16 +2652,16 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   if (sink && sink->best)
     { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkMinEdge>), grid, block, smem, s, coords,
                        n_rows, n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q,
-                       norms_q, perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink); sweep_timer_mark(0, false, s); }
+                       norms_q, perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink, CV); sweep_timer_mark(0, false, s); }
   else if (sink)
     { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkPairs>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
-                       perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink); sweep_timer_mark(0, false, s); }
+                       perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops, *sink, CV); sweep_timer_mark(0, false, s); }
   else
     { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, NRV, TQV, kSinkNone>), grid, block, smem, s, coords, n_rows,
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                        perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
-                       EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}); sweep_timer_mark(0, false, s); }
+                       EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, CV); sweep_timer_mark(0, false, s); }
 }
 
 template <int S, int NRV>
@@ -2633,7 +2713,7 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                           uint32_t i_from, uint32_t i_to, const Rad2& rad2, int n_rad,           \
                           uint32_t* pops, hipStream_t s);                                        \
   void pop_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,   \
-                            uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,      \
+                            uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2, \
                             int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s);     \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
                            void* d_ws, uint32_t n_q, int q_mode, QSeg q_seg, float cell2, \

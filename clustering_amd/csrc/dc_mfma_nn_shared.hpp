@@ -72,9 +72,11 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   constexpr int kUnits = NM * 64 + kNnRingExtra;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
-  const uint32_t group = xcd_contiguous(blockIdx.x, gridDim.x) * q_seg.stride + q_seg.offset;
-  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t TQT = (n_q + 31) / 32;
+  const uint32_t blk_unit = xcd_block(seg_groups((TQT + 4u * TQ - 1u) / (4u * TQ), q_seg));
+  if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid: the whole workgroup leaves)
+  const uint32_t group = blk_unit * q_seg.stride + q_seg.offset;
+  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   if (group * (4u * TQ) >= TQT) return;   // whole workgroup leaves
   const uint32_t qt0 = (group * 4u + (uint32_t)wib) * TQ;   // (a wave without tiles keeps meeting the barriers)
   const bool wave_live = qt0 < TQT;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
     const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2, int n_rad,
-    uint32_t* __restrict__ pops, int q_in_ref_order, uint32_t* __restrict__ pops_pos = nullptr) {
+    uint32_t* __restrict__ pops, int q_in_ref_order, CompView CV, uint32_t* __restrict__ pops_pos = nullptr) {
   static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
   static_assert(NR >= 1 && NR <= 8 && TQ * 32 <= 256, "queue entries: 8 radius flags, 8 bits of query index");
   __shared__ uint32_t lists[4][kShareSub];
@@ -140,9 +140,11 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
   constexpr int kUnits = kTileUnits<NM>;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31, wib = tid >> 6;
-  const uint32_t group = xcd_contiguous(blockIdx.x, gridDim.x) * q_seg.stride + q_seg.offset;
-  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
   const uint32_t TQT = (n_q + 31) / 32;
+  const uint32_t blk_unit = xcd_block(seg_groups((TQT + 4u * TQ - 1u) / (4u * TQ), q_seg));
+  if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid: the whole workgroup leaves)
+  const uint32_t group = blk_unit * q_seg.stride + q_seg.offset;
+  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
   if (group * (4u * TQ) >= TQT) return;   // whole workgroup leaves
   const uint32_t qt0 = (group * 4u + (uint32_t)wib) * TQ;
   const bool wave_live = qt0 < TQT;       // (a wave without tiles keeps loading and meeting the barriers)
@@ -169,9 +171,10 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     const uint32_t tile = qt0 + qt;
     const uint32_t tl = tile < TQT ? tile : TQT - 1;
     const uint32_t pos = tile * 32 + c;
-    const bool live = (tile < TQT) && (pos < n_q);
+    const uint32_t frame = ((tile < TQT) && (pos < n_q)) ? perm_q[pos] : kInvalidFrame;   // (pad positions: kInvalidFrame)
+    const bool live = frame != kInvalidFrame;
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
-    jq[qt] = live ? perm_q[pos] : 0u;
+    jq[qt] = live ? frame : 0u;
     const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : dead_const(P.sc);
     load_query<NM>(img_q, tl, lane, h, cq, P.sc, b[qt]);
 #pragma unroll
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   auto credit = [&](uint32_t t) {
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr)
-      if (rr < n_rad) ref_credit<TQ>(sb[rr], t, n_rows, pops_pos + (size_t)rr * pos_stride, credit_stage[wib], my_byte, lane);
+      if (rr < n_rad) ref_credit<TQ>(sb[rr], t, CV.n_pos, pops_pos + (size_t)rr * pos_stride, credit_stage[wib], my_byte, lane);
   };
   const float* q_rows = q_in_ref_order ? coords_r : coords;
   auto flush = [&]() {
@@ -268,9 +271,13 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   };
 
   uint32_t chains = 0;
-  const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
+  // (only the tiles of the workgroup's own COMPONENT: every other frame is at least r_max away -- CompView)
+  const uint32_t my_comp = CV.tile_comp_q[group * (4u * TQ)];
+  const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
+  const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
+  const uint32_t U = (t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u;
   auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
-  for (uint32_t base = 0; base < U; base += 4 * kShareSub) {
+  for (uint32_t base = u_lo; base < U; base += 4 * kShareSub) {
     // ---- scan: every wave tests its quarter of the round's boxes against the workgroup's box
     uint32_t cnt = 0;
 #pragma unroll
@@ -417,7 +424,7 @@ inline bool pop_shared_wanted(uint32_t n_rows, uint32_t n_cols, int n_rad) {
     return (v && v[0]) ? atoi(v) : -1;
   }();
   const int nm = nm_for((int)n_cols);
-  if (n_rows > kPopQueueMaxRows || nm > 8) return false;
+  if (n_rows + 32u * kPadTiles > kPopQueueMaxRows || nm > 8) return false;
   if (forced >= 0) return forced != 0;
   const size_t image = (size_t)((n_rows + 31) / 32) * (size_t)nm * 1024;
   if (nm >= 5 && image > ((size_t)96 << 20)) return true;

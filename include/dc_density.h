@@ -109,6 +109,15 @@ DC_API size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radi
 DC_API int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles,
                                          uint64_t* nn_tiles, void* stream);
 
+/* diagnostics of the last pruned POPULATION sweep that ran in this workspace (same n_rows, n_cols): the number of
+ * components the frames were cut into (sets at least r_max apart in columns 0/1, each measured from its own origin by
+ * the matrix-core sweep; 1 = one origin, the column means), the global max |x - mean|^2, the bound of
+ * max |x - origin(component of x)|^2 that the sweep's guard band follows, and the scale S of that sweep (band = 1 / S in
+ * the units of d2).  Synchronises the stream. */
+DC_API int dc_hip_workspace_components_dev(const void* d_workspace, size_t n_rows, size_t n_cols,
+                                          uint32_t* n_components, float* extent2_global, float* extent2_local,
+                                          float* scale, void* stream);
+
 /* measurement aid (bench.py's roofline entry): with timing enabled the library brackets its MAIN sweep
  * kernels (population_count / nearest_neighbor_search counterparts) with HIP events on the launch stream;
  * dc_hip_last_sweep_ms returns the duration of the kernels of one kind (0 population, 1 neighbour) launched on

@@ -180,20 +180,6 @@ def evaluated_tiles(device):
     return int(a.value), int(b.value)
 
 
-def components_info(coords):
-    """of the last pruned population sweep over coords on its device: dict(n_components, extent2_global, extent2_local,
-    scale) -- dc_hip_workspace_components_dev"""
-    n_rows, n_cols = _check_coords(coords)
-    ws = _workspace(coords.device)
-    n, a, b, s = C.c_uint32(0), C.c_float(0), C.c_float(0), C.c_float(0)
-    with torch.cuda.device(coords.device):
-        capi.check(capi.lib.dc_hip_workspace_components_dev(_dev(ws.buf), n_rows, n_cols, C.byref(n), C.byref(a),
-                                                            C.byref(b), C.byref(s), _stream_ptr()),
-                   "dc_hip_workspace_components_dev")
-    return {"n_components": int(n.value), "extent2_global": float(a.value), "extent2_local": float(b.value),
-            "scale": float(s.value)}
-
-
 def sweep_timing(enable):
     """dc_hip_sweep_timing: bracket the main sweep kernels with HIP events (measurement aid of bench.py)"""
     capi.check(capi.lib.dc_hip_sweep_timing(1 if enable else 0), "dc_hip_sweep_timing")
