@@ -75,7 +75,7 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   const uint32_t Dp = D | 1u;
   const size_t total = (size_t)n_rows * D;
   const uint32_t n_chunks = (n_rows + 255) / 256;
-  uint32_t m_norm = 0, m_rest = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  uint32_t m_norm = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
   bool bad = false;
   // chunks of 256 rows, grid-stride: the block publishes its five extrema once at the end
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -94,17 +94,10 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
       const float v = x[k] - means[k];
       nrm += (double)v * (double)v;
     }
-    double rest = nrm;   // (columns >= 2: the exact sum minus the exact squares of the first two)
-    for (uint32_t k = 0; k < min(D, 2u); ++k) {
-      const float v = x[k] - means[k];
-      rest -= (double)v * (double)v;
-    }
-    rest = fmax(rest, 0.0);
     const float nf = (float)nrm;
     const bool ok = live && (nf <= kNormLimit);
     bad = bad | (live && !ok);   // NaN / inf / overflow-prone row: MFMA kernels stand down
     m_norm = max(m_norm, ok ? __float_as_uint(nf) : 0u);
-    m_rest = max(m_rest, ok ? __float_as_uint(next_up(next_up((float)rest))) : 0u);   // (columns >= 2: the part no component origin moves)
     const float c0 = x[0], c1 = (D > 1) ? x[1] : 0.0f;
     const bool fin = live && (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
     m0 = max(m0, fin ? ~fkey(c0) : 0u);
@@ -115,7 +108,6 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   if (bad) atomicOr(hdr + 1, 1u);
   if (threadIdx.x == 0) hdr[kHdrCookie] = cookie;   // whose statistics these are (DC_FLAG_STATS_VALID is checked against it)
   publish_max(hdr, m_norm, wave_max);
-  publish_max(hdr + kHdrMrest, m_rest, wave_max);
   publish_max(hdr + 8, m0, wave_max);
   publish_max(hdr + 9, m1, wave_max);
   publish_max(hdr + 10, m2, wave_max);
@@ -214,12 +206,9 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
 __global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D,
                              const uint32_t* __restrict__ comp = nullptr) {
   float M = __uint_as_float(hdr[0]);   // (final: rowstats_kernel ran before)
-  // several components (pruned population sweeps): every row is measured from its component's origin -- the far
-  // corner of its tile's box in columns 0/1 (box_rows_kernel) plus the bound of the other columns (rowstats_kernel)
-  if (comp && comp[kCompGrid + 5] > 1u) {
-    const float a = __uint_as_float(hdr[kHdrMloc]), b = __uint_as_float(hdr[kHdrMrest]);
-    M = fminf(next_up(a + b), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);   // (never more than the triangle bound on the global extent)
-  }
+  // several components (pruned population sweeps): every row is measured from its component's origin (the maximum
+  // over the rows: box_rows_kernel)
+  if (comp && comp[kCompGrid + 5] > 1u) M = fminf(__uint_as_float(hdr[kHdrMloc]), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);
   const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
   hdr[kHdrScale + 0] = __float_as_uint(e.c);
   hdr[kHdrScale + 1] = __float_as_uint(e.s2);
@@ -469,7 +458,8 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
                                                           const float* __restrict__ means, uint32_t D,
                                                           float r_max, uint32_t n_rows, float frames_per_cell,
                                                           uint32_t fine_bits, uint32_t* __restrict__ comp,
-                                                          int force_single) {
+                                                          int force_single, float r_true) {
+  // r_max: the connectivity length rho (what the coarse grid was built for); r_true: the largest radius itself
   __shared__ uint32_t occ[kMaxOccupied], label[kMaxOccupied];
   __shared__ float4 obox[kMaxOccupied];
   __shared__ uint32_t n_occ_s, changed_s, n_comp_s;
@@ -629,6 +619,24 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
     f[3] = __float_as_uint(c1);
     comp[kCompNby + tid] = (uint32_t)ny;
   }
+  // boxes of the components, and which of them come closer than the largest radius (cross pairs: pop_cross_kernel)
+  if (tid < n_comp) {
+    const float4 mine = single ? make_float4(gmin0, gmax0, gmin1, gmax1)
+                               : make_float4(fkey_inv(~cbox[tid][0]), fkey_inv(cbox[tid][1]), fkey_inv(~cbox[tid][2]),
+                                             fkey_inv(cbox[tid][3]));
+    reinterpret_cast<float4*>(comp + kCompBox)[tid] = mine;
+    unsigned long long adj = 0;
+    const float r2t = r_true * r_true * 1.0002f;
+    if (!single && r_true <= FLT_MAX)
+      for (uint32_t k = 0; k < n_comp; ++k) {
+        if (k == tid) continue;
+        const float4 other = make_float4(fkey_inv(~cbox[k][0]), fkey_inv(cbox[k][1]), fkey_inv(~cbox[k][2]),
+                                         fkey_inv(cbox[k][3]));
+        if (box_gap2(mine, other) <= r2t) adj |= 1ull << k;
+      }
+    comp[kCompAdj + 2 * tid] = (uint32_t)adj;
+    comp[kCompAdj + 2 * tid + 1] = (uint32_t)(adj >> 32);
+  }
   if (tid == 0) {
     comp[kCompGrid + 0] = __float_as_uint(g.gc);
     comp[kCompGrid + 3] = g.ncx;
@@ -708,6 +716,89 @@ __global__ void pad_scatter_kernel(const uint32_t* __restrict__ keys_sorted, con
   if ((pos & 31u) == 0) tile_comp[pos >> 5] = c;
 }
 
+// Frame pairs between ADJACENT components (rho = r_max / 2: components may come closer than the largest radius): the
+// matrix-core sweep never meets them -- a query group only scans its own component -- so they are counted here, in the
+// canonical arithmetic, one wave per query group: the group's box against the boxes of the adjacent components, then
+// against their tiles, and every frame of a surviving tile against every query of the group.  Rare by construction
+// (only the outskirts of two clusters face each other across less than r_max); each direction is counted from its own
+// query side, so both the symmetric and the one-sided sweeps just add these counts.
+// out: by_position != 0: counts[rr * stride + query position] (the symmetric sweeps' pops_pos), else [rr * stride + frame]
+__global__ __launch_bounds__(64) void pop_cross_kernel(
+    const float* __restrict__ coords, uint32_t n_cols, const float* __restrict__ coords_r,
+    const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r, const uint32_t* __restrict__ perm_q,
+    const float4* __restrict__ box_q, const uint32_t* __restrict__ tile_comp_q, const uint32_t* __restrict__ comp,
+    uint32_t T_q, uint32_t group_tiles, QSeg q_seg, int q_in_ref_order, Rad2 rad2, int n_rad, float r2max,
+    const uint32_t* __restrict__ hdr, uint32_t* __restrict__ out, size_t stride, int by_position) {
+  __shared__ uint32_t cnt[kMaxGroupRows * kMaxRadiiPerLaunch];
+  __shared__ uint32_t list[64];
+  if (hdr[1] != 0) return;
+  const int lane = threadIdx.x;
+  const uint32_t group = blockIdx.x * q_seg.stride + q_seg.offset;
+  const uint32_t qt0 = group * group_tiles;
+  if (qt0 >= T_q) return;
+  const uint32_t my_comp = tile_comp_q[qt0];
+  if (my_comp >= (uint32_t)kMaxComp) return;
+  const unsigned long long adj = ((unsigned long long)comp[kCompAdj + 2 * my_comp + 1] << 32) | comp[kCompAdj + 2 * my_comp];
+  if (adj == 0) return;
+  const uint32_t group_rows = 32u * group_tiles;
+  float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+  for (uint32_t t = qt0; t < min(qt0 + group_tiles, T_q); ++t) {
+    const float4 b = box_q[t];
+    gbox.x = fminf(gbox.x, b.x);
+    gbox.y = fmaxf(gbox.y, b.y);
+    gbox.z = fminf(gbox.z, b.z);
+    gbox.w = fmaxf(gbox.w, b.w);
+  }
+  const float far2 = r2max * 1.0001f;
+  for (uint32_t k = lane; k < group_rows * (uint32_t)n_rad; k += 64) cnt[k] = 0;
+  __syncthreads();
+  bool any = false;
+  const uint32_t* range = comp + kCompRange;
+  for (uint32_t c2 = 0; c2 < (uint32_t)kMaxComp; ++c2) {
+    if (!((adj >> c2) & 1ull)) continue;
+    if (!(box_gap2(gbox, reinterpret_cast<const float4*>(comp + kCompBox)[c2]) < far2)) continue;
+    const uint32_t t_lo = range[2 * c2], t_hi = range[2 * c2 + 1];
+    for (uint32_t base = t_lo; base < t_hi; base += 64) {
+      const uint32_t t = base + lane;
+      const bool ok = t < t_hi && box_gap2(gbox, box_r[t]) < far2;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+      if (m == 0) continue;
+      if (ok) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+      __syncthreads();
+      const uint32_t n_list = (uint32_t)__builtin_popcountll(m);
+      any = true;
+      for (uint32_t s = 0; s < n_list; ++s) {
+        const uint32_t tr = list[s];
+        for (uint32_t r = 0; r < 32; ++r) {
+          const uint32_t pr = 32u * tr + r;
+          if (perm_r[pr] == kInvalidFrame) continue;   // (wave-uniform)
+          const float* xr = coords_r + (size_t)pr * n_cols;
+          for (uint32_t k = lane; k < group_rows; k += 64) {
+            const uint32_t pq = 32u * qt0 + k;
+            const uint32_t fq = (pq < 32u * T_q) ? perm_q[pq] : kInvalidFrame;
+            if (fq == kInvalidFrame) continue;
+            const float* yq = q_in_ref_order ? coords_r + (size_t)pq * n_cols : coords + (size_t)fq * n_cols;
+            const float d2 = dist2_canon_rows(yq, xr, (int)n_cols);
+            for (int rr = 0; rr < n_rad; ++rr)
+              if (d2 < rad2.v[rr]) cnt[(size_t)rr * group_rows + k] += 1u;   // (query k is this lane's alone)
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!any) return;
+  for (uint32_t k = lane; k < group_rows; k += 64) {
+    const uint32_t pq = 32u * qt0 + k;
+    const uint32_t fq = (pq < 32u * T_q) ? perm_q[pq] : kInvalidFrame;
+    if (fq == kInvalidFrame) continue;
+    for (int rr = 0; rr < n_rad; ++rr) {
+      const uint32_t v = cnt[(size_t)rr * group_rows + k];
+      if (v) atomicAdd(&out[(size_t)rr * stride + (by_position ? pq : fq)], v);
+    }
+  }
+}
+
 // bounding box (lo0, hi0, lo1, hi1) of the frames of each tile of an ordered frame list
 __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
                            const uint32_t* __restrict__ perm, uint32_t n_used, uint32_t T,
@@ -743,19 +834,29 @@ __global__ void box_rows_kernel(const float* __restrict__ coords_o, uint32_t D, 
                                 float2* __restrict__ ferange, const uint32_t* __restrict__ valid = nullptr,
                                 const uint32_t* __restrict__ tile_comp = nullptr,
                                 const float* __restrict__ origins = nullptr, uint32_t* __restrict__ hdr = nullptr) {
-  // valid: frame of every row of the order (kInvalidFrame: a pad row).  tile_comp / origins / hdr: the squared distance
-  // from the tile's origin to the far corner of its box bounds |x - origin|^2 in columns 0/1 for all its rows; the
-  // maximum over the tiles goes to hdr[kHdrMloc] (scale_kernel adds the bound of the other columns)
+  // valid: frame of every row of the order (kInvalidFrame: a pad row).  tile_comp / origins / hdr: the maximum over the
+  // rows of |x - origin(component of the row's tile)|^2 goes to hdr[kHdrMloc] -- what the sweep's scale and guard band
+  // follow when there are several components (scale_kernel)
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;   // 32 consecutive lanes = one tile
-  const uint32_t t = pos >> 5;
-  if (t >= T) return;                                           // (whole half-waves leave together)
-  const bool live = pos < n_used && (!valid || valid[pos] != kInvalidFrame);
+  const uint32_t t = min(pos >> 5, T - 1);                       // (the grid covers whole tiles: 256 | 32 T is not required)
+  const bool in_range = (pos >> 5) < T;
+  const bool live = in_range && pos < n_used && (!valid || valid[pos] != kInvalidFrame);
   const float x = live ? coords_o[(size_t)pos * D] : 0.0f;
   const float y = (live && D > 1) ? coords_o[(size_t)pos * D + 1] : 0.0f;
   float lo0 = live ? x : INFINITY, hi0 = live ? x : -INFINITY;
   float lo1 = live ? y : INFINITY, hi1 = live ? y : -INFINITY;
   const float f = (live && fe_o) ? fe_o[pos] : 0.0f;
   float flo = (live && fe_o) ? f : INFINITY, fhi = (live && fe_o) ? f : -INFINITY;
+  // |x - origin(component of the tile)|^2 of this row (all columns; float, with a margin for its own rounding)
+  float ext = 0.0f;
+  if (tile_comp && live) {
+    const float* a = origins + (size_t)tile_comp[t] * kMaxCols;
+    for (uint32_t k = 0; k < D; ++k) {
+      const float v = coords_o[(size_t)pos * D + k] - a[k];
+      ext += v * v;
+    }
+    ext = ext * 1.0001f + FLT_MIN;
+  }
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) {
     lo0 = fminf(lo0, __shfl_xor(lo0, off, 64));
@@ -764,15 +865,21 @@ __global__ void box_rows_kernel(const float* __restrict__ coords_o, uint32_t D, 
     hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
     flo = fminf(flo, __shfl_xor(flo, off, 64));
     fhi = fmaxf(fhi, __shfl_xor(fhi, off, 64));
+    ext = fmaxf(ext, __shfl_xor(ext, off, 64));
   }
-  if ((pos & 31u) == 0) {
+  if ((pos & 31u) == 0 && in_range) {
     boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
     if (ferange) ferange[t] = make_float2(flo, fhi);
-    if (tile_comp && lo0 <= hi0) {
-      const float* a = origins + (size_t)tile_comp[t] * kMaxCols;
-      const float dx = fmaxf(fabsf(lo0 - a[0]), fabsf(hi0 - a[0]));
-      const float dy = (D > 1) ? fmaxf(fabsf(lo1 - a[1]), fabsf(hi1 - a[1])) : 0.0f;
-      const float m = next_up(next_up(dx * dx + dy * dy));
+  }
+  if (tile_comp) {
+    // the block's maximum -> one atomic (and only when it would raise the word)
+    __shared__ float blk_max[8];
+    ext = fmaxf(ext, __shfl_xor(ext, 32, 64));
+    if ((threadIdx.x & 63u) == 0) blk_max[threadIdx.x >> 6] = ext;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.0f;
+      for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) m = fmaxf(m, blk_max[w]);
       if (m <= FLT_MAX) {
         const uint32_t bits = __float_as_uint(m);
         if (bits > __atomic_load_n(hdr + kHdrMloc, __ATOMIC_RELAXED)) atomicMax(hdr + kHdrMloc, bits);
@@ -840,6 +947,20 @@ int sweep_timer_read(int kind, float* ms) {
   return hipEventElapsedTime(ms, t.ev[0], t.ev[1]) == hipSuccess ? 0 : -1;
 }
 
+void launch_pop_cross(const float* coords, uint32_t n_cols, const float* coords_r, const uint32_t* perm_r,
+                      const float4* box_r, const uint32_t* perm_q, const float4* box_q, const uint32_t* tile_comp_q,
+                      const uint32_t* comp, uint32_t T_q, uint32_t group_tiles, QSeg q_seg, int q_in_ref_order,
+                      const Rad2& rad2, int n_rad, const uint32_t* hdr, uint32_t* out, size_t stride, int by_position,
+                      hipStream_t s) {
+  const uint32_t groups = seg_groups((T_q + group_tiles - 1) / group_tiles, q_seg);
+  if (groups == 0 || n_rad <= 0 || 32u * group_tiles > (uint32_t)kMaxGroupRows) return;
+  float r2max = rad2.v[0];
+  for (int r = 1; r < n_rad; ++r) r2max = std::max(r2max, rad2.v[r]);
+  hipLaunchKernelGGL(pop_cross_kernel, dim3(groups), dim3(64), 0, s, coords, n_cols, coords_r, perm_r, box_r, perm_q, box_q,
+                     tile_comp_q, comp, T_q, group_tiles, q_seg, q_in_ref_order, rad2, n_rad, r2max, hdr, out, stride,
+                     by_position);
+}
+
 // diagnostics of the last pruned population sweep in a workspace: components, global and component-wise extent
 int components_info(const void* d_ws, size_t n_rows, size_t n_cols, uint32_t* n_comp, float* m_global, float* m_local,
                     float* scale, hipStream_t stream) {
@@ -851,8 +972,7 @@ int components_info(const void* d_ws, size_t n_rows, size_t n_cols, uint32_t* n_
   if (hipStreamSynchronize(stream) != hipSuccess) return -1;
   *n_comp = grid[5];
   memcpy(m_global, &hdr[0], 4);
-  const float a = __builtin_bit_cast(float, hdr[kHdrMloc]), b = __builtin_bit_cast(float, hdr[kHdrMrest]);
-  *m_local = (grid[5] > 1u) ? a + b : *m_global;
+  *m_local = (grid[5] > 1u) ? __builtin_bit_cast(float, hdr[kHdrMloc]) : *m_global;
   memcpy(scale, &hdr[kHdrScale + 1], 4);
   return 0;
 }
@@ -1134,6 +1254,9 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   const uint32_t T_q = (n_q + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
   const size_t tmp_bytes = sort_temp_bytes(n_rows + kOrderPadRows);
   const float r_max = sqrtf(fmaxf(r2_scale, 0.0f)) * 1.0001f;
+  // connectivity length of the components: the largest radius itself for the sweeps that list pairs (no pair between
+  // components), half of it for the plain sweeps (pairs between adjacent components: pop_cross_kernel)
+  const float r_conn = sink_in ? r_max : 0.5f * r_max;
   const unsigned fine_bits = cell_key_bits(n_rows, kPopCellFrames) + 1u;
   const unsigned key_bits = fine_bits + 6u;   // kMaxComp = 64 components
   static_assert(kMaxComp == 64, "six component bits in the ordering keys");
@@ -1149,14 +1272,14 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     // components of the frames for this call's largest radius, their origins and fine grids
     (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
     (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_max,
+    hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn,
                        comp);
-    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_max, comp);
+    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, comp);
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
-                       (const float*)(p + kHdrMeans), n_cols, r_max, n_rows, kPopCellFrames, fine_bits, comp,
-                       components_off() ? 1 : 0);
+                       (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
+                       components_off() ? 1 : 0, r_max);
     // order all frames by (component, fine cell); every component then moves to a whole query group of the padded order
-    hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_max,
+    hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
                        (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in);
     if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits))
       return;
@@ -1197,7 +1320,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     if (q_mode == kQueryOwnOrder) {
       // query rows of this call: the same ordering restricted to [i_from, i_to)
       hipLaunchKernelGGL(compkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr,
-                         r_max, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in);
+                         r_conn, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in);
       if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_q, p + L.fixed_end, tmp_bytes, stream, key_bits))
         return;
       pad_order(keys_out, vals_sorted, n_q, fine_bits, group_rows, comp + kCompStart + (kMaxComp + 1),

@@ -94,6 +94,14 @@ void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t 
                             bool pruned, const void* d_ws, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
                             float* d_hd_d2, hipStream_t stream);
 
+// the frame pairs between ADJACENT components of a pruned population sweep (dc_mfma_kernels.hpp "components"), counted
+// exactly and added to out[rr * stride + (query position | frame)]
+void launch_pop_cross(const float* coords, uint32_t n_cols, const float* coords_r, const uint32_t* perm_r,
+                      const float4* box_r, const uint32_t* perm_q, const float4* box_q, const uint32_t* tile_comp_q,
+                      const uint32_t* comp, uint32_t T_q, uint32_t group_tiles, QSeg q_seg, int q_in_ref_order,
+                      const Rad2& rad2, int n_rad, const uint32_t* hdr, uint32_t* out, size_t stride, int by_position,
+                      hipStream_t s);
+
 // diagnostics of the last pruned population sweep that ran in a workspace (synchronises): number of components, the
 // global max |x - mean|^2, the bound of max |x - origin(component)|^2 the scale was chosen for, and that scale S
 int components_info(const void* d_ws, size_t n_rows, size_t n_cols, uint32_t* n_comp, float* m_global, float* m_local,

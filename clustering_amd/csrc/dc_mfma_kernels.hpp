@@ -106,12 +106,16 @@ constexpr float kNormLimit = 1.0e36f;  // larger |x'|^2 could overflow the Gram 
 // ---- components (pruned population sweeps) ------------------------------------------------------------------
 // The Gram form's guard band grows with max |x - origin|^2 (DESIGN.md "guard band"), so ONE origin for a data set
 // whose clusters lie far apart makes every chain wade through band pairs.  The population sweeps therefore cut the
-// frames into COMPONENTS: sets that are at least r_max apart in the (col 0, col 1) plane -- connected components of
-// a coarse occupancy grid under "point boxes closer than r_max" -- so that no pair of different components can be
-// inside any radius.  Each component gets its own origin (centre of its box in columns 0/1, the column means
-// elsewhere), its own fine cell grid, and a contiguous, group-aligned range of the sweep's order (pad positions
-// carry kInvalidFrame); a query group only ever scans the tiles of its own component.  One component (dense data,
-// more than kMaxComp components, a grid too busy to label) is exactly the old single-origin sweep.
+// frames into COMPONENTS: sets that are at least rho apart in the (col 0, col 1) plane -- connected components of
+// a coarse occupancy grid under "occupied boxes closer than rho".  Each component gets its own origin (centre of its
+// box in columns 0/1, the column means elsewhere), its own fine cell grid, and a contiguous, group-aligned range of the
+// sweep's order (pad positions carry kInvalidFrame); in the matrix-core sweep a query group only ever meets the tiles of
+// its own component.  rho = r_max (sweeps that list pairs): no pair of different components can be inside any radius.
+// rho = r_max / 2 (plain population sweeps): components that come closer than r_max are ADJACENT (kCompAdj), and the
+// few frame pairs between adjacent components are evaluated exactly, without the matrix cores, by pop_cross_kernel
+// (5M x 30: three clusters whose 2-D projections come within 0.55 of each other -- less than the largest radius, 0.65).
+// One component (dense data, more than kMaxComp components, a grid too busy to label) is exactly the old
+// single-origin sweep.
 constexpr uint32_t kInvalidFrame = 0xFFFFFFFFu;
 constexpr int kMaxComp = 64;                 // components with an origin of their own
 constexpr int kCoarseDim = 128;              // coarse occupancy grid: at most kCoarseDim^2 cells
@@ -131,7 +135,9 @@ constexpr size_t kCompStart = kCompNby + (size_t)kMaxComp;             // [2][kM
 constexpr size_t kCompRange = kCompStart + 2 * ((size_t)kMaxComp + 1); // [2][kMaxComp + 1][2]: tile range [lo, hi) of a component (reference / query
                                                                        // order); entry kMaxComp is the empty range of the all-pad tiles at the end
 constexpr size_t kCompRangeStride = 2 * ((size_t)kMaxComp + 1);
-constexpr size_t kCompBitmap = kCompRange + 2 * kCompRangeStride;      // occupancy of the sub-cells, one byte each
+constexpr size_t kCompAdj = kCompRange + 2 * kCompRangeStride;         // [kMaxComp][2]: 64-bit mask of the components whose boxes are closer than r_max
+constexpr size_t kCompBox = kCompAdj + 2 * (size_t)kMaxComp;           // [kMaxComp] float4: box of the component in columns 0/1
+constexpr size_t kCompBitmap = kCompBox + 4 * (size_t)kMaxComp;        // occupancy of the sub-cells, one byte each
 constexpr size_t kCompBitmapWords = (size_t)kCoarseCells * kFineSub * kFineSub / 4;
 constexpr size_t kCompWords = kCompBitmap + kCompBitmapWords;
 
@@ -317,8 +323,7 @@ struct Scale {
 };
 constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
 constexpr uint32_t kHdrCookie = 28;     // whose statistics the header holds (array, shape); 0 after a reset
-constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: bound of max |x - origin(component of x)|^2 (float bits)
-constexpr uint32_t kHdrMrest = 30;      // max over the rows of sum_{k >= 2} (x_k - mean_k)^2 (float bits; a statistic)
+constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: max |x - origin(component of x)|^2 (float bits, with a rounding margin)
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
                                               //  4 S M below 2^19.6; only a radius beyond the clamps of
@@ -2600,6 +2605,13 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   const bool own = q_mode == kQueryOwnOrder;
   // T: tiles of the (padded) reference order; n_q: positions of the query order
   const CompView CV{own ? P.tile_comp_q : P.tile_comp, P.comp + kCompRange, 32u * T};
+  // pairs between adjacent components (exact, after the matrix-core sweep): into the same counts
+  auto cross = [&](uint32_t group_tiles, uint32_t* out, size_t stride, int by_position) {
+    if (sink) return;   // (the sweeps that list pairs use components no pair can cross)
+    launch_pop_cross(coords, n_cols, P.coords_p, P.perm_p, P.box_p, own ? P.perm_q : P.perm_p, own ? P.box_q : P.box_p,
+                     CV.tile_comp_q, P.comp, (n_q + 31) / 32, group_tiles, q_seg, own ? 0 : 1, rad2, n_rad, P.hdr, out,
+                     stride, by_position, s);
+  };
   const uint4* img_q = P.img_q;
   const float* norms_q = own ? P.norms_q : P.norms_p;
   const uint32_t* perm_q = own ? P.perm_q : P.perm_p;
@@ -2622,6 +2634,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
       { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV, true>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols,
                          P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
                          chain_counter, rad2, n_rad, pops, own ? 0 : 1, CV, pops_pos); sweep_timer_mark(0, false, s); }
+      cross(4u * kTQS, pops_pos, (size_t)32 * T, 1);
       for (int rr = 0; rr < n_rad; ++rr)
         hipLaunchKernelGGL(pops_by_frame_kernel, dim3((32 * T + 255) / 256), dim3(256), 0, s,
                            (const uint32_t*)(pops_pos + (size_t)rr * 32 * T), P.perm_p, 32u * T, P.hdr,
@@ -2631,6 +2644,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
     { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_shared_kernel<S, kTQS, NRV>), grid_s, dim3(256), smem_s, s, coords, n_rows, n_cols, P.img_p,
                        P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
                        chain_counter, rad2, n_rad, pops, own ? 0 : 1, CV); sweep_timer_mark(0, false, s); }
+    cross(4u * kTQS, pops, (size_t)n_rows, 0);
     return;
   }
   if constexpr (NRV == 1 && TQV <= 6) {
@@ -2643,6 +2657,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
                          n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                          perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
                          EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, CV, pops_pos); sweep_timer_mark(0, false, s); }
+      cross((uint32_t)TQV, pops_pos, (size_t)32 * T, 1);
       hipLaunchKernelGGL(pops_by_frame_kernel, dim3((32 * T + 255) / 256), dim3(256), 0, s, (const uint32_t*)pops_pos,
                          P.perm_p, 32u * T, P.hdr, pops);
       return;
@@ -2662,6 +2677,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
                        n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                        perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
                        EdgeSink{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, CV); sweep_timer_mark(0, false, s); }
+  cross((uint32_t)TQV, pops, (size_t)n_rows, 0);
 }
 
 template <int S, int NRV>

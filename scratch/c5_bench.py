@@ -25,6 +25,7 @@ def timed(fn):
     return out, min(ts)
 p, pop_ms = timed(lambda: dens.calculate_populations_segment(c, a.radii, a.segment, G))
 pop_tiles = dens.evaluated_tiles(c.device)[0]
+comp_info = dens.components_info(c)
 # FE needs the populations of all rows: one full single-radius sweep here (a real run all-reduces the segments)
 pf, full_ms = timed(lambda: dens.calculate_populations_partial(c, [a.radii[len(a.radii) // 2]]))
 full_tiles = dens.evaluated_tiles(c.device)[0]
@@ -38,7 +39,7 @@ def roof(tiles, ms):
             "frac_f16_mfma_peak_2500": tiles * 1024.0 * 32 * nm / (ms * 1e-3) / 2.5e15}
 line = {
     "workload": f"{n} x {d}, radii {a.radii}, segment {a.segment} of {G} (one rank of the 8-GPU run)",
-    "rows_of_the_segment": rows, "mfma_per_tile_pair": nm,
+    "rows_of_the_segment": rows, "mfma_per_tile_pair": nm, "components": comp_info,
     "pop_8_radii_ms": pop_ms, "pop_per_radius_ms": pop_ms / len(a.radii), "nn_ms": nn_ms,
     "full_single_radius_sweep_all_rows_ms": full_ms,
     "frame_pairs_per_s_this_rank": {"pop": len(a.radii) * float(rows) * n / (pop_ms * 1e-3), "nn": float(rows) * n / (nn_ms * 1e-3)},
