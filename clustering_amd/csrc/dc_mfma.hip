@@ -209,6 +209,7 @@ __global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D
   // several components (pruned population sweeps): every row is measured from its component's origin (the maximum
   // over the rows: box_rows_kernel)
   if (comp && comp[kCompGrid + 5] > 1u) M = fminf(__uint_as_float(hdr[kHdrMloc]), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);
+  hdr[kHdrMused] = __float_as_uint(M);
   const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
   hdr[kHdrScale + 0] = __float_as_uint(e.c);
   hdr[kHdrScale + 1] = __float_as_uint(e.s2);
@@ -289,8 +290,8 @@ __global__ void fe_scatter_kernel(const uint32_t* __restrict__ perm, const float
                                   float* __restrict__ fe_s) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= 32 * T) return;
-  if (p < n_rows) {
-    const uint32_t i = perm[p];
+  const uint32_t i = (p < n_rows) ? perm[p] : kInvalidFrame;   // (n_rows: the positions that hold a perm entry)
+  if (i != kInvalidFrame) {
     invpos[i] = p;
     fe_s[p] = fe[i];
   } else {
@@ -372,8 +373,10 @@ struct CoarseGrid {
 };
 // coarse occupancy grid over the bounding box of columns 0/1: cells of a quarter of the largest radius, at most
 // kCoarseDim per dimension
-__device__ __forceinline__ CoarseGrid coarse_grid(const uint32_t* __restrict__ hdr, float r_max) {
+// r_max < 0 (the neighbour sweep has no radius): -r_max times the cell edge of its ordering for n_rows frames
+__device__ __forceinline__ CoarseGrid coarse_grid(const uint32_t* __restrict__ hdr, float r_max, uint32_t n_rows = 0) {
   CoarseGrid g;
+  if (r_max < 0.0f) r_max = -r_max * auto_cell(hdr, n_rows, kNnCellFrames);
   g.min0 = fkey_inv(~hdr[8]);
   g.min1 = fkey_inv(~hdr[10]);
   float e0 = fkey_inv(hdr[9]) - g.min0, e1 = fkey_inv(hdr[11]) - g.min1;
@@ -402,7 +405,7 @@ __global__ void fine_mark_kernel(const float* __restrict__ coords, uint32_t n_ro
   if (i >= n_rows) return;
   const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
   if (!(fabsf(x) <= FLT_MAX) || !(fabsf(y) <= FLT_MAX)) return;   // (flagged data: the sweep stands down anyway)
-  const CoarseGrid g = coarse_grid(hdr, r_max);
+  const CoarseGrid g = coarse_grid(hdr, r_max, n_rows);
   const float gf = g.gc / (float)kFineSub;
   const uint32_t fx = (uint32_t)fminf(fmaxf((x - g.min0) / gf, 0.0f), (float)(g.ncx * kFineSub - 1));
   const uint32_t fy = (uint32_t)fminf(fmaxf((y - g.min1) / gf, 0.0f), (float)(g.ncy * kFineSub - 1));
@@ -412,9 +415,10 @@ __global__ void fine_mark_kernel(const float* __restrict__ coords, uint32_t n_ro
 // box of the occupied sub-cells of every coarse cell (a little wider than the sub-cells: every frame of the cell lies
 // inside whatever the rounding of its sub-cell index did); lo0 > hi0 marks an empty cell.  NB: a frame is assigned to
 // the COARSE cell of its sub-cell (fx / kFineSub), see comp_of_point.
-__global__ void coarse_box_kernel(const uint32_t* __restrict__ hdr, float r_max, uint32_t* __restrict__ comp) {
+__global__ void coarse_box_kernel(const uint32_t* __restrict__ hdr, float r_max, uint32_t n_rows,
+                                  uint32_t* __restrict__ comp) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  const CoarseGrid g = coarse_grid(hdr, r_max);
+  const CoarseGrid g = coarse_grid(hdr, r_max, n_rows);
   if (c >= g.ncx * g.ncy) return;
   const uint32_t cx = c / g.ncy, cy = c % g.ncy;
   const unsigned char* bm = reinterpret_cast<const unsigned char*>(comp + kCompBitmap);
@@ -466,7 +470,8 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   __shared__ uint32_t root_cell[kMaxComp];
   __shared__ uint32_t cbox[kMaxComp][4];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  const CoarseGrid g = coarse_grid(hdr, r_max);
+  const CoarseGrid g = coarse_grid(hdr, r_max, n_rows);
+  if (r_max < 0.0f) r_max = g.gc * 4.0f;   // (the connectivity length the grid was built for: four coarse cells, or more)
   const uint32_t n_cells = g.ncx * g.ncy;
   uint32_t* cell_comp = comp + kCompCellComp;   // during the labelling: cell -> index in occ[] (0xFFFFFFFF: empty)
   if (tid == 0) {
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
     if (a_occ > 0.0 && a_occ < a_box)
       cell = (float)sqrt(a_occ * (double)frames_per_cell / (double)(n_rows ? n_rows : 1u));
   }
-  const float cells_max = ldexpf(1.0f, (int)fine_bits) * 0.5f;   // (x + 1)(y + 1) must stay below 2^fine_bits
+  __shared__ float s_lo0[kMaxComp], s_lo1[kMaxComp], s_e0[kMaxComp], s_e1[kMaxComp];
   if (tid < n_comp) {
     const float lo0 = single ? gmin0 : fkey_inv(~cbox[tid][0]), hi0 = single ? gmax0 : fkey_inv(cbox[tid][1]);
     const float lo1 = single ? gmin1 : fkey_inv(~cbox[tid][2]), hi1 = single ? gmax1 : fkey_inv(cbox[tid][3]);
@@ -599,25 +604,43 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
       a[0] = 0.5f * lo0 + 0.5f * hi0;
       if (D > 1) a[1] = 0.5f * lo1 + 0.5f * hi1;
     }
-    const float e0 = fmaxf(hi0 - lo0, 0.0f), e1 = fmaxf(hi1 - lo1, 0.0f);
-    float c0 = fmaxf(cell, e0 / 4000.0f), c1 = fmaxf(cell, e1 / 4000.0f);
-    if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
-    if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
-    // (a long thin component inside a sparse data set: never more cells than the key has bits for)
-    float nx = fminf(e0 / c0, 4001.0f) + 1.0f, ny = fminf(e1 / c1, 4001.0f) + 1.0f;
-    if (nx * ny > cells_max) {
-      const float f = sqrtf(nx * ny / cells_max) * 1.01f;
-      c0 *= f;
-      c1 *= f;
-      nx = fminf(e0 / c0, 4001.0f) + 1.0f;
-      ny = fminf(e1 / c1, 4001.0f) + 1.0f;
+    s_lo0[tid] = (fabsf(lo0) <= FLT_MAX) ? lo0 : 0.0f;
+    s_lo1[tid] = (fabsf(lo1) <= FLT_MAX) ? lo1 : 0.0f;
+    const float e0 = hi0 - lo0, e1 = hi1 - lo1;
+    s_e0[tid] = (e0 >= 0.0f && e0 <= FLT_MAX) ? e0 : 0.0f;
+    s_e1[tid] = (e1 >= 0.0f && e1 <= FLT_MAX) ? e1 : 0.0f;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // fine grids: one cell size for all components (at most 4001 cells per dimension and component), the cells of all
+    // components numbered consecutively -- fewer than 2^fine_bits of them, so the ordering keys stay short
+    const float limit = ldexpf(1.0f, (int)fine_bits) - 2.0f;
+    if (!(cell > 0.0f) || !(cell <= FLT_MAX)) cell = 1.0f;
+    for (int round = 0; round < 8; ++round) {
+      float total = 0.0f;
+      for (uint32_t c = 0; c < n_comp; ++c) {
+        const float c0 = fmaxf(cell, s_e0[c] / 4000.0f), c1 = fmaxf(cell, s_e1[c] / 4000.0f);
+        total += (floorf(fminf(s_e0[c] / c0, 4001.0f)) + 1.0f) * (floorf(fminf(s_e1[c] / c1, 4001.0f)) + 1.0f);
+      }
+      if (total <= limit) break;
+      cell *= sqrtf(total / limit) * 1.05f;
     }
-    uint32_t* f = comp + kCompFine + 4 * (size_t)tid;
-    f[0] = __float_as_uint((fabsf(lo0) <= FLT_MAX) ? lo0 : 0.0f);
-    f[1] = __float_as_uint((fabsf(lo1) <= FLT_MAX) ? lo1 : 0.0f);
-    f[2] = __float_as_uint(c0);
-    f[3] = __float_as_uint(c1);
-    comp[kCompNby + tid] = (uint32_t)ny;
+    uint32_t off = 0;
+    for (uint32_t c = 0; c < n_comp; ++c) {
+      float c0 = fmaxf(cell, s_e0[c] / 4000.0f), c1 = fmaxf(cell, s_e1[c] / 4000.0f);
+      if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
+      if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
+      const uint32_t nx = (uint32_t)fminf(s_e0[c] / c0, 4001.0f) + 1u, ny = (uint32_t)fminf(s_e1[c] / c1, 4001.0f) + 1u;
+      uint32_t* f = comp + kCompFine + 4 * (size_t)c;
+      f[0] = __float_as_uint(s_lo0[c]);
+      f[1] = __float_as_uint(s_lo1[c]);
+      f[2] = __float_as_uint(c0);
+      f[3] = __float_as_uint(c1);
+      comp[kCompNby + c] = ny;
+      comp[kCompCellOff + c] = off;
+      off = min(off + nx * ny, (1u << fine_bits) - 1u);
+    }
+    for (uint32_t c = n_comp; c <= (uint32_t)kMaxComp; ++c) comp[kCompCellOff + c] = off;
   }
   // boxes of the components, and which of them come closer than the largest radius (cross pairs: pop_cross_kernel)
   if (tid < n_comp) {
@@ -649,12 +672,17 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
 // the rows [i_from, i_to): keys[j], vals[j] = key, id of row i_from + j
 __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ hdr,
                                float r_max, const uint32_t* __restrict__ comp, uint32_t fine_bits, uint32_t i_from,
-                               uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                               uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                               uint32_t n_total = 0, const float* __restrict__ fe = nullptr, uint32_t fe_bits = 0) {
+  // fe / fe_bits (the neighbour sweep): the cell number moves up by fe_bits and the free energy, quantised linearly
+  // between the smallest and the largest finite value of the data set (header words 12 / 13), fills the low bits --
+  // the order inside a cell only shapes the tiles' free-energy ranges (the kernels read the ranges, they assume no
+  // order), so the quantisation costs a little pruning at worst and saves a second stable sort
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = i_from + j;
   if (i >= i_to) return;
   const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-  const CoarseGrid g = coarse_grid(hdr, r_max);
+  const CoarseGrid g = coarse_grid(hdr, r_max, n_total);
   uint32_t c = 0, bx = 0, by = 0, nby = 1;
   if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
     c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
@@ -665,20 +693,42 @@ __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, con
     bx = (uint32_t)fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f);
     by = min((uint32_t)fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f), nby - 1u);
   }
-  const uint32_t fine = min(bx * nby + by, (1u << fine_bits) - 1u);
-  keys[j] = (c << fine_bits) | fine;
+  // cells of all components numbered consecutively (kCompCellOff): fewer than 2^fine_bits keys
+  const uint32_t lo = comp[kCompCellOff + c], hi = comp[kCompCellOff + c + 1];
+  uint32_t key = min(lo + bx * nby + by, hi - (hi > lo ? 1u : 0u));
+  if (fe) {
+    const float fe_lo = fkey_inv(~hdr[12]), fe_hi = fkey_inv(hdr[13]);
+    const float span = fe_hi - fe_lo;
+    float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
+    u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
+    const uint32_t levels = (1u << fe_bits) - 1u;
+    key = (key << fe_bits) | (uint32_t)((double)u * (double)levels);
+  }
+  keys[j] = key;
   vals[j] = i;
 }
 
 // After the sort: where each component starts in the sorted list (a component without frames starts where the next
 // one does) ...
-__global__ void comp_start_kernel(const uint32_t* __restrict__ keys_sorted, uint32_t n, uint32_t fine_bits,
-                                  uint32_t* __restrict__ start /* [kMaxComp + 1], preset to n */) {
+// component of a (sorted) cell key: the last component whose first cell is not beyond it; key_shift: the cell key sits
+// above key_shift bits of something else (the neighbour sweep's quantised free energy)
+__device__ __forceinline__ uint32_t comp_of_key(const uint32_t* __restrict__ comp, uint32_t key, uint32_t key_shift) {
+  const uint32_t cellk = key >> key_shift, n_comp = comp[kCompGrid + 5];
+  uint32_t c = 0;
+  for (uint32_t k = 1; k < n_comp; ++k) c += (comp[kCompCellOff + k] <= cellk) ? 1u : 0u;
+  return c;
+}
+// (this kernel also presets the padded order: every position kInvalidFrame, every tile the all-pad component)
+__global__ void comp_start_kernel(const uint32_t* __restrict__ keys_sorted, uint32_t n, uint32_t key_shift,
+                                  const uint32_t* __restrict__ comp, uint32_t* __restrict__ start /* [kMaxComp + 1], preset to n */,
+                                  uint32_t* __restrict__ perm, uint32_t* __restrict__ tile_comp, uint32_t T_used) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 32u * T_used) perm[i] = kInvalidFrame;
+  if (i < T_used) tile_comp[i] = kMaxComp;
   if (i >= n) return;
-  const uint32_t c = keys_sorted[i] >> fine_bits;
-  const uint32_t prev = (i == 0) ? 0xFFFFFFFFu : (keys_sorted[i - 1] >> fine_bits);
-  if (c != prev && c < (uint32_t)kMaxComp) start[c] = i;
+  const uint32_t c = comp_of_key(comp, keys_sorted[i], key_shift);
+  const uint32_t prev = (i == 0) ? 0xFFFFFFFFu : comp_of_key(comp, keys_sorted[i - 1], key_shift);
+  if (c != prev) start[c] = i;
 }
 // ... the tile range of every component once each is padded to whole query groups (group_rows positions) ...
 __global__ void comp_ranges_kernel(uint32_t* __restrict__ start, uint32_t n, uint32_t group_rows,
@@ -705,12 +755,13 @@ __global__ void comp_ranges_kernel(uint32_t* __restrict__ start, uint32_t n, uin
 // ... and the padded order itself: sorted entry i of component c goes to position 32 range[c].lo + (i - start[c]);
 // every other position keeps kInvalidFrame, every tile gets its component (preset: kMaxComp, the all-pad tiles)
 __global__ void pad_scatter_kernel(const uint32_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted,
-                                   uint32_t n, uint32_t fine_bits, const uint32_t* __restrict__ start,
+                                   uint32_t n, uint32_t key_shift, const uint32_t* __restrict__ comp,
+                                   const uint32_t* __restrict__ start,
                                    const uint32_t* __restrict__ range, uint32_t* __restrict__ perm,
                                    uint32_t* __restrict__ tile_comp) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t c = min(keys_sorted[i] >> fine_bits, (uint32_t)kMaxComp - 1u);
+  const uint32_t c = comp_of_key(comp, keys_sorted[i], key_shift);
   const uint32_t pos = 32u * range[2 * c] + (i - start[c]);
   perm[pos] = vals_sorted[i];
   if ((pos & 31u) == 0) tile_comp[pos >> 5] = c;
@@ -1193,16 +1244,15 @@ void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_c
 }
 
 // the padded order of a sorted (component, fine cell) list: perm[position] = frame or kInvalidFrame, tile_comp[tile]
-static void pad_order(const uint32_t* keys_sorted, const uint32_t* vals_sorted, uint32_t n, unsigned fine_bits,
-                      uint32_t group_rows, uint32_t* start, uint32_t* range, uint32_t* perm, uint32_t* tile_comp,
-                      uint32_t T_used, hipStream_t stream) {
+static void pad_order(const uint32_t* keys_sorted, const uint32_t* vals_sorted, uint32_t n, unsigned key_shift,
+                      uint32_t group_rows, const uint32_t* comp, uint32_t* start, uint32_t* range, uint32_t* perm,
+                      uint32_t* tile_comp, uint32_t T_used, hipStream_t stream) {
   (void)hipMemsetD32Async((hipDeviceptr_t)start, (int)n, kMaxComp + 1, stream);
-  (void)hipMemsetAsync(perm, 0xFF, sizeof(uint32_t) * 32 * (size_t)T_used, stream);
-  (void)hipMemsetD32Async((hipDeviceptr_t)tile_comp, kMaxComp, T_used, stream);
   const dim3 blk(256), grid((n + 255) / 256);
-  hipLaunchKernelGGL(comp_start_kernel, grid, blk, 0, stream, keys_sorted, n, (uint32_t)fine_bits, start);
+  hipLaunchKernelGGL(comp_start_kernel, dim3((32 * T_used + 255) / 256), blk, 0, stream, keys_sorted, n,
+                     (uint32_t)key_shift, comp, start, perm, tile_comp, T_used);
   hipLaunchKernelGGL(comp_ranges_kernel, dim3(1), dim3(64), 0, stream, start, n, group_rows, range);
-  hipLaunchKernelGGL(pad_scatter_kernel, grid, blk, 0, stream, keys_sorted, vals_sorted, n, (uint32_t)fine_bits,
+  hipLaunchKernelGGL(pad_scatter_kernel, grid, blk, 0, stream, keys_sorted, vals_sorted, n, (uint32_t)key_shift, comp,
                      (const uint32_t*)start, (const uint32_t*)range, perm, tile_comp);
 }
 
@@ -1257,9 +1307,9 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   // connectivity length of the components: the largest radius itself for the sweeps that list pairs (no pair between
   // components), half of it for the plain sweeps (pairs between adjacent components: pop_cross_kernel)
   const float r_conn = sink_in ? r_max : 0.5f * r_max;
+  // (the cells of all components are numbered consecutively: fewer than 2^fine_bits keys)
   const unsigned fine_bits = cell_key_bits(n_rows, kPopCellFrames) + 1u;
-  const unsigned key_bits = fine_bits + 6u;   // kMaxComp = 64 components
-  static_assert(kMaxComp == 64, "six component bits in the ordering keys");
+  const unsigned key_bits = fine_bits;
   EdgeSink sink_local;
   const EdgeSink* sink = sink_in;
   if (sink_in && sink_in->best) {   // (component ids and ranks in the sweep's order: gathered below)
@@ -1274,7 +1324,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
     hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn,
                        comp);
-    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, comp);
+    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, r_max);
@@ -1283,7 +1333,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                        (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in);
     if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits))
       return;
-    pad_order(keys_out, vals_sorted, n_rows, fine_bits, group_rows, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
+    pad_order(keys_out, vals_sorted, n_rows, 0u, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
               T_r, stream);
     // original rows in the reference order: the deferred exact path reads them without a
     // permutation look-up, and the operand images are built from them with coalesced reads
@@ -1323,7 +1373,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                          r_conn, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in);
       if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_q, p + L.fixed_end, tmp_bytes, stream, key_bits))
         return;
-      pad_order(keys_out, vals_sorted, n_q, fine_bits, group_rows, comp + kCompStart + (kMaxComp + 1),
+      pad_order(keys_out, vals_sorted, n_q, 0u, group_rows, comp, comp + kCompStart + (kMaxComp + 1),
                 comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
       hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, 32u * T_q, n_cols,
                          L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
@@ -1369,6 +1419,139 @@ void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n
                 d_nn_d2, d_hd_idx, d_hd_d2, d_ws, stream);
 }
 
+// Neighbours that lie in ANOTHER component than their query (dc_mfma_kernels.hpp "components"): the matrix-core sweep
+// only ever looks inside the query's own component, so afterwards every query checks whether a frame of another
+// component could still beat (or tie) what it has -- the squared gap between the query and the component's box in
+// columns 0/1 bounds every distance into it from below -- and the few queries for which that is so (the frames at the
+// edge of a cluster; the lowest free energies of a cluster, whose lower-free-energy neighbour is in another one)
+// search those components exactly: tiles whose boxes are within the current incumbent, every row of a surviving tile
+// in the canonical arithmetic, lexicographic minimum on (d2, frame).  One wave per 64 positions of the query order;
+// an open query is served by the whole wave.
+__device__ __forceinline__ float point_box_gap2(float x, float y, const float4& b) {
+  const float dx = fmaxf(0.0f, fmaxf(b.x - x, x - b.y));
+  const float dy = fmaxf(0.0f, fmaxf(b.z - y, y - b.w));
+  return (dx * dx + dy * dy) * 0.99999f;   // (a lower bound of every d2 into the box, its own rounding included)
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__global__ __launch_bounds__(64) void nn_cross_kernel(
+    const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ fe,
+    const float* __restrict__ coords_r, const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r,
+    const float2* __restrict__ ferange_r, const float* __restrict__ fe_c, const uint32_t* __restrict__ perm_q,
+    const uint32_t* __restrict__ tile_comp_q, const uint32_t* __restrict__ comp, uint32_t T_q, uint32_t group_tiles,
+    QSeg q_seg, int q_in_ref_order, const uint32_t* __restrict__ hdr, uint32_t* __restrict__ nn_idx,
+    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+  __shared__ uint32_t list[64];
+  if (hdr[1] != 0) return;
+  const uint32_t n_comp = comp[kCompGrid + 5];
+  if (n_comp <= 1u) return;
+  const int lane = threadIdx.x;
+  const uint32_t p = blockIdx.x * 64u + (uint32_t)lane;
+  if ((blockIdx.x * 2u) >= T_q) return;
+  if (((blockIdx.x * 2u) / group_tiles) % q_seg.stride != q_seg.offset) return;   // (another segment's group)
+  const uint32_t frame = (p < 32u * T_q) ? perm_q[p] : kInvalidFrame;
+  const bool live = frame != kInvalidFrame;
+  const uint32_t my_comp = live ? tile_comp_q[p >> 5] : 0u;
+  const float* qrow = q_in_ref_order ? coords_r + (size_t)p * n_cols : coords + (size_t)(live ? frame : 0u) * n_cols;
+  const float x0 = live ? qrow[0] : 0.0f, x1 = (live && n_cols > 1) ? qrow[1] : 0.0f;
+  const float feq = live ? fe[frame] : 0.0f;
+  const float fe_floor = fkey_inv(~hdr[12]);
+  const bool hd_possible = live && (fe_floor < feq);
+  unsigned long long key_nn = ~0ull, key_hd = ~0ull;
+  if (live) {
+    key_nn = ((unsigned long long)__float_as_uint(nn_d2[frame]) << 32) | nn_idx[frame];
+    key_hd = ((unsigned long long)__float_as_uint(hd_d2[frame]) << 32) | hd_idx[frame];
+  }
+  const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
+  bool open = false;
+  if (live)
+    for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
+      if (c2 == my_comp) continue;
+      const float g2 = point_box_gap2(x0, x1, cbox[c2]);
+      open = open || (g2 <= __uint_as_float((uint32_t)(key_nn >> 32))) ||
+             (hd_possible && (g2 <= __uint_as_float((uint32_t)(key_hd >> 32))));
+    }
+  uint64_t todo = __builtin_amdgcn_ballot_w64(open);
+  const uint32_t* range = comp + kCompRange;
+  while (todo != 0) {
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    // the open query of lane l, served by the whole wave
+    const uint32_t q_frame = (uint32_t)__builtin_amdgcn_readlane((int)frame, l);
+    const uint32_t q_comp = (uint32_t)__builtin_amdgcn_readlane((int)my_comp, l);
+    const uint32_t q_pos = blockIdx.x * 64u + (uint32_t)l;
+    const float qx0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x0), l));
+    const float qx1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x1), l));
+    const float q_fe = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(feq), l));
+    const bool q_hd = __builtin_amdgcn_readlane((int)hd_possible, l) != 0;
+    unsigned long long best_nn = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key_nn >> 32), l) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key_nn, l);
+    unsigned long long best_hd = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key_hd >> 32), l) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key_hd, l);
+    const float* q_row = q_in_ref_order ? coords_r + (size_t)q_pos * n_cols : coords + (size_t)q_frame * n_cols;
+    for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
+      if (c2 == q_comp) continue;
+      {
+        const float g2 = point_box_gap2(qx0, qx1, cbox[c2]);
+        const float inc_nn = __uint_as_float((uint32_t)(best_nn >> 32)), inc_hd = __uint_as_float((uint32_t)(best_hd >> 32));
+        if (!(g2 <= inc_nn) && !(q_hd && g2 <= inc_hd)) continue;
+      }
+      const uint32_t t_lo = range[2 * c2], t_hi = range[2 * c2 + 1];
+      for (uint32_t base = t_lo; base < t_hi; base += 64) {
+        const float inc_nn = __uint_as_float((uint32_t)(best_nn >> 32)), inc_hd = __uint_as_float((uint32_t)(best_hd >> 32));
+        const uint32_t t = base + (uint32_t)lane;
+        bool ok = false;
+        if (t < t_hi) {
+          const float g2 = point_box_gap2(qx0, qx1, box_r[t]);
+          ok = (g2 <= inc_nn) | (q_hd & (g2 <= inc_hd) & (ferange_r[t].x < q_fe));
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+        if (m == 0) continue;
+        __syncthreads();
+        if (ok) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+        __syncthreads();
+        const uint32_t n_list = (uint32_t)__builtin_popcountll(m);
+        unsigned long long my_nn = ~0ull, my_hd = ~0ull;
+        // two tiles per step: the half-waves take one each, a lane one row
+        for (uint32_t s0 = 0; s0 < n_list; s0 += 2) {
+          const uint32_t si = s0 + (uint32_t)(lane >> 5);
+          if (si < n_list) {
+            const uint32_t pr = 32u * list[si] + (uint32_t)(lane & 31);
+            const uint32_t j = perm_r[pr];
+            if (j != kInvalidFrame && j != q_frame) {
+              const float d2 = dist2_canon_rows(q_row, coords_r + (size_t)pr * n_cols, (int)n_cols);
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | j;
+              my_nn = key < my_nn ? key : my_nn;
+              if (fe_c[pr] < q_fe) my_hd = key < my_hd ? key : my_hd;
+            }
+          }
+        }
+        const unsigned long long w_nn = wave_min_u64(my_nn), w_hd = wave_min_u64(my_hd);
+        best_nn = w_nn < best_nn ? w_nn : best_nn;
+        best_hd = w_hd < best_hd ? w_hd : best_hd;
+      }
+    }
+    if (lane == l) {
+      key_nn = best_nn;
+      key_hd = best_hd;
+    }
+  }
+  if (open) {   // (only the queries that searched can have changed)
+    nn_idx[frame] = (uint32_t)key_nn;
+    nn_d2[frame] = __uint_as_float((uint32_t)(key_nn >> 32));
+    hd_idx[frame] = (uint32_t)key_hd;
+    hd_d2[frame] = __uint_as_float((uint32_t)(key_hd >> 32));
+  }
+}
+
 static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                           const QuerySel& qs, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
                           float* d_hd_d2, void* d_ws, hipStream_t stream) {
@@ -1381,33 +1564,14 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
   uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
   uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
-  constexpr float kCellFramesHere = kNnCellFrames;
-  const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256),
-      grid_tiles((L.T + 255) / 256);
+  uint32_t* comp = (uint32_t*)(p + L.off_comp);
+  uint32_t* tile_comp = (uint32_t*)(p + L.off_tile_comp);
+  uint32_t* tile_comp_q = (uint32_t*)(p + L.off_tile_comp_q);
+  uint32_t* vals_sorted = (uint32_t*)(p + L.off_pq);   // (a region of the full neighbour sweep: free here)
+  const float* origins = (const float*)(comp + kCompOrigin);
+  const dim3 blk(256), grid_n((n_rows + 255) / 256);
   auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
-  const size_t tmp_bytes = sort_temp_bytes(n_rows);
-  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols);   // the neighbour scale
-  // frames by (cell, free energy): ONE sort on a combined key (cellfe_key_kernel); the pass over the free
-  // energies before it finds their range (and raises the flag for NaNs)
-  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
-                     (uint32_t*)nullptr, hdr);
-  const unsigned key_bits = cellfe_key_bits(n_rows, kNnCellFrames);
-  hipLaunchKernelGGL(cellfe_key_kernel, grid_n, blk, 0, stream, d_coords, n_cols, d_fe,
-                     (const uint32_t*)hdr, kNnCellFrames, n_rows, keys_in, vals_in, key_bits);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits))
-    return;
-  hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, (const uint32_t*)perm_p, d_fe, n_rows,
-                     L.T, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
-  const float* coords_p = (const float*)(p + L.off_coords_p);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)n_rows * n_cols + 255) / 256)), blk,
-                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, n_rows,
-                     (float*)(p + L.off_coords_p));
-  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
-                     L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p);
-  hipLaunchKernelGGL(box_rows_kernel, grid_t, blk, 0, stream, coords_p, n_cols, n_rows, L.T,
-                     (float4*)(p + L.off_box_p), (const float*)(p + L.off_fe_s),
-                     (float2*)(p + L.off_ferange_p));
+  const size_t tmp_bytes = sort_temp_bytes(n_rows + kOrderPadRows);
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
@@ -1417,36 +1581,79 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     n_q = n_rows;
     q_seg = QSeg{qs.n_segments, qs.segment};
   }
-  const uint32_t T_q = (n_q + 31) / 32;
+  // (query tiles per group: a wave's, or with the shared-operand sweep the workgroup's; the orders are padded so that
+  //  every component starts at a whole group -- see pop_pruned_one)
+  const uint32_t tq = (uint32_t)tq_of(n_cols) * (nn_shared_wanted(n_rows, n_cols) ? 4u : 1u), group_rows = 32u * tq;
+  const uint32_t T_r = (n_rows + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
+  const uint32_t T_q = (n_q + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
+  // ordering key: (cell number over all components, quantised free energy) in whole sort passes
+  const unsigned fine_bits = cell_key_bits(n_rows, kNnCellFrames) + 1u;
+  const unsigned key_bits = (fine_bits + 9u <= 24u) ? 24u : 32u;
+  const unsigned fe_bits = key_bits > fine_bits ? std::min(key_bits - fine_bits, 16u) : 0u;
+  const float r_conn = -8.0f;   // components: connected over 8 cells of the ordering (no radius in this sweep)
+  // the pass over the free energies finds their range (and raises the flag for NaNs)
+  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
+                     (uint32_t*)nullptr, hdr);
+  (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
+  (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
+  hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn, comp);
+  hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
+  hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
+                     (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
+                     components_off() ? 1 : 0, 0.0f);
+  // frames by (component, cell, free energy): ONE sort on a combined key
+  hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
+                     (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, fe_bits);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, fine_bits + fe_bits))
+    return;
+  pad_order(keys_out, vals_sorted, n_rows, fe_bits, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
+            T_r, stream);
+  hipLaunchKernelGGL(fe_scatter_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, (const uint32_t*)perm_p, d_fe,
+                     32u * T_r, T_r, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
+  const float* coords_p = (const float*)(p + L.off_coords_p);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)32 * T_r * n_cols + 255) / 256)), blk,
+                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, 32u * T_r,
+                     (float*)(p + L.off_coords_p));
+  hipLaunchKernelGGL(box_rows_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, coords_p, n_cols, 32u * T_r, T_r,
+                     (float4*)(p + L.off_box_p), (const float*)(p + L.off_fe_s),
+                     (float2*)(p + L.off_ferange_p), (const uint32_t*)perm_p, (const uint32_t*)tile_comp, origins, hdr);
+  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
+  hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+                     L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
+                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                     (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
   if (q_mode != kQueryOwnOrder) {
     // queries in the reference order: only their B form is missing (of the groups of this segment)
-    // (query tiles per group: a wave's, or with the shared-operand sweep the workgroup's)
-    const uint32_t tq = (uint32_t)tq_of(n_cols) * (nn_shared_wanted(n_rows, n_cols) ? 4u : 1u);
-    const uint32_t tiles_q = seg_groups((L.T + tq - 1) / tq, q_seg) * tq;
+    const uint32_t tiles_q = seg_groups((T_r + tq - 1) / tq, q_seg) * tq;
     if (tiles_q > 0)
-      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, n_rows, n_cols,
-                         L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                         (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg);
+      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+                         L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
+                         (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg,
+                         (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
   }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(cellkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)hdr, kCellFramesHere, i_from, i_to, keys_in, vals_in);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream,
-                       cell_key_bits(n_q, kCellFramesHere)))
+    hipLaunchKernelGGL(compkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr,
+                       r_conn, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in, n_rows);
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_q, p + L.fixed_end, tmp_bytes, stream, fine_bits))
       return;
-    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, n_q, n_cols,
+    pad_order(keys_out, vals_sorted, n_q, 0u, group_rows, comp, comp + kCompStart + (kMaxComp + 1),
+              comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
+    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, 32u * T_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p);
-    hipLaunchKernelGGL(box_kernel, grid_tiles, blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)perm_q, n_q, L.T, (float4*)(p + L.off_box_q),
+                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                       (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(box_kernel, dim3((T_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
+                       (const uint32_t*)perm_q, 32u * T_q, T_q, (float4*)(p + L.off_box_q),
                        (const float*)nullptr, (float2*)nullptr);
   }
+  const bool own = q_mode == kQueryOwnOrder;
+  const uint32_t n_pos_q = 32u * (own ? T_q : T_r);
   switch (nm_for((int)n_cols)) {
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
-      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, n_q, q_mode, q_seg, -1.0f,    \
+      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, T_r, n_pos_q, q_mode, q_seg, -1.0f, \
                           d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, stream);                        \
     break;
     DC_FOR_EACH_S(X)
@@ -1454,6 +1661,13 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     default:
       break;
   }
+  // what lies in other components than the query: exact, for the few queries that can have a neighbour there
+  hipLaunchKernelGGL(nn_cross_kernel, dim3(((own ? T_q : T_r) + 1u) / 2u), dim3(64), 0, stream, d_coords, n_rows, n_cols, d_fe,
+                     coords_p, (const uint32_t*)perm_p, (const float4*)(p + L.off_box_p),
+                     (const float2*)(p + L.off_ferange_p), (const float*)(p + L.off_fe_s),
+                     (const uint32_t*)(own ? perm_q : perm_p), (const uint32_t*)(own ? tile_comp_q : tile_comp),
+                     (const uint32_t*)comp, own ? T_q : T_r, tq, q_seg, own ? 0 : 1, (const uint32_t*)hdr, d_nn_idx, d_nn_d2,
+                     d_hd_idx, d_hd_d2);
 }
 
 // ---- blocks of a sharded neighbour sweep (all-gather merge) ---------------------------------------------------
@@ -1467,7 +1681,8 @@ __device__ __forceinline__ uint32_t block_none(uint32_t c, uint32_t n_rows) {
 }
 __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const float* __restrict__ nn_d2,
                                      const uint32_t* __restrict__ hd_idx, const float* __restrict__ hd_d2,
-                                     uint32_t n_rows, uint32_t gsize /* 32 tq, 0: row blocks only */, uint32_t seg,
+                                     uint32_t n_rows, uint32_t n_pos /* positions of the padded order */,
+                                     uint32_t gsize /* 32 tq, 0: row blocks only */, uint32_t seg,
                                      uint32_t G, uint32_t block_rows, const uint32_t* __restrict__ perm,
                                      const uint32_t* __restrict__ hdr, uint32_t* __restrict__ block) {
   const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1476,7 +1691,7 @@ __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const 
   uint32_t i = 0xFFFFFFFFu;
   if (by_position) {
     const unsigned long long p = ((unsigned long long)(l / gsize) * G + seg) * gsize + l % gsize;
-    if (p < n_rows) i = perm[p];
+    if (p < n_pos) i = perm[p];   // (kInvalidFrame for the pad positions of the order)
   } else {
     const uint32_t rng = n_rows / G, lo = seg * rng, hi = (seg == G - 1u) ? n_rows : lo + rng;
     if (lo + l < hi) i = lo + l;
@@ -1488,19 +1703,20 @@ __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const 
   block[3 * (size_t)block_rows + l] = live ? __float_as_uint(hd_d2[i]) : block_none(3, n_rows);
 }
 __global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G][4][block_rows] */, uint32_t n_rows,
-                                       uint32_t gsize, uint32_t G, uint32_t block_rows,
+                                       uint32_t n_pos, uint32_t gsize, uint32_t G, uint32_t block_rows,
                                        const uint32_t* __restrict__ perm, const uint32_t* __restrict__ hdr,
                                        uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                        uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_rows) return;
   const bool by_position = gsize != 0u && hdr[1] == 0u;
+  if (p >= (by_position ? n_pos : n_rows)) return;
   uint32_t i, r, l;
   if (by_position) {
     const uint32_t grp = p / gsize;
     r = grp % G;
     l = (grp / G) * gsize + p % gsize;
     i = perm[p];
+    if (i == kInvalidFrame) return;   // (a pad position of the order)
   } else {
     const uint32_t rng = n_rows / G;
     i = p;
@@ -1517,12 +1733,16 @@ __global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G
 static uint32_t nn_group_rows(uint32_t n_rows, uint32_t n_cols) {
   return 32u * (uint32_t)tq_of(n_cols) * (nn_shared_wanted(n_rows, n_cols) ? 4u : 1u);
 }
+// tiles of the neighbour sweep's padded order (every component starts at a whole query group)
+static uint32_t nn_order_tiles(uint32_t n_rows, uint32_t n_cols) {
+  return (n_rows + (uint32_t)kMaxComp * (nn_group_rows(n_rows, n_cols) - 1u) + 31u) / 32u;
+}
 size_t nn_block_rows(size_t n_rows, size_t n_cols, size_t n_segments) {
   if (n_segments == 0 || n_rows == 0) return 0;
   const size_t row_block = n_rows - (n_segments - 1) * (n_rows / n_segments);   // the last (largest) row block
   if (!mfma_supports(n_cols)) return row_block;
   const size_t gs = nn_group_rows((uint32_t)n_rows, (uint32_t)n_cols);
-  const size_t groups = (n_rows + gs - 1) / gs;
+  const size_t groups = ((size_t)32 * nn_order_tiles((uint32_t)n_rows, (uint32_t)n_cols) + gs - 1) / gs;
   return std::max(row_block, ((groups + n_segments - 1) / n_segments) * gs);
 }
 void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
@@ -1532,7 +1752,7 @@ void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const 
   const Layout L = make_layout(n_rows, n_cols);
   const char* p = (const char*)d_ws;
   hipLaunchKernelGGL(nn_block_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2, d_hd_idx,
-                     d_hd_d2, n_rows, pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, rows,
+                     d_hd_d2, n_rows, 32u * nn_order_tiles(n_rows, n_cols), pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block);
 }
 void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t n_cols, uint32_t n_segments,
@@ -1541,7 +1761,8 @@ void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t 
   const uint32_t rows = (uint32_t)nn_block_rows(n_rows, n_cols, n_segments);
   const Layout L = make_layout(n_rows, n_cols);
   const char* p = (const char*)d_ws;
-  hipLaunchKernelGGL(nn_block_unpack_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_blocks, n_rows,
+  const uint32_t n_pos = 32u * nn_order_tiles(n_rows, n_cols);
+  hipLaunchKernelGGL(nn_block_unpack_kernel, dim3((n_pos + 255) / 256), dim3(256), 0, stream, d_blocks, n_rows, n_pos,
                      pruned ? nn_group_rows(n_rows, n_cols) : 0u, n_segments, rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr,
                      d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);

@@ -131,7 +131,8 @@ constexpr size_t kCompCellComp = kCompCellBox + 4 * (size_t)kCoarseCells;   // [
 constexpr size_t kCompOrigin = kCompCellComp + (size_t)kCoarseCells;   // [kMaxComp][kMaxCols] floats
 constexpr size_t kCompFine = kCompOrigin + (size_t)kMaxComp * kMaxCols;      // [kMaxComp][4]: bits(min0), bits(min1), bits(cell edge 0), bits(cell edge 1)
 constexpr size_t kCompNby = kCompFine + 4 * (size_t)kMaxComp;          // [kMaxComp]: cells along column 1 of the component's fine grid
-constexpr size_t kCompStart = kCompNby + (size_t)kMaxComp;             // [2][kMaxComp + 1]: first sorted index of a component (reference / query order)
+constexpr size_t kCompCellOff = kCompNby + (size_t)kMaxComp;           // [kMaxComp + 1]: first cell number of a component (the cells of all components are numbered consecutively)
+constexpr size_t kCompStart = kCompCellOff + (size_t)kMaxComp + 1;     // [2][kMaxComp + 1]: first sorted index of a component (reference / query order)
 constexpr size_t kCompRange = kCompStart + 2 * ((size_t)kMaxComp + 1); // [2][kMaxComp + 1][2]: tile range [lo, hi) of a component (reference / query
                                                                        // order); entry kMaxComp is the empty range of the all-pad tiles at the end
 constexpr size_t kCompRangeStride = 2 * ((size_t)kMaxComp + 1);
@@ -201,7 +202,7 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.Tp);
   L.off_merge64 = align256(L.off_coords_p + sizeof(float) * 32 * (size_t)L.Tp * n_cols);
   L.off_box_t = align256(L.off_merge64 + sizeof(unsigned long long) * 2 * n_rows);
-  L.off_comp = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.T + L.T / 32 + 64));   // (+ one pad box per share)
+  L.off_comp = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.Tp + L.Tp / 32 + 64));   // (+ one pad box per share)
   L.off_tile_comp = align256(L.off_comp + sizeof(uint32_t) * kCompWords);
   L.off_tile_comp_q = align256(L.off_tile_comp + sizeof(uint32_t) * (size_t)L.Tp);
   L.fixed_end = align256(L.off_tile_comp_q + sizeof(uint32_t) * (size_t)L.Tp);
@@ -323,6 +324,7 @@ struct Scale {
 };
 constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
 constexpr uint32_t kHdrCookie = 28;     // whose statistics the header holds (array, shape); 0 after a reset
+constexpr uint32_t kHdrMused = 31;      // the extent max |x - origin|^2 the current sweep's scale was chosen for (float bits)
 constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: max |x - origin(component of x)|^2 (float bits, with a rounding margin)
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
@@ -1914,7 +1916,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
     unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, CompView CV) {
   // dynamic LDS, per wave of the workgroup: the survivor list of a scan round [kListCap], then [TQ*32][n_cols] query
   // rows (original coordinates), then the candidate queues [TQ][kQueueCap][64]
   extern __shared__ __attribute__((aligned(16))) float nn_dyn_lds[];
@@ -1947,7 +1949,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc);
+  const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc);   // (the extent the scale was chosen for)
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;
@@ -1965,9 +1967,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const uint32_t tile = qt0 + qt;
     const uint32_t tl = tile < TQT ? tile : TQT - 1;
     const uint32_t pos = tile * 32 + c;
-    const bool live = (tile < TQT) && (pos < n_q);
+    const uint32_t frame = ((tile < TQT) && (pos < n_q)) ? perm_q[pos] : kInvalidFrame;   // (pad positions: kInvalidFrame)
+    const bool live = frame != kInvalidFrame;
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
-    jq[qt] = live ? perm_q[pos] : 0u;
+    jq[qt] = live ? frame : 0u;
     load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
@@ -2016,7 +2019,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       const float* qrow = qrows + (qt * 32 + c) * n_cols;
       for (int k = 1; k <= kSeedNeighbours; ++k) {
         const long long p2 = (long long)Q.spos + (h ? -k : k);
-        if (p2 >= 0 && p2 < (long long)n_rows) {
+        if (p2 >= 0 && p2 < (long long)CV.n_pos && perm_r[p2] != kInvalidFrame) {
           const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)p2 * n_cols, 1, (int)n_cols);
           const uint32_t j = perm_r[p2];
           lexi_update(true, Q.bd_nn, Q.bj_nn, d2c, j, n_rows);
@@ -2078,14 +2081,19 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   uint32_t chains = 0, visited = 0;
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scans only touch their own boxes)
-  const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
+  // (the tiles of the group's own COMPONENT only -- dc_mfma_kernels.hpp "components": what lies in other components is
+  //  looked at afterwards, exactly, for the few queries whose neighbours may be there: nn_cross_kernel)
+  const uint32_t my_comp = CV.tile_comp_q[qt0];
+  const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
+  const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
+  const uint32_t U = max((t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u, u_lo);
   const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
   if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
   for (;;) {
-    for (uint32_t base = 0; base < U; base += kListCap) {
+    for (uint32_t base = u_lo; base < U; base += kListCap) {
       uint32_t cnt = 0;
       const uint32_t lim = min(U - base, (uint32_t)kListCap);
       auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
@@ -2186,7 +2194,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const uint32_t pos = tile_row(t, r, h);
-                const bool other = live & (pos != Q.spos) & (pos < n_rows);
+                const bool other = live & (pos != Q.spos) & (pos < CV.n_pos);
                 mn |= (other & (acc[r] < bn)) ? (0x8000u >> r) : 0u;
                 mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (0x8000u >> r) : 0u;
               }
@@ -2287,7 +2295,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     }
     flush();                                          // the settle test needs the exact incumbents
     reload();
-    if (!(r2_hi <= FLT_MAX) || visited >= U)
+    if (!(r2_hi <= FLT_MAX) || visited >= U - u_lo)
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
     const float sure = r2_hi * 0.9999f;
@@ -2364,6 +2372,7 @@ __global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ me
   // (rows of other segments keep what the caller initialised them with)
   if ((p / (32u * tq)) % q_seg.stride != q_seg.offset) return;
   const uint32_t i = perm_q[p];   // the query rows of this call
+  if (i == kInvalidFrame) return; // (a pad position of the order)
   const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
   nn_idx[i] = (uint32_t)a;
   nn_d2[i] = __uint_as_float((uint32_t)(a >> 32));
@@ -2451,6 +2460,8 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   QSeg q_seg;
   int full_range;
   float cell2;
+  const uint32_t* tile_comp_q;   // component of every tile of the query order
+  const uint32_t* comp;          // component region
 };
 
 // Reference chunks per query group (gridDim.y).  The cost of a query group follows the local density
@@ -2462,8 +2473,8 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // box scans must stay small next to the chains.  Measured on C3 (1M x 10): the full sweeps are
 // fastest at 12 chunks (pop 38.3 -> 35.6 ms, nn 50.2 -> 38.8 ms against one chunk), one eighth of the
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
-constexpr uint32_t kPopWaveTarget = 98304, kNnWaveTarget = 98304;
-constexpr uint32_t kPopShareFloor = 512, kNnShareFloor = 900;
+constexpr uint32_t kPopWaveTarget = 49152, kNnWaveTarget = 98304;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
+constexpr uint32_t kPopShareFloor = 1024, kNnShareFloor = 900;     //  49152 / 1024: C3 12.30 -> 12.12 ms, one eighth of it 1.82 -> 1.72 ms)
 // waves per workgroup of the per-wave sweeps (pop_pruned_kernel, nn_pruned_kernel; see nn_pruned_kernel): ONE while a
 // chain has at most two MFMAs -- no slot waits for the slowest wave of a workgroup (1M x 10: neighbours 16.1 -> 15.0 ms,
 // 1M x 3: 5.7 -> 5.3 / populations 6.3 -> 6.05 ms) -- and four beyond that: the four waves of a workgroup sit on one CU
@@ -2481,6 +2492,11 @@ inline uint32_t waves_per_group(int nm) {
 }
 inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles,
                             uint32_t share_floor, size_t /*tile_bytes*/) {
+  // DC_WAVE_TARGET / DC_SHARE_FLOOR: measurement overrides of the two tuning constants (both sweeps)
+  static const uint32_t env_target = [] { const char* v = getenv("DC_WAVE_TARGET"); return (v && v[0]) ? (uint32_t)atoi(v) : 0u; }();
+  static const uint32_t env_floor = [] { const char* v = getenv("DC_SHARE_FLOOR"); return (v && v[0]) ? (uint32_t)atoi(v) : 0u; }();
+  if (env_target) target = env_target;
+  if (env_floor) share_floor = env_floor;
   const uint32_t waves = (tiles + tq - 1) / tq;
   uint32_t r = waves >= target ? 1u : (target + waves - 1) / waves;
   const uint32_t by_share = ref_tiles / share_floor;
@@ -2495,6 +2511,8 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                       unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   if (A.n_q == 0) return;
+  // T: tiles of the (padded) reference order; A.n_q: positions of the query order
+  const CompView CV{A.tile_comp_q, A.comp + kCompRange, 32u * T};
   if (nn_shared_wanted(n_rows, n_cols)) {
     // reference operands shared through LDS (dc_mfma_nn_shared.hpp): the workgroup's 4 * TQV tiles are one group
     const uint32_t groups = seg_groups(((A.n_q + 31) / 32 + 4 * TQV - 1) / (4 * TQV), A.q_seg);
@@ -2507,7 +2525,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
     { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_shared_kernel<S, TQV>), dim3(grid_x8(groups), n_chunks), dim3(256), smem, s, coords, n_rows, n_cols, fe,
                        A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r, A.fe_c, A.coords_c,
                        A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg, A.full_range, A.cell2, hdr,
-                       chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2); sweep_timer_mark(1, false, s); }
+                       chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2, CV); sweep_timer_mark(1, false, s); }
     if (n_chunks > 1 && A.full_range)
       hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                          (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)(4 * TQV), A.q_seg, nn_idx,
@@ -2533,7 +2551,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                      coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
-                     hd_d2); sweep_timer_mark(1, false, s); }
+                     hd_d2, CV); sweep_timer_mark(1, false, s); }
   if (n_chunks > 1 && A.full_range)
     hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                        (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)TQV, A.q_seg,
@@ -2732,7 +2750,7 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                             uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2, \
                             int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s);     \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
-                           void* d_ws, uint32_t n_q, int q_mode, QSeg q_seg, float cell2, \
+                           void* d_ws, uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg, float cell2, \
                            uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,       \
                            hipStream_t s);                                                       \
   void nn_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,      \

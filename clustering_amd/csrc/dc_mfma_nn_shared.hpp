@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
     unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, CompView CV) {
   __shared__ uint32_t lists[4][kShareSub];
   __shared__ uint32_t list_cnt[4];
   __shared__ float4 wave_box[4];
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
-  const GuardBand gb = guard_band(__uint_as_float(hdr[0]) * sc.s2, 0.0f, (int)n_cols, sc);
+  const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc);   // (the extent the scale was chosen for)
   if (cell2 < 0.0f) {
     const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
     cell2 = cl * cl;
@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     const uint32_t tile = qt0 + qt;
     const uint32_t tl = tile < TQT ? tile : TQT - 1;
     const uint32_t pos = tile * 32 + c;
-    const bool live = (tile < TQT) && (pos < n_q);
+    const uint32_t frame = ((tile < TQT) && (pos < n_q)) ? perm_q[pos] : kInvalidFrame;   // (pad positions: kInvalidFrame)
+    const bool live = frame != kInvalidFrame;
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
-    jq[qt] = live ? perm_q[pos] : 0u;
+    jq[qt] = live ? frame : 0u;
     load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       const float* qrow = coords + (size_t)jq[qt] * n_cols;
       for (int k = 1; k <= kSeedNeighbours; ++k) {
         const long long p2 = (long long)Q.spos + (h ? -k : k);
-        if (p2 >= 0 && p2 < (long long)n_rows) {
+        if (p2 >= 0 && p2 < (long long)CV.n_pos && perm_r[p2] != kInvalidFrame) {
           const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)p2 * n_cols, 1, (int)n_cols);
           const uint32_t j = perm_r[p2];
           lexi_update(true, Q.bd_nn, Q.bj_nn, d2c, j, n_rows);
@@ -232,14 +233,19 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   uint32_t chains = 0, visited = 0;
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scans only touch their own boxes)
-  const uint32_t U = (T > chunk) ? (T - chunk + n_chunks - 1) / n_chunks : 0u;
+  // (the tiles of the group's own COMPONENT only -- dc_mfma_kernels.hpp "components": what lies in other components is
+  //  looked at afterwards, exactly, for the few queries whose neighbours may be there: nn_cross_kernel)
+  const uint32_t my_comp = CV.tile_comp_q[group * (4u * TQ)];
+  const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
+  const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
+  const uint32_t U = max((t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u, u_lo);
   const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
   if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
   for (;;) {
-    for (uint32_t base = 0; base < U; base += 4 * kShareSub) {
+    for (uint32_t base = u_lo; base < U; base += 4 * kShareSub) {
       // ---- scan: every wave tests its quarter of the round's boxes against the workgroup's box and ring
       uint32_t cnt = 0;
       auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const uint32_t pos = tile_row(t, r, h);
-                const bool other = live & (pos != Q.spos) & (pos < n_rows);
+                const bool other = live & (pos != Q.spos) & (pos < CV.n_pos);
                 mn |= (other & (acc[r] < bn)) ? (0x8000u >> r) : 0u;
                 mh |= (other & (acc[r] < bh) & (fef[r] < Q.feq)) ? (0x8000u >> r) : 0u;
               }
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     }
     flush();                                          // the settle test needs the exact incumbents
     reload();
-    if (!(r2_hi <= FLT_MAX) || visited >= U)
+    if (!(r2_hi <= FLT_MAX) || visited >= U - u_lo)
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
     const float sure = r2_hi * 0.9999f;
