@@ -401,10 +401,10 @@ int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, 
     else if (n_segments > 0)
       dc::launch_nn_pruned_segment(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe,
                                    (uint32_t)segment, (uint32_t)n_segments, d_nn_idx, d_nn_d2,
-                                   d_hd_idx, d_hd_d2, d_workspace, s);
+                                   d_hd_idx, d_hd_d2, d_workspace, s, stats_valid);
     else
       dc::launch_nn_pruned(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
-                           (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
+                           (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s, stats_valid);
   }
   if (i_from != i_to && !dc::launch_nn_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
                             (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2,

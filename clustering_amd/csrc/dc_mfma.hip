@@ -398,6 +398,9 @@ __device__ __forceinline__ uint32_t coarse_cell(const CoarseGrid& g, float x, fl
   return cx * g.ncy + cy;
 }
 
+// (the connectivity length a component partition was built with lives in its region: comp[kCompGrid + 7])
+__device__ __forceinline__ float comp_r_conn(const uint32_t* __restrict__ comp) { return __uint_as_float(comp[kCompGrid + 7]); }
+
 // occupancy bitmap of the sub-cells (kFineSub x kFineSub per coarse cell): plain byte stores, no atomics
 __global__ void fine_mark_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                                  const uint32_t* __restrict__ hdr, float r_max, uint32_t* __restrict__ comp) {
@@ -462,8 +465,12 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
                                                           const float* __restrict__ means, uint32_t D,
                                                           float r_max, uint32_t n_rows, float frames_per_cell,
                                                           uint32_t fine_bits, uint32_t* __restrict__ comp,
-                                                          int force_single, float r_true) {
-  // r_max: the connectivity length rho (what the coarse grid was built for); r_true: the largest radius itself
+                                                          int force_single, float r_true, uint32_t cookie) {
+  // r_max: the connectivity length rho (what the coarse grid was built for); r_true: the largest radius itself;
+  // cookie: whose partition this is (comp_guard_kernel)
+  (void)frames_per_cell;
+  (void)fine_bits;
+  const float r_conn_param = r_max;
   __shared__ uint32_t occ[kMaxOccupied], label[kMaxOccupied];
   __shared__ float4 obox[kMaxOccupied];
   __shared__ uint32_t n_occ_s, changed_s, n_comp_s;
@@ -583,71 +590,20 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
     for (uint32_t i = tid; i < n_occ; i += nt) cell_comp[occ[i]] = label[i];
   }
   __syncthreads();
-  // origins and fine grids
+  // origins, boxes, adjacency
   const float gmin0 = fkey_inv(~hdr[8]), gmax0 = fkey_inv(hdr[9]), gmin1 = fkey_inv(~hdr[10]), gmax1 = fkey_inv(hdr[11]);
-  float cell = auto_cell(hdr, n_rows, frames_per_cell);
-  if (!single) {
-    // sparse data: the frames cover a small part of the bounding box -- size the fine cells by the occupied area (x 8:
-    // what the blobs of the reference workload cover of theirs), so that the cells do not grow with the empty space
-    const double a_box = (double)fmaxf(gmax0 - gmin0, 0.0f) * (double)fmaxf(gmax1 - gmin1, 0.0f);
-    const double a_occ = 8.0 * (double)n_occ * (double)g.gc * (double)g.gc;
-    if (a_occ > 0.0 && a_occ < a_box)
-      cell = (float)sqrt(a_occ * (double)frames_per_cell / (double)(n_rows ? n_rows : 1u));
-  }
-  __shared__ float s_lo0[kMaxComp], s_lo1[kMaxComp], s_e0[kMaxComp], s_e1[kMaxComp];
-  if (tid < n_comp) {
-    const float lo0 = single ? gmin0 : fkey_inv(~cbox[tid][0]), hi0 = single ? gmax0 : fkey_inv(cbox[tid][1]);
-    const float lo1 = single ? gmin1 : fkey_inv(~cbox[tid][2]), hi1 = single ? gmax1 : fkey_inv(cbox[tid][3]);
-    float* a = reinterpret_cast<float*>(comp + kCompOrigin) + (size_t)tid * kMaxCols;
-    for (uint32_t k = 0; k < D; ++k) a[k] = means[k];
-    if (!single) {
-      a[0] = 0.5f * lo0 + 0.5f * hi0;
-      if (D > 1) a[1] = 0.5f * lo1 + 0.5f * hi1;
-    }
-    s_lo0[tid] = (fabsf(lo0) <= FLT_MAX) ? lo0 : 0.0f;
-    s_lo1[tid] = (fabsf(lo1) <= FLT_MAX) ? lo1 : 0.0f;
-    const float e0 = hi0 - lo0, e1 = hi1 - lo1;
-    s_e0[tid] = (e0 >= 0.0f && e0 <= FLT_MAX) ? e0 : 0.0f;
-    s_e1[tid] = (e1 >= 0.0f && e1 <= FLT_MAX) ? e1 : 0.0f;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    // fine grids: one cell size for all components (at most 4001 cells per dimension and component), the cells of all
-    // components numbered consecutively -- fewer than 2^fine_bits of them, so the ordering keys stay short
-    const float limit = ldexpf(1.0f, (int)fine_bits) - 2.0f;
-    if (!(cell > 0.0f) || !(cell <= FLT_MAX)) cell = 1.0f;
-    for (int round = 0; round < 8; ++round) {
-      float total = 0.0f;
-      for (uint32_t c = 0; c < n_comp; ++c) {
-        const float c0 = fmaxf(cell, s_e0[c] / 4000.0f), c1 = fmaxf(cell, s_e1[c] / 4000.0f);
-        total += (floorf(fminf(s_e0[c] / c0, 4001.0f)) + 1.0f) * (floorf(fminf(s_e1[c] / c1, 4001.0f)) + 1.0f);
-      }
-      if (total <= limit) break;
-      cell *= sqrtf(total / limit) * 1.05f;
-    }
-    uint32_t off = 0;
-    for (uint32_t c = 0; c < n_comp; ++c) {
-      float c0 = fmaxf(cell, s_e0[c] / 4000.0f), c1 = fmaxf(cell, s_e1[c] / 4000.0f);
-      if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
-      if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
-      const uint32_t nx = (uint32_t)fminf(s_e0[c] / c0, 4001.0f) + 1u, ny = (uint32_t)fminf(s_e1[c] / c1, 4001.0f) + 1u;
-      uint32_t* f = comp + kCompFine + 4 * (size_t)c;
-      f[0] = __float_as_uint(s_lo0[c]);
-      f[1] = __float_as_uint(s_lo1[c]);
-      f[2] = __float_as_uint(c0);
-      f[3] = __float_as_uint(c1);
-      comp[kCompNby + c] = ny;
-      comp[kCompCellOff + c] = off;
-      off = min(off + nx * ny, (1u << fine_bits) - 1u);
-    }
-    for (uint32_t c = n_comp; c <= (uint32_t)kMaxComp; ++c) comp[kCompCellOff + c] = off;
-  }
-  // boxes of the components, and which of them come closer than the largest radius (cross pairs: pop_cross_kernel)
   if (tid < n_comp) {
     const float4 mine = single ? make_float4(gmin0, gmax0, gmin1, gmax1)
                                : make_float4(fkey_inv(~cbox[tid][0]), fkey_inv(cbox[tid][1]), fkey_inv(~cbox[tid][2]),
                                              fkey_inv(cbox[tid][3]));
+    float* a = reinterpret_cast<float*>(comp + kCompOrigin) + (size_t)tid * kMaxCols;
+    for (uint32_t k = 0; k < D; ++k) a[k] = means[k];
+    if (!single) {
+      a[0] = 0.5f * mine.x + 0.5f * mine.y;
+      if (D > 1) a[1] = 0.5f * mine.z + 0.5f * mine.w;
+    }
     reinterpret_cast<float4*>(comp + kCompBox)[tid] = mine;
+    // which components come closer than the largest radius (cross pairs: pop_cross_kernel)
     unsigned long long adj = 0;
     const float r2t = r_true * r_true * 1.0002f;
     if (!single && r_true <= FLT_MAX)
@@ -662,10 +618,87 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   }
   if (tid == 0) {
     comp[kCompGrid + 0] = __float_as_uint(g.gc);
+    comp[kCompGrid + 1] = single ? 0u : n_occ;
     comp[kCompGrid + 3] = g.ncx;
     comp[kCompGrid + 4] = g.ncy;
     comp[kCompGrid + 5] = n_comp;
+    comp[kCompGrid + 6] = cookie;
+    comp[kCompGrid + 7] = __float_as_uint(r_conn_param);
   }
+}
+
+// A partition left in the workspace by an earlier sweep over the same coordinates serves this sweep too (any partition
+// does: what it cannot see across components, the exact cross passes look at) -- unless the cookie says it belongs to
+// other data: then one component, the column means as its origin.
+__global__ __launch_bounds__(1024) void comp_guard_kernel(const uint32_t* __restrict__ hdr, const float* __restrict__ means,
+                                                         uint32_t D, uint32_t* __restrict__ comp, uint32_t cookie) {
+  if (comp[kCompGrid + 6] == cookie) return;
+  for (uint32_t c = threadIdx.x; c < (uint32_t)kCoarseCells; c += blockDim.x) comp[kCompCellComp + c] = 0u;
+  if (threadIdx.x == 0) {
+    float* a = reinterpret_cast<float*>(comp + kCompOrigin);
+    for (uint32_t k = 0; k < D; ++k) a[k] = means[k];
+    reinterpret_cast<float4*>(comp + kCompBox)[0] =
+        make_float4(fkey_inv(~hdr[8]), fkey_inv(hdr[9]), fkey_inv(~hdr[10]), fkey_inv(hdr[11]));
+    comp[kCompAdj] = 0;
+    comp[kCompAdj + 1] = 0;
+    comp[kCompGrid + 1] = 0;
+    comp[kCompGrid + 5] = 1;
+    comp[kCompGrid + 7] = __float_as_uint(1.0f);
+  }
+}
+
+// the fine cell grids of the components for one sweep (frames_per_cell is the sweep's own): one cell size for all
+// components (at most 4001 cells per dimension and component), the cells of all components numbered consecutively --
+// fewer than 2^fine_bits of them, so the ordering keys stay short
+__global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell,
+                                 uint32_t fine_bits, uint32_t* __restrict__ comp) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t n_comp = min(comp[kCompGrid + 5], (uint32_t)kMaxComp);
+  const float gmin0 = fkey_inv(~hdr[8]), gmax0 = fkey_inv(hdr[9]), gmin1 = fkey_inv(~hdr[10]), gmax1 = fkey_inv(hdr[11]);
+  float cell = auto_cell(hdr, n_rows, frames_per_cell);
+  if (n_comp > 1u) {
+    // sparse data: the frames cover a small part of the bounding box -- size the fine cells by the occupied area (x 8:
+    // what the blobs of the reference workload cover of theirs), so that the cells do not grow with the empty space
+    const double gc = (double)__uint_as_float(comp[kCompGrid + 0]);
+    const double a_box = (double)fmaxf(gmax0 - gmin0, 0.0f) * (double)fmaxf(gmax1 - gmin1, 0.0f);
+    const double a_occ = 8.0 * (double)comp[kCompGrid + 1] * gc * gc;
+    if (a_occ > 0.0 && a_occ < a_box)
+      cell = (float)sqrt(a_occ * (double)frames_per_cell / (double)(n_rows ? n_rows : 1u));
+  }
+  const float4* cb = reinterpret_cast<const float4*>(comp + kCompBox);
+  auto ext = [&](uint32_t c, int dim) {
+    const float4 b = cb[c];
+    const float e = dim ? b.w - b.z : b.y - b.x;
+    return (e >= 0.0f && e <= FLT_MAX) ? e : 0.0f;
+  };
+  const float limit = ldexpf(1.0f, (int)fine_bits) - 2.0f;
+  if (!(cell > 0.0f) || !(cell <= FLT_MAX)) cell = 1.0f;
+  for (int round = 0; round < 8; ++round) {
+    float total = 0.0f;
+    for (uint32_t c = 0; c < n_comp; ++c) {
+      const float c0 = fmaxf(cell, ext(c, 0) / 4000.0f), c1 = fmaxf(cell, ext(c, 1) / 4000.0f);
+      total += (floorf(fminf(ext(c, 0) / c0, 4001.0f)) + 1.0f) * (floorf(fminf(ext(c, 1) / c1, 4001.0f)) + 1.0f);
+    }
+    if (total <= limit) break;
+    cell *= sqrtf(total / limit) * 1.05f;
+  }
+  uint32_t off = 0;
+  for (uint32_t c = 0; c < n_comp; ++c) {
+    float c0 = fmaxf(cell, ext(c, 0) / 4000.0f), c1 = fmaxf(cell, ext(c, 1) / 4000.0f);
+    if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
+    if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
+    const uint32_t nx = (uint32_t)fminf(ext(c, 0) / c0, 4001.0f) + 1u, ny = (uint32_t)fminf(ext(c, 1) / c1, 4001.0f) + 1u;
+    const float4 b = cb[c];
+    uint32_t* f = comp + kCompFine + 4 * (size_t)c;
+    f[0] = __float_as_uint((fabsf(b.x) <= FLT_MAX) ? b.x : 0.0f);
+    f[1] = __float_as_uint((fabsf(b.z) <= FLT_MAX) ? b.z : 0.0f);
+    f[2] = __float_as_uint(c0);
+    f[3] = __float_as_uint(c1);
+    comp[kCompNby + c] = ny;
+    comp[kCompCellOff + c] = off;
+    off = min(off + nx * ny, (1u << fine_bits) - 1u);
+  }
+  for (uint32_t c = n_comp; c <= (uint32_t)kMaxComp; ++c) comp[kCompCellOff + c] = off;
 }
 
 // ordering key of the pruned population sweeps: (component, cell of the component's fine grid on columns 0/1) for
@@ -682,7 +715,8 @@ __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, con
   const uint32_t i = i_from + j;
   if (i >= i_to) return;
   const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-  const CoarseGrid g = coarse_grid(hdr, r_max, n_total);
+  (void)r_max;   // (the grid of the partition in use: its own connectivity length)
+  const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_total);
   uint32_t c = 0, bx = 0, by = 0, nby = 1;
   if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
     c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
@@ -1037,11 +1071,15 @@ size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
   return make_layout(n_rows, n_cols).fixed_end + sort_temp_bytes(n_rows + kOrderPadRows);   // (the padded orders)
 }
 
+// whose statistics / components a workspace holds: the array (address) and its shape
+static uint32_t data_cookie(const float* d_coords, uint32_t n_rows, uint32_t n_cols) {
+  return (0x5354A7u ^ (n_rows * 2654435761u) ^ (n_cols * 40503u) ^ (uint32_t)((uintptr_t)d_coords >> 4)) | 1u;
+}
+
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
                  bool natural_image, hipStream_t stream, bool stats_valid) {
   char* p = (char*)d_ws;
-  const uint32_t cookie = (0x5354A7u ^ (n_rows * 2654435761u) ^ (n_cols * 40503u) ^
-                           (uint32_t)((uintptr_t)d_coords >> 4)) | 1u;
+  const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
   if (stats_valid) {
     // DC_FLAG_STATS_VALID: means, max norm, flag and bounding box of an earlier sweep over the same coordinates
     // stay; only the per-sweep words start over (evaluated-tile counters: words 2..5; free-energy range: 12..13)
@@ -1327,10 +1365,12 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
-                       components_off() ? 1 : 0, r_max);
+                       components_off() ? 1 : 0, r_max, data_cookie(d_coords, n_rows, n_cols));
+    hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, kPopCellFrames,
+                       (uint32_t)fine_bits, comp);
     // order all frames by (component, fine cell); every component then moves to a whole query group of the padded order
     hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
-                       (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in);
+                       (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in, n_rows);
     if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits))
       return;
     pad_order(keys_out, vals_sorted, n_rows, 0u, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
@@ -1370,7 +1410,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     if (q_mode == kQueryOwnOrder) {
       // query rows of this call: the same ordering restricted to [i_from, i_to)
       hipLaunchKernelGGL(compkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr,
-                         r_conn, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in);
+                         r_conn, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in, n_rows);
       if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_q, p + L.fixed_end, tmp_bytes, stream, key_bits))
         return;
       pad_order(keys_out, vals_sorted, n_q, 0u, group_rows, comp, comp + kCompStart + (kMaxComp + 1),
@@ -1402,21 +1442,21 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
 
 static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                           const QuerySel& qs, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
-                          float* d_hd_d2, void* d_ws, hipStream_t stream);
+                          float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components);
 
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
-                      uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream) {
+                      uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components) {
   nn_pruned_sel(d_coords, n_rows, n_cols, d_fe, QuerySel{i_from, i_to, 0, 0}, d_nn_idx, d_nn_d2,
-                d_hd_idx, d_hd_d2, d_ws, stream);
+                d_hd_idx, d_hd_d2, d_ws, stream, reuse_components);
 }
 
 void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
                               const float* d_fe, uint32_t segment, uint32_t n_segments,
                               uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
-                              void* d_ws, hipStream_t stream) {
+                              void* d_ws, hipStream_t stream, bool reuse_components) {
   nn_pruned_sel(d_coords, n_rows, n_cols, d_fe, QuerySel{0, n_rows, segment, n_segments}, d_nn_idx,
-                d_nn_d2, d_hd_idx, d_hd_d2, d_ws, stream);
+                d_nn_d2, d_hd_idx, d_hd_d2, d_ws, stream, reuse_components);
 }
 
 // Neighbours that lie in ANOTHER component than their query (dc_mfma_kernels.hpp "components"): the matrix-core sweep
@@ -1520,19 +1560,32 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
         __syncthreads();
         const uint32_t n_list = (uint32_t)__builtin_popcountll(m);
         unsigned long long my_nn = ~0ull, my_hd = ~0ull;
-        // two tiles per step: the half-waves take one each, a lane one row
-        for (uint32_t s0 = 0; s0 < n_list; s0 += 2) {
-          const uint32_t si = s0 + (uint32_t)(lane >> 5);
-          if (si < n_list) {
-            const uint32_t pr = 32u * list[si] + (uint32_t)(lane & 31);
-            const uint32_t j = perm_r[pr];
-            if (j != kInvalidFrame && j != q_frame) {
-              const float d2 = dist2_canon_rows(q_row, coords_r + (size_t)pr * n_cols, (int)n_cols);
-              const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | j;
-              my_nn = key < my_nn ? key : my_nn;
-              if (fe_c[pr] < q_fe) my_hd = key < my_hd ? key : my_hd;
-            }
+        // eight tiles per step: the half-waves take four each, a lane one row of each -- the four row fetches of a
+        // lane are independent and overlap (one tile pair per step was bound by the latency of its two loads)
+        for (uint32_t s0 = 0; s0 < n_list; s0 += 8) {
+          uint32_t pr[4], jr[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t si = s0 + 2u * (uint32_t)k + (uint32_t)(lane >> 5);
+            pr[k] = (si < n_list) ? 32u * list[si] + (uint32_t)(lane & 31) : 0xFFFFFFFFu;
+            jr[k] = (pr[k] != 0xFFFFFFFFu) ? perm_r[pr[k]] : kInvalidFrame;
           }
+          float d2[4], fr[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool use = jr[k] != kInvalidFrame && jr[k] != q_frame;
+            const size_t row = use ? (size_t)pr[k] : 0;
+            d2[k] = dist2_canon_rows(q_row, coords_r + row * n_cols, (int)n_cols);
+            fr[k] = fe_c[row];
+            if (!use) jr[k] = kInvalidFrame;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (jr[k] != kInvalidFrame) {
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d2[k]) << 32) | jr[k];
+              my_nn = key < my_nn ? key : my_nn;
+              if (fr[k] < q_fe) my_hd = key < my_hd ? key : my_hd;
+            }
         }
         const unsigned long long w_nn = wave_min_u64(my_nn), w_hd = wave_min_u64(my_hd);
         best_nn = w_nn < best_nn ? w_nn : best_nn;
@@ -1554,7 +1607,7 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
 
 static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                           const QuerySel& qs, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
-                          float* d_hd_d2, void* d_ws, hipStream_t stream) {
+                          float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components) {
   const uint32_t i_from = qs.i_from, i_to = qs.i_to;
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
@@ -1594,13 +1647,23 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   // the pass over the free energies finds their range (and raises the flag for NaNs)
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
                      (uint32_t*)nullptr, hdr);
-  (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
   (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
-  hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn, comp);
-  hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
-  hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
-                     (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
-                     components_off() ? 1 : 0, 0.0f);
+  const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
+  if (reuse_components) {
+    // the partition an earlier sweep over these coordinates left in the workspace (DC_FLAG_STATS_VALID: the
+    // populations -> neighbours pair) -- checked on the device
+    hipLaunchKernelGGL(comp_guard_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr, (const float*)(p + kHdrMeans),
+                       n_cols, comp, cookie);
+  } else {
+    (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
+    hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn, comp);
+    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
+    hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
+                       (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
+                       components_off() ? 1 : 0, 0.0f, cookie);
+  }
+  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, kNnCellFrames,
+                     (uint32_t)fine_bits, comp);
   // frames by (component, cell, free energy): ONE sort on a combined key
   hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
                      (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, fe_bits);

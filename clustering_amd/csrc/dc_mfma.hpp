@@ -65,9 +65,12 @@ void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_c
                             uint32_t* d_pops, void* d_ws, hipStream_t stream, uint32_t segment = 0,
                             uint32_t n_segments = 0);   // (n_segments > 0: the pairs seen from one segment's queries)
 // neighbour sweep over (cell, free energy)-ordered frames with ring-wise pruning
+// reuse_components: the component partition an earlier sweep over the same coordinates left in the workspace serves
+// this one too (the second call of a populations -> neighbours pair); checked against a cookie on the device
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
-                      uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
+                      uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream,
+                      bool reuse_components = false);
 // the same for one SEGMENT of the spatial order (segment s of n: a run of whole query groups): the
 // rows a rank of a spatially sharded multi-GPU run answers for.  Outputs as for a row range: zeros /
 // "none" for the rows of other segments.
@@ -77,7 +80,7 @@ void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t 
 void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
                               const float* d_fe, uint32_t segment, uint32_t n_segments,
                               uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
-                              void* d_ws, hipStream_t stream);
+                              void* d_ws, hipStream_t stream, bool reuse_components = false);
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                     uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                     uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream);
