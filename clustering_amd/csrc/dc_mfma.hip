@@ -436,6 +436,12 @@ __global__ void coarse_box_kernel(const uint32_t* __restrict__ hdr, float r_max,
       }
   float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
   if (x1 >= 0) {
+    // (the occupied sub-cells of the whole grid: what the frames cover of the plane, comp[kCompGrid + 2])
+    uint32_t n_sub = 0;
+    for (int sx = 0; sx < kFineSub; ++sx)
+      for (int sy = 0; sy < kFineSub; ++sy)
+        n_sub += bm[(size_t)(cx * kFineSub + sx) * (kCoarseDim * kFineSub) + (cy * kFineSub + sy)] ? 1u : 0u;
+    atomicAdd(comp + kCompGrid + 2, n_sub);
     const float gf = g.gc / (float)kFineSub, slack = 1.0e-3f * gf;
     box.x = g.min0 + (float)(cx * kFineSub + x0) * gf - slack;
     box.y = g.min0 + (float)(cx * kFineSub + x1 + 1) * gf + slack;
@@ -657,11 +663,12 @@ __global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_ro
   const float gmin0 = fkey_inv(~hdr[8]), gmax0 = fkey_inv(hdr[9]), gmin1 = fkey_inv(~hdr[10]), gmax1 = fkey_inv(hdr[11]);
   float cell = auto_cell(hdr, n_rows, frames_per_cell);
   if (n_comp > 1u) {
-    // sparse data: the frames cover a small part of the bounding box -- size the fine cells by the occupied area (x 8:
-    // what the blobs of the reference workload cover of theirs), so that the cells do not grow with the empty space
-    const double gc = (double)__uint_as_float(comp[kCompGrid + 0]);
+    // sparse data: the frames cover a small part of the bounding box -- size the fine cells by the occupied area (the
+    // occupied sub-cells of the coarse grid, x 2.7: what the bounding box of the reference workload is of the area its
+    // blobs cover, i.e. the same cells there), so that the cells do not grow with the empty space between clusters
+    const double gf = (double)__uint_as_float(comp[kCompGrid + 0]) / (double)kFineSub;
     const double a_box = (double)fmaxf(gmax0 - gmin0, 0.0f) * (double)fmaxf(gmax1 - gmin1, 0.0f);
-    const double a_occ = 8.0 * (double)comp[kCompGrid + 1] * gc * gc;
+    const double a_occ = 2.7 * (double)comp[kCompGrid + 2] * gf * gf;
     if (a_occ > 0.0 && a_occ < a_box)
       cell = (float)sqrt(a_occ * (double)frames_per_cell / (double)(n_rows ? n_rows : 1u));
   }

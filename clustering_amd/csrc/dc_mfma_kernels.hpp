@@ -1128,6 +1128,7 @@ struct CompView {
   const uint32_t* tile_comp_q;
   const uint32_t* range_r;   // [kMaxComp][2]
   uint32_t n_pos;
+  const uint32_t* comp;      // the component region itself (fine grids, boxes)
 };
 
 // SYM: the symmetric sweep (all rows as queries, one radius, no sink): a query group meets its own tiles as
@@ -1950,10 +1951,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
   const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc);   // (the extent the scale was chosen for)
-  if (cell2 < 0.0f) {
-    const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
-    cell2 = cl * cl;
-  }
+  (void)cell2;   // (the first ring's floor: the cell edge of the query's own component, set below)
 
   s16x8 b[TQ][NM];
   NnPQ q[TQ];
@@ -2087,6 +2085,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
   const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
   const uint32_t U = max((t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u, u_lo);
+  {
+    const float cl = __uint_as_float(CV.comp[kCompFine + 4 * min(my_comp, (uint32_t)kMaxComp - 1u) + 2]);
+    cell2 = cl * cl;
+  }
   const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
@@ -2512,7 +2514,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   if (A.n_q == 0) return;
   // T: tiles of the (padded) reference order; A.n_q: positions of the query order
-  const CompView CV{A.tile_comp_q, A.comp + kCompRange, 32u * T};
+  const CompView CV{A.tile_comp_q, A.comp + kCompRange, 32u * T, A.comp};
   if (nn_shared_wanted(n_rows, n_cols)) {
     // reference operands shared through LDS (dc_mfma_nn_shared.hpp): the workgroup's 4 * TQV tiles are one group
     const uint32_t groups = seg_groups(((A.n_q + 31) / 32 + 4 * TQV - 1) / (4 * TQV), A.q_seg);
@@ -2622,7 +2624,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   // reference order (img_q)
   const bool own = q_mode == kQueryOwnOrder;
   // T: tiles of the (padded) reference order; n_q: positions of the query order
-  const CompView CV{own ? P.tile_comp_q : P.tile_comp, P.comp + kCompRange, 32u * T};
+  const CompView CV{own ? P.tile_comp_q : P.tile_comp, P.comp + kCompRange, 32u * T, P.comp};
   // pairs between adjacent components (exact, after the matrix-core sweep): into the same counts
   auto cross = [&](uint32_t group_tiles, uint32_t* out, size_t stride, int by_position) {
     if (sink) return;   // (the sweeps that list pairs use components no pair can cross)

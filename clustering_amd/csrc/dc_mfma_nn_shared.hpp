@@ -94,10 +94,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
   const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc);   // (the extent the scale was chosen for)
-  if (cell2 < 0.0f) {
-    const float cl = auto_cell(hdr, n_rows, kNnCellFrames);
-    cell2 = cl * cl;
-  }
+  (void)cell2;   // (the first ring's floor: the cell edge of the query's own component, set below)
 
   s16x8 b[TQ][NM];
   NnPQ q[TQ];
@@ -239,6 +236,10 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
   const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
   const uint32_t U = max((t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u, u_lo);
+  {
+    const float cl = __uint_as_float(CV.comp[kCompFine + 4 * min(my_comp, (uint32_t)kMaxComp - 1u) + 2]);
+    cell2 = cl * cl;
+  }
   const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
