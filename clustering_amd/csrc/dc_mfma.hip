@@ -509,7 +509,7 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   bool single = force_single != 0 || n_occ > (uint32_t)kMaxOccupied || n_occ <= 1u || !(r_max <= FLT_MAX);
   const float r2c = r_max * r_max * 1.0002f;
   if (!single) {
-    const int R = min((int)ceilf(r_max / g.gc) + 1, kCoarseDim);
+    const int R = min((int)ceilf(r_max / g.gc) + 1, 5);   // (gc >= r_max / 4: at most five cells)
     for (uint32_t i = tid; i < n_occ; i += nt) label[i] = occ[i];
     __syncthreads();
     int iter = 0;
@@ -524,11 +524,17 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
         for (int dx = -R; dx <= R; ++dx) {
           const int nx = cx + dx;
           if (nx < 0 || nx >= (int)g.ncx) continue;
-          for (int dy = -R; dy <= R; ++dy) {
-            const int ny = cy + dy;
-            if (ny < 0 || ny >= (int)g.ncy) continue;
-            const uint32_t nc = (uint32_t)nx * g.ncy + (uint32_t)ny;
-            const uint32_t j = cell_comp[nc];
+          // (the look-ups of one row of the neighbourhood are independent: issued together, not one latency each)
+          uint32_t jj[11];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            const int ny = cy + k - 5;
+            const bool in = (k - 5 >= -R) && (k - 5 <= R) && ny >= 0 && ny < (int)g.ncy;
+            jj[k] = in ? cell_comp[(uint32_t)nx * g.ncy + (uint32_t)ny] : 0xFFFFFFFFu;
+          }
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            const uint32_t j = jj[k];
             if (j == 0xFFFFFFFFu || j >= n_occ) continue;
             if (box_gap2(bi, obox[j]) <= r2c) m = min(m, label[j]);
           }
@@ -1301,6 +1307,13 @@ static void pad_order(const uint32_t* keys_sorted, const uint32_t* vals_sorted, 
                      (const uint32_t*)start, (const uint32_t*)range, perm, tile_comp);
 }
 
+// DC_POP_CELL_FRAMES / DC_NN_CELL_FRAMES: measurement overrides of the frames per cell of the orderings
+static float cell_frames(bool nn) {
+  static const float v[2] = {[] { const char* e = getenv("DC_POP_CELL_FRAMES"); return (e && e[0]) ? (float)atof(e) : kPopCellFrames; }(),
+                             [] { const char* e = getenv("DC_NN_CELL_FRAMES"); return (e && e[0]) ? (float)atof(e) : kNnCellFrames; }()};
+  return v[nn ? 1 : 0];
+}
+
 // DC_POP_COMPONENTS=0: one component whatever the data looks like (measurements, tests)
 static bool components_off() {
   static const bool off = [] {
@@ -1373,7 +1386,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, r_max, data_cookie(d_coords, n_rows, n_cols));
-    hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, kPopCellFrames,
+    hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, cell_frames(false),
                        (uint32_t)fine_bits, comp);
     // order all frames by (component, fine cell); every component then moves to a whole query group of the padded order
     hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
@@ -1669,7 +1682,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, 0.0f, cookie);
   }
-  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, kNnCellFrames,
+  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, cell_frames(true),
                      (uint32_t)fine_bits, comp);
   // frames by (component, cell, free energy): ONE sort on a combined key
   hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,

@@ -123,6 +123,30 @@ def test_adjacent_components_exchange_their_cross_pairs(dens, oracle, n_cols, ra
     far = c.copy()
     far[c[:, 0] > np.median(c[:, 0]), 0] += 10.0
     assert (oracle.populations(far, radii[:1]) != want[:1]).any(), "the test data has no cross pairs"
+    # neighbours: the frames at the facing edges may have their (lower-free-energy) neighbour in the other cluster, the
+    # lowest free energy of a cluster always has -- the exact cross pass (nn_cross_kernel); all rows, a row range, segments
+    fe = oracle.free_energies(want[0])
+    exp = oracle.nearest_neighbors(c, fe)
+    fe_t = torch.from_numpy(fe).cuda()
+
+    def same(nn):
+        g = [t.cpu().numpy() for t in nn]
+        return ((g[0].astype(np.uint32).astype(np.uint64) == exp[0]).all() and (g[2].astype(np.uint32).astype(np.uint64) == exp[2]).all()
+                and (bits(g[1]) == bits(exp[1])).all() and (bits(g[3]) == bits(exp[3])).all())
+    assert same(dens.nearest_neighbors_partial(ct, fe_t, variant="pruned"))
+    assert same(dens.nearest_neighbors_partial(ct, fe_t, variant="pruned", stats_valid=True))   # (the partition of the last sweep)
+    part = [t.cpu().numpy() for t in dens.nearest_neighbors_partial(ct, fe_t, lo, hi, variant="pruned")]
+    assert (part[0][lo:hi].astype(np.uint32).astype(np.uint64) == exp[0][lo:hi]).all()
+    assert (part[2][lo:hi].astype(np.uint32).astype(np.uint64) == exp[2][lo:hi]).all()
+    assert (bits(part[1][lo:hi]) == bits(exp[1][lo:hi])).all() and (bits(part[3][lo:hi]) == bits(exp[3][lo:hi])).all()
+    words = None
+    for g in range(3):
+        w = dens.pack_neighbors(*dens.nearest_neighbors_segment(ct, fe_t, g, 3))
+        words = w if words is None else torch.minimum(words, w)
+    assert same(dens.unpack_neighbors(words.contiguous()))
+    comp_of = (c[:, 0] > 3.0).astype(int) * 2 + ((c[:, 0] > (c[c[:, 0] < 3.0, 0].min() + c[c[:, 0] < 3.0, 0].max()) / 2) & (c[:, 0] < 3.0))
+    crossing = comp_of[exp[2][exp[2] < len(c)].astype(int)] != comp_of[np.nonzero(exp[2] < len(c))[0]]
+    assert crossing.any(), "no lower-free-energy neighbour crosses between the clusters in this data"
 
 
 _SHARED_ADJ_CHILD = r"""
