@@ -1812,6 +1812,12 @@ struct NnPQ {            // per query tile, per lane
   uint32_t spos;         // position of the query itself in the reference order
 };
 
+// the same without the exact incumbents (nn_pruned_kernel keeps them in LDS only: best64)
+struct NnPQr {
+  float feq, m_nn, m_hd, bn, bh;
+  uint32_t spos;
+};
+
 __device__ __attribute__((noinline)) NnMin nn_special_fe(f32x16 acc, const float* __restrict__ fe_c,
                                                          uint32_t t, int h, uint32_t spos,
                                                          float feq) {
@@ -1940,12 +1946,16 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   uint32_t* list = lists_all + (size_t)wib * kListCap;
   float* qrows = qrows_all + (size_t)wib * (TQ * 32) * n_cols;
   uint32_t* queues = reinterpret_cast<uint32_t*>(qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
-                     (size_t)wib * TQ * kQueueCap * 64;
+                     (size_t)wib * (TQ * kQueueCap * 64 + 2 * TQ * 32);
   // the wave's LDS behind the query rows (TQ * kQueueCap * 64 words): the compact candidate list (kWaveQueue
   // entries of 8 B) and the packed exact incumbents [2][TQ*32] of 8 B
   static_assert(TQ * kQueueCap * 64 >= 2 * kWaveQueue + 4 * TQ * 32, "candidate list + incumbents fit the queue region");
   uint2* cand = reinterpret_cast<uint2*>(queues);
   unsigned long long* best64 = reinterpret_cast<unsigned long long*>(queues + 2 * kWaveQueue);
+  // exact incumbents other reference chunks had published when this wave started (FLT_MAX: none), [2][TQ*32] -- kept in
+  // LDS like the wave's own incumbents: neither is touched inside the chains, and as registers they were live (and
+  // partly spilled) across the whole sweep
+  float* g_pub = reinterpret_cast<float*>(queues + TQ * kQueueCap * 64);   // (2 * TQ * 32 words behind the queue region)
   uint32_t qn = 0;   // queued candidates (wave-uniform)
 
   // (scaled units, like the accumulators and the running minima taken from them)
@@ -1954,11 +1964,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   (void)cell2;   // (the first ring's floor: the cell edge of the query's own component, set below)
 
   s16x8 b[TQ][NM];
-  NnPQ q[TQ];
+  NnPQr q[TQ];
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
   float4 qbox[TQ];
-  float g_nn[TQ], g_hd[TQ];   // exact incumbents published by other reference chunks (FLT_MAX: none)
   float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
@@ -1977,25 +1986,24 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
     q[qt].m_nn = live ? INFINITY : -INFINITY;   // idle lanes can never trigger the exact path
     q[qt].m_hd = live ? INFINITY : -INFINITY;
-    g_nn[qt] = FLT_MAX;
-    g_hd[qt] = FLT_MAX;
+    float g_nn = FLT_MAX, g_hd = FLT_MAX;
     if (n_chunks > 1 && live) {
       // what the waves of other reference chunks have already published for this query: an exact
       // upper bound.  Only candidates that can still beat (or tie) it need to be looked at, i.e.
       // MFMA values below d2 + eps(d2); the band test adds its usual margin on top.
-      g_nn[qt] = __uint_as_float((uint32_t)(merge64[jq[qt]] >> 32));
-      g_hd[qt] = __uint_as_float((uint32_t)(merge64[(size_t)n_rows + jq[qt]] >> 32));
-      const float s_nn = g_nn[qt] * sc.s2, s_hd = g_hd[qt] * sc.s2;   // (exact d2 -> scaled units)
-      if (g_nn[qt] < FLT_MAX) q[qt].m_nn = s_nn + (gb.e0 + gb.kappa * s_nn);
-      if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
+      g_nn = __uint_as_float((uint32_t)(merge64[jq[qt]] >> 32));
+      g_hd = __uint_as_float((uint32_t)(merge64[(size_t)n_rows + jq[qt]] >> 32));
+      const float s_nn = g_nn * sc.s2, s_hd = g_hd * sc.s2;   // (exact d2 -> scaled units)
+      if (g_nn < FLT_MAX) q[qt].m_nn = s_nn + (gb.e0 + gb.kappa * s_nn);
+      if (g_hd < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
+    }
+    if (h == 0) {
+      g_pub[qt * 32 + c] = g_nn;
+      g_pub[TQ * 32 + qt * 32 + c] = g_hd;
     }
     q[qt].m_nn = fminf(q[qt].m_nn, q[qt].m_hd);   // (two reads of merge64 a moment apart: keep m_nn <= m_hd)
     q[qt].bn = nn_band(gb, q[qt].m_nn);
     q[qt].bh = nn_band(gb, q[qt].m_hd);
-    q[qt].bd_nn = FLT_MAX;
-    q[qt].bd_hd = FLT_MAX;
-    q[qt].bj_nn = n_rows + 1;
-    q[qt].bj_hd = n_rows + 1;
     qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
     gbox.x = fminf(gbox.x, qbox[qt].x);
     gbox.y = fmaxf(gbox.y, qbox[qt].y);
@@ -2011,7 +2019,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
     const bool live = (livemask[qt] >> lane) & 1;
-    NnPQ& Q = q[qt];
+    NnPQr& Q = q[qt];
+    float bd_nn = FLT_MAX, bd_hd = FLT_MAX;          // exact incumbents of this query (canonical d2, frame id)
+    uint32_t bj_nn = n_rows + 1, bj_hd = n_rows + 1;
     // (only the first reference share: the later ones start from what the earlier ones published)
     if (live && chunk == 0) {
       const float* qrow = qrows + (qt * 32 + c) * n_cols;
@@ -2020,41 +2030,39 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         if (p2 >= 0 && p2 < (long long)CV.n_pos && perm_r[p2] != kInvalidFrame) {
           const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)p2 * n_cols, 1, (int)n_cols);
           const uint32_t j = perm_r[p2];
-          lexi_update(true, Q.bd_nn, Q.bj_nn, d2c, j, n_rows);
-          lexi_update(fe_c[p2] < Q.feq, Q.bd_hd, Q.bj_hd, d2c, j, n_rows);
+          lexi_update(true, bd_nn, bj_nn, d2c, j, n_rows);
+          lexi_update(fe_c[p2] < Q.feq, bd_hd, bj_hd, d2c, j, n_rows);
         }
       }
       // (the two half-wave lanes looked at the frames after / before the query: merge, then both hold the result)
       {
-        float od = __shfl_xor(Q.bd_nn, 32, 64);
-        uint32_t oj = (uint32_t)__shfl_xor((int)Q.bj_nn, 32, 64);
-        lexi_update(oj <= n_rows, Q.bd_nn, Q.bj_nn, od, oj, n_rows);
-        od = __shfl_xor(Q.bd_hd, 32, 64);
-        oj = (uint32_t)__shfl_xor((int)Q.bj_hd, 32, 64);
-        lexi_update(oj <= n_rows, Q.bd_hd, Q.bj_hd, od, oj, n_rows);
+        float od = __shfl_xor(bd_nn, 32, 64);
+        uint32_t oj = (uint32_t)__shfl_xor((int)bj_nn, 32, 64);
+        lexi_update(oj <= n_rows, bd_nn, bj_nn, od, oj, n_rows);
+        od = __shfl_xor(bd_hd, 32, 64);
+        oj = (uint32_t)__shfl_xor((int)bj_hd, 32, 64);
+        lexi_update(oj <= n_rows, bd_hd, bj_hd, od, oj, n_rows);
       }
-      const float s_nn = Q.bd_nn * sc.s2, s_hd = Q.bd_hd * sc.s2;
-      if (Q.bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
-      if (Q.bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
+      const float s_nn = bd_nn * sc.s2, s_hd = bd_hd * sc.s2;
+      if (bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
+      if (bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
       Q.bn = nn_band(gb, Q.m_nn);
       Q.bh = nn_band(gb, Q.m_hd);
       // published at once: the other shares of this group start while this wave is still sweeping
       if (n_chunks > 1) {
-        if (Q.bd_nn < FLT_MAX)
-          atomicMin(&merge64[jq[qt]], ((unsigned long long)__float_as_uint(Q.bd_nn) << 32) | Q.bj_nn);
-        if (Q.bd_hd < FLT_MAX)
+        if (bd_nn < FLT_MAX)
+          atomicMin(&merge64[jq[qt]], ((unsigned long long)__float_as_uint(bd_nn) << 32) | bj_nn);
+        if (bd_hd < FLT_MAX)
           atomicMin(&merge64[(size_t)n_rows + jq[qt]],
-                    ((unsigned long long)__float_as_uint(Q.bd_hd) << 32) | Q.bj_hd);
+                    ((unsigned long long)__float_as_uint(bd_hd) << 32) | bj_hd);
       }
     }
-  }
-  // the exact incumbents of the wave's queries, as order-preserving words in LDS (see nn_wave_flush)
-#pragma unroll
-  for (int qt = 0; qt < TQ; ++qt)
+    // the exact incumbents of the wave's queries live in LDS as order-preserving words (see nn_wave_flush)
     if (h == 0) {
-      best64[qt * 32 + c] = ((unsigned long long)__float_as_uint(q[qt].bd_nn) << 32) | q[qt].bj_nn;
-      best64[TQ * 32 + qt * 32 + c] = ((unsigned long long)__float_as_uint(q[qt].bd_hd) << 32) | q[qt].bj_hd;
+      best64[qt * 32 + c] = ((unsigned long long)__float_as_uint(bd_nn) << 32) | bj_nn;
+      best64[TQ * 32 + qt * 32 + c] = ((unsigned long long)__float_as_uint(bd_hd) << 32) | bj_hd;
     }
+  }
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
   // ordering pass): a query at that level has no lower-FE neighbour
   const float fe_floor = fkey_inv(~hdr[12]);
@@ -2064,18 +2072,6 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     nn_wave_flush(cand, qn, qrows, best64, TQ * 32, coords_c, perm_r, n_cols, lane);
     qn = 0;
   };
-  // the registers' copy of the exact incumbents (both half-wave lanes of a query hold the same)
-  auto reload = [&]() {
-#pragma unroll
-    for (int qt = 0; qt < TQ; ++qt) {
-      const unsigned long long a = best64[qt * 32 + c], b2 = best64[TQ * 32 + qt * 32 + c];
-      q[qt].bd_nn = __uint_as_float((uint32_t)(a >> 32));
-      q[qt].bj_nn = (uint32_t)a;
-      q[qt].bd_hd = __uint_as_float((uint32_t)(b2 >> 32));
-      q[qt].bj_hd = (uint32_t)b2;
-    }
-  };
-
   uint32_t chains = 0, visited = 0;
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scans only touch their own boxes)
@@ -2133,7 +2129,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       // (t, fr) describe the reference tile the accumulator belongs to.
       auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t, float2 fr) {
         constexpr int qi = decltype(qi_c)::value;
-        NnPQ& Q = q[qi];
+        NnPQr& Q = q[qi];
         // Common path: two compares against the cached candidate thresholds.  "Lower free energy" is
         // taken conservatively here (the tile has SOME lower frame => its minimum might be one), and
         // the tile holding the query itself always passes (its own d2 ~ 0): whatever needs the
@@ -2295,8 +2291,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
       }
     }
-    flush();                                          // the settle test needs the exact incumbents
-    reload();
+    flush();                                          // the settle test needs the exact incumbents (in LDS)
     if (!(r2_hi <= FLT_MAX) || visited >= U - u_lo)
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
@@ -2307,9 +2302,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     for (int qt = 0; qt < TQ; ++qt) {
       const bool live = (livemask[qt] >> lane) & 1;
       const bool hd_possible = fe_floor < q[qt].feq;
-      // a query's incumbent is the better one of its two half-wave lanes
-      const float inc_nn = fminf(g_nn[qt], fminf(q[qt].bd_nn, __shfl_xor(q[qt].bd_nn, 32, 64)));
-      const float inc_hd = fminf(g_hd[qt], fminf(q[qt].bd_hd, __shfl_xor(q[qt].bd_hd, 32, 64)));
+      // (both half-wave lanes of a query read the same words)
+      const float inc_nn = fminf(g_pub[qt * 32 + c], __uint_as_float((uint32_t)(best64[qt * 32 + c] >> 32)));
+      const float inc_hd = fminf(g_pub[TQ * 32 + qt * 32 + c], __uint_as_float((uint32_t)(best64[TQ * 32 + qt * 32 + c] >> 32)));
       const float want = fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f);
       const bool open = live & !(want < sure);
       blind = blind | (open & !(want < FLT_MAX));
@@ -2332,26 +2327,18 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
-    NnPQ& Q = q[qt];
-    float od = __shfl_xor(Q.bd_nn, 32, 64);
-    uint32_t oj = (uint32_t)__shfl_xor((int)Q.bj_nn, 32, 64);
-    lexi_update(oj <= n_rows, Q.bd_nn, Q.bj_nn, od, oj, n_rows);
-    od = __shfl_xor(Q.bd_hd, 32, 64);
-    oj = (uint32_t)__shfl_xor((int)Q.bj_hd, 32, 64);
-    lexi_update(oj <= n_rows, Q.bd_hd, Q.bj_hd, od, oj, n_rows);
     if (h == 0 && ((livemask[qt] >> lane) & 1)) {
+      const unsigned long long w_nn = best64[qt * 32 + c], w_hd = best64[TQ * 32 + qt * 32 + c];
       if (n_chunks == 1) {
-        nn_idx[jq[qt]] = Q.bj_nn;
-        nn_d2[jq[qt]] = Q.bd_nn;
-        hd_idx[jq[qt]] = Q.bj_hd;
-        hd_d2[jq[qt]] = Q.bd_hd;
+        nn_idx[jq[qt]] = (uint32_t)w_nn;
+        nn_d2[jq[qt]] = __uint_as_float((uint32_t)(w_nn >> 32));
+        hd_idx[jq[qt]] = (uint32_t)w_hd;
+        hd_d2[jq[qt]] = __uint_as_float((uint32_t)(w_hd >> 32));
       } else {
         // d2 >= 0, so (d2 bits << 32 | frame id) orders like the lexicographic (d2, id): the merge
         // over the chunks is a 64-bit atomic min (merge64 was filled with (FLT_MAX, n_rows+1))
-        atomicMin(&merge64[jq[qt]],
-                  ((unsigned long long)__float_as_uint(Q.bd_nn) << 32) | Q.bj_nn);
-        atomicMin(&merge64[(size_t)n_rows + jq[qt]],
-                  ((unsigned long long)__float_as_uint(Q.bd_hd) << 32) | Q.bj_hd);
+        atomicMin(&merge64[jq[qt]], w_nn);
+        atomicMin(&merge64[(size_t)n_rows + jq[qt]], w_hd);
       }
     }
   }
@@ -2544,7 +2531,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
   // query rows (original coordinates) + candidate queues, per wave
   const uint32_t wpb = waves_per_group(S);
   const size_t smem = wpb * (sizeof(uint32_t) * kListCap + sizeof(float) * TQV * 32 * (size_t)n_cols +
-                             sizeof(uint32_t) * TQV * kQueueCap * 64);
+                             sizeof(uint32_t) * (TQV * kQueueCap * 64 + 2 * TQV * 32));
   if (n_chunks > 1)
     hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s,
                        A.merge64, n_rows);
