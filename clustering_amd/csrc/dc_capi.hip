@@ -582,6 +582,20 @@ int dc_hip_radius_min_edge_segment_dev(const float* d_coords, size_t n_rows, siz
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// the host-pointer entry points select their device themselves and leave the caller's current device as it was
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) {
+      (void)hipGetLastError();
+      prev = -1;
+    }
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 struct DeviceJob {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -629,6 +643,7 @@ int dc_hip_populations(const float* coords, size_t n_rows, size_t n_cols, const 
   if (int rc = check_sizes(n_rows, n_cols, i_from, i_to)) return rc;
   if (n_rows == 0 || n_radii == 0) return DC_OK;
   if (!coords || !radii || !pops) return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  DeviceGuard guard;
   DeviceJob j;
   int rc = job_open(j, device, coords, n_rows, n_cols);
   if (rc == DC_OK) {
@@ -655,6 +670,7 @@ int dc_hip_nearest_neighbors(const float* coords, size_t n_rows, size_t n_cols, 
   if (n_rows == 0) return DC_OK;
   if (!coords || !fe || !nn_idx || !nn_d2 || !hd_idx || !hd_d2)
     return fail(DC_ERR_INVALID_ARGUMENT, "null pointer");
+  DeviceGuard guard;
   DeviceJob j;
   int rc = job_open(j, device, coords, n_rows, n_cols);
   hipError_t e = hipSuccess;

@@ -1509,7 +1509,8 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
     const uint32_t* __restrict__ tile_comp_q, const uint32_t* __restrict__ comp, uint32_t T_q, uint32_t group_tiles,
     QSeg q_seg, int q_in_ref_order, const uint32_t* __restrict__ hdr, uint32_t* __restrict__ nn_idx,
     float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
-  __shared__ uint32_t list[64];
+  __shared__ uint32_t list[256];
+  __shared__ float list_gap[256];
   if (hdr[1] != 0) return;
   const uint32_t n_comp = comp[kCompGrid + 5];
   if (n_comp <= 1u) return;
@@ -1565,31 +1566,58 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
         if (!(g2 <= inc_nn) && !(q_hd && g2 <= inc_hd)) continue;
       }
       const uint32_t t_lo = range[2 * c2], t_hi = range[2 * c2 + 1];
-      for (uint32_t base = t_lo; base < t_hi; base += 64) {
+      // 256 tiles per step: a lane tests four boxes whose loads are independent (one box per lane and step was
+      // bound by the latency of its loads: 200 us for a query that has to look at all 20 000 tiles of C3)
+      for (uint32_t base = t_lo; base < t_hi; base += 256) {
         const float inc_nn = __uint_as_float((uint32_t)(best_nn >> 32)), inc_hd = __uint_as_float((uint32_t)(best_hd >> 32));
-        const uint32_t t = base + (uint32_t)lane;
-        bool ok = false;
-        if (t < t_hi) {
-          const float g2 = point_box_gap2(qx0, qx1, box_r[t]);
-          ok = (g2 <= inc_nn) | (q_hd & (g2 <= inc_hd) & (ferange_r[t].x < q_fe));
+        float4 bx[4];
+        float flo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t t = base + 64u * (uint32_t)k + (uint32_t)lane;
+          bx[k] = (t < t_hi) ? box_r[t] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+          flo[k] = (t < t_hi) ? ferange_r[t].x : INFINITY;
         }
-        const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
-        if (m == 0) continue;
+        uint32_t n_list = 0;
         __syncthreads();
-        if (ok) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t t = base + 64u * (uint32_t)k + (uint32_t)lane;
+          const float g2 = point_box_gap2(qx0, qx1, bx[k]);
+          const bool ok = (t < t_hi) && ((g2 <= inc_nn) | (q_hd & (g2 <= inc_hd) & (flo[k] < q_fe)));
+          const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+          if (ok) {
+            const uint32_t slot = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            list[slot] = t;
+            list_gap[slot] = g2;
+          }
+          n_list += (uint32_t)__builtin_popcountll(m);
+        }
+        if (n_list == 0) continue;
         __syncthreads();
-        const uint32_t n_list = (uint32_t)__builtin_popcountll(m);
-        unsigned long long my_nn = ~0ull, my_hd = ~0ull;
         // eight tiles per step: the half-waves take four each, a lane one row of each -- the four row fetches of a
-        // lane are independent and overlap (one tile pair per step was bound by the latency of its two loads)
+        // lane are independent and overlap (one tile pair per step was bound by the latency of its two loads).  The
+        // incumbents are renewed after every step and listed tiles they exclude by then are passed over: a query without
+        // a lower-energy neighbour so far (the minimum of its component) lists every tile with a lower energy at first
         for (uint32_t s0 = 0; s0 < n_list; s0 += 8) {
+          unsigned long long my_nn = ~0ull, my_hd = ~0ull;
+          const float cur_nn = __uint_as_float((uint32_t)(best_nn >> 32)), cur_hd = __uint_as_float((uint32_t)(best_hd >> 32));
           uint32_t pr[4], jr[4];
+          bool any = false;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint32_t si = s0 + 2u * (uint32_t)k + (uint32_t)(lane >> 5);
-            pr[k] = (si < n_list) ? 32u * list[si] + (uint32_t)(lane & 31) : 0xFFFFFFFFu;
-            jr[k] = (pr[k] != 0xFFFFFFFFu) ? perm_r[pr[k]] : kInvalidFrame;
+            bool take = si < n_list;
+            if (take) {
+              const float g2 = list_gap[si];
+              take = (g2 <= cur_nn) | (q_hd & (g2 <= cur_hd));
+            }
+            pr[k] = take ? 32u * list[si] + (uint32_t)(lane & 31) : 0xFFFFFFFFu;
+            any |= take;
           }
+          if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) jr[k] = (pr[k] != 0xFFFFFFFFu) ? perm_r[pr[k]] : kInvalidFrame;
           float d2[4], fr[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -1606,10 +1634,10 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
               my_nn = key < my_nn ? key : my_nn;
               if (fr[k] < q_fe) my_hd = key < my_hd ? key : my_hd;
             }
+          const unsigned long long w_nn = wave_min_u64(my_nn), w_hd = wave_min_u64(my_hd);
+          best_nn = w_nn < best_nn ? w_nn : best_nn;
+          best_hd = w_hd < best_hd ? w_hd : best_hd;
         }
-        const unsigned long long w_nn = wave_min_u64(my_nn), w_hd = wave_min_u64(my_hd);
-        best_nn = w_nn < best_nn ? w_nn : best_nn;
-        best_hd = w_hd < best_hd ? w_hd : best_hd;
       }
     }
     if (lane == l) {
