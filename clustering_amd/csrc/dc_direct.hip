@@ -363,13 +363,25 @@ __global__ void nn_unpack_kernel(const unsigned long long* __restrict__ words, u
 }
 
 __global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* out) {
+  __shared__ uint32_t wave_max[4];
   uint32_t m = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    m = max(m, v[i]);
+  // 16 bytes per lane and step (cudaMalloc-aligned arrays; the tail by the word)
+  const uint32_t n4 = ((reinterpret_cast<uintptr_t>(v) & 15u) == 0) ? n / 4 : 0;
+  const uint4* v4 = reinterpret_cast<const uint4*>(v);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const uint4 w = v4[i];
+    m = max(max(m, max(w.x, w.y)), max(w.z, w.w));
+  }
+  for (uint32_t i = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, v[i]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-  // (thousands of atomics on one word serialise: 49 us at 10^6 rows; most waves see that they cannot raise it)
-  if ((threadIdx.x & 63) == 0 && m > *reinterpret_cast<volatile uint32_t*>(out)) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per block, and only if it can raise the word (thousands of atomics on one word serialise: 35 us at 10^6 rows)
+  if (threadIdx.x == 0) {
+    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+  }
 }
 
 // ---- dispatch tables over n_cols ---------------------------------------------------------
@@ -496,7 +508,7 @@ void launch_nn_unpack(const unsigned long long* d_words, uint32_t n_rows, uint32
 void launch_max_u32(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_out, hipStream_t stream) {
   (void)hipMemsetAsync(d_out, 0, sizeof(uint32_t), stream);
   if (n_rows == 0) return;
-  const uint32_t grid = min((n_rows + 255u) / 256u, 512u);
+  const uint32_t grid = min((n_rows + 1023u) / 1024u, 256u);
   hipLaunchKernelGGL(max_u32_kernel, dim3(grid), dim3(256), 0, stream, d_pops, n_rows, d_out);
 }
 

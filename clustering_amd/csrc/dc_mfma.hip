@@ -28,12 +28,22 @@ __global__ void colsum_kernel(const float* __restrict__ coords, uint32_t n_rows,
   const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_rows * D;
   if (id < used) {
-    double s = 0.0;
-    for (size_t e = id; e < total; e += used) {
-      const float v = coords[e];
-      if (fabsf(v) <= FLT_MAX) s += (double)v;          // non-finite entries do not poison the mean
+    // four loads in flight per thread (one was bound by the latency of its load: 27 us for 40 MB); the sum of the
+    // four partial sums is a sum in another order -- the mean is an origin, any value near it serves
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    size_t e = id;
+    for (; e + 3 * (size_t)used < total; e += 4 * (size_t)used) {
+      const float v0 = coords[e], v1 = coords[e + used], v2 = coords[e + 2 * (size_t)used], v3 = coords[e + 3 * (size_t)used];
+      if (fabsf(v0) <= FLT_MAX) s0 += (double)v0;       // non-finite entries do not poison the mean
+      if (fabsf(v1) <= FLT_MAX) s1 += (double)v1;
+      if (fabsf(v2) <= FLT_MAX) s2 += (double)v2;
+      if (fabsf(v3) <= FLT_MAX) s3 += (double)v3;
     }
-    atomicAdd(&part[id % D], s);
+    for (; e < total; e += used) {
+      const float v = coords[e];
+      if (fabsf(v) <= FLT_MAX) s0 += (double)v;
+    }
+    atomicAdd(&part[id % D], (s0 + s1) + (s2 + s3));
   }
   __syncthreads();
   if (threadIdx.x < D) atomicAdd(&sums[threadIdx.x], part[threadIdx.x]);
@@ -67,39 +77,45 @@ __device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v, uint32_t
 // (word 1) and the extent of columns 0/1 (words 8..11: ~key(min col0), key(max col0), ~key(min col1),
 // key(max col1), all maintained with atomicMax).  |x'|^2 is formed exactly as image_kernel forms it,
 // so word 0 bounds every norm of every operand image built from these coordinates.
-// 256 rows per block staged through LDS (coalesced reads; odd row stride against bank conflicts).
 __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                                 const float* __restrict__ means, uint32_t* __restrict__ hdr, uint32_t cookie) {
-  extern __shared__ float rs_tile[];
   __shared__ uint32_t wave_max[4];
-  const uint32_t Dp = D | 1u;
-  const size_t total = (size_t)n_rows * D;
-  const uint32_t n_chunks = (n_rows + 255) / 256;
+  __shared__ float mu[kMaxCols];
+  if (threadIdx.x < D) mu[threadIdx.x] = means[threadIdx.x];
+  __syncthreads();
   uint32_t m_norm = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
   bool bad = false;
-  // chunks of 256 rows, grid-stride: the block publishes its five extrema once at the end
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const size_t base = (size_t)chunk * 256 * D;
-    __syncthreads();   // (the previous chunk's rows have been read)
-    for (uint32_t e = threadIdx.x; e < 256 * D; e += 256) {
-      const uint32_t r = e / D, k = e - r * D;
-      rs_tile[r * Dp + k] = (base + e < total) ? coords[base + e] : 0.0f;
-    }
-    __syncthreads();
-    const uint32_t row = chunk * 256 + threadIdx.x;
-    const bool live = row < n_rows;
-    const float* x = rs_tile + threadIdx.x * Dp;
+  // a row per lane, read where it lies: the ten loads of a wave touch the same 2.5 KB and meet in the vector cache
+  // (the rows went through an LDS tile with two barriers per 256 rows before: 42 - 53 us at 10^6 x 10, now the read)
+  const bool pairs = (D % 2u == 0) && ((reinterpret_cast<uintptr_t>(coords) & 7u) == 0);
+  for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += gridDim.x * blockDim.x) {
+    const float* x = coords + (size_t)row * D;
     double nrm = 0.0;
-    for (uint32_t k = 0; k < D; ++k) {
-      const float v = x[k] - means[k];
-      nrm += (double)v * (double)v;
+    float c0, c1 = 0.0f;
+    if (pairs) {
+      const float2* x2 = reinterpret_cast<const float2*>(x);
+      const float2 first = x2[0];
+      c0 = first.x;
+      c1 = first.y;
+      for (uint32_t k = 0; k < D; k += 2) {
+        const float2 v = x2[k >> 1];
+        const float a = v.x - mu[k], b = v.y - mu[k + 1];
+        nrm += (double)a * (double)a;
+        nrm += (double)b * (double)b;
+      }
+    } else {
+      c0 = x[0];
+      if (D > 1) c1 = x[1];
+      for (uint32_t k = 0; k < D; ++k) {
+        const float v = x[k] - mu[k];
+        nrm += (double)v * (double)v;
+      }
     }
     const float nf = (float)nrm;
-    const bool ok = live && (nf <= kNormLimit);
-    bad = bad | (live && !ok);   // NaN / inf / overflow-prone row: MFMA kernels stand down
+    const bool ok = nf <= kNormLimit;
+    bad = bad | !ok;   // NaN / inf / overflow-prone row: MFMA kernels stand down
     m_norm = max(m_norm, ok ? __float_as_uint(nf) : 0u);
-    const float c0 = x[0], c1 = (D > 1) ? x[1] : 0.0f;
-    const bool fin = live && (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
+    const bool fin = (fabsf(c0) <= FLT_MAX) && (fabsf(c1) <= FLT_MAX);
     m0 = max(m0, fin ? ~fkey(c0) : 0u);
     m1 = max(m1, fin ? fkey(c0) : 0u);
     m2 = max(m2, fin ? ~fkey(c1) : 0u);
@@ -210,6 +226,7 @@ __global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D
   // over the rows: box_rows_kernel)
   if (comp && comp[kCompGrid + 5] > 1u) M = fminf(__uint_as_float(hdr[kHdrMloc]), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);
   hdr[kHdrMused] = __float_as_uint(M);
+  hdr[kHdrOpen] = 0u;
   const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
   hdr[kHdrScale + 0] = __float_as_uint(e.c);
   hdr[kHdrScale + 1] = __float_as_uint(e.s2);
@@ -371,7 +388,7 @@ struct CoarseGrid {
   float gc, min0, min1;
   uint32_t ncx, ncy;
 };
-// coarse occupancy grid over the bounding box of columns 0/1: cells of a quarter of the largest radius, at most
+// coarse occupancy grid over the bounding box of columns 0/1: cells of half the connectivity length, at most
 // kCoarseDim per dimension
 // r_max < 0 (the neighbour sweep has no radius): -r_max times the cell edge of its ordering for n_rows frames
 __device__ __forceinline__ CoarseGrid coarse_grid(const uint32_t* __restrict__ hdr, float r_max, uint32_t n_rows = 0) {
@@ -384,8 +401,9 @@ __device__ __forceinline__ CoarseGrid coarse_grid(const uint32_t* __restrict__ h
   if (!(e1 >= 0.0f) || !(e1 <= FLT_MAX)) e1 = 0.0f;
   if (!(fabsf(g.min0) <= FLT_MAX)) g.min0 = 0.0f;
   if (!(fabsf(g.min1) <= FLT_MAX)) g.min1 = 0.0f;
-  const float quarter = (r_max <= FLT_MAX) ? 0.25f * r_max : FLT_MAX;
-  g.gc = fmaxf(quarter, fmaxf(e0, e1) / (float)(kCoarseDim - 1));
+  // (half the connectivity length: a quarter labelled four times the cells for boxes that the sub-cells make tight anyway)
+  const float half_r = (r_max <= FLT_MAX) ? 0.5f * r_max : FLT_MAX;
+  g.gc = fmaxf(half_r, fmaxf(e0, e1) / (float)(kCoarseDim - 1));
   if (!(g.gc > 0.0f)) g.gc = 1.0f;
   g.ncx = min((uint32_t)fminf(e0 / g.gc, (float)kCoarseDim) + 1u, (uint32_t)kCoarseDim);
   g.ncy = min((uint32_t)fminf(e1 / g.gc, (float)kCoarseDim) + 1u, (uint32_t)kCoarseDim);
@@ -480,11 +498,14 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   __shared__ uint32_t occ[kMaxOccupied], label[kMaxOccupied];
   __shared__ float4 obox[kMaxOccupied];
   __shared__ uint32_t n_occ_s, changed_s, n_comp_s;
+  // cell -> index in occ[] (0xFFFF: empty) during the labelling: in LDS, kCoarseDim^2 half-words (the look-ups of the
+  // neighbourhood went to global memory before: 11 dependent round trips per cell and round, 110 of the kernel's 130 us)
+  extern __shared__ uint16_t cell_idx[];
   __shared__ uint32_t root_cell[kMaxComp];
   __shared__ uint32_t cbox[kMaxComp][4];
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const CoarseGrid g = coarse_grid(hdr, r_max, n_rows);
-  if (r_max < 0.0f) r_max = g.gc * 4.0f;   // (the connectivity length the grid was built for: four coarse cells, or more)
+  if (r_max < 0.0f) r_max = g.gc * 2.0f;   // (the connectivity length the grid was built for: two coarse cells, or more)
   const uint32_t n_cells = g.ncx * g.ncy;
   uint32_t* cell_comp = comp + kCompCellComp;   // during the labelling: cell -> index in occ[] (0xFFFFFFFF: empty)
   if (tid == 0) {
@@ -502,14 +523,14 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
         obox[idx] = bx;
       }
     }
-    cell_comp[c] = idx;
+    cell_idx[c] = (uint16_t)min(idx, 0xFFFFu);
   }
   __syncthreads();
   const uint32_t n_occ = n_occ_s;
   bool single = force_single != 0 || n_occ > (uint32_t)kMaxOccupied || n_occ <= 1u || !(r_max <= FLT_MAX);
   const float r2c = r_max * r_max * 1.0002f;
   if (!single) {
-    const int R = min((int)ceilf(r_max / g.gc) + 1, 5);   // (gc >= r_max / 4: at most five cells)
+    const int R = min((int)ceilf(r_max / g.gc) + 1, 5);   // (gc >= r_max / 2: three cells)
     for (uint32_t i = tid; i < n_occ; i += nt) label[i] = occ[i];
     __syncthreads();
     int iter = 0;
@@ -530,12 +551,12 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
           for (int k = 0; k < 11; ++k) {
             const int ny = cy + k - 5;
             const bool in = (k - 5 >= -R) && (k - 5 <= R) && ny >= 0 && ny < (int)g.ncy;
-            jj[k] = in ? cell_comp[(uint32_t)nx * g.ncy + (uint32_t)ny] : 0xFFFFFFFFu;
+            jj[k] = in ? (uint32_t)cell_idx[(uint32_t)nx * g.ncy + (uint32_t)ny] : 0xFFFFu;
           }
 #pragma unroll
           for (int k = 0; k < 11; ++k) {
             const uint32_t j = jj[k];
-            if (j == 0xFFFFFFFFu || j >= n_occ) continue;
+            if (j >= n_occ) continue;
             if (box_gap2(bi, obox[j]) <= r2c) m = min(m, label[j]);
           }
         }
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
       // pointer jumping: the label of my label's cell
       for (int hop = 0; hop < 4; ++hop) {
         for (uint32_t i = tid; i < n_occ; i += nt) {
-          const uint32_t l = label[cell_comp[label[i]]];
+          const uint32_t l = label[cell_idx[label[i]]];
           if (l < label[i]) {
             atomicMin(&label[i], l);
             changed_s = 1;
@@ -637,6 +658,24 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
     comp[kCompGrid + 6] = cookie;
     comp[kCompGrid + 7] = __float_as_uint(r_conn_param);
   }
+}
+
+// row tiles of 256 x (D | 1) floats: 66 560 bytes at D = 64, above the 64 KB a launch gets without asking
+template <typename K>
+static size_t row_tile_smem(K kernel, uint32_t n_cols) {
+  const size_t bytes = sizeof(float) * 256 * (n_cols | 1u);
+  if (bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
+
+// dynamic LDS of components_kernel (the cell map); with its static arrays the workgroup needs 81 KB of the CU's 160
+static size_t components_smem() {
+  constexpr size_t bytes = sizeof(uint16_t) * kCoarseDim * kCoarseDim;
+  // (per device: set on every call, a host-side table update)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(components_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes);
+  return bytes;
 }
 
 // A partition left in the workspace by an earlier sweep over the same coordinates serves this sweep too (any partition
@@ -988,6 +1027,82 @@ __global__ void box_rows_kernel(const float* __restrict__ coords_o, uint32_t D, 
 
 // original coordinates gathered into an ordered frame list (the exact path then needs no
 // permutation look-up before it can fetch a row)
+// The rows of an order in one pass (gather_rows_kernel + box_rows_kernel + fe_scatter_kernel, which each read the
+// rows again): 256 positions = 8 tiles per block.  The rows are gathered element-wise (40-byte runs of the source,
+// coalesced stores) and parked in LDS, from where every row's lane takes what the tile boxes, the free-energy ranges
+// and the component-wise extent (hdr[kHdrMloc], see box_rows_kernel) need.  fe == nullptr: a population sweep.
+__global__ __launch_bounds__(256) void order_rows_kernel(
+    const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ perm, uint32_t T,
+    float* __restrict__ coords_o, float4* __restrict__ boxes, const float* __restrict__ fe, float* __restrict__ fe_s,
+    uint32_t* __restrict__ invpos, float2* __restrict__ ferange, const uint32_t* __restrict__ tile_comp,
+    const float* __restrict__ origins, uint32_t* __restrict__ hdr) {
+  extern __shared__ float or_tile[];            // [256][D | 1]
+  __shared__ uint32_t s_frame[256];
+  __shared__ float blk_max[4];
+  const uint32_t Dp = D | 1u;
+  const uint32_t pos0 = blockIdx.x * 256u, pos = pos0 + threadIdx.x, n_pos = 32u * T;
+  const uint32_t frame = (pos < n_pos) ? perm[pos] : kInvalidFrame;
+  s_frame[threadIdx.x] = frame;
+  __syncthreads();
+  const size_t base = (size_t)pos0 * D, total = (size_t)n_pos * D;
+  for (uint32_t e = threadIdx.x; e < 256u * D; e += 256u) {
+    const uint32_t r = e / D, k = e - r * D;
+    const uint32_t i = s_frame[r];
+    const float v = (i != kInvalidFrame) ? coords[(size_t)i * D + k] : 0.0f;   // (pad positions of a padded order)
+    or_tile[r * Dp + k] = v;
+    if (base + e < total) coords_o[base + e] = v;
+  }
+  __syncthreads();
+  const bool in_range = pos < n_pos, live = frame != kInvalidFrame;
+  const uint32_t t = min(pos >> 5, T - 1);
+  const float* row = or_tile + threadIdx.x * Dp;
+  const float x = live ? row[0] : 0.0f, y = (live && D > 1) ? row[1] : 0.0f;
+  float lo0 = live ? x : INFINITY, hi0 = live ? x : -INFINITY;
+  float lo1 = live ? y : INFINITY, hi1 = live ? y : -INFINITY;
+  float flo = INFINITY, fhi = -INFINITY;
+  if (fe) {
+    const float f = live ? fe[frame] : INFINITY;
+    if (in_range) fe_s[pos] = f;
+    if (live) {
+      invpos[frame] = pos;
+      flo = f;
+      fhi = f;
+    }
+  }
+  float ext = 0.0f;
+  if (live) {
+    const float* a = origins + (size_t)tile_comp[t] * kMaxCols;
+    for (uint32_t k = 0; k < D; ++k) {
+      const float v = row[k] - a[k];
+      ext += v * v;
+    }
+    ext = ext * 1.0001f + FLT_MIN;
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    lo0 = fminf(lo0, __shfl_xor(lo0, off, 64));
+    hi0 = fmaxf(hi0, __shfl_xor(hi0, off, 64));
+    lo1 = fminf(lo1, __shfl_xor(lo1, off, 64));
+    hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
+    flo = fminf(flo, __shfl_xor(flo, off, 64));
+    fhi = fmaxf(fhi, __shfl_xor(fhi, off, 64));
+    ext = fmaxf(ext, __shfl_xor(ext, off, 64));
+  }
+  if ((pos & 31u) == 0 && in_range) {
+    boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
+    if (ferange) ferange[t] = make_float2(flo, fhi);
+  }
+  ext = fmaxf(ext, __shfl_xor(ext, 32, 64));
+  if ((threadIdx.x & 63u) == 0) blk_max[threadIdx.x >> 6] = ext;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(blk_max[0], blk_max[1]), fmaxf(blk_max[2], blk_max[3]));
+    if (m <= FLT_MAX) {
+      const uint32_t bits = __float_as_uint(m);
+      if (bits > __atomic_load_n(hdr + kHdrMloc, __ATOMIC_RELAXED)) atomicMax(hdr + kHdrMloc, bits);
+    }
+  }
+}
 __global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
                                    const uint32_t* __restrict__ perm, uint32_t n,
                                    float* __restrict__ out) {
@@ -1107,8 +1222,7 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
                      (double*)(p + kHdrSums));
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, stream, (const double*)(p + kHdrSums), n_rows,
                      n_cols, (float*)(p + kHdrMeans));
-  hipLaunchKernelGGL(rowstats_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 1024u)), dim3(256),
-                     sizeof(float) * 256 * (n_cols | 1u), stream, d_coords, n_rows, n_cols,
+  hipLaunchKernelGGL(rowstats_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048u)), dim3(256), 0, stream, d_coords, n_rows, n_cols,
                      (const float*)(p + kHdrMeans), (uint32_t*)p, cookie);
   (void)natural_image;   // (the full sweeps build their natural-order images themselves, at their own scale)
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1383,7 +1497,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn,
                        comp);
     hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
-    hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
+    hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), components_smem(), stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, r_max, data_cookie(d_coords, n_rows, n_cols));
     hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, cell_frames(false),
@@ -1397,12 +1511,10 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
               T_r, stream);
     // original rows in the reference order: the deferred exact path reads them without a
     // permutation look-up, and the operand images are built from them with coalesced reads
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)32 * T_r * n_cols + 255) / 256)), blk,
-                       0, stream, d_coords, n_cols, (const uint32_t*)perm_p, 32u * T_r,
-                       (float*)(p + L.off_coords_p));
-    hipLaunchKernelGGL(box_rows_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, coords_p, n_cols, 32u * T_r, T_r,
-                       (float4*)(p + L.off_box_p), (const float*)nullptr, (float2*)nullptr, (const uint32_t*)perm_p,
-                       (const uint32_t*)tile_comp, origins, hdr);
+    hipLaunchKernelGGL(order_rows_kernel, dim3((32 * T_r + 255) / 256), blk, row_tile_smem(order_rows_kernel, n_cols), stream,
+                       d_coords, n_cols, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p),
+                       (float4*)(p + L.off_box_p), (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr,
+                       (float2*)nullptr, (const uint32_t*)tile_comp, origins, hdr);
     // the scale follows the components' extents
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, fmaxf(r2_scale, 0.0f), n_cols,
                        (const uint32_t*)comp);
@@ -1502,62 +1614,98 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   }
   return v;
 }
+// Which queries can have a neighbour in ANOTHER component: their incumbent (or, where a lower-energy neighbour is possible
+// at all, their lower-energy incumbent) reaches another component's box.  By FRAME when the queries are the rows of the
+// reference order (every read coalesced: the by-position form spent 145 us on its six scattered reads per query), by
+// position of the query order otherwise.  The component of a frame is looked up as compkey_kernel assigned it.
+__global__ void nn_open_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D, const float* __restrict__ fe,
+                               const uint32_t* __restrict__ invpos_r, const uint32_t* __restrict__ perm_q, uint32_t n_items,
+                               const uint32_t* __restrict__ comp, uint32_t group_rows, QSeg q_seg,
+                               const uint32_t* __restrict__ hdr, const float* __restrict__ nn_d2,
+                               const float* __restrict__ hd_d2, const uint32_t* __restrict__ nn_idx,
+                               const uint32_t* __restrict__ hd_idx, unsigned long long* __restrict__ merge64,
+                               uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  // merge64 [2][n_rows] by frame: the packed (d2, frame) incumbents of the listed queries, which the search lowers
+  // with 64-bit atomic minima (several waves per query) and nn_cross_write_kernel hands back
+  if (hdr[1] != 0) return;
+  const uint32_t n_comp = comp[kCompGrid + 5];
+  if (n_comp <= 1u) return;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = j < n_items;
+  uint32_t i = j;
+  if (perm_q) {   // (a position of the query order)
+    i = live ? perm_q[j] : kInvalidFrame;
+    live = live && i != kInvalidFrame && (j / group_rows) % q_seg.stride == q_seg.offset;
+  } else if (live && q_seg.stride > 1) {
+    live = (invpos_r[i] / group_rows) % q_seg.stride == q_seg.offset;
+  }
+  bool open = false;
+  if (live) {
+    const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
+    const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_rows);
+    uint32_t c = 0;
+    if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
+    const float inc_nn = nn_d2[i], inc_hd = hd_d2[i];
+    const bool hd_possible = fkey_inv(~hdr[12]) < fe[i];
+    const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
+    for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
+      if (c2 == c) continue;
+      const float g2 = point_box_gap2(x, y, cbox[c2]);
+      open = open || (g2 <= inc_nn) || (hd_possible && g2 <= inc_hd);
+    }
+  }
+  const uint64_t m = __builtin_amdgcn_ballot_w64(open);
+  if (m == 0) return;
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+  uint32_t base = 0;
+  if (rank == 0 && open) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+  if (open) {
+    list[base + rank] = i;
+    merge64[i] = ((unsigned long long)__float_as_uint(nn_d2[i]) << 32) | nn_idx[i];
+    merge64[(size_t)n_rows + i] = ((unsigned long long)__float_as_uint(hd_d2[i]) << 32) | hd_idx[i];
+  }
+}
+
+// The open queries: exact search of the other components' tiles (boxes and free-energy ranges first, rows of the
+// surviving tiles in the canonical order).  A work item is (query, share of the order's tiles) and takes a wave: the few
+// queries of well-separated clusters (the free-energy minimum of each looks through ALL tiles of the others for its
+// lower-energy neighbour: 77 us for one wave at C3) are spread over kCrossShares waves each; with many open queries
+// (touching clusters) a query is one item.  Incumbents meet in merge64 (64-bit atomic minima).
+constexpr uint32_t kCrossShares = 32;
 __global__ __launch_bounds__(64) void nn_cross_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ fe,
     const float* __restrict__ coords_r, const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r,
-    const float2* __restrict__ ferange_r, const float* __restrict__ fe_c, const uint32_t* __restrict__ perm_q,
-    const uint32_t* __restrict__ tile_comp_q, const uint32_t* __restrict__ comp, uint32_t T_q, uint32_t group_tiles,
-    QSeg q_seg, int q_in_ref_order, const uint32_t* __restrict__ hdr, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+    const float2* __restrict__ ferange_r, const float* __restrict__ fe_c, const uint32_t* __restrict__ comp,
+    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ open_list, const uint32_t* __restrict__ open_count,
+    uint32_t T, unsigned long long* __restrict__ merge64) {
   __shared__ uint32_t list[256];
   __shared__ float list_gap[256];
   if (hdr[1] != 0) return;
   const uint32_t n_comp = comp[kCompGrid + 5];
   if (n_comp <= 1u) return;
   const int lane = threadIdx.x;
-  const uint32_t p = blockIdx.x * 64u + (uint32_t)lane;
-  if ((blockIdx.x * 2u) >= T_q) return;
-  if (((blockIdx.x * 2u) / group_tiles) % q_seg.stride != q_seg.offset) return;   // (another segment's group)
-  const uint32_t frame = (p < 32u * T_q) ? perm_q[p] : kInvalidFrame;
-  const bool live = frame != kInvalidFrame;
-  const uint32_t my_comp = live ? tile_comp_q[p >> 5] : 0u;
-  const float* qrow = q_in_ref_order ? coords_r + (size_t)p * n_cols : coords + (size_t)(live ? frame : 0u) * n_cols;
-  const float x0 = live ? qrow[0] : 0.0f, x1 = (live && n_cols > 1) ? qrow[1] : 0.0f;
-  const float feq = live ? fe[frame] : 0.0f;
-  const float fe_floor = fkey_inv(~hdr[12]);
-  const bool hd_possible = live && (fe_floor < feq);
-  unsigned long long key_nn = ~0ull, key_hd = ~0ull;
-  if (live) {
-    key_nn = ((unsigned long long)__float_as_uint(nn_d2[frame]) << 32) | nn_idx[frame];
-    key_hd = ((unsigned long long)__float_as_uint(hd_d2[frame]) << 32) | hd_idx[frame];
-  }
+  const uint32_t n_open = *open_count;
+  const uint32_t shares = (n_open >= 1024u) ? 1u : kCrossShares;
+  const uint32_t share_tiles = (T + shares - 1) / shares;
   const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
-  bool open = false;
-  if (live)
-    for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
-      if (c2 == my_comp) continue;
-      const float g2 = point_box_gap2(x0, x1, cbox[c2]);
-      open = open || (g2 <= __uint_as_float((uint32_t)(key_nn >> 32))) ||
-             (hd_possible && (g2 <= __uint_as_float((uint32_t)(key_hd >> 32))));
-    }
-  uint64_t todo = __builtin_amdgcn_ballot_w64(open);
   const uint32_t* range = comp + kCompRange;
-  while (todo != 0) {
-    const int l = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    // the open query of lane l, served by the whole wave
-    const uint32_t q_frame = (uint32_t)__builtin_amdgcn_readlane((int)frame, l);
-    const uint32_t q_comp = (uint32_t)__builtin_amdgcn_readlane((int)my_comp, l);
-    const uint32_t q_pos = blockIdx.x * 64u + (uint32_t)l;
-    const float qx0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x0), l));
-    const float qx1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x1), l));
-    const float q_fe = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(feq), l));
-    const bool q_hd = __builtin_amdgcn_readlane((int)hd_possible, l) != 0;
-    unsigned long long best_nn = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key_nn >> 32), l) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key_nn, l);
-    unsigned long long best_hd = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key_hd >> 32), l) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key_hd, l);
-    const float* q_row = q_in_ref_order ? coords_r + (size_t)q_pos * n_cols : coords + (size_t)q_frame * n_cols;
+  const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_rows);
+  const float fe_floor = fkey_inv(~hdr[12]);
+  for (uint32_t item = blockIdx.x; item < n_open * shares; item += gridDim.x) {
+    const uint32_t e = item / shares, share = item - e * shares;
+    const uint32_t s_lo = share * share_tiles, s_hi = min(s_lo + share_tiles, T);
+    const uint32_t q_frame = open_list[e];
+    const float* q_row = coords + (size_t)q_frame * n_cols;
+    const float qx0 = q_row[0], qx1 = (n_cols > 1) ? q_row[1] : 0.0f;
+    uint32_t q_comp = 0;
+    if (fabsf(qx0) <= FLT_MAX && fabsf(qx1) <= FLT_MAX) q_comp = comp[kCompCellComp + coarse_cell_of_point(g, qx0, qx1)];
+    const float q_fe = fe[q_frame];
+    const bool q_hd = fe_floor < q_fe;
+    // (what the other shares of this query have found by now is an upper bound like any other)
+    unsigned long long best_nn = __atomic_load_n(&merge64[q_frame], __ATOMIC_RELAXED);
+    unsigned long long best_hd = __atomic_load_n(&merge64[(size_t)n_rows + q_frame], __ATOMIC_RELAXED);
+    const unsigned long long start_nn = best_nn, start_hd = best_hd;
     for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
       if (c2 == q_comp) continue;
       {
@@ -1565,9 +1713,8 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
         const float inc_nn = __uint_as_float((uint32_t)(best_nn >> 32)), inc_hd = __uint_as_float((uint32_t)(best_hd >> 32));
         if (!(g2 <= inc_nn) && !(q_hd && g2 <= inc_hd)) continue;
       }
-      const uint32_t t_lo = range[2 * c2], t_hi = range[2 * c2 + 1];
-      // 256 tiles per step: a lane tests four boxes whose loads are independent (one box per lane and step was
-      // bound by the latency of its loads: 200 us for a query that has to look at all 20 000 tiles of C3)
+      const uint32_t t_lo = max(range[2 * c2], s_lo), t_hi = min(range[2 * c2 + 1], s_hi);
+      // 256 tiles per step: a lane tests four boxes whose loads are independent
       for (uint32_t base = t_lo; base < t_hi; base += 256) {
         const float inc_nn = __uint_as_float((uint32_t)(best_nn >> 32)), inc_hd = __uint_as_float((uint32_t)(best_hd >> 32));
         float4 bx[4];
@@ -1640,16 +1787,29 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
         }
       }
     }
-    if (lane == l) {
-      key_nn = best_nn;
-      key_hd = best_hd;
+    if (lane == 0) {
+      if (best_nn < start_nn) atomicMin(&merge64[q_frame], best_nn);
+      if (best_hd < start_hd) atomicMin(&merge64[(size_t)n_rows + q_frame], best_hd);
     }
+    __syncthreads();
   }
-  if (open) {   // (only the queries that searched can have changed)
-    nn_idx[frame] = (uint32_t)key_nn;
-    nn_d2[frame] = __uint_as_float((uint32_t)(key_nn >> 32));
-    hd_idx[frame] = (uint32_t)key_hd;
-    hd_d2[frame] = __uint_as_float((uint32_t)(key_hd >> 32));
+}
+
+// the answers of the listed queries back into the caller's arrays
+__global__ void nn_cross_write_kernel(const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ comp,
+                                      const uint32_t* __restrict__ open_list, const uint32_t* __restrict__ open_count,
+                                      const unsigned long long* __restrict__ merge64, uint32_t n_rows,
+                                      uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
+                                      uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+  if (hdr[1] != 0 || comp[kCompGrid + 5] <= 1u) return;
+  const uint32_t n_open = *open_count;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_open; e += gridDim.x * blockDim.x) {
+    const uint32_t i = open_list[e];
+    const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
+    nn_idx[i] = (uint32_t)a;
+    nn_d2[i] = __uint_as_float((uint32_t)(a >> 32));
+    hd_idx[i] = (uint32_t)b;
+    hd_d2[i] = __uint_as_float((uint32_t)(b >> 32));
   }
 }
 
@@ -1706,7 +1866,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
     hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn, comp);
     hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
-    hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr,
+    hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), components_smem(), stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, 0.0f, cookie);
   }
@@ -1719,15 +1879,11 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     return;
   pad_order(keys_out, vals_sorted, n_rows, fe_bits, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
             T_r, stream);
-  hipLaunchKernelGGL(fe_scatter_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, (const uint32_t*)perm_p, d_fe,
-                     32u * T_r, T_r, (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
   const float* coords_p = (const float*)(p + L.off_coords_p);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)(((size_t)32 * T_r * n_cols + 255) / 256)), blk,
-                     0, stream, d_coords, n_cols, (const uint32_t*)perm_p, 32u * T_r,
-                     (float*)(p + L.off_coords_p));
-  hipLaunchKernelGGL(box_rows_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, coords_p, n_cols, 32u * T_r, T_r,
-                     (float4*)(p + L.off_box_p), (const float*)(p + L.off_fe_s),
-                     (float2*)(p + L.off_ferange_p), (const uint32_t*)perm_p, (const uint32_t*)tile_comp, origins, hdr);
+  hipLaunchKernelGGL(order_rows_kernel, dim3((32 * T_r + 255) / 256), blk, row_tile_smem(order_rows_kernel, n_cols), stream,
+                     d_coords, n_cols, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p),
+                     (float4*)(p + L.off_box_p), d_fe, (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos),
+                     (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr);
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
   hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
                      L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
@@ -1772,13 +1928,25 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     default:
       break;
   }
-  // what lies in other components than the query: exact, for the few queries that can have a neighbour there
-  hipLaunchKernelGGL(nn_cross_kernel, dim3(((own ? T_q : T_r) + 1u) / 2u), dim3(64), 0, stream, d_coords, n_rows, n_cols, d_fe,
-                     coords_p, (const uint32_t*)perm_p, (const float4*)(p + L.off_box_p),
-                     (const float2*)(p + L.off_ferange_p), (const float*)(p + L.off_fe_s),
-                     (const uint32_t*)(own ? perm_q : perm_p), (const uint32_t*)(own ? tile_comp_q : tile_comp),
-                     (const uint32_t*)comp, own ? T_q : T_r, tq, q_seg, own ? 0 : 1, (const uint32_t*)hdr, d_nn_idx, d_nn_d2,
-                     d_hd_idx, d_hd_d2);
+  // what lies in other components than the query: exact, for the few queries that can have a neighbour there (listed
+  // in the sort's key buffer; their incumbents go through the merge buffer, both free again; the counter is header
+  // word kHdrOpen, zeroed by scale_kernel)
+  uint32_t* open_list = keys_in;
+  uint32_t* open_count = hdr + kHdrOpen;
+  unsigned long long* merge64 = (unsigned long long*)(p + L.off_merge64);
+  const uint32_t n_items = own ? 32u * T_q : n_rows;
+  hipLaunchKernelGGL(nn_open_kernel, dim3((n_items + 255) / 256), blk, 0, stream, d_coords, n_rows, n_cols, d_fe,
+                     (const uint32_t*)(p + L.off_invpos), own ? (const uint32_t*)perm_q : (const uint32_t*)nullptr, n_items,
+                     (const uint32_t*)comp, 32u * tq, q_seg, (const uint32_t*)hdr, (const float*)d_nn_d2,
+                     (const float*)d_hd_d2, (const uint32_t*)d_nn_idx, (const uint32_t*)d_hd_idx, merge64, open_list,
+                     open_count);
+  hipLaunchKernelGGL(nn_cross_kernel, dim3(2048), dim3(64), 0, stream, d_coords, n_rows, n_cols, d_fe, coords_p,
+                     (const uint32_t*)perm_p, (const float4*)(p + L.off_box_p), (const float2*)(p + L.off_ferange_p),
+                     (const float*)(p + L.off_fe_s), (const uint32_t*)comp, (const uint32_t*)hdr,
+                     (const uint32_t*)open_list, (const uint32_t*)open_count, T_r, merge64);
+  hipLaunchKernelGGL(nn_cross_write_kernel, dim3(64), blk, 0, stream, (const uint32_t*)hdr, (const uint32_t*)comp,
+                     (const uint32_t*)open_list, (const uint32_t*)open_count, (const unsigned long long*)merge64, n_rows,
+                     d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
 }
 
 // ---- blocks of a sharded neighbour sweep (all-gather merge) ---------------------------------------------------

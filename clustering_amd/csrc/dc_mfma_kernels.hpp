@@ -325,6 +325,7 @@ struct Scale {
 constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
 constexpr uint32_t kHdrCookie = 28;     // whose statistics the header holds (array, shape); 0 after a reset
 constexpr uint32_t kHdrMused = 31;      // the extent max |x - origin|^2 the current sweep's scale was chosen for (float bits)
+constexpr uint32_t kHdrOpen = 30;       // neighbour sweeps: queries listed for the search in other components (nn_open_kernel)
 constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: max |x - origin(component of x)|^2 (float bits, with a rounding margin)
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and

@@ -11,6 +11,8 @@ mem = json.loads(subprocess.check_output(['python3', 'scratch/pmc_summary.py'] +
 bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
 if 'roofline_pop' in bench:
     chains = {'pop': bench['roofline_pop']['tile_pairs'], 'nn': bench['roofline_nn']['tile_pairs']}
+elif 'pop_tiles' in bench:   # scratch/spread_bench.py
+    chains = {'pop': bench['pop_tiles'], 'nn': bench['nn_tiles']}
 else:
     fr = bench['roofline']['evaluated_fraction']
     t = (bench['config']['n_rows'] + 31) // 32
