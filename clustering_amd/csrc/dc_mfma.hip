@@ -1850,7 +1850,11 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   // ordering key: (cell number over all components, quantised free energy) in whole sort passes
   const unsigned fine_bits = cell_key_bits(n_rows, kNnCellFrames) + 1u;
   const unsigned key_bits = (fine_bits + 9u <= 24u) ? 24u : 32u;
-  const unsigned fe_bits = key_bits > fine_bits ? std::min(key_bits - fine_bits, 16u) : 0u;
+  unsigned fe_bits = key_bits > fine_bits ? std::min(key_bits - fine_bits, 16u) : 0u;
+  {  // DC_NN_FE_BITS: measurements (0 = the frames of a cell in any order)
+    static const int forced = [] { const char* e = getenv("DC_NN_FE_BITS"); return (e && e[0]) ? atoi(e) : -1; }();
+    if (forced >= 0) fe_bits = std::min((unsigned)forced, fe_bits);
+  }
   const float r_conn = -8.0f;   // components: connected over 8 cells of the ordering (no radius in this sweep)
   // the pass over the free energies finds their range (and raises the flag for NaNs)
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
