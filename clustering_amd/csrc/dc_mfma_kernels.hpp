@@ -2068,6 +2068,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   // ordering pass): a query at that level has no lower-FE neighbour
   const float fe_floor = fkey_inv(~hdr[12]);
 
+#ifdef DC_NN_PROFILE
+  uint32_t prof_rare = 0, prof_trig = 0, prof_cand = 0;
+#endif
   // evaluate and empty the candidate list (64 candidates at a time, one per lane)
   auto flush = [&]() {
     nn_wave_flush(cand, qn, qrows, best64, TQ * 32, coords_c, perm_r, n_cols, lane);
@@ -2142,6 +2145,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         const float thr = (fr.x < Q.feq) ? Q.bh : Q.bn;
         const bool rare = tmin < thr;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+#ifdef DC_NN_PROFILE
+          ++prof_rare;
+#endif
           const bool all_lower = fr.y < Q.feq;
           const bool mixed = (fr.x < Q.feq) & !all_lower;
           const bool special = mixed | (t == (Q.spos >> 5));
@@ -2171,6 +2177,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
           const bool trig = (tmin < bn) | (hmin < bh);
           if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+#ifdef DC_NN_PROFILE
+            ++prof_trig;
+#endif
             // park this tile's candidates (values within the band of the running minima); element r
             // of the accumulator is bit (15 - r) of the masks
             uint32_t mn = 0, mh = 0;
@@ -2212,6 +2221,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
                 m &= m - 1;
               }
               qn += n_new;
+#ifdef DC_NN_PROFILE
+              prof_cand += n_new;
+#endif
             }
             if (qn >= 64u) flush();
           }
@@ -2325,6 +2337,13 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
   }
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
+#ifdef DC_NN_PROFILE
+  if (lane == 0 && chain_counter) {   // header words 14..19 (scratch/nn_profile.sh)
+    atomicAdd(chain_counter + 5, (unsigned long long)prof_rare);
+    atomicAdd(chain_counter + 6, (unsigned long long)prof_trig);
+    atomicAdd(chain_counter + 7, (unsigned long long)prof_cand);
+  }
+#endif
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
@@ -2463,8 +2482,9 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // box scans must stay small next to the chains.  Measured on C3 (1M x 10): the full sweeps are
 // fastest at 12 chunks (pop 38.3 -> 35.6 ms, nn 50.2 -> 38.8 ms against one chunk), one eighth of the
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
-constexpr uint32_t kPopWaveTarget = 49152, kNnWaveTarget = 98304;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
-constexpr uint32_t kPopShareFloor = 1024, kNnShareFloor = 900;     //  49152 / 1024: C3 12.30 -> 12.12 ms, one eighth of it 1.82 -> 1.72 ms)
+constexpr uint32_t kPopWaveTarget = 49152, kNnWaveTarget = 98304, kNnWaveTargetPerWave = 57344;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
+constexpr uint32_t kPopShareFloor = 1024, kNnShareFloor = 900;     //  49152 / 1024: C3 12.30 -> 12.12 ms, one eighth of it 1.82 -> 1.72 ms;
+                                                                   //  per-wave neighbour sweep 98304 -> 57344: C3 14.26 -> 14.10 ms, two boxes)
 // waves per workgroup of the per-wave sweeps (pop_pruned_kernel, nn_pruned_kernel; see nn_pruned_kernel): ONE while a
 // chain has at most two MFMAs -- no slot waits for the slowest wave of a workgroup (1M x 10: neighbours 16.1 -> 15.0 ms,
 // 1M x 3: 5.7 -> 5.3 / populations 6.3 -> 6.05 ms) -- and four beyond that: the four waves of a workgroup sit on one CU
@@ -2528,7 +2548,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
   }
   const uint32_t waves = seg_groups(((A.n_q + 31) / 32 + TQV - 1) / TQV, A.q_seg), tiles = waves * TQV;
   if (waves == 0) return;
-  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTarget, T, kNnShareFloor, (size_t)S * 1024 + 128);
+  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTargetPerWave, T, kNnShareFloor, (size_t)S * 1024 + 128);
   // query rows (original coordinates) + candidate queues, per wave
   const uint32_t wpb = waves_per_group(S);
   const size_t smem = wpb * (sizeof(uint32_t) * kListCap + sizeof(float) * TQV * 32 * (size_t)n_cols +
