@@ -147,7 +147,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
                              uint32_t D, uint32_t NM, uint32_t T, const float* __restrict__ means,
                              const uint32_t* __restrict__ perm, int b_form, uint4* __restrict__ img,
                              float* __restrict__ norms, const uint32_t* __restrict__ hdr,
-                             uint32_t grp_tq = 1, QSeg grp = QSeg{1u, 0u},
+                             uint32_t grp_tq = 1, QSeg grp = QSeg{1u, 0u, 1u},
                              const uint32_t* __restrict__ tile_comp = nullptr,
                              const float* __restrict__ origins = nullptr,
                              const uint32_t* __restrict__ valid = nullptr) {
@@ -161,7 +161,7 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   const uint32_t lane = (uint32_t)(id & 63), m = (uint32_t)((id >> 6) % NM);
   // tile: the launch covers the tiles of every grp.stride-th group of grp_tq tiles (all tiles: {1, 0})
   const uint32_t tc = (uint32_t)((id >> 6) / NM);
-  const uint32_t t = ((tc / grp_tq) * grp.stride + grp.offset) * grp_tq + tc % grp_tq;
+  const uint32_t t = seg_group(tc / grp_tq, grp) * grp_tq + tc % grp_tq;
   if (t >= T) return;
   const uint32_t row = 32 * t + (lane & 31), h = lane >> 5;
   bool live = row < n_rows;
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(64) void pop_cross_kernel(
   __shared__ uint32_t list[64];
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x;
-  const uint32_t group = blockIdx.x * q_seg.stride + q_seg.offset;
+  const uint32_t group = seg_group(blockIdx.x, q_seg);
   const uint32_t qt0 = group * group_tiles;
   if (qt0 >= T_q) return;
   const uint32_t my_comp = tile_comp_q[qt0];
@@ -1428,6 +1428,12 @@ static float cell_frames(bool nn) {
   return v[nn ? 1 : 0];
 }
 
+uint32_t seg_block(uint32_t n_segments) {
+  static const uint32_t forced = [] { const char* e = getenv("DC_SEG_BLOCK"); return (e && e[0]) ? (uint32_t)std::max(1, atoi(e)) : 0u; }();
+  if (n_segments <= 1u) return 1u;
+  return forced ? forced : kSegBlockGroups;
+}
+
 // DC_POP_COMPONENTS=0: one component whatever the data looks like (measurements, tests)
 static bool components_off() {
   static const bool off = [] {
@@ -1463,11 +1469,11 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
-  QSeg q_seg{1u, 0u};
+  QSeg q_seg{1u, 0u, 1u};
   if (qs.n_segments > 0) {   // one segment of a sharded run: every n_segments-th query group of all rows
     q_mode = kQueryAll;
     n_q = n_rows;
-    q_seg = QSeg{qs.n_segments, qs.segment};
+    q_seg = QSeg{qs.n_segments, qs.segment, seg_block(qs.n_segments)};
   }
   // The orders are PADDED: every component of the frames (dc_mfma_kernels.hpp "components") starts at a whole query
   // group; the sort's input carries kMaxComp * (group_rows - 1) extra (key, kInvalidFrame) entries for that.
@@ -1520,7 +1526,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                        (const uint32_t*)comp);
     hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
                        L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                       (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                       (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                        (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
     // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
     // buffers are free again)
@@ -1549,7 +1555,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                 comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
       hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, 32u * T_q, n_cols,
                          L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                         (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                         (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                          (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
       hipLaunchKernelGGL(box_kernel, dim3((T_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
                          (const uint32_t*)perm_q, 32u * T_q, T_q, (float4*)(p + L.off_box_q),
@@ -1635,9 +1641,9 @@ __global__ void nn_open_kernel(const float* __restrict__ coords, uint32_t n_rows
   uint32_t i = j;
   if (perm_q) {   // (a position of the query order)
     i = live ? perm_q[j] : kInvalidFrame;
-    live = live && i != kInvalidFrame && (j / group_rows) % q_seg.stride == q_seg.offset;
+    live = live && i != kInvalidFrame && seg_owns(j / group_rows, q_seg);
   } else if (live && q_seg.stride > 1) {
-    live = (invpos_r[i] / group_rows) % q_seg.stride == q_seg.offset;
+    live = seg_owns(invpos_r[i] / group_rows, q_seg);
   }
   bool open = false;
   if (live) {
@@ -1836,11 +1842,11 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
-  QSeg q_seg{1u, 0u};
+  QSeg q_seg{1u, 0u, 1u};
   if (qs.n_segments > 0) {   // one segment of a sharded run: every n_segments-th query group of all rows
     q_mode = kQueryAll;
     n_q = n_rows;
-    q_seg = QSeg{qs.n_segments, qs.segment};
+    q_seg = QSeg{qs.n_segments, qs.segment, seg_block(qs.n_segments)};
   }
   // (query tiles per group: a wave's, or with the shared-operand sweep the workgroup's; the orders are padded so that
   //  every component starts at a whole group -- see pop_pruned_one)
@@ -1891,7 +1897,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
   hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
                      L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                      (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
   if (q_mode != kQueryOwnOrder) {
     // queries in the reference order: only their B form is missing (of the groups of this segment)
@@ -1912,7 +1918,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
               comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
     hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, 32u * T_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u},
+                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                        (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(box_kernel, dim3((T_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
                        (const uint32_t*)perm_q, 32u * T_q, T_q, (float4*)(p + L.off_box_q),
@@ -1966,14 +1972,14 @@ __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const 
                                      const uint32_t* __restrict__ hd_idx, const float* __restrict__ hd_d2,
                                      uint32_t n_rows, uint32_t n_pos /* positions of the padded order */,
                                      uint32_t gsize /* 32 tq, 0: row blocks only */, uint32_t seg,
-                                     uint32_t G, uint32_t block_rows, const uint32_t* __restrict__ perm,
+                                     uint32_t G, uint32_t seg_blk, uint32_t block_rows, const uint32_t* __restrict__ perm,
                                      const uint32_t* __restrict__ hdr, uint32_t* __restrict__ block) {
   const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= block_rows) return;
   const bool by_position = gsize != 0u && hdr[1] == 0u;
   uint32_t i = 0xFFFFFFFFu;
   if (by_position) {
-    const unsigned long long p = ((unsigned long long)(l / gsize) * G + seg) * gsize + l % gsize;
+    const unsigned long long p = (unsigned long long)seg_group(l / gsize, QSeg{G, seg, seg_blk}) * gsize + l % gsize;
     if (p < n_pos) i = perm[p];   // (kInvalidFrame for the pad positions of the order)
   } else {
     const uint32_t rng = n_rows / G, lo = seg * rng, hi = (seg == G - 1u) ? n_rows : lo + rng;
@@ -1986,7 +1992,7 @@ __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const 
   block[3 * (size_t)block_rows + l] = live ? __float_as_uint(hd_d2[i]) : block_none(3, n_rows);
 }
 __global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G][4][block_rows] */, uint32_t n_rows,
-                                       uint32_t n_pos, uint32_t gsize, uint32_t G, uint32_t block_rows,
+                                       uint32_t n_pos, uint32_t gsize, uint32_t G, uint32_t seg_blk, uint32_t block_rows,
                                        const uint32_t* __restrict__ perm, const uint32_t* __restrict__ hdr,
                                        uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                        uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
@@ -1996,8 +2002,8 @@ __global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G
   uint32_t i, r, l;
   if (by_position) {
     const uint32_t grp = p / gsize;
-    r = grp % G;
-    l = (grp / G) * gsize + p % gsize;
+    r = (grp / seg_blk) % G;
+    l = seg_unit(grp, QSeg{G, r, seg_blk}) * gsize + p % gsize;
     i = perm[p];
     if (i == kInvalidFrame) return;   // (a pad position of the order)
   } else {
@@ -2026,7 +2032,9 @@ size_t nn_block_rows(size_t n_rows, size_t n_cols, size_t n_segments) {
   if (!mfma_supports(n_cols)) return row_block;
   const size_t gs = nn_group_rows((uint32_t)n_rows, (uint32_t)n_cols);
   const size_t groups = ((size_t)32 * nn_order_tiles((uint32_t)n_rows, (uint32_t)n_cols) + gs - 1) / gs;
-  return std::max(row_block, ((groups + n_segments - 1) / n_segments) * gs);
+  // (segment 0 owns the most groups of a block-cyclic deal)
+  const size_t most = seg_groups((uint32_t)groups, QSeg{(uint32_t)n_segments, 0u, seg_block((uint32_t)n_segments)});
+  return std::max(row_block, most * gs);
 }
 void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
                           const float* d_hd_d2, uint32_t n_rows, uint32_t n_cols, uint32_t segment,
@@ -2035,7 +2043,7 @@ void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const 
   const Layout L = make_layout(n_rows, n_cols);
   const char* p = (const char*)d_ws;
   hipLaunchKernelGGL(nn_block_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2, d_hd_idx,
-                     d_hd_d2, n_rows, 32u * nn_order_tiles(n_rows, n_cols), pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, rows,
+                     d_hd_d2, n_rows, 32u * nn_order_tiles(n_rows, n_cols), pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, seg_block(n_segments), rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block);
 }
 void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t n_cols, uint32_t n_segments,
@@ -2046,7 +2054,7 @@ void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t 
   const char* p = (const char*)d_ws;
   const uint32_t n_pos = 32u * nn_order_tiles(n_rows, n_cols);
   hipLaunchKernelGGL(nn_block_unpack_kernel, dim3((n_pos + 255) / 256), dim3(256), 0, stream, d_blocks, n_rows, n_pos,
-                     pruned ? nn_group_rows(n_rows, n_cols) : 0u, n_segments, rows,
+                     pruned ? nn_group_rows(n_rows, n_cols) : 0u, n_segments, seg_block(n_segments), rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr,
                      d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
 }

@@ -43,16 +43,32 @@ void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
 void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols, float r2,
                          uint32_t* d_pops, uint2* d_pairs, unsigned long long capacity,
                          unsigned long long* d_count, void* d_ws, hipStream_t stream);
-// one segment of a sharded sweep: the query groups (TQ consecutive tiles of the sweep's order) number
-// offset, offset + stride, offset + 2 stride, ...  ({1, 0}: all of them).  Dealing the groups out cyclically
-// gives every segment the same mix of dense and sparse regions (contiguous runs of groups differed by up
-// to 16 % in work at 1/8 of C3), and each group stays as compact as in the full sweep.
+// one segment of a sharded sweep: the query groups (TQ consecutive tiles of the sweep's order) are dealt out to the
+// segments in BLOCKS of `block` consecutive groups, block-cyclically: segment `offset` of `stride` owns the groups g
+// with (g / block) % stride == offset ({1, 0, 1}: all of them).  Dealing cyclically gives every segment the same mix of
+// dense and sparse regions (contiguous eighths of C3 differed by up to 16 % in work); dealing whole blocks keeps the
+// groups that run side by side on an XCD next to each other in the order, so that they stream the same reference tiles
+// through its L2 (group by group -- block 1 -- an eighth of C3 read 3 x the bytes of the unsharded sweep per tile pair
+// at the L2's memory side, L2 hit rate 0.76 against 0.91, and its kernels took 12 - 17 % more than an eighth).
 struct QSeg {
-  uint32_t stride, offset;
+  uint32_t stride, offset, block;
 };
-__host__ __device__ inline uint32_t seg_groups(uint32_t n_groups, QSeg q) {
-  return n_groups > q.offset ? (n_groups - q.offset + q.stride - 1) / q.stride : 0u;
+__host__ __device__ inline uint32_t seg_groups(uint32_t n_groups, QSeg q) {   // groups the segment owns
+  const uint32_t cyc = q.block * q.stride, full = n_groups / cyc, rem = n_groups - full * cyc;
+  const uint32_t lo = q.offset * q.block;
+  return full * q.block + (rem > lo ? (rem - lo < q.block ? rem - lo : q.block) : 0u);
 }
+__host__ __device__ inline uint32_t seg_group(uint32_t unit, QSeg q) {        // the unit-th group of the segment
+  return (unit / q.block) * (q.block * q.stride) + q.offset * q.block + unit % q.block;
+}
+__host__ __device__ inline bool seg_owns(uint32_t group, QSeg q) { return (group / q.block) % q.stride == q.offset; }
+__host__ __device__ inline uint32_t seg_unit(uint32_t group, QSeg q) {        // (inverse of seg_group for an owned group)
+  return (group / (q.block * q.stride)) * q.block + group % q.block;
+}
+// groups per block for n_segments segments (every rank derives the same number: DC_SEG_BLOCK overrides it for
+// measurements, in every process alike)
+constexpr uint32_t kSegBlockGroups = 1;
+uint32_t seg_block(uint32_t n_segments);
 // positions the padded orders of the pruned population sweeps add (dc_mfma_kernels.hpp: components padded to whole
 // query groups: kMaxComp x kMaxGroupRows)
 constexpr size_t kOrderPadRows = 64 * 512;

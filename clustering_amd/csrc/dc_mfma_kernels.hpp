@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t blk_unit = xcd_block((seg_groups((TQT + TQ - 1) / TQ, q_seg) + wpb - 1) / wpb);
   if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid)
-  const uint32_t wave = (blk_unit * wpb + wib) * q_seg.stride + q_seg.offset;
+  const uint32_t wave = seg_group(blk_unit * wpb + wib, q_seg);
   // gridDim.y > 1: the reference tiles are dealt round-robin to gridDim.y waves per query group and
   // the partial counts are merged with atomics (keeps small launches, e.g. one rank of an 8-GPU
   // run, at >= 2 waves per SIMD without giving up the operand reuse of TQ query tiles per wave)
@@ -1940,7 +1940,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t blk_unit = xcd_block((seg_groups((TQT + TQ - 1) / TQ, q_seg) + wpb - 1) / wpb);
   if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid)
-  const uint32_t wave = (blk_unit * wpb + wib) * q_seg.stride + q_seg.offset;
+  const uint32_t wave = seg_group(blk_unit * wpb + wib, q_seg);
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;
@@ -2379,7 +2379,7 @@ __global__ void nn_merge_unpack_kernel(const unsigned long long* __restrict__ me
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_q) return;
   // (rows of other segments keep what the caller initialised them with)
-  if ((p / (32u * tq)) % q_seg.stride != q_seg.offset) return;
+  if (!seg_owns(p / (32u * tq), q_seg)) return;
   const uint32_t i = perm_q[p];   // the query rows of this call
   if (i == kInvalidFrame) return; // (a pad position of the order)
   const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
@@ -2398,7 +2398,7 @@ __global__ void nn_merge_unpack_rows_kernel(const unsigned long long* __restrict
                                             float* __restrict__ hd_d2) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
-  if (q_seg.stride > 1 && (invpos[i] / (32u * tq)) % q_seg.stride != q_seg.offset) return;
+  if (q_seg.stride > 1 && !seg_owns(invpos[i] / (32u * tq), q_seg)) return;
   const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
   nn_idx[i] = (uint32_t)a;
   nn_d2[i] = __uint_as_float((uint32_t)(a >> 32));

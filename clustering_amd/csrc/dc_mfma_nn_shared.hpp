@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   const uint32_t TQT = (n_q + 31) / 32;
   const uint32_t blk_unit = xcd_block(seg_groups((TQT + 4u * TQ - 1u) / (4u * TQ), q_seg));
   if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid: the whole workgroup leaves)
-  const uint32_t group = blk_unit * q_seg.stride + q_seg.offset;
+  const uint32_t group = seg_group(blk_unit, q_seg);
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   if (group * (4u * TQ) >= TQT) return;   // whole workgroup leaves
   const uint32_t qt0 = (group * 4u + (uint32_t)wib) * TQ;   // (a wave without tiles keeps meeting the barriers)
