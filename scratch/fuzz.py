@@ -6,12 +6,16 @@ from clustering_amd import density as dens
 from clustering_amd.synth import gaussian_blobs
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+big = len(sys.argv) > 3 and sys.argv[3] == 'big'   # large shapes, clustered data only
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
     n = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 257, 1000, 3000, 9000, 40000, 150000], p=[.03,.03,.05,.05,.05,.05,.1,.14,.2,.12,.08,.07,.03]))
     d = int(rng.integers(1, 65)) if rng.random() < 0.3 else int(rng.integers(1, 33))
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 8)
+    if big:
+        n = int(rng.choice([9000, 40000, 150000, 400000]))
+        kind = int(rng.integers(5, 8))
     c = gaussian_blobs(n, d, seed=int(rng.integers(1, 1 << 30)), sigma=float(rng.choice([0.02, 0.08, 0.3])))
     if kind == 1:   # duplicates
         c[rng.integers(0, n, n // 3)] = c[rng.integers(0, n, n // 3)]
@@ -21,8 +25,21 @@ for case in range(n_cases):
         c *= np.float32(1e-3)
     if kind == 4:   # far from 1: the power-of-two scale of the fp16 operand images
         c *= np.float32(rng.choice([1e-12, 1e-6, 1e4, 1e8]))
+    sig_loc = None
+    if kind >= 5 and n > 1:   # clusters spread over the (col 0, col 1) plane: the components of the pruned sweeps (round 3)
+        k = int(rng.choice([2, 3, 5, 12, 40, 90]))
+        sig_loc = float(rng.choice([0.02, 0.08, 0.3]))
+        spread = float(rng.choice([1.0, 4.0, 30.0, 300.0, 3000.0])) * sig_loc * np.sqrt(d)
+        cen = np.zeros((k, d), dtype=np.float32)
+        cen[:, :min(d, 2)] = rng.uniform(-spread, spread, size=(k, min(d, 2)))
+        if kind == 7 and d > 2:   # the clusters differ in the other columns too
+            cen[:, 2:] = rng.uniform(-spread, spread, size=(k, d - 2)) * 0.1
+        lab = rng.integers(0, k, n)
+        c = (cen[lab] + rng.normal(0.0, sig_loc, size=(n, d))).astype(np.float32)
+        if kind == 6:           # a few far outliers
+            c[rng.integers(0, n, max(1, n // 500))] += np.float32(50.0 * spread)
     ct = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).cuda()
-    scale = float(np.sqrt(d)) * float(c.std(axis=0).mean() if n > 1 else 1.0)
+    scale = float(np.sqrt(d)) * (sig_loc if sig_loc is not None else float(c.std(axis=0).mean() if n > 1 else 1.0))
     radii = [float(x) for x in (scale * rng.uniform(0.05, 1.5, size=int(rng.integers(1, 4))))]
     lo = int(rng.integers(0, n)); hi = int(rng.integers(lo, n + 1))
     if rng.random() < 0.5: lo, hi = 0, n

@@ -12,12 +12,12 @@ from clustering_amd.synth import gaussian_blobs
 pytestmark = pytest.mark.gpu
 
 
-def one_case(dens, rng, case):
+def one_case(dens, rng, case, clustered=False):
     import torch
     n = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 257, 1000, 3000, 9000, 40000],
                        p=[.03, .03, .05, .05, .05, .05, .1, .17, .2, .12, .08, .07]))
     d = int(rng.integers(1, 65)) if rng.random() < 0.3 else int(rng.integers(1, 33))
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(5, 8)) if clustered else int(rng.integers(0, 5))
     c = gaussian_blobs(n, d, seed=int(rng.integers(1, 1 << 30)), sigma=float(rng.choice([0.02, 0.08, 0.3])))
     if kind == 1:   # duplicates
         c[rng.integers(0, n, n // 3)] = c[rng.integers(0, n, n // 3)]
@@ -27,8 +27,23 @@ def one_case(dens, rng, case):
         c *= np.float32(1e-3)
     if kind == 4:   # far from 1
         c *= np.float32(rng.choice([1e-12, 1e-6, 1e4, 1e8]))
+    sig_loc = None
+    if kind >= 5 and n > 1:
+        # clusters spread over the (col 0, col 1) plane, 1 ... 3000 cluster widths apart: the components of the pruned
+        # sweeps -- one origin per cluster, cross-component pairs and neighbours, the one-component
+        # fallbacks (90 clusters; clusters that touch)
+        k = int(rng.choice([2, 3, 5, 12, 40, 90]))
+        sig_loc = float(rng.choice([0.02, 0.08, 0.3]))
+        spread = float(rng.choice([1.0, 4.0, 30.0, 300.0, 3000.0])) * sig_loc * np.sqrt(d)
+        cen = np.zeros((k, d), dtype=np.float32)
+        cen[:, :min(d, 2)] = rng.uniform(-spread, spread, size=(k, min(d, 2)))
+        if kind == 7 and d > 2:   # the clusters differ in the other columns too
+            cen[:, 2:] = rng.uniform(-spread, spread, size=(k, d - 2)) * 0.1
+        c = (cen[rng.integers(0, k, n)] + rng.normal(0.0, sig_loc, size=(n, d))).astype(np.float32)
+        if kind == 6:             # a few far outliers
+            c[rng.integers(0, n, max(1, n // 500))] += np.float32(50.0 * spread)
     ct = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).cuda()
-    scale = float(np.sqrt(d)) * float(c.std(axis=0).mean() if n > 1 else 1.0)
+    scale = float(np.sqrt(d)) * (sig_loc if sig_loc is not None else float(c.std(axis=0).mean() if n > 1 else 1.0))
     radii = [float(x) for x in (scale * rng.uniform(0.05, 1.5, size=int(rng.integers(1, 4))))]
     lo = int(rng.integers(0, n))
     hi = int(rng.integers(lo, n + 1))
@@ -74,3 +89,14 @@ def test_fuzz_matrix_core_variants_against_direct(seed):
     rng = np.random.default_rng(seed)
     for case in range(40):
         one_case(dens, rng, case)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_clustered_data_against_direct(seed):
+    """the same loop on data made of 2 ... 90 clusters spread over the plane of the first two columns"""
+    import torch
+    assert torch.cuda.is_available()
+    from clustering_amd import density as dens
+    rng = np.random.default_rng(seed)
+    for case in range(40):
+        one_case(dens, rng, case, clustered=True)
