@@ -1289,7 +1289,11 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 struct QuerySel {
   uint32_t i_from, i_to, segment, n_segments;
 };
+#ifdef DC_EXP_NN_TQ2
+static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 2 : (nm_for((int)n_cols) <= 5 ? 4 : 2); }   // = tq_for<NM>
+#else
 static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 5 ? 4 : 2; }   // = tq_for<NM>
+#endif
 static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
 // query tiles per group of the population sweep that will run: the unit segments are dealt out in and the
 // query image is built for (pop_shared_kernel: the four waves of a workgroup form one group)

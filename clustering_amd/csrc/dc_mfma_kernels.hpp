@@ -1910,8 +1910,11 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+#ifndef DC_NN_MIN_WG   // (experiment builds: workgroups of 256 threads per CU the compiler must leave room for)
+#define DC_NN_MIN_WG 2
+#endif
 template <int NM, int TQ>
-__global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
+__global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ fe, const uint4* __restrict__ img_r,
     const float* __restrict__ norms_r, const uint32_t* __restrict__ perm_r,
@@ -2413,8 +2416,14 @@ __global__ void nn_merge_unpack_rows_kernel(const unsigned long long* __restrict
 // leave room for at two waves per SIMD; each reference fragment is fetched once per TQ chains.  Measured at
 // 300k rows: NM = 5 (D = 24) 5.6 / 6.2 ms with four tiles against 6.4 / 6.5 with two; NM = 6 (D = 30) 7.8 / 9.3 against
 // 7.1 / 7.4; NM = 7 (D = 32) 8.2 / 10.0 against 7.7 / 8.3; NM = 8 (D = 40) 11.0 / 11.4 against 8.8 / 10.0.
+#ifdef DC_EXP_NN_TQ2   // (experiment builds, scratch/nn_tq_exp.sh: two query tiles per wave at NM <= 2 as well)
+template <int NM>
+constexpr int tq_for = (NM <= 2) ? 2 : ((NM <= 5) ? 4 : 2);
+#else
 template <int NM>
 constexpr int tq_for = (NM <= 5) ? 4 : 2;
+#endif
+
 // the population sweep keeps less state per query tile: with two MFMAs per chain six tiles fit
 // (measured at C3: 23.6 ms against 25.1 ms with four; eight spill; the neighbour sweep loses at six)
 template <int NM>
