@@ -1035,8 +1035,12 @@ __global__ __launch_bounds__(256) void order_rows_kernel(
     const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ perm, uint32_t T,
     float* __restrict__ coords_o, float4* __restrict__ boxes, const float* __restrict__ fe, float* __restrict__ fe_s,
     uint32_t* __restrict__ invpos, float2* __restrict__ ferange, const uint32_t* __restrict__ tile_comp,
-    const float* __restrict__ origins, uint32_t* __restrict__ hdr) {
+    const float* __restrict__ origins, uint32_t* __restrict__ hdr, uint32_t* __restrict__ group_conf = nullptr,
+    uint32_t n_conf = 0) {
   extern __shared__ float or_tile[];            // [256][D | 1]
+  // (group_conf: visited radius^2 of the query groups of the neighbour sweep that follows, preset to +inf = "all the group
+  //  needed", nn_pruned_kernel)
+  if (group_conf && blockIdx.x * 256u + threadIdx.x < n_conf) group_conf[blockIdx.x * 256u + threadIdx.x] = 0x7F800000u;
   __shared__ uint32_t s_frame[256];
   __shared__ float blk_max[4];
   const uint32_t Dp = D | 1u;
@@ -1432,6 +1436,13 @@ static float cell_frames(bool nn) {
   return v[nn ? 1 : 0];
 }
 
+// queries a group of the per-wave neighbour sweep may leave to the exact follow-up (nn_pruned_kernel "left-over queries");
+// DC_NN_LEAVE overrides (0: none)
+static uint32_t nn_leave() {
+  static const uint32_t v = [] { const char* e = getenv("DC_NN_LEAVE"); return (e && e[0]) ? (uint32_t)std::min(32, std::max(0, atoi(e))) : kNnLeave; }();
+  return v;
+}
+
 uint32_t seg_block(uint32_t n_segments) {
   static const uint32_t forced = [] { const char* e = getenv("DC_SEG_BLOCK"); return (e && e[0]) ? (uint32_t)std::max(1, atoi(e)) : 0u; }();
   if (n_segments <= 1u) return 1u;
@@ -1633,45 +1644,63 @@ __global__ void nn_open_kernel(const float* __restrict__ coords, uint32_t n_rows
                                const uint32_t* __restrict__ comp, uint32_t group_rows, QSeg q_seg,
                                const uint32_t* __restrict__ hdr, const float* __restrict__ nn_d2,
                                const float* __restrict__ hd_d2, const uint32_t* __restrict__ nn_idx,
-                               const uint32_t* __restrict__ hd_idx, unsigned long long* __restrict__ merge64,
-                               uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+                               const uint32_t* __restrict__ hd_idx, const uint32_t* __restrict__ group_conf,
+                               unsigned long long* __restrict__ merge64, uint32_t* __restrict__ list,
+                               uint32_t* __restrict__ list_pos, uint32_t* __restrict__ count) {
   // merge64 [2][n_rows] by frame: the packed (d2, frame) incumbents of the listed queries, which the search lowers
-  // with 64-bit atomic minima (several waves per query) and nn_cross_write_kernel hands back
+  // with 64-bit atomic minima (several waves per query) and nn_cross_write_kernel hands back.
+  // group_conf: the radius^2 up to which the query's group has visited its OWN component (nn_pruned_kernel, "left-over
+  // queries"; +inf: everything the group needed) -- a query whose incumbent lies beyond it is listed as well.
   if (hdr[1] != 0) return;
   const uint32_t n_comp = comp[kCompGrid + 5];
-  if (n_comp <= 1u) return;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = j < n_items;
-  uint32_t i = j;
+  uint32_t i = j, pos = j;
   if (perm_q) {   // (a position of the query order)
     i = live ? perm_q[j] : kInvalidFrame;
     live = live && i != kInvalidFrame && seg_owns(j / group_rows, q_seg);
-  } else if (live && q_seg.stride > 1) {
-    live = seg_owns(invpos_r[i] / group_rows, q_seg);
+  } else if (live) {
+    pos = invpos_r[i];
+    live = q_seg.stride <= 1 || seg_owns(pos / group_rows, q_seg);
   }
   bool open = false;
   if (live) {
     const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-    const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_rows);
-    uint32_t c = 0;
-    if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
     const float inc_nn = nn_d2[i], inc_hd = hd_d2[i];
     const bool hd_possible = fkey_inv(~hdr[12]) < fe[i];
-    const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
-    for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
-      if (c2 == c) continue;
-      const float g2 = point_box_gap2(x, y, cbox[c2]);
-      open = open || (g2 <= inc_nn) || (hd_possible && g2 <= inc_hd);
+    const float conf = __uint_as_float(group_conf[pos / group_rows]);
+    open = !(fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f) < conf);   // (left over by its group)
+    if (n_comp > 1u) {
+      const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_rows);
+      uint32_t c = 0;
+      if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
+      const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
+      for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
+        if (c2 == c) continue;
+        const float g2 = point_box_gap2(x, y, cbox[c2]);
+        open = open || (g2 <= inc_nn) || (hd_possible && g2 <= inc_hd);
+      }
     }
   }
+  // one atomic per block (a wave each was 15 000 atomics on one word with four left-over queries per group: 150 us)
+  __shared__ uint32_t wave_n[4], wave_base[4];
   const uint64_t m = __builtin_amdgcn_ballot_w64(open);
-  if (m == 0) return;
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-  uint32_t base = 0;
-  if (rank == 0 && open) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
-  base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+  if ((threadIdx.x & 63u) == 0) wave_n[threadIdx.x >> 6] = (uint32_t)__builtin_popcountll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    uint32_t b = total ? atomicAdd(count, total) : 0u;
+    for (int w = 0; w < 4; ++w) {
+      wave_base[w] = b;
+      b += wave_n[w];
+    }
+  }
+  __syncthreads();
+  const uint32_t base = wave_base[threadIdx.x >> 6];
   if (open) {
     list[base + rank] = i;
+    list_pos[base + rank] = pos;
     merge64[i] = ((unsigned long long)__float_as_uint(nn_d2[i]) << 32) | nn_idx[i];
     merge64[(size_t)n_rows + i] = ((unsigned long long)__float_as_uint(hd_d2[i]) << 32) | hd_idx[i];
   }
@@ -1687,16 +1716,19 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ fe,
     const float* __restrict__ coords_r, const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r,
     const float2* __restrict__ ferange_r, const float* __restrict__ fe_c, const uint32_t* __restrict__ comp,
-    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ open_list, const uint32_t* __restrict__ open_count,
-    uint32_t T, unsigned long long* __restrict__ merge64) {
+    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ open_list, const uint32_t* __restrict__ open_pos,
+    const uint32_t* __restrict__ open_count, uint32_t T, unsigned long long* __restrict__ merge64,
+    const uint32_t* __restrict__ group_conf, const float4* __restrict__ box_q, uint32_t group_tiles, uint32_t T_q) {
+  // group_conf / box_q / group_tiles / T_q: the query's group of the sweep (tiles [g group_tiles, (g + 1) group_tiles) of
+  // the query order, T_q tiles) has visited every tile of its own component whose box is closer to the GROUP's box than
+  // sqrt(group_conf[g]); a query left over by its group searches the rest of the component here
   __shared__ uint32_t list[256];
   __shared__ float list_gap[256];
   if (hdr[1] != 0) return;
   const uint32_t n_comp = comp[kCompGrid + 5];
-  if (n_comp <= 1u) return;
   const int lane = threadIdx.x;
   const uint32_t n_open = *open_count;
-  const uint32_t shares = (n_open >= 1024u) ? 1u : kCrossShares;
+  const uint32_t shares = (n_open >= (1u << 17)) ? 1u : kCrossShares;
   const uint32_t share_tiles = (T + shares - 1) / shares;
   const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
   const uint32_t* range = comp + kCompRange;
@@ -1716,12 +1748,31 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
     unsigned long long best_nn = __atomic_load_n(&merge64[q_frame], __ATOMIC_RELAXED);
     unsigned long long best_hd = __atomic_load_n(&merge64[(size_t)n_rows + q_frame], __ATOMIC_RELAXED);
     const unsigned long long start_nn = best_nn, start_hd = best_hd;
+    // the group's box and what the group has visited of its own component
+    const uint32_t q_group = open_pos[e] / (32u * group_tiles);
+    float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    for (uint32_t k = 0; k < group_tiles; ++k) {
+      const uint32_t t = q_group * group_tiles + k;
+      if (t < T_q) {
+        const float4 b = box_q[t];
+        gbox.x = fminf(gbox.x, b.x);
+        gbox.y = fmaxf(gbox.y, b.y);
+        gbox.z = fminf(gbox.z, b.z);
+        gbox.w = fmaxf(gbox.w, b.w);
+      }
+    }
+    const float conf = __uint_as_float(group_conf[q_group]);
+    const float conf_lo = conf * 0.999f;   // (tiles whose gap to the group's box is below this were visited by the sweep)
     for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
-      if (c2 == q_comp) continue;
+      const bool own_comp = c2 == q_comp;
       {
-        const float g2 = point_box_gap2(qx0, qx1, cbox[c2]);
         const float inc_nn = __uint_as_float((uint32_t)(best_nn >> 32)), inc_hd = __uint_as_float((uint32_t)(best_hd >> 32));
-        if (!(g2 <= inc_nn) && !(q_hd && g2 <= inc_hd)) continue;
+        if (own_comp) {
+          if (fmaxf(inc_nn, q_hd ? inc_hd : 0.0f) < conf) continue;   // (settled inside what the group visited)
+        } else {
+          const float g2 = point_box_gap2(qx0, qx1, cbox[c2]);
+          if (!(g2 <= inc_nn) && !(q_hd && g2 <= inc_hd)) continue;
+        }
       }
       const uint32_t t_lo = max(range[2 * c2], s_lo), t_hi = min(range[2 * c2 + 1], s_hi);
       // 256 tiles per step: a lane tests four boxes whose loads are independent
@@ -1741,7 +1792,8 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
         for (int k = 0; k < 4; ++k) {
           const uint32_t t = base + 64u * (uint32_t)k + (uint32_t)lane;
           const float g2 = point_box_gap2(qx0, qx1, bx[k]);
-          const bool ok = (t < t_hi) && ((g2 <= inc_nn) | (q_hd & (g2 <= inc_hd) & (flo[k] < q_fe)));
+          bool ok = (t < t_hi) && ((g2 <= inc_nn) | (q_hd & (g2 <= inc_hd) & (flo[k] < q_fe)));
+          if (own_comp) ok = ok && !(box_gap2(gbox, bx[k]) < conf_lo);   // (not visited by the group's sweep)
           const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
           if (ok) {
             const uint32_t slot = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -1811,7 +1863,8 @@ __global__ void nn_cross_write_kernel(const uint32_t* __restrict__ hdr, const ui
                                       const unsigned long long* __restrict__ merge64, uint32_t n_rows,
                                       uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                       uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
-  if (hdr[1] != 0 || comp[kCompGrid + 5] <= 1u) return;
+  (void)comp;
+  if (hdr[1] != 0) return;
   const uint32_t n_open = *open_count;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_open; e += gridDim.x * blockDim.x) {
     const uint32_t i = open_list[e];
@@ -1832,6 +1885,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   uint32_t* hdr = (uint32_t*)p;
   uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
   uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
+  uint32_t* group_conf = (uint32_t*)(p + L.off_perm);   // (a region of the full neighbour sweep, free here: the visited radii of the query groups, nn_pruned_kernel)
   uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
   uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
   uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
@@ -1897,7 +1951,8 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   hipLaunchKernelGGL(order_rows_kernel, dim3((32 * T_r + 255) / 256), blk, row_tile_smem(order_rows_kernel, n_cols), stream,
                      d_coords, n_cols, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p),
                      (float4*)(p + L.off_box_p), d_fe, (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos),
-                     (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr);
+                     (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr, group_conf,
+                     std::min(std::max(T_r, T_q), 32u * T_r));
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
   hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
                      L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
@@ -1934,7 +1989,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
-      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, T_r, n_pos_q, q_mode, q_seg, -1.0f, \
+      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, T_r, n_pos_q, q_mode, q_seg, -1.0f, nn_leave(), \
                           d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, stream);                        \
     break;
     DC_FOR_EACH_S(X)
@@ -1949,15 +2004,18 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   uint32_t* open_count = hdr + kHdrOpen;
   unsigned long long* merge64 = (unsigned long long*)(p + L.off_merge64);
   const uint32_t n_items = own ? 32u * T_q : n_rows;
+  uint32_t* open_pos = (uint32_t*)(p + L.off_norm_s);   // (a region of the full neighbour sweep: free here)
   hipLaunchKernelGGL(nn_open_kernel, dim3((n_items + 255) / 256), blk, 0, stream, d_coords, n_rows, n_cols, d_fe,
                      (const uint32_t*)(p + L.off_invpos), own ? (const uint32_t*)perm_q : (const uint32_t*)nullptr, n_items,
                      (const uint32_t*)comp, 32u * tq, q_seg, (const uint32_t*)hdr, (const float*)d_nn_d2,
-                     (const float*)d_hd_d2, (const uint32_t*)d_nn_idx, (const uint32_t*)d_hd_idx, merge64, open_list,
-                     open_count);
-  hipLaunchKernelGGL(nn_cross_kernel, dim3(2048), dim3(64), 0, stream, d_coords, n_rows, n_cols, d_fe, coords_p,
+                     (const float*)d_hd_d2, (const uint32_t*)d_nn_idx, (const uint32_t*)d_hd_idx,
+                     (const uint32_t*)group_conf, merge64, open_list, open_pos, open_count);
+  hipLaunchKernelGGL(nn_cross_kernel, dim3(8192), dim3(64), 0, stream, d_coords, n_rows, n_cols, d_fe, coords_p,
                      (const uint32_t*)perm_p, (const float4*)(p + L.off_box_p), (const float2*)(p + L.off_ferange_p),
                      (const float*)(p + L.off_fe_s), (const uint32_t*)comp, (const uint32_t*)hdr,
-                     (const uint32_t*)open_list, (const uint32_t*)open_count, T_r, merge64);
+                     (const uint32_t*)open_list, (const uint32_t*)open_pos, (const uint32_t*)open_count, T_r, merge64,
+                     (const uint32_t*)group_conf, (const float4*)(p + (own ? L.off_box_q : L.off_box_p)), tq,
+                     own ? T_q : T_r);
   hipLaunchKernelGGL(nn_cross_write_kernel, dim3(64), blk, 0, stream, (const uint32_t*)hdr, (const uint32_t*)comp,
                      (const uint32_t*)open_list, (const uint32_t*)open_count, (const unsigned long long*)merge64, n_rows,
                      d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);

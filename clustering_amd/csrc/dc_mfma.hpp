@@ -68,6 +68,7 @@ __host__ __device__ inline uint32_t seg_unit(uint32_t group, QSeg q) {        //
 // groups per block for n_segments segments (every rank derives the same number: DC_SEG_BLOCK overrides it for
 // measurements, in every process alike)
 constexpr uint32_t kSegBlockGroups = 1;
+constexpr uint32_t kNnLeave = 0;   // (queries a group may leave to the exact follow-up: measured, no net gain -- DESIGN.md 4.8)
 uint32_t seg_block(uint32_t n_segments);
 // positions the padded orders of the pruned population sweeps add (dc_mfma_kernels.hpp: components padded to whole
 // query groups: kMaxComp x kMaxGroupRows)

@@ -1927,7 +1927,9 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
     unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, CompView CV) {
+    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, CompView CV,
+    uint32_t* __restrict__ group_conf, uint32_t leave) {
+  // group_conf / leave: see "left-over queries" at the settle test below
   // dynamic LDS, per wave of the workgroup: the survivor list of a scan round [kListCap], then [TQ*32][n_cols] query
   // rows (original coordinates), then the candidate queues [TQ][kQueueCap][64]
   extern __shared__ __attribute__((aligned(16))) float nn_dyn_lds[];
@@ -2094,6 +2096,7 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
   }
   const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
+  float conf_r2 = INFINITY;                                // radius^2 below which this share has been visited completely when the sweep stops early
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
   if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
@@ -2312,8 +2315,15 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
     const float sure = r2_hi * 0.9999f;
-    float need = 0.0f;      // largest incumbent that still has to be confirmed
-    bool blind = false;     // some query has no candidate at all yet
+    // Left-over queries.  The ring a group must still visit is set by its WORST query -- and a group's few worst
+    // queries (a frame at the edge of the cluster, one whose lower-energy neighbour is far) are far worse than the
+    // rest: leaving the four worst of 128 to an exact follow-up takes 19 % off the tile pairs of C3
+    // (scratch/nn_outlier_study.py) for 1 300 exact (query, tile) searches per group.  So the next ring covers the
+    // (leave + 1)-th worst open query; the sweep stops when at most `leave` (distinct values of) open queries remain,
+    // records the radius up to which this share has been visited (group_conf[group], minimum over the shares), and
+    // nn_open_kernel / nn_cross_kernel finish the queries whose incumbent lies beyond it.  leave = 0: the group
+    // confirms all its queries itself.
+    float w4[TQ];            // what each open query of this lane still has to confirm (0: settled; h = 1 lanes: their twin's)
 #pragma unroll
     for (int qt = 0; qt < TQ; ++qt) {
       const bool live = (livemask[qt] >> lane) & 1;
@@ -2321,24 +2331,36 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
       // (both half-wave lanes of a query read the same words)
       const float inc_nn = fminf(g_pub[qt * 32 + c], __uint_as_float((uint32_t)(best64[qt * 32 + c] >> 32)));
       const float inc_hd = fminf(g_pub[TQ * 32 + qt * 32 + c], __uint_as_float((uint32_t)(best64[TQ * 32 + qt * 32 + c] >> 32)));
-      const float want = fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f);
-      const bool open = live & !(want < sure);
-      blind = blind | (open & !(want < FLT_MAX));
-      need = fmaxf(need, open ? want : 0.0f);
+      const float want = fminf(fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f), 3.0e38f);   // (no candidate at all: 3e38)
+      const bool open = live & (h == 0) & !(want < sure);
+      w4[qt] = open ? want : 0.0f;
     }
-    const bool any_open = __builtin_amdgcn_ballot_w64(need > 0.0f) != 0;
-    if (!any_open) break;
-    const bool any_blind = __builtin_amdgcn_ballot_w64(blind) != 0;
+    // the (leave + 1)-th largest distinct value among the open queries (0: there are at most `leave`)
+    float need = 0.0f, bound = INFINITY;
+    for (uint32_t i = 0; i <= leave; ++i) {
+      float m = 0.0f;
+#pragma unroll
+      for (int qt = 0; qt < TQ; ++qt) m = fmaxf(m, (w4[qt] < bound) ? w4[qt] : 0.0f);
+      m = wave_max(m);
+      need = m;
+      bound = m;
+      if (!(m > 0.0f)) break;
+    }
+    if (!(need > 0.0f)) {
+      conf_r2 = sure;   // (everything closer than this has been visited; what is still open is left over)
+      break;
+    }
     r2_lo = r2_hi;
-    if (any_blind) {
-      r2_hi = r2_hi * 4.0f;
+    if (need >= 1.0e38f) {
+      r2_hi = r2_hi * 4.0f;   // (a query without any candidate yet)
     } else {
       // (an intermediate ring at 0.35 .. 0.7 of this radius, to tighten the incumbents before the confirming
       //  ring, was measured 3 % slower at C3: the incumbents of the first ring are already close to final)
-      r2_hi = fmaxf(wave_max(need) * 1.001f, r2_hi * 1.001f);
+      r2_hi = fmaxf(need * 1.001f, r2_hi * 1.001f);
     }
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
   }
+  if (lane == 0 && leave > 0 && conf_r2 < 3.0e38f) atomicMin(group_conf + wave, __float_as_uint(conf_r2));
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
 #ifdef DC_NN_PROFILE
   if (lane == 0 && chain_counter) {   // header words 14..19 (scratch/nn_profile.sh)
@@ -2480,6 +2502,8 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   float cell2;
   const uint32_t* tile_comp_q;   // component of every tile of the query order
   const uint32_t* comp;          // component region
+  uint32_t* group_conf;          // [query groups] visited radius^2 (float bits) of a group that left queries over
+  uint32_t leave;                // queries a group of the per-wave sweep may leave to the exact follow-up
 };
 
 // Reference chunks per query group (gridDim.y).  The cost of a query group follows the local density
@@ -2570,7 +2594,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                      coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
-                     hd_d2, CV); sweep_timer_mark(1, false, s); }
+                     hd_d2, CV, A.group_conf, A.leave); sweep_timer_mark(1, false, s); }
   if (n_chunks > 1 && A.full_range)
     hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                        (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)TQV, A.q_seg,
@@ -2770,7 +2794,7 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                             int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s);     \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
                            void* d_ws, uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg, float cell2, \
-                           uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,       \
+                           uint32_t leave, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2, \
                            hipStream_t s);                                                       \
   void nn_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,      \
                          uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2,         \
