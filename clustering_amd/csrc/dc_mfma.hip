@@ -223,7 +223,7 @@ __global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D
                              const uint32_t* __restrict__ comp = nullptr) {
   float M = __uint_as_float(hdr[0]);   // (final: rowstats_kernel ran before)
   // several components (pruned population sweeps): every row is measured from its component's origin (the maximum
-  // over the rows: box_rows_kernel)
+  // over the rows: order_rows_kernel)
   if (comp && comp[kCompGrid + 5] > 1u) M = fminf(__uint_as_float(hdr[kHdrMloc]), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);
   hdr[kHdrMused] = __float_as_uint(M);
   hdr[kHdrOpen] = 0u;
@@ -263,44 +263,6 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
   publish_max(hdr + 13, top, wave_max);
 }
 
-// ordering key of the pruned neighbour sweep: (cell of columns 0/1, free energy) in ONE 32-bit word --
-// the cell index in the high bits, the free energy quantised to the remaining bits (linear between the
-// smallest and the largest finite value of the data set).  The order inside a cell only shapes the tiles'
-// free-energy ranges (the kernels read the ranges, they assume no order), so the quantisation costs a
-// little pruning at worst and saves one of the two stable sorts.
-__global__ void cellfe_key_kernel(const float* __restrict__ coords, uint32_t D,
-                                  const float* __restrict__ fe, const uint32_t* __restrict__ hdr,
-                                  float frames_per_cell, uint32_t n_rows, uint32_t* __restrict__ keys,
-                                  uint32_t* __restrict__ vals, uint32_t key_bits) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  vals[i] = i;
-  const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
-  const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
-  const float cell = auto_cell(hdr, n_rows, frames_per_cell);
-  float c0 = fmaxf(cell, (max0 - min0) / 4000.0f), c1 = fmaxf(cell, (max1 - min1) / 4000.0f);
-  if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
-  if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
-  const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-  uint32_t bx = 0, by = 0;
-  if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
-    bx = (uint32_t)fminf(fmaxf((x - min0) / c0, 0.0f), 4001.0f);
-    by = (uint32_t)fminf(fmaxf((y - min1) / c1, 0.0f), 4001.0f);
-  }
-  const uint32_t nbx = (uint32_t)fminf(fmaxf((max0 - min0) / c0, 0.0f), 4001.0f) + 1u;
-  const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 4001.0f) + 1u;
-  const uint32_t cells = nbx * nby;                               // <= 4002^2 < 2^24
-  const uint32_t cell_bits = 32u - (uint32_t)__builtin_clz(cells | 1u);
-  // key_bits: what the sort will look at (cellfe_key_bits: the host's bound of the cell bits + >= 10, whole passes)
-  const uint32_t fe_bits = key_bits > cell_bits ? key_bits - cell_bits : 0u;
-  const float fe_lo = fkey_inv(~hdr[12]), fe_hi = fkey_inv(hdr[13]);
-  const float span = fe_hi - fe_lo;
-  float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
-  u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
-  const uint32_t levels = (fe_bits >= 32u) ? 0xFFFFFFFFu : ((1u << fe_bits) - 1u);
-  const uint32_t q = (uint32_t)((double)u * (double)levels);
-  keys[i] = (fe_bits >= 32u) ? q : (((bx * nby + by) << fe_bits) | q);
-}
 
 __global__ void fe_scatter_kernel(const uint32_t* __restrict__ perm, const float* __restrict__ fe,
                                   uint32_t n_rows, uint32_t T, uint32_t* __restrict__ invpos,
@@ -352,35 +314,6 @@ static unsigned cellfe_key_bits(uint32_t n_rows, float frames_per_cell) {
   return rounded > 32u ? 32u : rounded;
 }
 
-// ---- spatial ordering of the frames (pruned sweeps) ----------------------------------------------
-// key = row-major index of the frame's cell in a 2-D grid on columns 0/1 (like compute_box_grid,
-// density_clustering.cpp:41-89) for the rows [i_from, i_to): keys[j], vals[j] = key, id of row i_from+j
-// frames_per_cell: the cell edge is chosen so that a cell of the bounding box holds about that many of
-// the i_to - i_from frames being ordered (auto_cell)
-__global__ void cellkey_kernel(const float* __restrict__ coords, uint32_t D,
-                               const uint32_t* __restrict__ hdr, float frames_per_cell,
-                               uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ keys,
-                               uint32_t* __restrict__ vals) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t i = i_from + j;
-  if (i >= i_to) return;
-  vals[j] = i;
-  const float min0 = fkey_inv(~hdr[8]), max0 = fkey_inv(hdr[9]);
-  const float min1 = fkey_inv(~hdr[10]), max1 = fkey_inv(hdr[11]);
-  const float cell = auto_cell(hdr, i_to - i_from, frames_per_cell);
-  // never so small that a dimension gets more than 4000 cells (keys stay below 2^kCellKeyBits)
-  float c0 = fmaxf(cell, (max0 - min0) / 4000.0f), c1 = fmaxf(cell, (max1 - min1) / 4000.0f);
-  if (!(c0 > 0.0f) || !(c0 <= FLT_MAX)) c0 = 1.0f;
-  if (!(c1 > 0.0f) || !(c1 <= FLT_MAX)) c1 = 1.0f;
-  const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-  uint32_t bx = 0, by = 0;
-  if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
-    bx = (uint32_t)fminf(fmaxf((x - min0) / c0, 0.0f), 4001.0f);
-    by = (uint32_t)fminf(fmaxf((y - min1) / c1, 0.0f), 4001.0f);
-  }
-  const uint32_t nby = (uint32_t)fminf(fmaxf((max1 - min1) / c1, 0.0f), 4001.0f) + 1u;
-  keys[j] = bx * nby + by;   // < 4002 * 4003 < 2^24
-}
 
 
 // ---- components of the pruned population sweeps (dc_mfma_kernels.hpp "components") -------------------------------
@@ -964,73 +897,15 @@ __global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
   if (ferange) ferange[t] = make_float2(flo, fhi);
 }
 
-// the same from rows that are already gathered into the ordered list (coords_o, fe_o in list order): one
-// lane per row, a half-wave per tile (box_kernel's one thread per tile is latency-bound: 27 - 40 us at C3)
-__global__ void box_rows_kernel(const float* __restrict__ coords_o, uint32_t D, uint32_t n_used,
-                                uint32_t T, float4* __restrict__ boxes, const float* __restrict__ fe_o,
-                                float2* __restrict__ ferange, const uint32_t* __restrict__ valid = nullptr,
-                                const uint32_t* __restrict__ tile_comp = nullptr,
-                                const float* __restrict__ origins = nullptr, uint32_t* __restrict__ hdr = nullptr) {
-  // valid: frame of every row of the order (kInvalidFrame: a pad row).  tile_comp / origins / hdr: the maximum over the
-  // rows of |x - origin(component of the row's tile)|^2 goes to hdr[kHdrMloc] -- what the sweep's scale and guard band
-  // follow when there are several components (scale_kernel)
-  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;   // 32 consecutive lanes = one tile
-  const uint32_t t = min(pos >> 5, T - 1);                       // (the grid covers whole tiles: 256 | 32 T is not required)
-  const bool in_range = (pos >> 5) < T;
-  const bool live = in_range && pos < n_used && (!valid || valid[pos] != kInvalidFrame);
-  const float x = live ? coords_o[(size_t)pos * D] : 0.0f;
-  const float y = (live && D > 1) ? coords_o[(size_t)pos * D + 1] : 0.0f;
-  float lo0 = live ? x : INFINITY, hi0 = live ? x : -INFINITY;
-  float lo1 = live ? y : INFINITY, hi1 = live ? y : -INFINITY;
-  const float f = (live && fe_o) ? fe_o[pos] : 0.0f;
-  float flo = (live && fe_o) ? f : INFINITY, fhi = (live && fe_o) ? f : -INFINITY;
-  // |x - origin(component of the tile)|^2 of this row (all columns; float, with a margin for its own rounding)
-  float ext = 0.0f;
-  if (tile_comp && live) {
-    const float* a = origins + (size_t)tile_comp[t] * kMaxCols;
-    for (uint32_t k = 0; k < D; ++k) {
-      const float v = coords_o[(size_t)pos * D + k] - a[k];
-      ext += v * v;
-    }
-    ext = ext * 1.0001f + FLT_MIN;
-  }
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    lo0 = fminf(lo0, __shfl_xor(lo0, off, 64));
-    hi0 = fmaxf(hi0, __shfl_xor(hi0, off, 64));
-    lo1 = fminf(lo1, __shfl_xor(lo1, off, 64));
-    hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
-    flo = fminf(flo, __shfl_xor(flo, off, 64));
-    fhi = fmaxf(fhi, __shfl_xor(fhi, off, 64));
-    ext = fmaxf(ext, __shfl_xor(ext, off, 64));
-  }
-  if ((pos & 31u) == 0 && in_range) {
-    boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
-    if (ferange) ferange[t] = make_float2(flo, fhi);
-  }
-  if (tile_comp) {
-    // the block's maximum -> one atomic (and only when it would raise the word)
-    __shared__ float blk_max[8];
-    ext = fmaxf(ext, __shfl_xor(ext, 32, 64));
-    if ((threadIdx.x & 63u) == 0) blk_max[threadIdx.x >> 6] = ext;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float m = 0.0f;
-      for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) m = fmaxf(m, blk_max[w]);
-      if (m <= FLT_MAX) {
-        const uint32_t bits = __float_as_uint(m);
-        if (bits > __atomic_load_n(hdr + kHdrMloc, __ATOMIC_RELAXED)) atomicMax(hdr + kHdrMloc, bits);
-      }
-    }
-  }
-}
 
 // original coordinates gathered into an ordered frame list (the exact path then needs no
 // permutation look-up before it can fetch a row)
-// The rows of an order in one pass (gather_rows_kernel + box_rows_kernel + fe_scatter_kernel, which each read the
-// rows again): 256 positions = 8 tiles per block.  The rows are gathered element-wise (40-byte runs of the source,
+// The rows of an order in one pass (a gather, a box and a free-energy kernel before, which each read the rows
+// again): 256 positions = 8 tiles per block.  The rows are gathered element-wise (40-byte runs of the source,
 // coalesced stores) and parked in LDS, from where every row's lane takes what the tile boxes, the free-energy ranges
-// and the component-wise extent (hdr[kHdrMloc], see box_rows_kernel) need.  fe == nullptr: a population sweep.
+// and the component-wise extent need (hdr[kHdrMloc]: the maximum over the rows of |x - origin(component of the row's
+// tile)|^2, what the sweep's scale and guard band follow when there are several components, scale_kernel).
+// fe == nullptr: a population sweep.
 __global__ __launch_bounds__(256) void order_rows_kernel(
     const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ perm, uint32_t T,
     float* __restrict__ coords_o, float4* __restrict__ boxes, const float* __restrict__ fe, float* __restrict__ fe_s,
@@ -1106,15 +981,6 @@ __global__ __launch_bounds__(256) void order_rows_kernel(
       if (bits > __atomic_load_n(hdr + kHdrMloc, __ATOMIC_RELAXED)) atomicMax(hdr + kHdrMloc, bits);
     }
   }
-}
-__global__ void gather_rows_kernel(const float* __restrict__ coords, uint32_t D,
-                                   const uint32_t* __restrict__ perm, uint32_t n,
-                                   float* __restrict__ out) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)n * D) return;
-  const uint32_t pos = (uint32_t)(e / D), k = (uint32_t)(e - (size_t)pos * D);
-  const uint32_t i = perm[pos];
-  out[e] = (i != kInvalidFrame) ? coords[(size_t)i * D + k] : 0.0f;   // (pad positions of a padded order)
 }
 
 
