@@ -691,7 +691,11 @@ __global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_ro
 __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ hdr,
                                float r_max, const uint32_t* __restrict__ comp, uint32_t fine_bits, uint32_t i_from,
                                uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                               uint32_t n_total = 0, const float* __restrict__ fe = nullptr, uint32_t fe_bits = 0) {
+                               uint32_t n_total = 0, const float* __restrict__ fe = nullptr, uint32_t fe_bits = 0,
+                               uint32_t coarse_bits = 0) {
+  // coarse_bits > 0 (DC_NN_BLOCK_KEY, measurements): the cells of the grid are BLOCKS of 2 x 2 cells and the low part of
+  // the key is (coarse free energy, quarter of the block, fine free energy), fe_bits + 2 bits: query groups of similar
+  // free energy (similar confirming radii) out of four neighbouring cells, tiles still inside one cell
   // fe / fe_bits (the neighbour sweep): the cell number moves up by fe_bits and the free energy, quantised linearly
   // between the smallest and the largest finite value of the data set (header words 12 / 13), fills the low bits --
   // the order inside a cell only shapes the tiles' free-energy ranges (the kernels read the ranges, they assume no
@@ -702,15 +706,17 @@ __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, con
   const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
   (void)r_max;   // (the grid of the partition in use: its own connectivity length)
   const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_total);
-  uint32_t c = 0, bx = 0, by = 0, nby = 1;
+  uint32_t c = 0, bx = 0, by = 0, nby = 1, sub = 0;
   if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
     c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
     const uint32_t* f = comp + kCompFine + 4 * (size_t)c;
     const float lo0 = __uint_as_float(f[0]), lo1 = __uint_as_float(f[1]);
     const float c0 = __uint_as_float(f[2]), c1 = __uint_as_float(f[3]);
     nby = comp[kCompNby + c];
-    bx = (uint32_t)fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f);
-    by = min((uint32_t)fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f), nby - 1u);
+    const float fx = fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f), fy = fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f);
+    bx = (uint32_t)fx;
+    by = min((uint32_t)fy, nby - 1u);
+    sub = ((fx - (float)bx >= 0.5f) ? 2u : 0u) | ((fy - (float)by >= 0.5f) ? 1u : 0u);
   }
   // cells of all components numbered consecutively (kCompCellOff): fewer than 2^fine_bits keys
   const uint32_t lo = comp[kCompCellOff + c], hi = comp[kCompCellOff + c + 1];
@@ -721,7 +727,13 @@ __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, con
     float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
     u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
     const uint32_t levels = (1u << fe_bits) - 1u;
-    key = (key << fe_bits) | (uint32_t)((double)u * (double)levels);
+    const uint32_t level = (uint32_t)((double)u * (double)levels);
+    if (coarse_bits > 0 && coarse_bits <= fe_bits) {
+      const uint32_t fb = fe_bits - coarse_bits;
+      key = (((key << coarse_bits) | (level >> fb)) << 2 | sub) << fb | (level & ((1u << fb) - 1u));
+    } else {
+      key = (key << fe_bits) | level;
+    }
   }
   keys[j] = key;
   vals[j] = i;
@@ -1804,14 +1816,18 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, 0.0f, cookie);
   }
-  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, cell_frames(true),
-                     (uint32_t)fine_bits, comp);
+  // DC_NN_BLOCK_KEY = coarse free-energy bits (measurements): blocks of 2 x 2 cells, see compkey_kernel
+  static const unsigned block_coarse = [] { const char* e = getenv("DC_NN_BLOCK_KEY"); return (e && e[0]) ? (unsigned)std::max(0, atoi(e)) : 0u; }();
+  const unsigned coarse = (block_coarse > 0 && block_coarse <= fe_bits && fine_bits > 4) ? block_coarse : 0u;
+  const unsigned grid_bits = coarse ? fine_bits - 2u : fine_bits, low_bits = coarse ? fe_bits + 2u : fe_bits;
+  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows,
+                     cell_frames(true) * (coarse ? 4.0f : 1.0f), (uint32_t)grid_bits, comp);
   // frames by (component, cell, free energy): ONE sort on a combined key
   hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
-                     (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, fe_bits);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, fine_bits + fe_bits))
+                     (const uint32_t*)comp, grid_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, fe_bits, coarse);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, grid_bits + low_bits))
     return;
-  pad_order(keys_out, vals_sorted, n_rows, fe_bits, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
+  pad_order(keys_out, vals_sorted, n_rows, low_bits, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
             T_r, stream);
   const float* coords_p = (const float*)(p + L.off_coords_p);
   hipLaunchKernelGGL(order_rows_kernel, dim3((32 * T_r + 255) / 256), blk, row_tile_smem(order_rows_kernel, n_cols), stream,
