@@ -86,12 +86,11 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   uint32_t m_norm = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
   bool bad = false;
   // a row per lane, read where it lies: the ten loads of a wave touch the same 2.5 KB and meet in the vector cache
-  // (the rows went through an LDS tile with two barriers per 256 rows before: 42 - 53 us at 10^6 x 10, now the read)
   const bool pairs = (D % 2u == 0) && ((reinterpret_cast<uintptr_t>(coords) & 7u) == 0);
   for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += gridDim.x * blockDim.x) {
     const float* x = coords + (size_t)row * D;
     double nrm = 0.0;
-    float c0, c1 = 0.0f;
+    float c0 = 0.0f, c1 = 0.0f;
     if (pairs) {
       const float2* x2 = reinterpret_cast<const float2*>(x);
       const float2 first = x2[0];
@@ -139,6 +138,9 @@ __global__ void stats_guard_kernel(uint32_t* __restrict__ hdr, uint32_t cookie) 
   hdr[1] = (hdr[1] & 1u) | ((hdr[kHdrCookie] != cookie) ? 2u : 0u);
 }
 
+// dynamic LDS of image_kernel: per wave of the 256-thread block the 32 rows of its tile and their origin
+static inline size_t image_smem(uint32_t n_cols) { return sizeof(float) * 4 * 33 * (size_t)n_cols; }
+
 // operand image of the (centred, scaled) coordinates in the fp16x2 slot layout (dc_mfma_kernels.hpp), rows
 // in natural order (perm == nullptr) or gathered through perm (an ordered frame list).  One thread
 // writes the 16-byte fragment of one lane of one MFMA of one tile; the threads of MFMA 0, half 0
@@ -170,7 +172,34 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   if (live && valid && valid[row] == kInvalidFrame) live = false;
   src = live ? src : 0u;
   if (tile_comp) means = origins + (size_t)tile_comp[t] * kMaxCols;
-  const float* x = coords + (size_t)src * D;
+  // The tile's rows and its origin go through LDS, a slice per wave: 32 x D floats read coalesced (or gathered by frame,
+  // four loads in flight) instead of eight 4-byte loads per lane at a stride of D words, which kept the address units
+  // busier than the 64 MB the kernel writes (50 us at 10^6 x 10).
+  extern __shared__ float img_lds[];
+  float* xs = img_lds + (size_t)(threadIdx.x >> 6) * (33u * D);
+  float* org = xs + 32u * D;
+  {
+    const uint32_t rows_here = (32u * t < n_rows) ? min(32u, n_rows - 32u * t) : 0u;
+    if (perm) {
+      stage_query_rows(xs, nullptr, coords, src, live, D, (int)lane);
+    } else {
+      const float* contig = coords + (size_t)32 * t * D;
+      const uint32_t total = rows_here * D;
+      for (uint32_t e0 = lane; e0 < total; e0 += 256u) {
+        float v4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) v4[j] = (e0 + 64u * j < total) ? contig[e0 + 64u * j] : 0.0f;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+          if (e0 + 64u * j < total) xs[e0 + 64u * j] = v4[j];
+      }
+    }
+    for (uint32_t k = lane; k < D; k += 64u) org[k] = means[k];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float* x = xs + (size_t)(lane & 31u) * D;
+  means = org;
   const Scale sc = load_scale(hdr);   // (the sweep's scale: scale_kernel ran before)
   const float s1 = b_form ? sc.sb : sc.sa;
   auto col = [&](uint32_t k) -> float { return (x[k] - means[k]) * s1; };   // x'' = 2^k fl(x - mu)
@@ -207,10 +236,22 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   img[((size_t)t * NM + m) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);   // pad rows: all zero
   if (norms && m == 0 && h == 0) {
     // |x''|^2 of the SCALED coordinates (double accumulate, rounded once); a power-of-two scale commutes with it
+    // (four columns per step, their loads issued together; summed in column order)
     double nrm = 0.0;
-    for (uint32_t k = 0; k < D; ++k) {
-      const float v = live ? col(k) : 0.0f;
-      nrm += (double)v * (double)v;
+    for (uint32_t k0 = 0; k0 < D; k0 += 4) {
+      float xv[4], mv[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t k = min(k0 + j, D - 1u);
+        xv[j] = x[k];
+        mv[j] = means[k];
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (k0 + j < D) {
+          const float v = live ? (xv[j] - mv[j]) * s1 : 0.0f;   // (= col(k))
+          nrm += (double)v * (double)v;
+        }
     }
     norms[row] = live ? (float)nrm : INFINITY;   // pad rows can never be "inside"
   }
@@ -244,8 +285,7 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
   uint32_t inv = 0, top = 0;
   bool nan = false;
   // grid-stride: a block publishes its extrema once (two block reductions), however many rows it sees
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
-    const float f = fe[i];
+  auto take = [&](float f, uint32_t i) {
     nan = nan | (f != f);
     const uint32_t u = __float_as_uint(f);
     const uint32_t key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
@@ -255,7 +295,18 @@ __global__ void fe_key_kernel(const float* __restrict__ fe, uint32_t n_rows,
     }
     inv = max(inv, ~key);
     top = max(top, (fabsf(f) <= FLT_MAX) ? key : 0u);
+  };
+  // 16 bytes per lane and step where the array allows it (one word per trip of the loop waited for every load)
+  const uint32_t n4 = ((reinterpret_cast<uintptr_t>(fe) & 15u) == 0) ? n_rows / 4 : 0;
+  const float4* fe4 = reinterpret_cast<const float4*>(fe);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const float4 f = fe4[i];
+    take(f.x, 4 * i);
+    take(f.y, 4 * i + 1);
+    take(f.z, 4 * i + 2);
+    take(f.w, 4 * i + 3);
   }
+  for (uint32_t i = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) take(fe[i], i);
   if (nan) atomicOr(hdr + 1, 4u);
   // global minimum free energy -> header word 12 (as ~key, maintained with atomicMax), largest FINITE
   // one -> word 13 (as key); at most one atomic per block and word
@@ -936,12 +987,26 @@ __global__ __launch_bounds__(256) void order_rows_kernel(
   s_frame[threadIdx.x] = frame;
   __syncthreads();
   const size_t base = (size_t)pos0 * D, total = (size_t)n_pos * D;
-  for (uint32_t e = threadIdx.x; e < 256u * D; e += 256u) {
-    const uint32_t r = e / D, k = e - r * D;
-    const uint32_t i = s_frame[r];
-    const float v = (i != kInvalidFrame) ? coords[(size_t)i * D + k] : 0.0f;   // (pad positions of a padded order)
-    or_tile[r * Dp + k] = v;
-    if (base + e < total) coords_o[base + e] = v;
+  // (four elements per thread and step, their loads issued together: a load per trip of this run-time loop waited for each)
+  for (uint32_t e0 = threadIdx.x; e0 < 256u * D; e0 += 1024u) {
+    float v[4];
+    uint32_t off[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t e = e0 + 256u * j;
+      const uint32_t r = min(e / D, 255u), k = e - (e / D) * D;
+      const uint32_t i = s_frame[r];
+      off[j] = r * Dp + k;
+      v[j] = (e < 256u * D && i != kInvalidFrame) ? coords[(size_t)i * D + k] : 0.0f;   // (pad positions of a padded order)
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t e = e0 + 256u * j;
+      if (e < 256u * D) {
+        or_tile[off[j]] = v[j];
+        if (base + e < total) coords_o[base + e] = v[j];
+      }
+    }
   }
   __syncthreads();
   const bool in_range = pos < n_pos, live = frame != kInvalidFrame;
@@ -963,9 +1028,16 @@ __global__ __launch_bounds__(256) void order_rows_kernel(
   float ext = 0.0f;
   if (live) {
     const float* a = origins + (size_t)tile_comp[t] * kMaxCols;
-    for (uint32_t k = 0; k < D; ++k) {
-      const float v = row[k] - a[k];
-      ext += v * v;
+    for (uint32_t k0 = 0; k0 < D; k0 += 4) {   // (four origin words per step, loaded together)
+      float av[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) av[j] = a[min(k0 + j, D - 1u)];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (k0 + j < D) {
+          const float v = row[k0 + j] - av[j];
+          ext += v * v;
+        }
     }
     ext = ext * 1.0001f + FLT_MIN;
   }
@@ -1104,7 +1176,9 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
                      (double*)(p + kHdrSums));
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, stream, (const double*)(p + kHdrSums), n_rows,
                      n_cols, (float*)(p + kHdrMeans));
-  hipLaunchKernelGGL(rowstats_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 2048u)), dim3(256), 0, stream, d_coords, n_rows, n_cols,
+  // (512 blocks: every block ends with five same-address atomics -- at 2 048 blocks they were half of the kernel's 46 us,
+  //  scratch/pb/rowstats_bench.hip)
+  hipLaunchKernelGGL(rowstats_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 512u)), dim3(256), 0, stream, d_coords, n_rows, n_cols,
                      (const float*)(p + kHdrMeans), (uint32_t*)p, cookie);
   (void)natural_image;   // (the full sweeps build their natural-order images themselves, at their own scale)
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1134,11 +1208,11 @@ static void natural_images(const float* d_coords, uint32_t n_rows, uint32_t n_co
   char* p = (char*)d_ws;
   const dim3 grid_img((uint32_t)(((size_t)L.T * L.NM * 64 + 255) / 256));
   if (a_form)
-    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
+    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), image_smem(n_cols), stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                        (uint4*)(p + L.off_img), (float*)(p + L.off_norm), (const uint32_t*)p);
   if (b_form)
-    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), 0, stream, d_coords, n_rows, n_rows, n_cols,
+    hipLaunchKernelGGL(image_kernel, grid_img, dim3(256), image_smem(n_cols), stream, d_coords, n_rows, n_rows, n_cols,
                        L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
                        (uint4*)(p + L.off_img_b), a_form ? (float*)nullptr : (float*)(p + L.off_norm),
                        (const uint32_t*)p);
@@ -1417,7 +1491,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     // the scale follows the components' extents
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, fmaxf(r2_scale, 0.0f), n_cols,
                        (const uint32_t*)comp);
-    hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+    hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
                        L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                        (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                        (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
@@ -1433,7 +1507,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
       // queries in the reference order: only their B form is missing (of the groups of this segment)
       const uint32_t tiles_q = seg_groups((T_r + tq - 1) / tq, q_seg) * tq;
       if (tiles_q > 0)
-        hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+        hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
                            L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
                            (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg,
                            (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
@@ -1446,7 +1520,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
         return;
       pad_order(keys_out, vals_sorted, n_q, 0u, group_rows, comp, comp + kCompStart + (kMaxComp + 1),
                 comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
-      hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, 32u * T_q, n_cols,
+      hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, image_smem(n_cols), stream, d_coords, n_rows, 32u * T_q, n_cols,
                          L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
                          (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                          (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
@@ -1799,7 +1873,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   }
   const float r_conn = -8.0f;   // components: connected over 8 cells of the ordering (no radius in this sweep)
   // the pass over the free energies finds their range (and raises the flag for NaNs)
-  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
+  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 256u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
                      (uint32_t*)nullptr, hdr);
   (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
   const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
@@ -1836,7 +1910,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                      (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr, group_conf,
                      std::min(std::max(T_r, T_q), 32u * T_r));
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
-  hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+  hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
                      L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                      (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
@@ -1844,7 +1918,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     // queries in the reference order: only their B form is missing (of the groups of this segment)
     const uint32_t tiles_q = seg_groups((T_r + tq - 1) / tq, q_seg) * tq;
     if (tiles_q > 0)
-      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, 0, stream, coords_p, n_rows, 32u * T_r, n_cols,
+      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
                          L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
                          (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg,
                          (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
@@ -1857,7 +1931,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
       return;
     pad_order(keys_out, vals_sorted, n_q, 0u, group_rows, comp, comp + kCompStart + (kMaxComp + 1),
               comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
-    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, 0, stream, d_coords, n_rows, 32u * T_q, n_cols,
+    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, image_smem(n_cols), stream, d_coords, n_rows, 32u * T_q, n_cols,
                        L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
                        (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                        (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
@@ -2026,7 +2100,7 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
                      (uint32_t*)(p + L.off_invpos), (float*)(p + L.off_fe_s));
   hipLaunchKernelGGL(fe_rank_kernel, grid_n, blk, 0, stream, d_fe, (const float*)(p + L.off_fe_s),
                      n_rows, (uint32_t*)(p + L.off_pq));
-  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, 0, stream, d_coords, n_rows, n_rows, n_cols,
+  hipLaunchKernelGGL(image_kernel, grid_img(L.T), blk, image_smem(n_cols), stream, d_coords, n_rows, n_rows, n_cols,
                      L.NM, L.T, (const float*)(p + kHdrMeans), (const uint32_t*)perm, 0,
                      (uint4*)(p + L.off_img_s), (float*)(p + L.off_norm_s), (const uint32_t*)p);
   switch (nm_for((int)n_cols)) {

@@ -1135,6 +1135,36 @@ struct CompView {
 // SYM: the symmetric sweep (all rows as queries, one radius, no sink): a query group meets its own tiles as
 // before and, of the other groups, the half that lies ahead of it on the circle of groups -- every unordered pair
 // of groups once -- crediting both sides (ref_credit); all counts go to pops_pos (by position, zero-filled).
+// Query rows of one tile (original coordinates, for the exact path) into LDS [32][n_cols]: from the ordered copy of the
+// rows -- contiguous, coalesced -- when the queries are rows of the reference order, gathered by frame otherwise; four
+// loads per lane in flight either way (a load per trip of a run-time column loop waited for each: ten round trips at the
+// start of every wave, which an eighth of C3 -- short waves -- felt most).
+__device__ __forceinline__ void stage_query_rows(float* __restrict__ dst, const float* __restrict__ contig,
+                                                 const float* __restrict__ coords, uint32_t frame, bool live,
+                                                 uint32_t n_cols, int lane) {
+  if (contig) {
+    const uint32_t total = 32u * n_cols;
+    for (uint32_t e0 = (uint32_t)lane; e0 < total; e0 += 256u) {
+      float v[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) v[j] = (e0 + 64u * j < total) ? contig[e0 + 64u * j] : 0.0f;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (e0 + 64u * j < total) dst[e0 + 64u * j] = v[j];
+    }
+  } else if (lane < 32) {
+    const float* x = coords + (size_t)frame * n_cols;
+    for (uint32_t k0 = 0; k0 < n_cols; k0 += 4) {
+      float v[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) v[j] = (live && k0 + j < n_cols) ? x[k0 + j] : 0.0f;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (k0 + j < n_cols) dst[(uint32_t)lane * n_cols + k0 + j] = v[j];
+    }
+  }
+}
+
 template <int NM, int NR, int TQ, int MODE = kSinkNone, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -1217,9 +1247,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       comp_q[qt] = live ? sink.comp[pos] : 0xFFFFFFFFu;
       rank_q[qt] = live ? sink.rank[pos] : 0u;
     }
-    if (h == 0) {   // original coordinates of this lane's query, for the exact path
-      for (uint32_t k = 0; k < n_cols; ++k)
-        qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
+    // original coordinates of the tile's queries, for the exact path
+    stage_query_rows(qrows + (size_t)qt * 32 * n_cols, (perm_q == perm_r) ? coords_r + (size_t)tl * 32 * n_cols : nullptr,
+                     coords, jq[qt], live, n_cols, lane);
+    if (h == 0) {
       if constexpr (kWaveWide) fix_tab[qt * 32 + c] = 0;
     }
 #pragma unroll
@@ -1987,9 +2018,9 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
-    if (h == 0)   // original coordinates of this lane's query, for the exact path
-      for (uint32_t k = 0; k < n_cols; ++k)
-        qrows[(qt * 32 + c) * n_cols + k] = live ? coords[(size_t)jq[qt] * n_cols + k] : 0.0f;
+    // original coordinates of the tile's queries, for the exact path
+    stage_query_rows(qrows + (size_t)qt * 32 * n_cols, full_range ? coords_c + (size_t)tl * 32 * n_cols : nullptr, coords,
+                     jq[qt], live, n_cols, lane);
     q[qt].m_nn = live ? INFINITY : -INFINITY;   // idle lanes can never trigger the exact path
     q[qt].m_hd = live ? INFINITY : -INFINITY;
     float g_nn = FLT_MAX, g_hd = FLT_MAX;
