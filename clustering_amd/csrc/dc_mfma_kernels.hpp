@@ -1197,6 +1197,9 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
+  // (the component of the group and its tile range: two dependent look-ups, started before everything else)
+  const uint32_t my_comp = CV.tile_comp_q[qt0];
+  const uint32_t comp_lo = CV.range_r[2 * my_comp], comp_hi = CV.range_r[2 * my_comp + 1];
   uint32_t* list = lists_all + (size_t)wib * kListCap;
   float* qrows = pop_qrows_all + (size_t)wib * (TQ * 32) * n_cols;
   uint32_t* queues = reinterpret_cast<uint32_t*>(pop_qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
@@ -1247,12 +1250,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       comp_q[qt] = live ? sink.comp[pos] : 0xFFFFFFFFu;
       rank_q[qt] = live ? sink.rank[pos] : 0u;
     }
-    // original coordinates of the tile's queries, for the exact path
-    stage_query_rows(qrows + (size_t)qt * 32 * n_cols, (perm_q == perm_r) ? coords_r + (size_t)tl * 32 * n_cols : nullptr,
-                     coords, jq[qt], live, n_cols, lane);
-    if (h == 0) {
-      if constexpr (kWaveWide) fix_tab[qt * 32 + c] = 0;
-    }
+
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) q[qt].cnt[rr] = 0;
     qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
@@ -1260,6 +1258,33 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     gbox.y = fmaxf(gbox.y, qbox[qt].y);
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
+  }
+  // the original coordinates of the queries (for the exact path) into LDS -- after the loop, so that the loads of all the
+  // tiles above are issued together (nn_pruned_kernel: a store per tile in between cost a fifth of a wave's set-up)
+  if (perm_q == perm_r && qt0 + TQ <= TQT) {
+    // (the rows of the wave's tiles are one contiguous piece of the ordered copy)
+    const float* src = coords_r + (size_t)qt0 * 32 * n_cols;
+    const uint32_t total = (uint32_t)TQ * 32u * n_cols;
+    for (uint32_t e0 = (uint32_t)lane; e0 < total; e0 += 1280u) {
+      float v[20];
+#pragma unroll
+      for (uint32_t j = 0; j < 20; ++j) v[j] = (e0 + 64u * j < total) ? src[e0 + 64u * j] : 0.0f;
+#pragma unroll
+      for (uint32_t j = 0; j < 20; ++j)
+        if (e0 + 64u * j < total) qrows[e0 + 64u * j] = v[j];
+    }
+  } else {
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt) {
+      const uint32_t tile = qt0 + qt, tl = tile < TQT ? tile : TQT - 1;
+      stage_query_rows(qrows + (size_t)qt * 32 * n_cols, (perm_q == perm_r) ? coords_r + (size_t)tl * 32 * n_cols : nullptr,
+                       coords, jq[qt], (livemask[qt] >> lane) & 1, n_cols, lane);
+    }
+  }
+  if constexpr (kWaveWide) {
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt)
+      if (h == 0) fix_tab[qt * 32 + c] = 0;
   }
 
   // SYM: groups of TQ tiles on a circle; this wave's group and its count; the strings of the chains on the pending
@@ -1293,8 +1318,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scan only touches its own boxes)
   // ... of the tiles of the group's own COMPONENT: every other frame is at least r_max away (CompView)
-  const uint32_t my_comp = CV.tile_comp_q[qt0];
-  const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
+  const uint32_t t_lo = comp_lo, t_hi = min(comp_hi, T);
   const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
   const uint32_t U = (t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u;
   for (uint32_t base = u_lo; base < U; base += kListCap) {
@@ -1965,6 +1989,9 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
   // rows (original coordinates), then the candidate queues [TQ][kQueueCap][64]
   extern __shared__ __attribute__((aligned(16))) float nn_dyn_lds[];
   if (hdr[1] != 0) return;
+#ifdef DC_NN_PROFILE
+  const unsigned long long prof_t0 = clock64();
+#endif
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
   // waves per workgroup (kWavesPerGroup): the waves share nothing, and a workgroup holds its LDS until its LAST
@@ -1980,6 +2007,10 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;
+  // (the component of the group, its tile range and cell edge: three dependent look-ups, started before everything else)
+  const uint32_t my_comp = CV.tile_comp_q[qt0];
+  const uint32_t comp_lo = CV.range_r[2 * my_comp], comp_hi = CV.range_r[2 * my_comp + 1];
+  const float comp_cell = __uint_as_float(CV.comp[kCompFine + 4 * min(my_comp, (uint32_t)kMaxComp - 1u) + 2]);
   uint32_t* list = lists_all + (size_t)wib * kListCap;
   float* qrows = qrows_all + (size_t)wib * (TQ * 32) * n_cols;
   uint32_t* queues = reinterpret_cast<uint32_t*>(qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
@@ -2006,6 +2037,7 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
   uint64_t livemask[TQ];
   float4 qbox[TQ];
   float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+  float g_nn[TQ], g_hd[TQ];
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
     const uint32_t tile = qt0 + qt;
@@ -2018,25 +2050,21 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
-    // original coordinates of the tile's queries, for the exact path
-    stage_query_rows(qrows + (size_t)qt * 32 * n_cols, full_range ? coords_c + (size_t)tl * 32 * n_cols : nullptr, coords,
-                     jq[qt], live, n_cols, lane);
     q[qt].m_nn = live ? INFINITY : -INFINITY;   // idle lanes can never trigger the exact path
     q[qt].m_hd = live ? INFINITY : -INFINITY;
-    float g_nn = FLT_MAX, g_hd = FLT_MAX;
-    if (n_chunks > 1 && live) {
-      // what the waves of other reference chunks have already published for this query: an exact
-      // upper bound.  Only candidates that can still beat (or tie) it need to be looked at, i.e.
-      // MFMA values below d2 + eps(d2); the band test adds its usual margin on top.
-      g_nn = __uint_as_float((uint32_t)(merge64[jq[qt]] >> 32));
-      g_hd = __uint_as_float((uint32_t)(merge64[(size_t)n_rows + jq[qt]] >> 32));
-      const float s_nn = g_nn * sc.s2, s_hd = g_hd * sc.s2;   // (exact d2 -> scaled units)
-      if (g_nn < FLT_MAX) q[qt].m_nn = s_nn + (gb.e0 + gb.kappa * s_nn);
-      if (g_hd < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
-    }
-    if (h == 0) {
-      g_pub[qt * 32 + c] = g_nn;
-      g_pub[TQ * 32 + qt * 32 + c] = g_hd;
+    // what the waves of other reference chunks have already published for this query: an exact upper bound.  Only
+    // candidates that can still beat (or tie) it need to be looked at, i.e. MFMA values below d2 + eps(d2); the band
+    // test adds its usual margin on top.  (Branch-free, and nothing goes to LDS inside this loop: the loads of the four
+    // tiles are issued together -- with a store per tile in between the set-up of a wave was 32 000 cycles, an eighth of
+    // a wave of an eight-way sharded sweep.)
+    const bool pub = (n_chunks > 1) & live;
+    const unsigned long long w_nn = merge64[pub ? jq[qt] : 0u], w_hd = merge64[pub ? (size_t)n_rows + jq[qt] : 0u];
+    g_nn[qt] = pub ? __uint_as_float((uint32_t)(w_nn >> 32)) : FLT_MAX;
+    g_hd[qt] = pub ? __uint_as_float((uint32_t)(w_hd >> 32)) : FLT_MAX;
+    {
+      const float s_nn = g_nn[qt] * sc.s2, s_hd = g_hd[qt] * sc.s2;   // (exact d2 -> scaled units)
+      if (g_nn[qt] < FLT_MAX) q[qt].m_nn = s_nn + (gb.e0 + gb.kappa * s_nn);
+      if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
     }
     q[qt].m_nn = fminf(q[qt].m_nn, q[qt].m_hd);   // (two reads of merge64 a moment apart: keep m_nn <= m_hd)
     q[qt].bn = nn_band(gb, q[qt].m_nn);
@@ -2047,6 +2075,40 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
+#ifdef DC_NN_PROFILE
+  const unsigned long long prof_ta = clock64();   // (the loads of the four tiles have been issued -- and used)
+#endif
+  // published bounds and the original coordinates of the queries (for the exact path) into LDS
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt)
+    if (h == 0) {
+      g_pub[qt * 32 + c] = g_nn[qt];
+      g_pub[TQ * 32 + qt * 32 + c] = g_hd[qt];
+    }
+  if (full_range && qt0 + TQ <= TQT) {
+    // (the rows of the wave's tiles are one contiguous piece of the ordered copy: twenty loads per lane in flight, all
+    //  of them at ten columns)
+    const float* src = coords_c + (size_t)qt0 * 32 * n_cols;
+    const uint32_t total = (uint32_t)TQ * 32u * n_cols;
+    for (uint32_t e0 = (uint32_t)lane; e0 < total; e0 += 1280u) {
+      float v[20];
+#pragma unroll
+      for (uint32_t j = 0; j < 20; ++j) v[j] = (e0 + 64u * j < total) ? src[e0 + 64u * j] : 0.0f;
+#pragma unroll
+      for (uint32_t j = 0; j < 20; ++j)
+        if (e0 + 64u * j < total) qrows[e0 + 64u * j] = v[j];
+    }
+  } else {
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt) {
+      const uint32_t tile = qt0 + qt, tl = tile < TQT ? tile : TQT - 1;
+      stage_query_rows(qrows + (size_t)qt * 32 * n_cols, full_range ? coords_c + (size_t)tl * 32 * n_cols : nullptr, coords,
+                       jq[qt], (livemask[qt] >> lane) & 1, n_cols, lane);
+    }
+  }
+#ifdef DC_NN_PROFILE
+  const unsigned long long prof_tb = clock64();   // (rows and bounds are in LDS)
+#endif
   // Seeds: the frames next to each query in the sweep's order (same cell, neighbouring free energy; the
   // ones before it have a lower free energy) are evaluated exactly before the first ring.  They are
   // ordinary candidates; what they buy is finite running minima from the start -- without them the first
@@ -2106,6 +2168,8 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
 
 #ifdef DC_NN_PROFILE
   uint32_t prof_rare = 0, prof_trig = 0, prof_cand = 0;
+  const unsigned long long prof_t1 = clock64();   // (queries, seeds and thresholds are set up)
+  unsigned long long prof_t2 = 0;                 // (the first chain is about to start)
 #endif
   // evaluate and empty the candidate list (64 candidates at a time, one per lane)
   auto flush = [&]() {
@@ -2117,14 +2181,10 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
   // every share sees every region; the scans only touch their own boxes)
   // (the tiles of the group's own COMPONENT only -- dc_mfma_kernels.hpp "components": what lies in other components is
   //  looked at afterwards, exactly, for the few queries whose neighbours may be there: nn_cross_kernel)
-  const uint32_t my_comp = CV.tile_comp_q[qt0];
-  const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
+  const uint32_t t_lo = comp_lo, t_hi = min(comp_hi, T);
   const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
   const uint32_t U = max((t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u, u_lo);
-  {
-    const float cl = __uint_as_float(CV.comp[kCompFine + 4 * min(my_comp, (uint32_t)kMaxComp - 1u) + 2]);
-    cell2 = cl * cl;
-  }
+  cell2 = comp_cell * comp_cell;
   const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
   float conf_r2 = INFINITY;                                // radius^2 below which this share has been visited completely when the sweep stops early
@@ -2161,6 +2221,9 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
       // Reference tile data in two register buffers (the loads run one survivor ahead); the chains
       // are software-pipelined over two accumulator tiles: while the MFMAs of one chain run, the
       // tile minimum of the previous chain issues in their shadow (a wave issues in order).
+#ifdef DC_NN_PROFILE
+      if (prof_t2 == 0) prof_t2 = clock64();
+#endif
       s16x8 a0[NM];
       float4 n0[4];
       auto entry = [&](uint32_t i) {
@@ -2398,6 +2461,14 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     atomicAdd(chain_counter + 5, (unsigned long long)prof_rare);
     atomicAdd(chain_counter + 6, (unsigned long long)prof_trig);
     atomicAdd(chain_counter + 7, (unsigned long long)prof_cand);
+    // header words 32.. (bytes 128..): waves, cycles in all, until the set-up is done, until the first chain
+    const unsigned long long t3 = clock64();
+    atomicAdd(chain_counter + 14, 1ull);
+    atomicAdd(chain_counter + 15, t3 - prof_t0);
+    atomicAdd(chain_counter + 16, prof_t1 - prof_t0);
+    atomicAdd(chain_counter + 17, (prof_t2 ? prof_t2 : t3) - prof_t0);
+    atomicAdd(chain_counter + 18, prof_ta - prof_t0);
+    atomicAdd(chain_counter + 19, prof_tb - prof_t0);
   }
 #endif
 
