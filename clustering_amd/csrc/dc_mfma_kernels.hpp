@@ -1138,7 +1138,7 @@ struct CompView {
 // Query rows of one tile (original coordinates, for the exact path) into LDS [32][n_cols]: from the ordered copy of the
 // rows -- contiguous, coalesced -- when the queries are rows of the reference order, gathered by frame otherwise; four
 // loads per lane in flight either way (a load per trip of a run-time column loop waited for each: ten round trips at the
-// start of every wave; A/B on one box: C3 -1 % in both sweeps, an eighth of C3 -3 %).
+// start of every wave; a quarter less memory-side traffic, kernel times within the noise of a box).
 __device__ __forceinline__ void stage_query_rows(float* __restrict__ dst, const float* __restrict__ contig,
                                                  const float* __restrict__ coords, uint32_t frame, bool live,
                                                  uint32_t n_cols, int lane) {
