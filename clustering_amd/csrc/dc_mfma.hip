@@ -742,11 +742,7 @@ __global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_ro
 __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ hdr,
                                float r_max, const uint32_t* __restrict__ comp, uint32_t fine_bits, uint32_t i_from,
                                uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                               uint32_t n_total = 0, const float* __restrict__ fe = nullptr, uint32_t fe_bits = 0,
-                               uint32_t coarse_bits = 0) {
-  // coarse_bits > 0 (DC_NN_BLOCK_KEY, measurements): the cells of the grid are BLOCKS of 2 x 2 cells and the low part of
-  // the key is (coarse free energy, quarter of the block, fine free energy), fe_bits + 2 bits: query groups of similar
-  // free energy (similar confirming radii) out of four neighbouring cells, tiles still inside one cell
+                               uint32_t n_total = 0, const float* __restrict__ fe = nullptr, uint32_t fe_bits = 0) {
   // fe / fe_bits (the neighbour sweep): the cell number moves up by fe_bits and the free energy, quantised linearly
   // between the smallest and the largest finite value of the data set (header words 12 / 13), fills the low bits --
   // the order inside a cell only shapes the tiles' free-energy ranges (the kernels read the ranges, they assume no
@@ -757,7 +753,7 @@ __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, con
   const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
   (void)r_max;   // (the grid of the partition in use: its own connectivity length)
   const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_total);
-  uint32_t c = 0, bx = 0, by = 0, nby = 1, sub = 0;
+  uint32_t c = 0, bx = 0, by = 0, nby = 1;
   if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
     c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
     const uint32_t* f = comp + kCompFine + 4 * (size_t)c;
@@ -767,7 +763,6 @@ __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, con
     const float fx = fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f), fy = fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f);
     bx = (uint32_t)fx;
     by = min((uint32_t)fy, nby - 1u);
-    sub = ((fx - (float)bx >= 0.5f) ? 2u : 0u) | ((fy - (float)by >= 0.5f) ? 1u : 0u);
   }
   // cells of all components numbered consecutively (kCompCellOff): fewer than 2^fine_bits keys
   const uint32_t lo = comp[kCompCellOff + c], hi = comp[kCompCellOff + c + 1];
@@ -779,12 +774,7 @@ __global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, con
     u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
     const uint32_t levels = (1u << fe_bits) - 1u;
     const uint32_t level = (uint32_t)((double)u * (double)levels);
-    if (coarse_bits > 0 && coarse_bits <= fe_bits) {
-      const uint32_t fb = fe_bits - coarse_bits;
-      key = (((key << coarse_bits) | (level >> fb)) << 2 | sub) << fb | (level & ((1u << fb) - 1u));
-    } else {
-      key = (key << fe_bits) | level;
-    }
+    key = (key << fe_bits) | level;
   }
   keys[j] = key;
   vals[j] = i;
@@ -973,12 +963,8 @@ __global__ __launch_bounds__(256) void order_rows_kernel(
     const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ perm, uint32_t T,
     float* __restrict__ coords_o, float4* __restrict__ boxes, const float* __restrict__ fe, float* __restrict__ fe_s,
     uint32_t* __restrict__ invpos, float2* __restrict__ ferange, const uint32_t* __restrict__ tile_comp,
-    const float* __restrict__ origins, uint32_t* __restrict__ hdr, uint32_t* __restrict__ group_conf = nullptr,
-    uint32_t n_conf = 0) {
+    const float* __restrict__ origins, uint32_t* __restrict__ hdr) {
   extern __shared__ float or_tile[];            // [256][D | 1]
-  // (group_conf: visited radius^2 of the query groups of the neighbour sweep that follows, preset to +inf = "all the group
-  //  needed", nn_pruned_kernel)
-  if (group_conf && blockIdx.x * 256u + threadIdx.x < n_conf) group_conf[blockIdx.x * 256u + threadIdx.x] = 0x7F800000u;
   __shared__ uint32_t s_frame[256];
   __shared__ float blk_max[4];
   const uint32_t Dp = D | 1u;
@@ -1245,11 +1231,7 @@ void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, ui
 struct QuerySel {
   uint32_t i_from, i_to, segment, n_segments;
 };
-#ifdef DC_EXP_NN_TQ2
-static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 2 : (nm_for((int)n_cols) <= 5 ? 4 : 2); }   // = tq_for<NM>
-#else
 static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 5 ? 4 : 2; }   // = tq_for<NM>
-#endif
 static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
 // query tiles per group of the population sweep that will run: the unit segments are dealt out in and the
 // query image is built for (pop_shared_kernel: the four waves of a workgroup form one group)
@@ -1388,18 +1370,7 @@ static float cell_frames(bool nn) {
   return v[nn ? 1 : 0];
 }
 
-// queries a group of the per-wave neighbour sweep may leave to the exact follow-up (nn_pruned_kernel "left-over queries");
-// DC_NN_LEAVE overrides (0: none)
-static uint32_t nn_leave() {
-  static const uint32_t v = [] { const char* e = getenv("DC_NN_LEAVE"); return (e && e[0]) ? (uint32_t)std::min(32, std::max(0, atoi(e))) : kNnLeave; }();
-  return v;
-}
-
-uint32_t seg_block(uint32_t n_segments) {
-  static const uint32_t forced = [] { const char* e = getenv("DC_SEG_BLOCK"); return (e && e[0]) ? (uint32_t)std::max(1, atoi(e)) : 0u; }();
-  if (n_segments <= 1u) return 1u;
-  return forced ? forced : kSegBlockGroups;
-}
+uint32_t seg_block(uint32_t n_segments) { return n_segments <= 1u ? 1u : kSegBlockGroups; }
 
 // DC_POP_COMPONENTS=0: one component whatever the data looks like (measurements, tests)
 static bool components_off() {
@@ -1596,45 +1567,39 @@ __global__ void nn_open_kernel(const float* __restrict__ coords, uint32_t n_rows
                                const uint32_t* __restrict__ comp, uint32_t group_rows, QSeg q_seg,
                                const uint32_t* __restrict__ hdr, const float* __restrict__ nn_d2,
                                const float* __restrict__ hd_d2, const uint32_t* __restrict__ nn_idx,
-                               const uint32_t* __restrict__ hd_idx, const uint32_t* __restrict__ group_conf,
+                               const uint32_t* __restrict__ hd_idx,
                                unsigned long long* __restrict__ merge64, uint32_t* __restrict__ list,
-                               uint32_t* __restrict__ list_pos, uint32_t* __restrict__ count) {
+                               uint32_t* __restrict__ count) {
   // merge64 [2][n_rows] by frame: the packed (d2, frame) incumbents of the listed queries, which the search lowers
   // with 64-bit atomic minima (several waves per query) and nn_cross_write_kernel hands back.
-  // group_conf: the radius^2 up to which the query's group has visited its OWN component (nn_pruned_kernel, "left-over
-  // queries"; +inf: everything the group needed) -- a query whose incumbent lies beyond it is listed as well.
   if (hdr[1] != 0) return;
   const uint32_t n_comp = comp[kCompGrid + 5];
+  if (n_comp <= 1u) return;   // (one component: the sweep saw everything)
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = j < n_items;
-  uint32_t i = j, pos = j;
+  uint32_t i = j;
   if (perm_q) {   // (a position of the query order)
     i = live ? perm_q[j] : kInvalidFrame;
     live = live && i != kInvalidFrame && seg_owns(j / group_rows, q_seg);
   } else if (live) {
-    pos = invpos_r[i];
-    live = q_seg.stride <= 1 || seg_owns(pos / group_rows, q_seg);
+    live = q_seg.stride <= 1 || seg_owns(invpos_r[i] / group_rows, q_seg);
   }
   bool open = false;
   if (live) {
     const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
     const float inc_nn = nn_d2[i], inc_hd = hd_d2[i];
     const bool hd_possible = fkey_inv(~hdr[12]) < fe[i];
-    const float conf = __uint_as_float(group_conf[pos / group_rows]);
-    open = !(fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f) < conf);   // (left over by its group)
-    if (n_comp > 1u) {
-      const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_rows);
-      uint32_t c = 0;
-      if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
-      const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
-      for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
-        if (c2 == c) continue;
-        const float g2 = point_box_gap2(x, y, cbox[c2]);
-        open = open || (g2 <= inc_nn) || (hd_possible && g2 <= inc_hd);
-      }
+    const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_rows);
+    uint32_t c = 0;
+    if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
+    const float4* cbox = reinterpret_cast<const float4*>(comp + kCompBox);
+    for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
+      if (c2 == c) continue;
+      const float g2 = point_box_gap2(x, y, cbox[c2]);
+      open = open || (g2 <= inc_nn) || (hd_possible && g2 <= inc_hd);
     }
   }
-  // one atomic per block (a wave each was 15 000 atomics on one word with four left-over queries per group: 150 us)
+  // one atomic per block
   __shared__ uint32_t wave_n[4], wave_base[4];
   const uint64_t m = __builtin_amdgcn_ballot_w64(open);
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -1652,7 +1617,6 @@ __global__ void nn_open_kernel(const float* __restrict__ coords, uint32_t n_rows
   const uint32_t base = wave_base[threadIdx.x >> 6];
   if (open) {
     list[base + rank] = i;
-    list_pos[base + rank] = pos;
     merge64[i] = ((unsigned long long)__float_as_uint(nn_d2[i]) << 32) | nn_idx[i];
     merge64[(size_t)n_rows + i] = ((unsigned long long)__float_as_uint(hd_d2[i]) << 32) | hd_idx[i];
   }
@@ -1668,12 +1632,8 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ fe,
     const float* __restrict__ coords_r, const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r,
     const float2* __restrict__ ferange_r, const float* __restrict__ fe_c, const uint32_t* __restrict__ comp,
-    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ open_list, const uint32_t* __restrict__ open_pos,
-    const uint32_t* __restrict__ open_count, uint32_t T, unsigned long long* __restrict__ merge64,
-    const uint32_t* __restrict__ group_conf, const float4* __restrict__ box_q, uint32_t group_tiles, uint32_t T_q) {
-  // group_conf / box_q / group_tiles / T_q: the query's group of the sweep (tiles [g group_tiles, (g + 1) group_tiles) of
-  // the query order, T_q tiles) has visited every tile of its own component whose box is closer to the GROUP's box than
-  // sqrt(group_conf[g]); a query left over by its group searches the rest of the component here
+    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ open_list,
+    const uint32_t* __restrict__ open_count, uint32_t T, unsigned long long* __restrict__ merge64) {
   __shared__ uint32_t list[256];
   __shared__ float list_gap[256];
   if (hdr[1] != 0) return;
@@ -1700,31 +1660,12 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
     unsigned long long best_nn = __atomic_load_n(&merge64[q_frame], __ATOMIC_RELAXED);
     unsigned long long best_hd = __atomic_load_n(&merge64[(size_t)n_rows + q_frame], __ATOMIC_RELAXED);
     const unsigned long long start_nn = best_nn, start_hd = best_hd;
-    // the group's box and what the group has visited of its own component
-    const uint32_t q_group = open_pos[e] / (32u * group_tiles);
-    float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
-    for (uint32_t k = 0; k < group_tiles; ++k) {
-      const uint32_t t = q_group * group_tiles + k;
-      if (t < T_q) {
-        const float4 b = box_q[t];
-        gbox.x = fminf(gbox.x, b.x);
-        gbox.y = fmaxf(gbox.y, b.y);
-        gbox.z = fminf(gbox.z, b.z);
-        gbox.w = fmaxf(gbox.w, b.w);
-      }
-    }
-    const float conf = __uint_as_float(group_conf[q_group]);
-    const float conf_lo = conf * 0.999f;   // (tiles whose gap to the group's box is below this were visited by the sweep)
     for (uint32_t c2 = 0; c2 < n_comp; ++c2) {
-      const bool own_comp = c2 == q_comp;
+      if (c2 == q_comp) continue;   // (its own component: the sweep's business)
       {
         const float inc_nn = __uint_as_float((uint32_t)(best_nn >> 32)), inc_hd = __uint_as_float((uint32_t)(best_hd >> 32));
-        if (own_comp) {
-          if (fmaxf(inc_nn, q_hd ? inc_hd : 0.0f) < conf) continue;   // (settled inside what the group visited)
-        } else {
-          const float g2 = point_box_gap2(qx0, qx1, cbox[c2]);
-          if (!(g2 <= inc_nn) && !(q_hd && g2 <= inc_hd)) continue;
-        }
+        const float g2 = point_box_gap2(qx0, qx1, cbox[c2]);
+        if (!(g2 <= inc_nn) && !(q_hd && g2 <= inc_hd)) continue;
       }
       const uint32_t t_lo = max(range[2 * c2], s_lo), t_hi = min(range[2 * c2 + 1], s_hi);
       // 256 tiles per step: a lane tests four boxes whose loads are independent
@@ -1744,8 +1685,7 @@ __global__ __launch_bounds__(64) void nn_cross_kernel(
         for (int k = 0; k < 4; ++k) {
           const uint32_t t = base + 64u * (uint32_t)k + (uint32_t)lane;
           const float g2 = point_box_gap2(qx0, qx1, bx[k]);
-          bool ok = (t < t_hi) && ((g2 <= inc_nn) | (q_hd & (g2 <= inc_hd) & (flo[k] < q_fe)));
-          if (own_comp) ok = ok && !(box_gap2(gbox, bx[k]) < conf_lo);   // (not visited by the group's sweep)
+          const bool ok = (t < t_hi) && ((g2 <= inc_nn) | (q_hd & (g2 <= inc_hd) & (flo[k] < q_fe)));
           const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
           if (ok) {
             const uint32_t slot = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -1837,7 +1777,6 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   uint32_t* hdr = (uint32_t*)p;
   uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
   uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
-  uint32_t* group_conf = (uint32_t*)(p + L.off_perm);   // (a region of the full neighbour sweep, free here: the visited radii of the query groups, nn_pruned_kernel)
   uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
   uint32_t* perm_p = (uint32_t*)(p + L.off_perm_p);
   uint32_t* perm_q = (uint32_t*)(p + L.off_perm_q);
@@ -1890,25 +1829,20 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, 0.0f, cookie);
   }
-  // DC_NN_BLOCK_KEY = coarse free-energy bits (measurements): blocks of 2 x 2 cells, see compkey_kernel
-  static const unsigned block_coarse = [] { const char* e = getenv("DC_NN_BLOCK_KEY"); return (e && e[0]) ? (unsigned)std::max(0, atoi(e)) : 0u; }();
-  const unsigned coarse = (block_coarse > 0 && block_coarse <= fe_bits && fine_bits > 4) ? block_coarse : 0u;
-  const unsigned grid_bits = coarse ? fine_bits - 2u : fine_bits, low_bits = coarse ? fe_bits + 2u : fe_bits;
-  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows,
-                     cell_frames(true) * (coarse ? 4.0f : 1.0f), (uint32_t)grid_bits, comp);
+  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, cell_frames(true),
+                     (uint32_t)fine_bits, comp);
   // frames by (component, cell, free energy): ONE sort on a combined key
   hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
-                     (const uint32_t*)comp, grid_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, fe_bits, coarse);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, grid_bits + low_bits))
+                     (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, fe_bits);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, fine_bits + fe_bits))
     return;
-  pad_order(keys_out, vals_sorted, n_rows, low_bits, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
+  pad_order(keys_out, vals_sorted, n_rows, fe_bits, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
             T_r, stream);
   const float* coords_p = (const float*)(p + L.off_coords_p);
   hipLaunchKernelGGL(order_rows_kernel, dim3((32 * T_r + 255) / 256), blk, row_tile_smem(order_rows_kernel, n_cols), stream,
                      d_coords, n_cols, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p),
                      (float4*)(p + L.off_box_p), d_fe, (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos),
-                     (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr, group_conf,
-                     std::min(std::max(T_r, T_q), 32u * T_r));
+                     (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr);
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
   hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
                      L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
@@ -1945,7 +1879,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
 #define X(SV)                                                                                   \
   case SV:                                                                                      \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                        \
-      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, T_r, n_pos_q, q_mode, q_seg, -1.0f, nn_leave(), \
+      nn_pruned_step_##SV(d_coords, n_rows, n_cols, d_fe, d_ws, T_r, n_pos_q, q_mode, q_seg, -1.0f, \
                           d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, stream);                        \
     break;
     DC_FOR_EACH_S(X)
@@ -1960,18 +1894,15 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   uint32_t* open_count = hdr + kHdrOpen;
   unsigned long long* merge64 = (unsigned long long*)(p + L.off_merge64);
   const uint32_t n_items = own ? 32u * T_q : n_rows;
-  uint32_t* open_pos = (uint32_t*)(p + L.off_norm_s);   // (a region of the full neighbour sweep: free here)
   hipLaunchKernelGGL(nn_open_kernel, dim3((n_items + 255) / 256), blk, 0, stream, d_coords, n_rows, n_cols, d_fe,
                      (const uint32_t*)(p + L.off_invpos), own ? (const uint32_t*)perm_q : (const uint32_t*)nullptr, n_items,
                      (const uint32_t*)comp, 32u * tq, q_seg, (const uint32_t*)hdr, (const float*)d_nn_d2,
                      (const float*)d_hd_d2, (const uint32_t*)d_nn_idx, (const uint32_t*)d_hd_idx,
-                     (const uint32_t*)group_conf, merge64, open_list, open_pos, open_count);
+                     merge64, open_list, open_count);
   hipLaunchKernelGGL(nn_cross_kernel, dim3(8192), dim3(64), 0, stream, d_coords, n_rows, n_cols, d_fe, coords_p,
                      (const uint32_t*)perm_p, (const float4*)(p + L.off_box_p), (const float2*)(p + L.off_ferange_p),
                      (const float*)(p + L.off_fe_s), (const uint32_t*)comp, (const uint32_t*)hdr,
-                     (const uint32_t*)open_list, (const uint32_t*)open_pos, (const uint32_t*)open_count, T_r, merge64,
-                     (const uint32_t*)group_conf, (const float4*)(p + (own ? L.off_box_q : L.off_box_p)), tq,
-                     own ? T_q : T_r);
+                     (const uint32_t*)open_list, (const uint32_t*)open_count, T_r, merge64);
   hipLaunchKernelGGL(nn_cross_write_kernel, dim3(64), blk, 0, stream, (const uint32_t*)hdr, (const uint32_t*)comp,
                      (const uint32_t*)open_list, (const uint32_t*)open_count, (const unsigned long long*)merge64, n_rows,
                      d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);

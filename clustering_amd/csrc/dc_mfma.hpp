@@ -65,10 +65,9 @@ __host__ __device__ inline bool seg_owns(uint32_t group, QSeg q) { return (group
 __host__ __device__ inline uint32_t seg_unit(uint32_t group, QSeg q) {        // (inverse of seg_group for an owned group)
   return (group / (q.block * q.stride)) * q.block + group % q.block;
 }
-// groups per block for n_segments segments (every rank derives the same number: DC_SEG_BLOCK overrides it for
-// measurements, in every process alike)
+// groups per block for n_segments segments (a constant: every rank derives the same deal; blocks of 4 .. 256 groups
+// were measured at C3 and change nothing -- DESIGN.md 6)
 constexpr uint32_t kSegBlockGroups = 1;
-constexpr uint32_t kNnLeave = 0;   // (queries a group may leave to the exact follow-up: measured, no net gain -- DESIGN.md 4.8)
 uint32_t seg_block(uint32_t n_segments);
 // positions the padded orders of the pruned population sweeps add (dc_mfma_kernels.hpp: components padded to whole
 // query groups: kMaxComp x kMaxGroupRows)

@@ -1965,11 +1965,8 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-#ifndef DC_NN_MIN_WG   // (experiment builds: workgroups of 256 threads per CU the compiler must leave room for)
-#define DC_NN_MIN_WG 2
-#endif
 template <int NM, int TQ>
-__global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
+__global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ fe, const uint4* __restrict__ img_r,
     const float* __restrict__ norms_r, const uint32_t* __restrict__ perm_r,
@@ -1982,16 +1979,11 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     int full_range, float cell2,
     const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter,
     unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, CompView CV,
-    uint32_t* __restrict__ group_conf, uint32_t leave) {
-  // group_conf / leave: see "left-over queries" at the settle test below
+    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2, CompView CV) {
   // dynamic LDS, per wave of the workgroup: the survivor list of a scan round [kListCap], then [TQ*32][n_cols] query
   // rows (original coordinates), then the candidate queues [TQ][kQueueCap][64]
   extern __shared__ __attribute__((aligned(16))) float nn_dyn_lds[];
   if (hdr[1] != 0) return;
-#ifdef DC_NN_PROFILE
-  const unsigned long long prof_t0 = clock64();
-#endif
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const int wib = threadIdx.x >> 6;
   // waves per workgroup (kWavesPerGroup): the waves share nothing, and a workgroup holds its LDS until its LAST
@@ -2075,9 +2067,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
-#ifdef DC_NN_PROFILE
-  const unsigned long long prof_ta = clock64();   // (the loads of the four tiles have been issued -- and used)
-#endif
   // published bounds and the original coordinates of the queries (for the exact path) into LDS
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt)
@@ -2106,9 +2095,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
                        jq[qt], (livemask[qt] >> lane) & 1, n_cols, lane);
     }
   }
-#ifdef DC_NN_PROFILE
-  const unsigned long long prof_tb = clock64();   // (rows and bounds are in LDS)
-#endif
   // Seeds: the frames next to each query in the sweep's order (same cell, neighbouring free energy; the
   // ones before it have a lower free energy) are evaluated exactly before the first ring.  They are
   // ordinary candidates; what they buy is finite running minima from the start -- without them the first
@@ -2166,11 +2152,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
   // ordering pass): a query at that level has no lower-FE neighbour
   const float fe_floor = fkey_inv(~hdr[12]);
 
-#ifdef DC_NN_PROFILE
-  uint32_t prof_rare = 0, prof_trig = 0, prof_cand = 0;
-  const unsigned long long prof_t1 = clock64();   // (queries, seeds and thresholds are set up)
-  unsigned long long prof_t2 = 0;                 // (the first chain is about to start)
-#endif
   // evaluate and empty the candidate list (64 candidates at a time, one per lane)
   auto flush = [&]() {
     nn_wave_flush(cand, qn, qrows, best64, TQ * 32, coords_c, perm_r, n_cols, lane);
@@ -2187,7 +2168,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
   cell2 = comp_cell * comp_cell;
   const uint32_t U_stride = (T + n_chunks - 1) / n_chunks;   // boxes of a share in box_t
   const float dgx = gbox.y - gbox.x, dgy = gbox.w - gbox.z;
-  float conf_r2 = INFINITY;                                // radius^2 below which this share has been visited completely when the sweep stops early
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
   if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
@@ -2221,9 +2201,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
       // Reference tile data in two register buffers (the loads run one survivor ahead); the chains
       // are software-pipelined over two accumulator tiles: while the MFMAs of one chain run, the
       // tile minimum of the previous chain issues in their shadow (a wave issues in order).
-#ifdef DC_NN_PROFILE
-      if (prof_t2 == 0) prof_t2 = clock64();
-#endif
       s16x8 a0[NM];
       float4 n0[4];
       auto entry = [&](uint32_t i) {
@@ -2245,9 +2222,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
         const float thr = (fr.x < Q.feq) ? Q.bh : Q.bn;
         const bool rare = tmin < thr;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
-#ifdef DC_NN_PROFILE
-          ++prof_rare;
-#endif
           const bool all_lower = fr.y < Q.feq;
           const bool mixed = (fr.x < Q.feq) & !all_lower;
           const bool special = mixed | (t == (Q.spos >> 5));
@@ -2277,9 +2251,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
           const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
           const bool trig = (tmin < bn) | (hmin < bh);
           if (__builtin_amdgcn_ballot_w64(trig) != 0) {
-#ifdef DC_NN_PROFILE
-            ++prof_trig;
-#endif
             // park this tile's candidates (values within the band of the running minima); element r
             // of the accumulator is bit (15 - r) of the masks
             uint32_t mn = 0, mh = 0;
@@ -2321,9 +2292,6 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
                 m &= m - 1;
               }
               qn += n_new;
-#ifdef DC_NN_PROFILE
-              prof_cand += n_new;
-#endif
             }
             if (qn >= 64u) flush();
           }
@@ -2409,15 +2377,8 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
     const float sure = r2_hi * 0.9999f;
-    // Left-over queries.  The ring a group must still visit is set by its WORST query -- and a group's few worst
-    // queries (a frame at the edge of the cluster, one whose lower-energy neighbour is far) are far worse than the
-    // rest: leaving the four worst of 128 to an exact follow-up takes 19 % off the tile pairs of C3
-    // (scratch/nn_outlier_study.py) for 1 300 exact (query, tile) searches per group.  So the next ring covers the
-    // (leave + 1)-th worst open query; the sweep stops when at most `leave` (distinct values of) open queries remain,
-    // records the radius up to which this share has been visited (group_conf[group], minimum over the shares), and
-    // nn_open_kernel / nn_cross_kernel finish the queries whose incumbent lies beyond it.  leave = 0: the group
-    // confirms all its queries itself.
-    float w4[TQ];            // what each open query of this lane still has to confirm (0: settled; h = 1 lanes: their twin's)
+    // The next ring must cover the WORST open query of the group: the largest incumbent still to be confirmed.
+    float need = 0.0f;
 #pragma unroll
     for (int qt = 0; qt < TQ; ++qt) {
       const bool live = (livemask[qt] >> lane) & 1;
@@ -2427,23 +2388,10 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
       const float inc_hd = fminf(g_pub[TQ * 32 + qt * 32 + c], __uint_as_float((uint32_t)(best64[TQ * 32 + qt * 32 + c] >> 32)));
       const float want = fminf(fmaxf(inc_nn, hd_possible ? inc_hd : 0.0f), 3.0e38f);   // (no candidate at all: 3e38)
       const bool open = live & (h == 0) & !(want < sure);
-      w4[qt] = open ? want : 0.0f;
+      need = fmaxf(need, open ? want : 0.0f);
     }
-    // the (leave + 1)-th largest distinct value among the open queries (0: there are at most `leave`)
-    float need = 0.0f, bound = INFINITY;
-    for (uint32_t i = 0; i <= leave; ++i) {
-      float m = 0.0f;
-#pragma unroll
-      for (int qt = 0; qt < TQ; ++qt) m = fmaxf(m, (w4[qt] < bound) ? w4[qt] : 0.0f);
-      m = wave_max(m);
-      need = m;
-      bound = m;
-      if (!(m > 0.0f)) break;
-    }
-    if (!(need > 0.0f)) {
-      conf_r2 = sure;   // (everything closer than this has been visited; what is still open is left over)
-      break;
-    }
+    need = wave_max(need);
+    if (!(need > 0.0f)) break;   // every query of the group is settled
     r2_lo = r2_hi;
     if (need >= 1.0e38f) {
       r2_hi = r2_hi * 4.0f;   // (a query without any candidate yet)
@@ -2454,23 +2402,7 @@ __global__ __launch_bounds__(256, DC_NN_MIN_WG) void nn_pruned_kernel(
     }
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
   }
-  if (lane == 0 && leave > 0 && conf_r2 < 3.0e38f) atomicMin(group_conf + wave, __float_as_uint(conf_r2));
   if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
-#ifdef DC_NN_PROFILE
-  if (lane == 0 && chain_counter) {   // header words 14..19 (scratch/nn_profile.sh)
-    atomicAdd(chain_counter + 5, (unsigned long long)prof_rare);
-    atomicAdd(chain_counter + 6, (unsigned long long)prof_trig);
-    atomicAdd(chain_counter + 7, (unsigned long long)prof_cand);
-    // header words 32.. (bytes 128..): waves, cycles in all, until the set-up is done, until the first chain
-    const unsigned long long t3 = clock64();
-    atomicAdd(chain_counter + 14, 1ull);
-    atomicAdd(chain_counter + 15, t3 - prof_t0);
-    atomicAdd(chain_counter + 16, prof_t1 - prof_t0);
-    atomicAdd(chain_counter + 17, (prof_t2 ? prof_t2 : t3) - prof_t0);
-    atomicAdd(chain_counter + 18, prof_ta - prof_t0);
-    atomicAdd(chain_counter + 19, prof_tb - prof_t0);
-  }
-#endif
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
@@ -2540,13 +2472,8 @@ __global__ void nn_merge_unpack_rows_kernel(const unsigned long long* __restrict
 // leave room for at two waves per SIMD; each reference fragment is fetched once per TQ chains.  Measured at
 // 300k rows: NM = 5 (D = 24) 5.6 / 6.2 ms with four tiles against 6.4 / 6.5 with two; NM = 6 (D = 30) 7.8 / 9.3 against
 // 7.1 / 7.4; NM = 7 (D = 32) 8.2 / 10.0 against 7.7 / 8.3; NM = 8 (D = 40) 11.0 / 11.4 against 8.8 / 10.0.
-#ifdef DC_EXP_NN_TQ2   // (experiment builds, scratch/nn_tq_exp.sh: two query tiles per wave at NM <= 2 as well)
-template <int NM>
-constexpr int tq_for = (NM <= 2) ? 2 : ((NM <= 5) ? 4 : 2);
-#else
 template <int NM>
 constexpr int tq_for = (NM <= 5) ? 4 : 2;
-#endif
 
 // the population sweep keeps less state per query tile: with two MFMAs per chain six tiles fit
 // (measured at C3: 23.6 ms against 25.1 ms with four; eight spill; the neighbour sweep loses at six)
@@ -2604,8 +2531,6 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
   float cell2;
   const uint32_t* tile_comp_q;   // component of every tile of the query order
   const uint32_t* comp;          // component region
-  uint32_t* group_conf;          // [query groups] visited radius^2 (float bits) of a group that left queries over
-  uint32_t leave;                // queries a group of the per-wave sweep may leave to the exact follow-up
 };
 
 // Reference chunks per query group (gridDim.y).  The cost of a query group follows the local density
@@ -2696,7 +2621,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
                      coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
                      A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
                      A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx,
-                     hd_d2, CV, A.group_conf, A.leave); sweep_timer_mark(1, false, s); }
+                     hd_d2, CV); sweep_timer_mark(1, false, s); }
   if (n_chunks > 1 && A.full_range)
     hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                        (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)TQV, A.q_seg,
@@ -2896,7 +2821,7 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                             int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s);     \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
                            void* d_ws, uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg, float cell2, \
-                           uint32_t leave, uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2, \
+                           uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,             \
                            hipStream_t s);                                                       \
   void nn_mfma_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,      \
                          uint32_t i_from, uint32_t i_to, uint32_t* nn_idx, float* nn_d2,         \

@@ -31,7 +31,7 @@ void DC_CAT(pop_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uin
 
 void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
                                       const float* fe, void* d_ws, uint32_t T_ref, uint32_t n_q, int q_mode,
-                                      QSeg q_seg, float cell2, uint32_t leave, uint32_t* nn_idx, float* nn_d2,
+                                      QSeg q_seg, float cell2, uint32_t* nn_idx, float* nn_d2,
                                       uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
@@ -58,8 +58,6 @@ void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint
   A.cell2 = cell2;
   A.tile_comp_q = (const uint32_t*)(p + (own ? L.off_tile_comp_q : L.off_tile_comp));
   A.comp = (const uint32_t*)(p + L.off_comp);
-  A.group_conf = (uint32_t*)(p + L.off_perm);   // (a region of the full neighbour sweep: free here)
-  A.leave = leave;
   // (T_ref: tiles of the padded reference order; n_q: positions of the query order)
   nn_pruned_dispatch<DC_STEP>(coords, n_rows, n_cols, fe, A, T_ref, (const uint32_t*)p,
                               (unsigned long long*)(p + 16), nn_idx, nn_d2, hd_idx, hd_d2, s);

@@ -228,20 +228,3 @@ def test_components_switched_off_give_the_same_populations():
         out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("OUT ")][-1][4:]))
     assert out[0]["n"] == 3 and out[1]["n"] == 1
     assert out[0]["sum"] == out[1]["sum"] and out[0]["w"] == out[1]["w"]
-
-
-@pytest.mark.gpu
-def test_left_over_queries_of_the_neighbour_sweep():
-    """DC_NN_LEAVE (nn_pruned_kernel "left-over queries", off by default): a query group stops its rings before its few
-    worst queries are confirmed and the exact follow-up (nn_open_kernel / nn_cross_kernel) finishes them -- the neighbour
-    tests of this file and the segment tests again in a child process with four left-over queries per group."""
-    import os, subprocess, sys
-    if os.environ.get("DC_NN_LEAVE_CHILD"):
-        pytest.skip("the child run itself")
-    env = dict(os.environ, DC_NN_LEAVE="4", DC_NN_LEAVE_CHILD="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_components.py"),
-                        os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
-                        "spread or adjacent or extent or segments_of_a_sharded or neighbours or nearest"],
-                       env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here))
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -522,22 +522,6 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
         assert bool((got.view(torch.int32) == want.view(torch.int32)).all())   # dc_hip_neighbors_block_unpack_dev
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("block", [3, 64])
-def test_segments_dealt_in_blocks_of_groups(block):
-    """QSeg::block (dc_mfma.hpp): the query groups dealt to the segments in blocks of consecutive groups instead of one
-    by one -- DC_SEG_BLOCK is read once per process, so the segment tests above run again in a child process (block 64:
-    most segments of the small shapes own no group at all)."""
-    import os, subprocess, sys
-    if os.environ.get("DC_SEG_BLOCK_CHILD"):
-        pytest.skip("the child run itself")
-    env = dict(os.environ, DC_SEG_BLOCK=str(block), DC_SEG_BLOCK_CHILD="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                        "test_segments_of_a_sharded_run_merge_to_the_full_result", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 SHARED_CHILD = r"""
 import sys
 import numpy as np, torch
