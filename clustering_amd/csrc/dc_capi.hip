@@ -391,7 +391,8 @@ int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, 
       return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                   dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
     // (the pruned sweep packs reference positions into 30 bits of its candidate queue entries)
-    const bool full_sweep = variant == DC_VARIANT_MFMA || n_rows >= ((size_t)1 << 30);
+    // (the pruned sweep packs reference POSITIONS of the padded order into 30 bits: kQueuePosMask)
+    const bool full_sweep = variant == DC_VARIANT_MFMA || n_rows + dc::kOrderPadRows > ((size_t)1 << 30);
     if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
                                   full_sweep, s, stats_valid))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
@@ -465,7 +466,7 @@ namespace {
 // did dc_hip_nearest_neighbors_segment_dev(variant) run the pruned matrix-core sweep (segments of the spatial order)?
 bool segment_sweep_is_pruned(int variant, size_t n_rows, size_t n_cols) {
   variant &= DC_VARIANT_MASK;
-  return want_mfma(variant, n_cols) && variant != DC_VARIANT_MFMA && n_rows < ((size_t)1 << 30);
+  return want_mfma(variant, n_cols) && variant != DC_VARIANT_MFMA && n_rows + dc::kOrderPadRows <= ((size_t)1 << 30);
 }
 }  // namespace
 

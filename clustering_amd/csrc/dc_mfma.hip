@@ -73,6 +73,40 @@ __device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v, uint32_t
   __syncthreads();
 }
 
+// Content fingerprint of a coordinate array (header words kHdrFp..+1, 64 bits): the wrap-around sum over all elements of
+// (bits + c) * (2 * element index + 1) -- order-independent, so any kernel that reads every element can form it with
+// integer atomics.  The statistics pass stores it; a call that CLAIMS the statistics are still valid
+// (DC_FLAG_STATS_VALID) recomputes it in one streaming pass and the guard compares: an array rewritten in place, or a
+// new array of the same shape at the same address, no longer passes for the old one.
+__device__ __forceinline__ unsigned long long fp_term(uint32_t bits, unsigned long long e) {
+  return (unsigned long long)(bits + 0x9E3779B9u) * (2ull * e + 1ull);
+}
+__device__ __forceinline__ void fp_publish(unsigned long long v, unsigned long long* dst, unsigned long long* part /* LDS [4] */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, part[0] + part[1] + part[2] + part[3]);
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void fingerprint_kernel(const float* __restrict__ coords, size_t total,
+                                                          unsigned long long* __restrict__ dst) {
+  __shared__ unsigned long long part[4];
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(coords);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long f = 0;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; e + 3 * stride < total; e += 4 * stride) {   // four loads in flight
+    const uint32_t v0 = w[e], v1 = w[e + stride], v2 = w[e + 2 * stride], v3 = w[e + 3 * stride];
+    f += fp_term(v0, e) + fp_term(v1, e + stride) + fp_term(v2, e + 2 * stride) + fp_term(v3, e + 3 * stride);
+  }
+  for (; e < total; e += stride) f += fp_term(w[e], e);
+  fp_publish(f, dst, part);
+}
+
 // Header pass over the frames in natural order: max |x'|^2 (word 0), non-finite / overflow flag
 // (word 1) and the extent of columns 0/1 (words 8..11: ~key(min col0), key(max col0), ~key(min col1),
 // key(max col1), all maintained with atomicMax).  |x'|^2 is formed exactly as image_kernel forms it,
@@ -80,10 +114,12 @@ __device__ __forceinline__ void publish_max(uint32_t* addr, uint32_t v, uint32_t
 __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                                 const float* __restrict__ means, uint32_t* __restrict__ hdr, uint32_t cookie) {
   __shared__ uint32_t wave_max[4];
+  __shared__ unsigned long long fp_part[4];
   __shared__ float mu[kMaxCols];
   if (threadIdx.x < D) mu[threadIdx.x] = means[threadIdx.x];
   __syncthreads();
   uint32_t m_norm = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  unsigned long long fp = 0;   // content fingerprint of the rows this thread reads (fp_term)
   bool bad = false;
   // a row per lane, read where it lies: the ten loads of a wave touch the same 2.5 KB and meet in the vector cache
   const bool pairs = (D % 2u == 0) && ((reinterpret_cast<uintptr_t>(coords) & 7u) == 0);
@@ -98,6 +134,7 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
       c1 = first.y;
       for (uint32_t k = 0; k < D; k += 2) {
         const float2 v = x2[k >> 1];
+        fp += fp_term(__float_as_uint(v.x), (unsigned long long)row * D + k) + fp_term(__float_as_uint(v.y), (unsigned long long)row * D + k + 1);
         const float a = v.x - mu[k], b = v.y - mu[k + 1];
         nrm += (double)a * (double)a;
         nrm += (double)b * (double)b;
@@ -106,6 +143,7 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
       c0 = x[0];
       if (D > 1) c1 = x[1];
       for (uint32_t k = 0; k < D; ++k) {
+        fp += fp_term(__float_as_uint(x[k]), (unsigned long long)row * D + k);
         const float v = x[k] - mu[k];
         nrm += (double)v * (double)v;
       }
@@ -127,15 +165,20 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   publish_max(hdr + 9, m1, wave_max);
   publish_max(hdr + 10, m2, wave_max);
   publish_max(hdr + 11, m3, wave_max);
+  fp_publish(fp, reinterpret_cast<unsigned long long*>(hdr + kHdrFp), fp_part);
 }
 
 // DC_FLAG_STATS_VALID: the caller says the header still holds the statistics of these coordinates.  If the cookie
-// says otherwise (the previous call on this workspace was not a matrix-core sweep over the same array and shape) the
-// data is flagged: the matrix-core kernels stand down and the gated direct kernels answer -- slow, never wrong.
+// (array address and shape) or the content fingerprint (recomputed by this call: words kHdrFp + 2..3) says otherwise
+// -- the previous call on this workspace was not a matrix-core sweep over the same array, or the array has been
+// rewritten since -- the data is flagged: the matrix-core kernels stand down and the gated direct kernels answer --
+// slow, never wrong.
 // Flag word 1: bit 0 = non-finite / overflow-prone coordinates (a statistic: it stays), bit 1 = cookie mismatch,
 // bit 2 = NaN free energies (belongs to one neighbour sweep: cleared here).
 __global__ void stats_guard_kernel(uint32_t* __restrict__ hdr, uint32_t cookie) {
-  hdr[1] = (hdr[1] & 1u) | ((hdr[kHdrCookie] != cookie) ? 2u : 0u);
+  const bool same = hdr[kHdrCookie] == cookie && hdr[kHdrFp] == hdr[kHdrFp + 2] && hdr[kHdrFp + 1] == hdr[kHdrFp + 3];
+  hdr[1] = (hdr[1] & 1u) | (same ? 0u : 2u);
+  if (!same) hdr[kHdrCookie] = 0u;   // (the component partition in the workspace is not this array's either)
 }
 
 // dynamic LDS of image_kernel: per wave of the 256-thread block the 32 rows of its tile and their origin
@@ -1153,6 +1196,10 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
     // stay; only the per-sweep words start over (evaluated-tile counters: words 2..5; free-energy range: 12..13)
     if (hipMemsetAsync(p + 8, 0, 16, stream) != hipSuccess) return -1;
     if (hipMemsetAsync(p + 48, 0, 8, stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(p + 4 * (kHdrFp + 2), 0, 8, stream) != hipSuccess) return -1;
+    const size_t total = (size_t)n_rows * n_cols;
+    hipLaunchKernelGGL(fingerprint_kernel, dim3((uint32_t)std::min<size_t>(1024, (total + 1023) / 1024)), dim3(256), 0, stream,
+                       d_coords, total, (unsigned long long*)(p + 4 * (kHdrFp + 2)));
     hipLaunchKernelGGL(stats_guard_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)p, cookie);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
@@ -1917,6 +1964,18 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
 __device__ __forceinline__ uint32_t block_none(uint32_t c, uint32_t n_rows) {
   return (c & 1u) ? __float_as_uint(FLT_MAX) : n_rows + 1u;
 }
+// Layout header: the last kBlockHdrRows entries of plane 0 of a block say under which layout it was packed (by position
+// or row block, positions of the padded order, group size, segment count, groups per deal, and a 64-bit hash of the
+// order itself): every rank must have derived the SAME order, or its rows would be scattered to the wrong frames
+// without any sign.  The hosts compare the headers of the gathered blocks (clustering_amd/distributed.py, dc_session.hip).
+constexpr uint32_t kBlockHdrRows = 32, kBlockMagic = 0x6E6E4200u;   // "nnB" | by_position
+__global__ __launch_bounds__(256) void perm_hash_kernel(const uint32_t* __restrict__ perm, uint32_t n_pos,
+                                                        unsigned long long* __restrict__ dst) {
+  __shared__ unsigned long long part[4];
+  unsigned long long f = 0;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pos; p += gridDim.x * blockDim.x) f += fp_term(perm[p], p);
+  fp_publish(f, dst, part);
+}
 __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const float* __restrict__ nn_d2,
                                      const uint32_t* __restrict__ hd_idx, const float* __restrict__ hd_d2,
                                      uint32_t n_rows, uint32_t n_pos /* positions of the padded order */,
@@ -1926,6 +1985,20 @@ __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const 
   const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= block_rows) return;
   const bool by_position = gsize != 0u && hdr[1] == 0u;
+  const uint32_t payload = block_rows - kBlockHdrRows;
+  if (l >= payload) {
+    const uint32_t k = l - payload;
+    uint32_t w = 0;
+    if (k == 0) w = kBlockMagic | (by_position ? 1u : 0u);
+    if (k == 1) w = by_position ? n_pos : n_rows;
+    if (k == 2) w = by_position ? gsize : 0u;
+    if (k == 3) w = G;
+    if (k == 4) w = by_position ? seg_blk : 0u;
+    if (k == 5 || k == 6) w = by_position ? hdr[kHdrFp + 4 + (k - 5)] : 0u;   // (perm_hash_kernel)
+    block[l] = w;
+    for (uint32_t c = 1; c < 4; ++c) block[c * (size_t)block_rows + l] = block_none(c, n_rows);
+    return;
+  }
   uint32_t i = 0xFFFFFFFFu;
   if (by_position) {
     const unsigned long long p = (unsigned long long)seg_group(l / gsize, QSeg{G, seg, seg_blk}) * gsize + l % gsize;
@@ -1978,12 +2051,12 @@ static uint32_t nn_order_tiles(uint32_t n_rows, uint32_t n_cols) {
 size_t nn_block_rows(size_t n_rows, size_t n_cols, size_t n_segments) {
   if (n_segments == 0 || n_rows == 0) return 0;
   const size_t row_block = n_rows - (n_segments - 1) * (n_rows / n_segments);   // the last (largest) row block
-  if (!mfma_supports(n_cols)) return row_block;
+  if (!mfma_supports(n_cols)) return row_block + kBlockHdrRows;
   const size_t gs = nn_group_rows((uint32_t)n_rows, (uint32_t)n_cols);
   const size_t groups = ((size_t)32 * nn_order_tiles((uint32_t)n_rows, (uint32_t)n_cols) + gs - 1) / gs;
   // (segment 0 owns the most groups of a block-cyclic deal)
   const size_t most = seg_groups((uint32_t)groups, QSeg{(uint32_t)n_segments, 0u, seg_block((uint32_t)n_segments)});
-  return std::max(row_block, most * gs);
+  return std::max(row_block, most * gs) + kBlockHdrRows;   // (+ the layout header, nn_block_pack_kernel)
 }
 void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,
                           const float* d_hd_d2, uint32_t n_rows, uint32_t n_cols, uint32_t segment,
@@ -1991,6 +2064,13 @@ void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const 
   const uint32_t rows = (uint32_t)nn_block_rows(n_rows, n_cols, n_segments);
   const Layout L = make_layout(n_rows, n_cols);
   const char* p = (const char*)d_ws;
+  if (pruned) {   // hash of the order the block is packed by (header words kHdrFp + 4..5)
+    unsigned long long* dst = (unsigned long long*)(const_cast<char*>(p) + 4 * (kHdrFp + 4));
+    (void)hipMemsetAsync(dst, 0, 8, stream);
+    const uint32_t n_pos = 32u * nn_order_tiles(n_rows, n_cols);
+    hipLaunchKernelGGL(perm_hash_kernel, dim3(std::min<uint32_t>((n_pos + 255) / 256, 512u)), dim3(256), 0, stream,
+                       (const uint32_t*)(p + L.off_perm_p), n_pos, dst);
+  }
   hipLaunchKernelGGL(nn_block_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2, d_hd_idx,
                      d_hd_d2, n_rows, 32u * nn_order_tiles(n_rows, n_cols), pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, seg_block(n_segments), rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block);

@@ -323,6 +323,9 @@ struct Scale {
   int g, a, rounded;
 };
 constexpr uint32_t kHdrScale = 20;      // header words 20..24: bits(c), bits(s2), g, a, rounded
+constexpr uint32_t kHdrFp = 14;         // words 14..15: content fingerprint of the array the statistics belong to (64 bits); 16..17: the
+                                        // fingerprint a DC_FLAG_STATS_VALID call recomputes for the guard (dc_mfma.hip fp_term); 18..19: hash of the
+                                        // neighbour sweep's order (layout header of the all-gather blocks)
 constexpr uint32_t kHdrCookie = 28;     // whose statistics the header holds (array, shape); 0 after a reset
 constexpr uint32_t kHdrMused = 31;      // the extent max |x - origin|^2 the current sweep's scale was chosen for (float bits)
 constexpr uint32_t kHdrOpen = 30;       // neighbour sweeps: queries listed for the search in other components (nn_open_kernel)

@@ -6,6 +6,7 @@
 #include "../../include/dc_density.h"
 
 #include <algorithm>
+#include <cstring>
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
@@ -285,19 +286,35 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
   // partner lists of ALL frames come from one GPU sweep (radius graph), cached per (coords, max_dist).
   namespace H = Clustering::Density::HIP;
   const std::size_t n_rows = sorted_fe.size();
+  // The reference calls this once per FRAME of a screening pass (density_clustering_common.cpp:37-134), so a cache hit
+  // must cost O(1): the key is the identity of both arrays (address, size) plus a fingerprint of 64 samples of each --
+  // a rewritten buffer or a re-sorted list changes a sample with near certainty; the full-buffer fingerprint of
+  // resident_session decides on every miss.
   struct Cache {
     const float* coords = nullptr;
+    const FreeEnergy* order = nullptr;
     std::size_t n_rows = 0, n_cols = 0;
     float max_dist = 0.0f;
-    std::uint64_t order_fp = 0;
+    std::uint64_t sample_fp = 0;
     H::RadiusGraph graph;
     std::vector<std::uint32_t> pos_of;   // frame -> position in sorted_fe
   };
   static Cache cache;
-  std::uint64_t order_fp = 1469598103934665603ull;
-  for (const auto& e : sorted_fe) order_fp = (order_fp ^ e.first) * 1099511628211ull;
-  if (cache.coords != coords || cache.n_rows != n_rows || cache.n_cols != n_cols || cache.max_dist != max_dist ||
-      cache.order_fp != order_fp) {
+  std::uint64_t sample_fp = 1469598103934665603ull;
+  {
+    const std::uint32_t* w = reinterpret_cast<const std::uint32_t*>(coords);
+    const std::size_t n_words = n_rows * n_cols;
+    for (std::size_t k = 0; k < 64 && n_words > 0; ++k)
+      sample_fp = (sample_fp ^ w[(k * 0x9E3779B97F4A7C15ull) % n_words]) * 1099511628211ull;
+    for (std::size_t k = 0; k < 64 && n_rows > 0; ++k) {
+      const FreeEnergy& e = sorted_fe[(k * 0xC2B2AE3D27D4EB4Full) % n_rows];
+      std::uint32_t fb;
+      std::memcpy(&fb, &e.second, sizeof fb);
+      sample_fp = (sample_fp ^ e.first ^ ((std::uint64_t)fb << 32)) * 1099511628211ull;
+    }
+  }
+  if (cache.coords != coords || cache.order != sorted_fe.data() || cache.n_rows != n_rows || cache.n_cols != n_cols ||
+      cache.max_dist != max_dist || cache.sample_fp != sample_fp) {
     cache = Cache();
     std::string err;
     if (!H::build_radius_graph(resident_session(coords, n_rows, n_cols), n_rows, max_dist, &cache.graph, &err)) {
@@ -305,12 +322,19 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
       exit(EXIT_FAILURE);
     }
     cache.coords = coords;
+    cache.order = sorted_fe.data();
     cache.n_rows = n_rows;
     cache.n_cols = n_cols;
     cache.max_dist = max_dist;
-    cache.order_fp = order_fp;
-    cache.pos_of.resize(n_rows);
-    for (std::size_t p = 0; p < n_rows; ++p) cache.pos_of[sorted_fe[p].first] = (std::uint32_t)p;
+    cache.sample_fp = sample_fp;
+    cache.pos_of.assign(n_rows, 0xFFFFFFFFu);
+    for (std::size_t p = 0; p < n_rows; ++p) {
+      if (sorted_fe[p].first >= n_rows) {
+        std::cerr << "error in high_density_neighborhood: frame id " << sorted_fe[p].first << " out of range" << std::endl;
+        exit(EXIT_FAILURE);
+      }
+      cache.pos_of[sorted_fe[p].first] = (std::uint32_t)p;
+    }
   }
   std::set<std::size_t> nh;
   const std::size_t frame = sorted_fe[i_frame].first;

@@ -324,13 +324,26 @@ def pack_neighbor_block(coords, nn_idx, nn_d2, hd_idx, hd_d2, segment, n_segment
     return out
 
 
+BLOCK_HEADER_ROWS = 32    # the last entries of plane 0 of a block: its layout header (dc_mfma.hip nn_block_pack_kernel)
+
+
+def check_neighbor_block_layout(blocks):
+    """All ranks must have packed their blocks under the SAME layout (by position or row block, the same padded order,
+    group size and deal -- words 0..6 of the header); a rank that derived another order would have its rows scattered
+    to the wrong frames without any other sign.  One small device comparison + a synchronisation."""
+    hdr = blocks[:, 0, -BLOCK_HEADER_ROWS:-BLOCK_HEADER_ROWS + 8]
+    if not bool((hdr == hdr[0:1]).all()):
+        raise RuntimeError("neighbour blocks of the ranks were packed under different layouts: " + str(hdr.cpu().tolist()))
+
+
 def unpack_neighbor_blocks(coords, blocks, n_segments, variant="auto", out=None):
     """blocks int32 [n_segments, 4, block_rows] gathered from all ranks -> (nn_idx, nn_d2, hd_idx, hd_d2) by frame
-    (dc_hip_neighbors_block_unpack_dev)"""
+    (dc_hip_neighbors_block_unpack_dev); the blocks' layout headers are compared first"""
     n_rows, n_cols = _check_coords(coords)
     dev = coords.device
     rows = neighbor_block_rows(n_rows, n_cols, n_segments)
     assert blocks.is_contiguous() and blocks.dtype == torch.int32 and blocks.numel() == n_segments * 4 * rows
+    check_neighbor_block_layout(blocks.view(n_segments, 4, rows))
     if out is None:
         out = (torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev),
                torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev))

@@ -73,7 +73,11 @@ typedef enum dc_variant {
  * non-finite flag and the bounding box in this workspace's header were computed by an earlier sweep over
  * the SAME d_coords (same contents) and are still valid -- the sweep skips its three statistics passes.
  * The reference runs populations and then neighbours over one coordinate array
- * (density_clustering.cpp:616-621, 659-663): the second call of such a pair may set it. */
+ * (density_clustering.cpp:616-621, 659-663): the second call of such a pair may set it.  The claim is
+ * CHECKED on the device: address, shape and a 64-bit content fingerprint of the whole array (one streaming
+ * pass, recomputed by the claiming call) must equal what the statistics pass stored; otherwise -- another
+ * array, the same buffer rewritten in place, a reused allocation -- the sweep is answered by the exact
+ * direct kernels: slower, same results. */
 #define DC_FLAG_STATS_VALID 0x100
 #define DC_VARIANT_MASK 0xFF
 

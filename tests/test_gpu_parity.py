@@ -516,8 +516,14 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
     # the all-gather merge: the segments' dense blocks, stacked as an all_gather_into_tensor would, scattered back
     rows = dens.neighbor_block_rows(n_rows, n_cols, n_seg)
     assert all(tuple(b.shape) == (4, rows) for b in blocks) and n_seg * rows >= n_rows
-    live = sum(int((b[0] <= n_rows).sum()) for b in blocks) if n_rows > 1 else n_rows
+    H = dens.BLOCK_HEADER_ROWS    # (the layout header at the end of plane 0)
+    live = sum(int((b[0, :-H] <= n_rows).sum()) for b in blocks) if n_rows > 1 else n_rows
     assert live == n_rows, "every row sits in exactly one block"
+    assert all(bool((b[0, -H:-H + 8] == blocks[0][0, -H:-H + 8]).all()) for b in blocks), "one layout for all ranks"
+    bad = torch.stack(blocks).contiguous()
+    bad[1, 0, -H + 5] ^= 1                                  # a rank that derived another order
+    with pytest.raises(RuntimeError):
+        dens.unpack_neighbor_blocks(ct, bad, n_seg)
     for got, want in zip(dens.unpack_neighbor_blocks(ct, torch.stack(blocks).contiguous(), n_seg), full_n):
         assert bool((got.view(torch.int32) == want.view(torch.int32)).all())   # dc_hip_neighbors_block_unpack_dev
 
@@ -744,8 +750,9 @@ def test_degenerate_inputs_pruned_equals_direct(dens):
 def test_stats_valid_flag_is_checked_on_the_device(dens, oracle):
     """DC_FLAG_STATS_VALID: the neighbour call of a populations -> neighbours pair over ONE array skips the three
     statistics passes and gives the same bits; claimed for an array whose statistics the workspace does NOT hold
-    (another array of the same shape went through last, or a direct-variant call that left no statistics) the cookie
-    check on the device flags the sweep and the direct kernels answer: slower, never different."""
+    (another array of the same shape went through last, a direct-variant call that left no statistics, or the SAME
+    buffer rewritten in place: the guard compares address, shape and a content fingerprint) the check on the device
+    flags the sweep and the direct kernels answer: slower, never different."""
     import torch
     n, d = 6000, 10
     c1 = gaussian_blobs(n, d, seed=41)
@@ -753,7 +760,7 @@ def test_stats_valid_flag_is_checked_on_the_device(dens, oracle):
     t1, t2 = torch.from_numpy(c1).cuda(), torch.from_numpy(c2).cuda()
 
     def reference(c):
-        pops = oracle.populations(c, [0.2 if c is c1 else 7.0])
+        pops = oracle.populations(c, [7.0 if c is c2 else 0.2])
         fe = oracle.free_energies(pops[0])
         return pops, fe, oracle.nearest_neighbors(c, fe)
 
@@ -778,3 +785,18 @@ def test_stats_valid_flag_is_checked_on_the_device(dens, oracle):
     dens.calculate_populations_partial(t2, [7.0])                      # (fresh statistics of c2)
     assert same(dens.nearest_neighbors_partial(t2, f2, stats_valid=True), nn2)
     assert dens.evaluated_tiles(t2.device)[1] > 0
+    # the same buffer REWRITTEN IN PLACE (same address, same shape, other contents): the fingerprint catches it
+    t2.copy_(t1)
+    assert same(dens.nearest_neighbors_partial(t2, f1, stats_valid=True), nn1)
+    assert dens.evaluated_tiles(t2.device)[1] == 0                     # flagged: the statistics were c2's
+    assert (dens.calculate_populations_partial(t2, [0.2], stats_valid=True).cpu().numpy().astype(np.uint32).astype(np.uint64) == p1).all()
+    assert dens.evaluated_tiles(t2.device)[0] == 0
+    dens.calculate_populations_partial(t2, [0.2])                      # (fresh statistics of the new contents)
+    assert same(dens.nearest_neighbors_partial(t2, f1, stats_valid=True), nn1)
+    assert dens.evaluated_tiles(t2.device)[1] > 0
+    # one element changed by one ulp
+    t2.view(torch.int32)[4321, 7] += 1
+    c3 = t2.cpu().numpy()
+    p3, fe3, nn3 = reference(c3)
+    assert same(dens.nearest_neighbors_partial(t2, torch.from_numpy(fe3).cuda(), stats_valid=True), nn3)
+    assert dens.evaluated_tiles(t2.device)[1] == 0
