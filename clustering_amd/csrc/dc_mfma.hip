@@ -888,7 +888,8 @@ __global__ void pad_scatter_kernel(const uint32_t* __restrict__ keys_sorted, con
 // against their tiles, and every frame of a surviving tile against every query of the group.  Rare by construction
 // (only the outskirts of two clusters face each other across less than r_max); each direction is counted from its own
 // query side, so both the symmetric and the one-sided sweeps just add these counts.
-// out: by_position != 0: counts[rr * stride + query position] (the symmetric sweeps' pops_pos), else [rr * stride + frame]
+// out: by_position == 1: counts[rr * stride + query position] (the symmetric sweeps' pops_pos), 2: counts[tile][stride][32]
+// (the multi-radius symmetric sweep), 0: [rr * stride + frame]
 __global__ __launch_bounds__(64) void pop_cross_kernel(
     const float* __restrict__ coords, uint32_t n_cols, const float* __restrict__ coords_r,
     const uint32_t* __restrict__ perm_r, const float4* __restrict__ box_r, const uint32_t* __restrict__ perm_q,
@@ -960,7 +961,11 @@ __global__ __launch_bounds__(64) void pop_cross_kernel(
     if (fq == kInvalidFrame) continue;
     for (int rr = 0; rr < n_rad; ++rr) {
       const uint32_t v = cnt[(size_t)rr * group_rows + k];
-      if (v) atomicAdd(&out[(size_t)rr * stride + (by_position ? pq : fq)], v);
+      if (!v) continue;
+      if (by_position == 2)   // counts [tile][stride = radii per sweep][32] (dc_mfma_msym.hpp)
+        atomicAdd(&out[(size_t)(pq >> 5) * (stride * 32) + (size_t)rr * 32 + (pq & 31u)], v);
+      else
+        atomicAdd(&out[(size_t)rr * stride + (by_position ? pq : fq)], v);
     }
   }
 }

@@ -1601,6 +1601,7 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
 
 
 #include "dc_mfma_shared.hpp"
+#include "dc_mfma_msym.hpp"
 
 // =============================================================================================
 // nearest neighbour / nearest neighbour with lower free energy
@@ -2717,6 +2718,21 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
     if (groups == 0) return;
     const dim3 grid_s(grid_x8(groups), pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
     const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * shared_wave_words(kTQS, NRV);
+    if constexpr (NRV > 1 && kTQS == kMsTQ) {
+      if (pop_sym_wanted(false, q_mode, q_seg, n_rows, 1) && pop_msym_wanted()) {
+        // symmetric form for several radii (dc_mfma_msym.hpp): counts by position [tile][NRV][32] in the regions from
+        // norms_s to vals_in of the workspace (the population sweeps leave them alone once the orders are built)
+        uint32_t* pops_pos = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(P.norms_s));
+        (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T * NRV, s);
+        { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_msym_kernel<S, NRV>), grid_s, dim3(256), (msym_smem<S, NRV>()), s, coords, n_rows, n_cols,
+                           P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
+                           chain_counter, rad2, n_rad, CV, pops_pos); sweep_timer_mark(0, false, s); }
+        cross(4u * kTQS, pops_pos, (size_t)NRV, 2);
+        hipLaunchKernelGGL((pops_by_frame_ms_kernel<NRV>), dim3((32 * T + 255) / 256), dim3(256), 0, s, (const uint32_t*)pops_pos,
+                           P.perm_p, 32u * T, n_rows, n_rad, P.hdr, pops);
+        return;
+      }
+    }
     if (pop_sym_wanted(false, q_mode, q_seg, n_rows, 1) && pop_shared_sym_wanted(NRV)) {
       // symmetric form: counts by position, one array of 32 T words per radius (the regions from norms_s to
       // vals_in of the workspace: the population sweeps leave them alone once the orders are built)

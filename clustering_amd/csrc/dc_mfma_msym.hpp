@@ -1,0 +1,420 @@
+// dc_mfma_msym.hpp -- SYMMETRIC population sweep for SEVERAL radii (included by dc_mfma_kernels.hpp, inside namespace
+// dc::{anonymous}, after dc_mfma_shared.hpp).
+//
+// The reference counts every unordered frame pair once for all radii and credits both frames
+// (density_clustering.cpp:170-188: j > i only, descending radii with an early break).  pop_shared_kernel<NM, 2, NR> is
+// one-sided: it evaluates every ORDERED tile pair, because crediting the reference side of a chain is a sum ACROSS the
+// 32 query lanes per reference row and radius -- with the round-2 form of that sum (ref_credit: a DPP tree and one
+// 128-byte global atomic per reference tile, WAVE and radius) the eight-radius sweep of one C5 rank went from 797 to
+// 2 062 ms (2 * 10^9 atomics).  This kernel keeps the structure of pop_shared_kernel -- a workgroup of four waves, two
+// resident query tiles per wave, the surviving reference tiles streamed once per workgroup through an LDS ring -- and
+// moves the lane sum out of the chains:
+//   in the chain loop   per reference tile and radius a wave adds the sign strings of its two chains bit-sliced
+//                       (2-bit counts), spreads them to 4-bit fields (two words: odd / even elements) and adds those to
+//                       a LANE-PRIVATE accumulator of the tile's ring slot in LDS with ONE ds_add_u64 -- no lane
+//                       reduction, no conflict (address = slot, radius, lane), 7 VALU instructions per radius and tile
+//                       against the 2 x 32 of the second chain pair it replaces.  Four waves x two tiles: fields <= 8.
+//   two windows later   (every wave has long left the tile) the four waves share out the (tile, radius) accumulators of
+//                       the retired window: fields to bytes, four DPP steps inside the 16-lane rows, the row sums
+//                       staged in LDS, lane i picks the two bytes of reference row i -- and ONE 256-byte atomic per
+//                       tile and PAIR of radii into counts laid out [tile][radius][32 rows]: 4 atomics per reference
+//                       tile and WORKGROUP instead of 32.
+// Ownership of the unordered pairs is that of the one-radius symmetric sweeps (dc_mfma_kernels.hpp "symmetric
+// population sweep"): groups of 4 * TQ = 8 tiles on a circle, a group meets its own tiles in both orders (query side
+// only) and the half of the other groups that lies ahead of it; the rule does not depend on the rank that runs a
+// group, so segments of a sharded run produce PARTIAL counts of all rows that merge by summation.
+#ifndef DC_MS_WIN
+#define DC_MS_WIN 3
+#endif
+constexpr int kMsWin = DC_MS_WIN;       // reference tiles per window: one barrier per window (LDS: two workgroups per CU at 3)
+constexpr int kMsRing = 2 * kMsWin;     // operand slots: the window in use and the one in flight
+constexpr int kMsAccSlots = 2 * kMsWin; // accumulator slots: the window in use and the one being reduced
+constexpr int kMsTQ = 2;
+
+// position -> word of the counts [tile][NR][32]
+template <int NR>
+__device__ __forceinline__ size_t ms_index(uint32_t pos, int rr) {
+  return (size_t)(pos >> 5) * (NR * 32) + (size_t)rr * 32 + (pos & 31u);
+}
+
+template <int NR>
+__device__ __attribute__((noinline)) void pop_wave_flush_ms(const uint2* queue, uint32_t qn, const uint32_t* jq_tab,
+                                                            uint32_t* fix_tab, uint32_t n_queries,
+                                                            const float* __restrict__ coords,
+                                                            const float* __restrict__ coords_r, uint32_t n_cols, Rad2 rad2,
+                                                            int lane, uint32_t* __restrict__ pops_pos, uint32_t group_tiles,
+                                                            uint32_t own_group) {
+  for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
+    if (k0 + lane < qn) {
+      const uint2 ent = queue[k0 + lane];
+      const uint32_t qidx = ent.y & 0xFFu, flags = ent.y >> 8;
+      const float d2c = dist2_canon_rows(coords + (size_t)jq_tab[qidx] * n_cols, coords_r + (size_t)ent.x * n_cols, (int)n_cols);
+      const bool both = (ent.x >> 5) / group_tiles != own_group;   // (this workgroup alone evaluates the pair)
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr)
+        if (((flags >> rr) & 1u) && d2c < rad2.v[rr]) {
+          atomicAdd(&fix_tab[rr * n_queries + qidx], 1u);
+          if (both) atomicAdd(&pops_pos[ms_index<NR>(ent.x, rr)], 1u);
+        }
+    }
+  }
+}
+
+template <int NM, int NR>
+__global__ __launch_bounds__(256, 2) void pop_msym_kernel(
+    const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
+    const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
+    const float4* __restrict__ box_r, const float* __restrict__ coords_r, uint32_t T,
+    const uint4* __restrict__ img_q, const float* __restrict__ norms_q,
+    const uint32_t* __restrict__ perm_q, const float4* __restrict__ box_q, uint32_t n_q, QSeg q_seg,
+    const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ chain_counter, Rad2 rad2, int n_rad,
+    CompView CV, uint32_t* __restrict__ pops_pos) {
+  constexpr int TQ = kMsTQ;
+  static_assert(NR == 4 || NR == 8, "radius pairs per reducing wave");
+  static_assert(4 * TQ <= 15, "4-bit fields of the lane-private accumulators hold a workgroup's chains on one tile");
+  __shared__ uint32_t lists[4][kShareSub];
+  __shared__ uint32_t list_cnt[4];
+  __shared__ float4 wave_box[4];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[4][2][16];   // per wave: the row sums of a unit's two radii (lanes 15/31/47/63)
+  // dynamic LDS: operand ring [kMsRing][kTileUnits] x 16 B, the accumulators [kMsAccSlots][NR][64] x 8 B, then per wave
+  // the compact queue of deferred exact evaluations [kWaveQueue] x 8 B, the positions of its queries [TQ*32] and their
+  // exact-path counts [NR][TQ*32]
+  extern __shared__ __attribute__((aligned(16))) float shared_dyn[];
+  if (hdr[1] != 0) return;   // flagged data: the gated direct kernel runs instead
+  constexpr int kUnits = kTileUnits<NM>;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31, wib = tid >> 6;
+  const uint32_t TQT = (n_q + 31) / 32;
+  const uint32_t n_groups = (TQT + 4u * TQ - 1u) / (4u * TQ);
+  const uint32_t blk_unit = xcd_block(seg_groups(n_groups, q_seg));
+  if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid: the whole workgroup leaves)
+  const uint32_t group = seg_group(blk_unit, q_seg);
+  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
+  if (group * (4u * TQ) >= TQT) return;   // whole workgroup leaves
+  const uint32_t qt0 = (group * 4u + (uint32_t)wib) * TQ;
+  const bool wave_live = qt0 < TQT;       // (a wave without tiles keeps loading, reducing and meeting the barriers)
+  uint4* ring = reinterpret_cast<uint4*>(shared_dyn);
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(shared_dyn + kMsRing * kUnits * 4);   // [slot][NR][64]
+  uint32_t* wave_lds = reinterpret_cast<uint32_t*>(acc + kMsAccSlots * NR * 64) + (size_t)wib * shared_wave_words(TQ, NR);
+  uint2* queue = reinterpret_cast<uint2*>(wave_lds);   // (reference position, query | radius flags << 8)
+  uint32_t* jq_tab = wave_lds + 2 * kWaveQueue;        // position of query (qt, c) in the order
+  uint32_t* fix_tab = jq_tab + TQ * 32;                // [NR][TQ*32]: band pairs the exact path found inside
+  uint32_t qn = 0;                                     // queued entries (wave-uniform)
+
+  const PopSetup<NR> P = pop_setup<NR>(hdr, rad2, n_cols);
+  float r2max = rad2.v[0];
+#pragma unroll
+  for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
+  const float far2 = r2max * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
+
+  for (uint32_t k = tid; k < (uint32_t)(kMsAccSlots * NR * 64); k += 256) acc[k] = 0ull;
+
+  s16x8 b[TQ][NM];
+  uint32_t cnt_q[TQ][NR], jq[TQ];
+  uint64_t livemask[TQ];
+  float4 gbox = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const uint32_t tile = qt0 + qt;
+    const uint32_t tl = tile < TQT ? tile : TQT - 1;
+    const uint32_t pos = tile * 32 + c;
+    const uint32_t frame = ((tile < TQT) && (pos < n_q)) ? perm_q[pos] : kInvalidFrame;   // (pad positions: kInvalidFrame)
+    const bool live = frame != kInvalidFrame;
+    livemask[qt] = __builtin_amdgcn_ballot_w64(live);
+    jq[qt] = live ? frame : 0u;
+    const float cq = live ? norms_q[tl * 32 + c] - P.rad2e.v[0] : dead_const(P.sc);
+    load_query<NM>(img_q, tl, lane, h, cq, P.sc, b[qt]);
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) cnt_q[qt][rr] = 0;
+    if (h == 0) {
+      jq_tab[qt * 32 + c] = pos;   // (the queries are rows of the reference order: their original coordinates sit in coords_r)
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) fix_tab[rr * (TQ * 32) + qt * 32 + c] = 0;
+    }
+    const float4 qb = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    gbox.x = fminf(gbox.x, qb.x);
+    gbox.y = fmaxf(gbox.y, qb.y);
+    gbox.z = fminf(gbox.z, qb.z);
+    gbox.w = fmaxf(gbox.w, qb.w);
+  }
+  if (lane == 0) wave_box[wib] = gbox;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {   // the workgroup's box: one survivor list for all four waves
+    const float4 wb = wave_box[w];
+    gbox.x = fminf(gbox.x, wb.x);
+    gbox.y = fmaxf(gbox.y, wb.y);
+    gbox.z = fminf(gbox.z, wb.z);
+    gbox.w = fmaxf(gbox.w, wb.w);
+  }
+
+  uint32_t sb[NR][TQ];   // strings of the two chains on the current reference tile
+  auto flush = [&]() {
+    pop_wave_flush_ms<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords_r, coords_r, n_cols, rad2, lane, pops_pos, 4u * TQ, group);
+    qn = 0;
+  };
+  // the rest of an epilogue: query-side counts, band test, parking of the band pairs
+  auto finish = [&](auto qi_c, const MrAcc<NR>& e, uint32_t t) {
+    constexpr int qi = decltype(qi_c)::value;
+    uint32_t decided = 0xFFFFFFFFu;   // bit 31 - 2 r: element r is inside or outside for EVERY radius
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      cnt_q[qi][rr] += __builtin_popcount(inside_of(e.bits[rr]));
+      decided &= e.bits[rr] | (e.bits[rr] << 1);
+      sb[rr][qi] = e.bits[rr];
+    }
+    uint32_t m = ~decided & kSignBits;
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(m != 0) & livemask[qi]) != 0, 0)) {
+      // Pad rows (acc = +inf) and idle lanes (acc ~ 2^22) are never in a band.
+      uint32_t fl[NR];   // per radius: bit (31 - 2 r) set <=> element r sits in that radius' band
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) fl[rr] = band_of(e.bits[rr]);
+      for (;;) {
+        const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
+        if (have == 0) break;
+        const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
+        if (qn + n_new > (uint32_t)kWaveQueue) flush();
+        if (m != 0) {
+          const int p = __builtin_ctz(m);
+          uint32_t flags = 0;
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) flags |= ((fl[rr] >> p) & 1u) << rr;
+          const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
+          queue[slot] = make_uint2(tile_row(t, element_of(p), h), (uint32_t)(qi * 32 + c) | (flags << 8));
+          m &= m - 1;
+        }
+        qn += n_new;
+      }
+      if (qn >= 64u) flush();
+    }
+  };
+  // reference side of the pending tile: per radius the two strings added bit-sliced (2-bit counts at the elements'
+  // string positions), the counts spread to 4-bit fields -- odd elements in the low word, even ones in the high word --
+  // and added to this lane's accumulator of the tile's slot
+  auto credit = [&](uint32_t acc_slot) {
+    unsigned long long* a_lane = acc + (size_t)acc_slot * (NR * 64) + lane;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      if (rr < n_rad) {
+        const uint32_t s0 = sb[rr][0], s1 = sb[rr][1];
+        const uint32_t hi = s0 & s1 & kSignBits, lo = (s0 ^ s1) & kSignBits;
+        const uint32_t x = hi | (lo >> 1);                       // element r: 0..2 at bits 31-2r, 30-2r
+        if (__builtin_amdgcn_ballot_w64(x != 0u) != 0) {         // (small radii: most tiles hold nothing inside)
+          const uint32_t A = x & 0x33333333u, B = (x >> 2) & 0x33333333u;
+          __hip_atomic_fetch_add(a_lane + rr * 64, ((unsigned long long)B << 32) | A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  };
+  // reduce the accumulators of a retired window: its (tile, pair of radii) units are dealt to the four waves;
+  // entry_of(k): the k-th reference tile of the window, n_tiles of them
+  const uint32_t my_byte = ref_credit_byte(lane);   // byte (of the 16 a row-end lane stages) with the count of reference row lane & 31
+  auto reduce_window = [&](uint32_t win, auto&& entry_of, uint32_t n_tiles) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 LdsU4;
+    typedef __attribute__((address_space(3))) unsigned char LdsU8;
+    constexpr uint32_t kPairs = NR / 2;
+    for (uint32_t p = (uint32_t)wib; p < n_tiles * kPairs; p += 4u) {
+      const uint32_t which = p / kPairs, rr0 = 2u * (p % kPairs);
+      const uint32_t slot = (win & 1u) * kMsWin + which;
+      uint32_t cnt2 = 0;   // lanes 0..31: count of reference row `lane` for radius rr0; lanes 32..63: for radius rr0 + 1
+      bool nz_u[2] = {false, false};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        unsigned long long* a_lane = acc + (size_t)slot * (NR * 64) + (size_t)(rr0 + u) * 64 + lane;
+        const unsigned long long v = *a_lane;
+        const uint32_t A = (uint32_t)v, B = (uint32_t)(v >> 32);
+        const bool nz = __builtin_amdgcn_ballot_w64((A | B) != 0u) != 0;
+        if (nz) {
+          *a_lane = 0ull;
+          uint32_t W[4] = {A & 0x0F0F0F0Fu, B & 0x0F0F0F0Fu, (A >> 4) & 0x0F0F0F0Fu, (B >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {   // bytes <= 8 -> <= 128 over the 16 lanes of a row
+            W[e] += dpp_take<0x111>(W[e]);         // row_shr:1
+            W[e] += dpp_take<0x112>(W[e]);         // row_shr:2
+            W[e] += dpp_take<0x114>(W[e]);         // row_shr:4
+            W[e] += dpp_take<0x118>(W[e]);         // row_shr:8
+          }
+          if ((lane & 15) == 15) ((LdsU4*)stage[wib][u])[lane >> 4] = u32x4{W[0], W[1], W[2], W[3]};
+          nz_u[u] = true;
+        }
+      }
+      if (!(nz_u[0] | nz_u[1])) continue;   // (wave-uniform)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: its LDS operations execute in order)
+      __builtin_amdgcn_wave_barrier();
+      {
+        // lane L: radius rr0 + (L >> 5), reference row L & 31: the row lies in half hh = bit 2 of the row index; the sums
+        // of that half's 32 query lanes are the row-end lanes 2 hh and 2 hh + 1
+        const int u = lane >> 5;
+        const uint32_t hh = my_byte >> 4, byte = my_byte & 15u;
+        const volatile LdsU8* st = (const volatile LdsU8*)stage[wib][u];
+        cnt2 = (uint32_t)st[(2u * hh) * 16u + byte] + (uint32_t)st[(2u * hh + 1u) * 16u + byte];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!((lane >> 5) ? nz_u[1] : nz_u[0])) cnt2 = 0u;   // (a unit that was all zero staged nothing: stale bytes)
+      const uint32_t t = entry_of(which);
+#ifdef DC_MS_ABL_NOATOMIC
+      if (cnt2 == 0xFFFFFFFFu)
+#else
+      if (cnt2 != 0u && rr0 + (uint32_t)(lane >> 5) < (uint32_t)n_rad && 32u * t + (uint32_t)(lane & 31) < CV.n_pos)
+#endif
+        atomicAdd(&pops_pos[(size_t)t * (NR * 32) + (size_t)(rr0 + (lane >> 5)) * 32 + (uint32_t)(lane & 31)], cnt2);
+    }
+  };
+
+  uint32_t chains = 0;
+  // (only the tiles of the workgroup's own COMPONENT: every other frame is at least r_max away -- CompView)
+  const uint32_t my_comp = CV.tile_comp_q[group * (4u * TQ)];
+  const uint32_t t_lo = CV.range_r[2 * my_comp], t_hi = min(CV.range_r[2 * my_comp + 1], T);
+  const uint32_t u_lo = (t_lo > chunk) ? (t_lo - chunk + n_chunks - 1) / n_chunks : 0u;
+  const uint32_t U = (t_hi > chunk) ? (t_hi - chunk + n_chunks - 1) / n_chunks : 0u;
+  auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
+  for (uint32_t base = u_lo; base < U; base += 4 * kShareSub) {
+    // ---- scan: every wave tests its quarter of the round's boxes against the workgroup's box
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kShareSub; k += 64) {
+      const uint32_t u = base + (uint32_t)wib * kShareSub + k + lane;
+      bool ok = false;
+      uint32_t t = 0;
+      if (u < U) {
+        t = tile_of(u);
+        ok = box_gap2(gbox, box_r[t]) < far2;
+        // the workgroup's own group, or a group at most half the circle ahead (exactly half: the lower index)
+        const uint32_t gt = t / (4u * TQ);
+        const uint32_t ahead = (gt >= group) ? gt - group : gt + n_groups - group;
+        ok = ok & ((2u * ahead < n_groups) | ((2u * ahead == n_groups) & (group < gt)));
+      }
+      const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+      if (ok) lists[wib][cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
+      cnt += (uint32_t)__builtin_popcountll(m);
+    }
+    if (lane == 0) list_cnt[wib] = cnt;
+    __syncthreads();
+    const uint32_t o1 = list_cnt[0], o2 = o1 + list_cnt[1], o3 = o2 + list_cnt[2], total = o3 + list_cnt[3];
+    if (total != 0) {
+      auto entry = [&](uint32_t i) {
+        i = i < total ? i : total - 1;
+        const uint32_t w = (i >= o1 ? 1u : 0u) + (i >= o2 ? 1u : 0u) + (i >= o3 ? 1u : 0u);
+        const uint32_t off = i - (w == 0 ? 0u : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
+        return (uint32_t)__builtin_amdgcn_readfirstlane(lists[w][off]);
+      };
+      // the tiles of a window are fetched fragment-wise: the NM + 1 pieces of a tile (its MFMA fragments and its 32
+      // row norms) go round the four waves
+      auto fetch_window = [&](uint32_t i0) {
+        for (uint32_t k = 0; k < (uint32_t)kMsWin; ++k) {
+          const uint32_t i = i0 + k;
+          if (i >= total) break;
+          const uint32_t t = entry(i);
+          const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + (i % kMsRing) * kUnits));
+          const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
+#pragma unroll
+          for (int m = 0; m < NM; ++m)
+            if (((m + (int)k) & 3) == wib) lds_dma16(src + m * 64, dst + (uint32_t)m * 1024u);
+          if (((NM + (int)k) & 3) == wib && lane < 8)
+            lds_dma16(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane, dst + (uint32_t)NM * 1024u);
+        }
+      };
+      fetch_window(0);
+      for (uint32_t i = 0; i < total; ++i) {
+        if ((i % kMsWin) == 0) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the window starting at i
+          __syncthreads();                      // ... and every wave's adds to the previous window's accumulators have landed
+          fetch_window(i + kMsWin);
+#ifndef DC_MS_ABL_NOREDUCE
+          if (i >= (uint32_t)kMsWin) {
+            const uint32_t j = i - kMsWin;
+            reduce_window(j / kMsWin, [&](uint32_t k) { return entry(j + k); }, (uint32_t)kMsWin);
+          }
+#endif
+        }
+        const uint32_t t = entry(i);
+        const uint4* slot = ring + (i % kMsRing) * kUnits;
+        // (operands and accumulators are locals of the tile: kept alive across the reducer above -- as they are when
+        //  the first chain of the next tile is started early -- they cost 16 - 44 spilled registers and 20 - 40 ms of 450)
+        s16x8 a[NM];
+        float4 nv[4];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) a[m] = __builtin_bit_cast(s16x8, slot[m * 64 + lane]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nv[g] = reinterpret_cast<const float4*>(slot + NM * 64)[2 * g + h];
+        if (wave_live) {
+          // The two chains of a tile, and nothing pending beyond the tile: the sweep is bound by its epilogues (8 radii x
+          // 32 instructions against 6 MFMAs), so only the second chain's MFMAs sit in the shadow of the first one's
+          // epilogue -- and the tile's reference-side counts are in LDS before the wave moves on, which is what lets
+          // the window's accumulators be reduced one window later.
+          const f32x16 c0 = frag16(nv);
+          chains += TQ;
+          f32x16 acc0 = gram_chain<NM>(a, b[0], c0), acc1;
+          MrAcc<NR> e;
+          mr_begin<NR>(e);
+          mr_chain<NM, NR>(a, b[1], c0, acc1, acc0, P.dl, e);
+          keep_alive(c0);
+          finish(std::integral_constant<int, 0>{}, e, t);
+          mr_begin<NR>(e);
+          mr_epi<NR, 0, 16>(acc1, P.dl, e);
+          finish(std::integral_constant<int, 1>{}, e, t);
+#ifndef DC_MS_ABL_NOCREDIT
+          if ((t / (4u * TQ)) != group)   // (not the workgroup's own group)
+#else
+          if (t == 0xFFFFFFFFu)
+#endif
+            credit((((i / kMsWin) & 1u) * kMsWin) + (i % kMsWin));
+        }
+      }
+      __syncthreads();   // every add of this round has landed
+      {  // the last window
+        const uint32_t n_win = (total + kMsWin - 1) / kMsWin, w = n_win - 1u, j = w * kMsWin;
+        reduce_window(w, [&](uint32_t k) { return entry(j + k); }, min((uint32_t)kMsWin, total - j));
+      }
+    }
+    __syncthreads();   // lists, ring and accumulators are free for the next round
+  }
+  if (lane == 0 && chain_counter && wave_live) atomicAdd(chain_counter, (unsigned long long)chains);
+  flush();
+
+#pragma unroll
+  for (int qt = 0; qt < TQ; ++qt) {
+    const bool live = (livemask[qt] >> lane) & 1;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      const uint32_t total = cnt_q[qt][rr] + (uint32_t)__shfl_xor((int)cnt_q[qt][rr], 32, 64) +
+                             fix_tab[rr * (TQ * 32) + qt * 32 + c];
+      if (h == 0 && live && rr < n_rad) {
+        // the sweep met the self pair (box gap 0: never pruned) and counted it iff d2(i,i) < rad2; the reference
+        // starts every population at 1 (:132-134): corrected once, by chunk 0
+        uint32_t v = total;
+        if (chunk == 0) {
+          const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
+          v += 1u - ((dself < rad2.v[rr]) ? 1u : 0u);
+        }
+        if (v != 0u) atomicAdd(&pops_pos[ms_index<NR>((qt0 + (uint32_t)qt) * 32u + (uint32_t)c, rr)], v);
+      }
+    }
+  }
+}
+
+// counts [tile][NR][32] by position in the sweep's order -> populations [radius][frame]
+template <int NR>
+__global__ void pops_by_frame_ms_kernel(const uint32_t* __restrict__ pops_pos, const uint32_t* __restrict__ perm,
+                                        uint32_t n_pos, uint32_t n_rows, int n_rad, const uint32_t* __restrict__ hdr,
+                                        uint32_t* __restrict__ pops) {
+  if (hdr[1] != 0) return;
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n_pos) return;
+  const uint32_t f = perm[pos];
+  if (f == kInvalidFrame) return;
+  for (int rr = 0; rr < n_rad; ++rr) pops[(size_t)rr * n_rows + f] = pops_pos[ms_index<NR>(pos, rr)];
+}
+
+// DC_POP_MSYM = 0 keeps the one-sided multi-radius sweep (pop_shared_kernel<NM, 2, NR>; tests, measurements)
+inline bool pop_msym_wanted() {
+  static const bool off = [] {
+    const char* v = getenv("DC_POP_MSYM");
+    return v && v[0] == '0';
+  }();
+  return !off;
+}
+template <int NM, int NR>
+constexpr size_t msym_smem() {
+  return (size_t)kMsRing * kTileUnits<NM> * 16 + (size_t)kMsAccSlots * NR * 64 * 8 + sizeof(uint32_t) * 4 * shared_wave_words(kMsTQ, NR);
+}

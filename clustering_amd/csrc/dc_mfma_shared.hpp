@@ -219,6 +219,9 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
   bool symB = false;
   const uint32_t my_byte = ref_credit_byte(lane);
   auto credit = [&](uint32_t t) {
+#ifdef DC_ABL_SHARED_NOCREDIT
+    if (t != 0xFFFFFFFFu) return;
+#endif
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr)
       if (rr < n_rad) ref_credit<TQ>(sb[rr], t, CV.n_pos, pops_pos + (size_t)rr * pos_stride, credit_stage[wib], my_byte, lane);

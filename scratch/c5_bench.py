@@ -12,6 +12,7 @@ ap.add_argument('--d', type=int, default=30)
 ap.add_argument('--segments', type=int, default=8)
 ap.add_argument('--segment', type=int, default=3)
 ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--pop-only', action='store_true')
 ap.add_argument('--radii', type=float, nargs='+', default=[0.30, 0.35, 0.40, 0.45, 0.50, 0.55, 0.60, 0.65])
 a = ap.parse_args()
 n, d, G = a.n, a.d, a.segments
@@ -26,6 +27,9 @@ def timed(fn):
 p, pop_ms = timed(lambda: dens.calculate_populations_segment(c, a.radii, a.segment, G))
 pop_tiles = dens.evaluated_tiles(c.device)[0]
 comp_info = dens.components_info(c)
+if a.pop_only:
+    print(json.dumps({'pop_8_radii_ms': pop_ms, 'tile_pairs': pop_tiles}))
+    sys.exit(0)
 # FE needs the populations of all rows: one full single-radius sweep here (a real run all-reduces the segments)
 pf, full_ms = timed(lambda: dens.calculate_populations_partial(c, [a.radii[len(a.radii) // 2]]))
 full_tiles = dens.evaluated_tiles(c.device)[0]

@@ -125,26 +125,38 @@ C5_RADII = [0.30, 0.35, 0.40, 0.45, 0.50, 0.55, 0.60, 0.65]
 
 
 def test_c5_one_segment_of_eight_all_radii_and_neighbours(dens, fast_oracle):
-    """C5 = 5M x 30, 8 radii, on 8 GPUs (BASELINE.json configs[4]): what ONE rank computes -- segment 3 of 8 --
-    for ALL eight radii and for nn / nn_hd, against the oracle on > 500 rows of that segment (each against
-    all 5M reference frames), against the row-block call of the reference's partition, and through
-    size-independent properties on every row of the segment."""
+    """C5 = 5M x 30, 8 radii, on 8 GPUs (BASELINE.json configs[4]): what the ranks compute.  Populations: the eight
+    radii go through ONE symmetric sweep per rank (pop_msym_kernel: every unordered pair of query groups once, both
+    frames credited), so a segment's counts are PARTIAL counts of all rows -- the eight segments are run one after the
+    other and SUMMED (the all-reduce of a real run) and the sums are compared with the oracle on a row block (each row
+    against all 5M reference frames) and with the row-block call of the reference's partition.  Neighbours: segment 3
+    of 8, nn / nn_hd against the oracle on > 500 of its rows, and size-independent properties on every row."""
     import torch
     n, d, G, seg_id = 5_000_000, 30, 8, 3
     c = gaussian_blobs(n, d)
     ct = torch.from_numpy(c).cuda()
-    seg = dens.calculate_populations_segment(ct, C5_RADII, seg_id, G).cpu().numpy().astype(np.uint32)
-    rows = np.nonzero(seg[0])[0]                      # populations are >= 1 on the rows of the segment
-    assert abs(len(rows) - n / G) < 0.02 * n
-    for k in range(1, len(C5_RADII)):                 # same support, monotone in the radius
-        assert (np.nonzero(seg[k])[0] == rows).all() and (seg[k][rows] >= seg[k - 1][rows]).all()
-    lo, width = int(rows[len(rows) // 2]), 4400       # a row block that holds > 500 rows of the segment
-    mine = rows[(rows >= lo) & (rows < lo + width)]
-    assert len(mine) >= 500
+    total = None
+    for g in range(G):
+        part = dens.calculate_populations_segment(ct, C5_RADII, g, G)
+        if g == seg_id:
+            seg_part = part.cpu().numpy().astype(np.uint32)
+        total = part if total is None else total + part
+    seg = total.cpu().numpy().astype(np.uint32)       # populations of ALL rows, all eight radii
+    del total, part
+    assert (seg_part <= seg).all() and 0.05 * seg[7].astype(np.int64).sum() < seg_part[7].astype(np.int64).sum() < 0.25 * seg[7].astype(np.int64).sum()
+    assert (seg[0] >= 1).all()
+    for k in range(1, len(C5_RADII)):                 # monotone in the radius
+        assert (seg[k] >= seg[k - 1]).all()
+    for k in range(len(C5_RADII)):                    # every pair is counted at both ends
+        assert (seg[k].astype(np.int64).sum() - n) % 2 == 0
+    rows = np.arange(n)
+    lo, width = n // 2 + 1234, 600                    # a row block: every row against all 5M references
     want = fast_oracle.populations(c, C5_RADII, lo, lo + width)
-    assert (seg[:, mine].astype(np.uint64) == want[:, mine]).all()
+    assert (seg[:, lo:lo + width].astype(np.uint64) == want[:, lo:lo + width]).all()
     block = dens.calculate_populations_partial(ct, C5_RADII, lo, lo + 700).cpu().numpy().astype(np.uint32)
-    assert (block[:, lo:lo + 700].astype(np.uint64) == want[:, lo:lo + 700]).all()
+    assert (block[:, lo:lo + 600].astype(np.uint64) == want[:, lo:lo + 600]).all()
+    assert (block[:, lo:lo + 700] == seg[:, lo:lo + 700]).all()
+    width = 4400                                      # (the neighbour check below: a block that holds > 500 rows of the segment)
     # free energies of ALL frames at r = 0.5 (a real run all-reduces the eight segments; here one full sweep)
     full = dens.calculate_populations_partial(ct, [0.5])
     fh = full[0].cpu().numpy().astype(np.uint32)

@@ -580,13 +580,14 @@ def test_shared_operand_population_sweep():
     rows and large images, e.g. C5) forced on for small shapes of every kind -- all rows, a row range, the
     segments of a sharded run, duplicates, 1..8 MFMAs per chain, and (wide rows) up to eight radii per sweep --
     against the direct kernels AND against the oracle (all rows, the segment sums and the 4 / 8 / 17-radius sweeps of
-    every shape), bit for bit; a second run with the symmetric form forced for several radii too
-    (DC_POP_SHARED_SYM=2)."""
+    every shape), bit for bit.  Three runs: the default (several radii in one SYMMETRIC sweep, pop_msym_kernel:
+    reference-side counts through lane-private LDS accumulators), the one-sided multi-radius sweep (DC_POP_MSYM=0) and
+    the round-2 symmetric form with its per-wave atomics (DC_POP_MSYM=0 DC_POP_SHARED_SYM=2)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({}, {"DC_POP_SHARED_SYM": "2"}):
+    for extra in ({}, {"DC_POP_MSYM": "0"}, {"DC_POP_MSYM": "0", "DC_POP_SHARED_SYM": "2"}):
         r = subprocess.run([sys.executable, "-c", SHARED_CHILD, root], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, DC_POP_SHARED="1", **extra))
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stderr[-3000:])
