@@ -109,7 +109,7 @@ def parse_args():
     ap.add_argument("--n-rows", type=int, default=1_000_000)
     ap.add_argument("--n-cols", type=int, default=10)
     ap.add_argument("--radii", type=float, nargs="+", default=[0.2])
-    ap.add_argument("--variant", default="auto", choices=["auto", "direct", "mfma", "pruned"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "direct", "mfma", "pruned", "mfma32"])
     ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="rows of the workload the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-nn", action="store_true", help="populations + free energies only (C2-style)")
@@ -307,7 +307,16 @@ def main():
             algorithmic = pairs * 2.0 * d / t / 1e12                     # 2*D flop per pair
             executed = pairs * executed_flop_per_pair(d) / t / 1e12      # what the f16 pipe does
             pmc = measured_counters(kernel, n, d, args.radii, args.variant) if world == 1 else {}
-            if matrix:
+            if args.variant == "mfma32":
+                # the literal fp32-input MFMA instance: K = 2 * ceil(D / 2) slots, one fp32 multiply-add each
+                ex32 = pairs * 2.0 * (2 * ((d + 1) // 2)) / t / 1e12
+                r = {"bound": "mfma", "pipe": "fp32 (v_mfma_f32_32x32x2_f32: the vector rate on gfx950)", "kernel": kernel,
+                     "achieved": algorithmic, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": algorithmic / PEAK_FP32_TFLOPS,
+                     "frac_definition": "SURVEY.md 8(d): 2*D fp32 flop per evaluated ordered frame pair / the kernel's launch "
+                                        "duration / the fp32 MFMA peak (BASELINE.json's target: >= 0.60)",
+                     "flop_per_pair_algorithmic": 2 * d, "achieved_executed": ex32, "frac_executed": ex32 / PEAK_FP32_TFLOPS}
+            elif matrix:
                 r = {"bound": "mfma", "pipe": "f16 (v_mfma_f32_32x32x16_f16, dense)", "kernel": kernel,
                      "achieved": algorithmic, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": algorithmic / PEAK_BF16_TFLOPS,
@@ -365,8 +374,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 (Gram form on two fp16 pieces per coordinate on the f16 MFMA pipe, f32 accumulate, as a "
-                     "classifier with a guard band; undecided pairs re-checked in canonical f32)",
+            "dtype": ("f32 (Gram form on the fp32-input MFMA, every pair, as a classifier with a guard band; undecided pairs "
+                      "re-checked in canonical f32)" if args.variant == "mfma32" else
+                      "f32 (Gram form on two fp16 pieces per coordinate on the f16 MFMA pipe, f32 accumulate, as a "
+                      "classifier with a guard band; undecided pairs re-checked in canonical f32)"),
             "data": "synthetic",
             "config": {
                 "workload": f"{n} frames x {d} dims, 3-Gaussian-blob (sigma 0.08, seed 20240), radii {args.radii}, "

@@ -15,7 +15,7 @@ ABI_VERSION = 2               # include/dc_density.h: DC_HIP_ABI_VERSION this bi
 FLAG_STATS_VALID = 0x100      # DC_FLAG_STATS_VALID
 VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA, VARIANT_MFMA_PRUNED = 0, 1, 2, 3
 VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA,
-            "pruned": VARIANT_MFMA_PRUNED}
+            "pruned": VARIANT_MFMA_PRUNED, "mfma32": 4}
 
 # every symbol include/dc_density.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = (

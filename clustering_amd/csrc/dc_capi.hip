@@ -204,6 +204,8 @@ int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const 
   const bool mfma = want_mfma(variant, n_cols);
   if ((variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA_PRUNED) && !mfma)
     return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
+  if (variant == DC_VARIANT_MFMA32 && (!mfma || !dc::mfma32_supports(n_cols) || n_segments > 0))
+    return fail(DC_ERR_INVALID_ARGUMENT, "the fp32-MFMA variant handles n_cols 9..10 and row ranges only (n_cols=%zu)", n_cols);
   if (mfma) {
     if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
       return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
@@ -221,7 +223,10 @@ int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const 
     // MFMA variant: the MFMA kernel runs unless the operand-image pass flagged the data
     // (non-finite / overflow-prone rows), in which case the gated direct kernel does the work;
     // both are enqueued, the choice is made on the device (no host synchronisation).
-    if (mfma && variant == DC_VARIANT_MFMA)
+    if (mfma && variant == DC_VARIANT_MFMA32)
+      dc::launch_pop_mfma32(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from, (uint32_t)i_to, rad2, n_rad,
+                            out, d_workspace, s);
+    else if (mfma && variant == DC_VARIANT_MFMA)
       dc::launch_pop_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                           (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
     else if (mfma && n_segments > 0)
@@ -386,17 +391,21 @@ int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, 
   const bool mfma = want_mfma(variant, n_cols);
   if ((variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA_PRUNED) && !mfma)
     return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
+  if (variant == DC_VARIANT_MFMA32 && (!mfma || !dc::mfma32_supports(n_cols) || n_segments > 0))
+    return fail(DC_ERR_INVALID_ARGUMENT, "the fp32-MFMA variant handles n_cols 9..10 and row ranges only (n_cols=%zu)", n_cols);
   if (mfma) {
     if (!d_workspace || workspace_bytes < dc::mfma_workspace_bytes(n_rows, n_cols))
       return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                   dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
-    // (the pruned sweep packs reference positions into 30 bits of its candidate queue entries)
     // (the pruned sweep packs reference POSITIONS of the padded order into 30 bits: kQueuePosMask)
-    const bool full_sweep = variant == DC_VARIANT_MFMA || n_rows + dc::kOrderPadRows > ((size_t)1 << 30);
+    const bool full_sweep = variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA32 || n_rows + dc::kOrderPadRows > ((size_t)1 << 30);
     if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
                                   full_sweep, s, stats_valid))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
-    if (full_sweep)
+    if (variant == DC_VARIANT_MFMA32)
+      dc::launch_nn_mfma32(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from, (uint32_t)i_to, d_nn_idx,
+                           d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
+    else if (full_sweep)
       dc::launch_nn_mfma(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from,
                          (uint32_t)i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2, d_workspace, s);
     else if (n_segments > 0)

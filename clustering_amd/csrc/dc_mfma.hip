@@ -15,6 +15,8 @@ namespace dc {
 
 namespace {
 
+#include "dc_mfma32.hpp"
+
 // ---------------------------------------------------------------------------------------------
 // operand images
 // ---------------------------------------------------------------------------------------------
@@ -2131,6 +2133,66 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
     default:
       break;
   }
+}
+
+// ---- DC_VARIANT_MFMA32: the fp32-input MFMA instance (dc_mfma32.hpp) ---------------------------------------------
+bool mfma32_supports(size_t n_cols) { return n_cols == 9 || n_cols == 10; }
+
+void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from, uint32_t i_to,
+                       const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws, hipStream_t stream) {
+  const Layout L = make_layout(n_rows, n_cols);
+  char* p = (char*)d_ws;
+  float* img = (float*)(p + L.off_img);
+  float* norms = (float*)(p + L.off_norm);
+  hipLaunchKernelGGL(image32_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords, n_rows, n_cols, L.T,
+                     (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, img, norms);
+#ifdef DC_MFMA32_TQ
+  constexpr int kTQ = DC_MFMA32_TQ;
+#else
+  constexpr int kTQ = 4;
+#endif
+  const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
+  for (int r = 0; r < n_rad; ++r) {
+    sweep_timer_mark(0, true, stream);
+    hipLaunchKernelGGL((pop_mfma32_kernel<kS32, kTQ>), grid, block, 0, stream, d_coords, n_rows, n_cols, (const float*)img,
+                       (const float*)norms, (const uint32_t*)p, L.T, i_from, i_to, rad2.v[r], d_pops + (size_t)r * n_rows);
+    sweep_timer_mark(0, false, stream);
+  }
+}
+
+void launch_nn_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe, uint32_t i_from,
+                      uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws,
+                      hipStream_t stream) {
+  // the reference frames ordered by free energy, exactly as launch_nn_mfma orders them; fp32 images instead of fp16 x 2
+  const Layout L = make_layout(n_rows, n_cols);
+  char* p = (char*)d_ws;
+  uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
+  uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
+  uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
+  uint32_t* perm = (uint32_t*)(p + L.off_perm);
+  const dim3 blk(256), grid_n((n_rows + 255) / 256), grid_t((32 * L.T + 255) / 256);
+  float* img = (float*)(p + L.off_img);
+  float* norms = (float*)(p + L.off_norm);
+  float* img_s = (float*)(p + L.off_img_s);
+  float* norms_s = (float*)(p + L.off_norm_s);
+  hipLaunchKernelGGL(image32_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_cols, L.T, (const float*)(p + kHdrMeans),
+                     (const uint32_t*)nullptr, img, norms);
+  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, keys_in, vals_in,
+                     (uint32_t*)p);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm, n_rows, p + L.fixed_end, sort_temp_bytes(n_rows), stream) != 0) return;
+  hipLaunchKernelGGL(fe_scatter_kernel, grid_t, blk, 0, stream, perm, d_fe, n_rows, L.T, (uint32_t*)(p + L.off_invpos),
+                     (float*)(p + L.off_fe_s));
+  hipLaunchKernelGGL(fe_rank_kernel, grid_n, blk, 0, stream, d_fe, (const float*)(p + L.off_fe_s), n_rows,
+                     (uint32_t*)(p + L.off_pq));
+  hipLaunchKernelGGL(image32_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_cols, L.T, (const float*)(p + kHdrMeans),
+                     (const uint32_t*)perm, img_s, norms_s);
+  constexpr int kTQ = 4;
+  sweep_timer_mark(1, true, stream);
+  hipLaunchKernelGGL((nn_mfma32_kernel<kS32, kTQ>), dim3(grid_for(i_from, i_to, kTQ)), blk, 0, stream, d_coords, n_rows, n_cols,
+                     (const float*)img, (const float*)norms, (const float*)img_s, (const float*)norms_s, (const uint32_t*)perm,
+                     (const uint32_t*)(p + L.off_invpos), (const uint32_t*)(p + L.off_pq), (const uint32_t*)p, L.T, i_from, i_to,
+                     d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
+  sweep_timer_mark(1, false, stream);
 }
 
 }  // namespace dc

@@ -33,6 +33,13 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
                      void* d_ws, hipStream_t stream);
+// DC_VARIANT_MFMA32 (dc_mfma32.hpp): the fp32-input MFMA instance, n_cols 9..10, every pair (needs mfma_prepare first)
+bool mfma32_supports(size_t n_cols);
+void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from, uint32_t i_to,
+                       const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row, void* d_ws, hipStream_t stream);
+void launch_nn_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe, uint32_t i_from,
+                      uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws,
+                      hipStream_t stream);
 // population sweep over spatially ordered frames with tile-pair pruning (needs mfma_prepare first)
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,

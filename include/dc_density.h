@@ -65,9 +65,12 @@ typedef enum dc_variant {
   DC_VARIANT_DIRECT = 1,      /* VALU, direct differences in the canonical order: exact by construction */
   DC_VARIANT_MFMA = 2,        /* matrix-core Gram form (two fp16 pieces per coordinate, n_cols <= 64) as a
                                  classifier + guard band + canonical re-check; every pair evaluated */
-  DC_VARIANT_MFMA_PRUNED = 3  /* the same on spatially ordered frames, skipping tile pairs farther apart than
+  DC_VARIANT_MFMA_PRUNED = 3, /* the same on spatially ordered frames, skipping tile pairs farther apart than
                                  the radius (the GPU counterpart of the reference's box grid,
                                  density_clustering.cpp:41-89); identical results */
+  DC_VARIANT_MFMA32 = 4       /* the literal fp32-input MFMA (v_mfma_f32_32x32x2_f32) Gram form, every pair evaluated:
+                                 the instance BASELINE's "fraction of the fp32 MFMA roofline" is quoted on; n_cols
+                                 9..10 only, one radius per sweep; identical results (classifier + band + re-check) */
 } dc_variant;
 /* may be OR-ed into the `variant` argument of the _dev sweeps: the column means, max |x - mean|^2, the
  * non-finite flag and the bounding box in this workspace's header were computed by an earlier sweep over

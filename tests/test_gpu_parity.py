@@ -98,6 +98,28 @@ def test_parity_templated_dims(dens, oracle, D, variant):
     check_full(dens, oracle, c, radii, variant)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,D", [(3000, 10), (4111, 9), (20000, 10), (33, 10)])
+def test_fp32_mfma_variant_against_the_oracle(dens, oracle, n_rows, D):
+    """DC_VARIANT_MFMA32 (dc_mfma32.hpp): the literal fp32-input MFMA instance (v_mfma_f32_32x32x2_f32, n_cols 9..10,
+    every pair) that BASELINE.json's "fraction of the fp32 MFMA roofline" is quoted on -- populations (two radii, a row
+    range), free energies and nn / nn_hd with their d2 bits against the oracle, duplicates included; other column
+    counts are refused."""
+    import torch
+    c = gaussian_blobs(n_rows, D, seed=4000 + n_rows)
+    if n_rows > 100:
+        rng = np.random.default_rng(n_rows)
+        c[rng.integers(0, n_rows, n_rows // 9)] = c[rng.integers(0, n_rows, n_rows // 9)]   # ties: lowest index wins
+    check_full(dens, oracle, c, [0.2, 0.11], "mfma32")
+    ct = torch.from_numpy(c).cuda()
+    lo, hi = n_rows // 3, n_rows // 3 + max(1, n_rows // 2)
+    got = dens.calculate_populations_partial(ct, [0.2], lo, hi, variant="mfma32").cpu().numpy().astype(np.uint32)
+    want = oracle.populations(c, [0.2], lo, hi)
+    assert (got.astype(np.uint64) == want).all()
+    with pytest.raises(RuntimeError):
+        dens.calculate_populations_partial(torch.from_numpy(gaussian_blobs(500, 12, seed=1)).cuda(), [0.3], variant="mfma32")
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("D", [33, 40, 48, 64, 65, 100])
 def test_parity_generic_dims(dens, oracle, D, variant):
