@@ -5,7 +5,7 @@
 // of 60 % of the fp32 MFMA roofline (157.3 TFLOP/s: on gfx950 the fp32-input MFMA runs at the VECTOR rate and, measured,
 // does not overlap VALU work -- DESIGN.md 4.2).  The default path therefore moved to fp16 pieces on the 16-bit pipe
 // (16x the rate); this file keeps the fp32 instance that round 1 measured at 58 - 61 % of that roof (tag fp32-mfma-r1)
-// buildable, testable against the oracle and benchable (bench.py --variant mfma32), for n_cols 9 .. 10 (five K-steps of
+// buildable, covered by the parity tests and benchable (bench.py --variant mfma32), for n_cols 9 .. 10 (five K-steps of
 // two columns).  Same classifier idea as the fp16 kernels, with the fp32 band of round 1:
 //     acc = |y'|^2 - 2 x'.y'  (A = centred reference coordinates, B = -2 centred query coordinates, C = |y'|^2)
 //     t   = acc - ((r^2 - eps) - |x'|^2):  sign -> inside, bits(t) <u bits(2 eps) -> band -> canonical re-check
