@@ -56,6 +56,7 @@ struct Rccl {
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -82,6 +83,7 @@ Rccl* rccl() {
     x->CommInitAll = (decltype(x->CommInitAll))sym("ncclCommInitAll");
     x->CommDestroy = (decltype(x->CommDestroy))sym("ncclCommDestroy");
     x->AllReduce = (decltype(x->AllReduce))sym("ncclAllReduce");
+    x->AllGather = (decltype(x->AllGather))sym("ncclAllGather");
     x->GroupStart = (decltype(x->GroupStart))sym("ncclGroupStart");
     x->GroupEnd = (decltype(x->GroupEnd))sym("ncclGroupEnd");
     x->GetErrorString = (decltype(x->GetErrorString))sym("ncclGetErrorString");
@@ -102,6 +104,8 @@ struct DevState {
   uint32_t* d_idx = nullptr;    // [2][n_rows]: nn, nn_hd
   float* d_d2 = nullptr;        // [2][n_rows]
   unsigned long long* d_words = nullptr;   // [2][n_rows] packed neighbour words / Boruvka candidates
+  uint32_t* d_block = nullptr;  // [4][block_rows]: this device's neighbour block (all-gather merge)
+  uint32_t* d_blocks = nullptr; // [G][4][block_rows]: the gathered blocks
   uint32_t* d_comp = nullptr;   // forest: component ids, ranks
   uint32_t* d_rank = nullptr;
   ncclComm_t comm = nullptr;
@@ -227,6 +231,40 @@ int merge_partials(dc_hip_session* s, const std::function<void*(DevState&)>& buf
   });
 }
 
+// All-gather of one block of `count` uint32 per device (the neighbours of its own segment by local position,
+// dc_hip_neighbors_block_pack_dev) into [G][count] on every device: what density_clustering_cuda.cu:311-326 does by
+// copying row blocks on the host, and what BASELINE's north star asks of the collectives ("a final all-gather of
+// nearest-neighbour indices").  RCCL: one grouped ncclAllGather; host merge: blocks to the host, all of them back.
+int gather_blocks(dc_hip_session* s, size_t count) {
+  const size_t G = s->dev.size();
+  if (s->use_rccl) {
+    Rccl* r = rccl();
+    ncclResult_t e = r->GroupStart();
+    for (auto& d : s->dev) {
+      if (e != ncclSuccess) break;
+      e = r->AllGather(d.d_block, d.d_blocks, count, ncclUint32, d.comm, d.stream);
+    }
+    const ncclResult_t e2 = r->GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return failf(DC_ERR_HIP, "RCCL all-gather (neighbour blocks): %s", r->GetErrorString(e));
+    return DC_OK;
+  }
+  std::vector<uint32_t> all(G * count);
+  int rc = on_every_device(s, [&](int g) -> int {
+    DevState& d = s->dev[g];
+    SESSION_HIP_TRY(hipMemcpyAsync(all.data() + (size_t)g * count, d.d_block, count * 4, hipMemcpyDeviceToHost, d.stream));
+    SESSION_HIP_TRY(hipStreamSynchronize(d.stream));
+    return DC_OK;
+  });
+  if (rc != DC_OK) return rc;
+  return on_every_device(s, [&](int g) -> int {
+    DevState& d = s->dev[g];
+    SESSION_HIP_TRY(hipMemcpyAsync(d.d_blocks, all.data(), G * count * 4, hipMemcpyHostToDevice, d.stream));
+    SESSION_HIP_TRY(hipStreamSynchronize(d.stream));
+    return DC_OK;
+  });
+}
+
 int sync_all(dc_hip_session* s, const char* what) {
   for (auto& d : s->dev) {
     SESSION_HIP_TRY(hipSetDevice(d.device));
@@ -261,7 +299,7 @@ void dc_hip_session_close(dc_hip_session* s) {
     (void)hipSetDevice(d.device);
     if (d.stream) (void)hipStreamSynchronize(d.stream);
     if (d.comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(d.comm);
-    void* bufs[] = {d.d_coords, d.d_ws, d.d_pops, d.d_fe, d.d_idx, d.d_d2, d.d_words, d.d_comp, d.d_rank};
+    void* bufs[] = {d.d_coords, d.d_ws, d.d_pops, d.d_fe, d.d_idx, d.d_d2, d.d_words, d.d_comp, d.d_rank, d.d_block, d.d_blocks};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -478,6 +516,11 @@ int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float*
     return DC_OK;
   }
   if (!s->have_fe) return failf(DC_ERR_INVALID_ARGUMENT, "nearest neighbours need free energies (none resident)");
+  // neighbour merge: all-gather of position-ordered blocks (default), or DC_SESSION_NN_MERGE=allreduce: the all-reduce(min)
+  // of packed (d2, index) words
+  const char* nn_mode = getenv("DC_SESSION_NN_MERGE");
+  const bool gather = !(nn_mode && strcmp(nn_mode, "allreduce") == 0);
+  const size_t block_rows = dc_hip_neighbors_block_rows(n, s->n_cols, G);
   int rc = on_every_device(s, [&](int g) -> int {
     DevState& d = s->dev[g];
     if (!d.d_idx) SESSION_HIP_TRY(hipMalloc((void**)&d.d_idx, sizeof(uint32_t) * 2 * n));
@@ -489,17 +532,39 @@ int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float*
       d.stats_ready = (r == DC_OK);
       return r;
     }
-    if (!d.d_words) SESSION_HIP_TRY(hipMalloc((void**)&d.d_words, sizeof(unsigned long long) * 2 * n));
     r = dc_hip_nearest_neighbors_segment_dev(d.d_coords, n, s->n_cols, d.d_fe, (size_t)g, G, d.d_idx, d.d_d2,
                                              d.d_idx + n, d.d_d2 + n, d.d_ws, d.ws_bytes, d.variant(), d.stream);
     d.stats_ready = (r == DC_OK);
     if (r != DC_OK) return r;
+    if (gather) {   // the rows of this device's segment as a dense block, by local position
+      if (!d.d_block) SESSION_HIP_TRY(hipMalloc((void**)&d.d_block, sizeof(uint32_t) * 4 * block_rows));
+      if (!d.d_blocks) SESSION_HIP_TRY(hipMalloc((void**)&d.d_blocks, sizeof(uint32_t) * 4 * block_rows * G));
+      return dc_hip_neighbors_block_pack_dev(d.d_idx, d.d_d2, d.d_idx + n, d.d_d2 + n, n, s->n_cols, (size_t)g, G, d.d_ws,
+                                             d.ws_bytes, DC_VARIANT_AUTO, d.d_block, d.stream);
+    }
+    if (!d.d_words) SESSION_HIP_TRY(hipMalloc((void**)&d.d_words, sizeof(unsigned long long) * 2 * n));
     return dc_hip_neighbors_pack_dev(d.d_idx, d.d_d2, d.d_idx + n, d.d_d2 + n, n, d.d_words, d.stream);
   });
   if (rc != DC_OK) return rc;
-  if (s->use_rccl || s->host_merge) {
-    // every row has one owner; all other devices hold the larger "none" word (density_clustering_cuda.cu:311-326
-    // copies row blocks on the host)
+  std::vector<uint32_t> layout;   // the layout headers of the gathered blocks (checked after the final synchronisation)
+  if ((s->use_rccl || s->host_merge) && gather) {
+    // ALL-GATHER of position-ordered blocks (density_clustering_cuda.cu:311-326 copies row blocks on the host): half the
+    // bytes of the all-reduce(min) below and no reduction
+    if ((rc = gather_blocks(s, 4 * block_rows)) != DC_OK) return rc;
+    rc = on_every_device(s, [&](int g) -> int {
+      DevState& d = s->dev[g];
+      return dc_hip_neighbors_block_unpack_dev(d.d_blocks, n, s->n_cols, G, d.d_ws, d.ws_bytes, DC_VARIANT_AUTO, d.d_idx,
+                                               d.d_d2, d.d_idx + n, d.d_d2 + n, d.stream);
+    });
+    if (rc != DC_OK) return rc;
+    layout.resize(G * 8);
+    DevState& d0 = s->dev[0];
+    SESSION_HIP_TRY(hipSetDevice(d0.device));
+    for (size_t g = 0; g < G; ++g)   // (words 0..6 of the header: the last 32 entries of plane 0 of a block)
+      SESSION_HIP_TRY(hipMemcpyAsync(layout.data() + 8 * g, d0.d_blocks + g * 4 * block_rows + (block_rows - 32), 32,
+                                     hipMemcpyDeviceToHost, d0.stream));
+  } else if (s->use_rccl || s->host_merge) {
+    // DC_SESSION_NN_MERGE=allreduce: every row has one owner; all other devices hold the larger "none" word
     if ((rc = merge_partials(s, [](DevState& d) { return (void*)d.d_words; }, 2 * n, ncclUint64, ncclMin,
                          "neighbours")) != DC_OK)
       return rc;
@@ -522,6 +587,9 @@ int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float*
   if (d2_host) SESSION_HIP_TRY(hipMemcpyAsync(d2_host, d0.d_d2, sizeof(float) * n, hipMemcpyDeviceToHost, d0.stream));
   if (hd_d2) SESSION_HIP_TRY(hipMemcpyAsync(hd_d2, d0.d_d2 + n, sizeof(float) * n, hipMemcpyDeviceToHost, d0.stream));
   if ((rc = sync_all(s, "nearest-neighbour sweep")) != DC_OK) return rc;
+  for (size_t g = 1; g * 8 < layout.size(); ++g)   // every device must have packed under the same layout (order, deal)
+    if (memcmp(layout.data(), layout.data() + 8 * g, 7 * sizeof(uint32_t)) != 0)
+      return failf(DC_ERR_HIP, "neighbour blocks of devices 0 and %zu were packed under different layouts", g);
   if (sigma2) {
     double acc = 0.0;   // frame order, double: density_clustering.cpp:334-343
     for (size_t i = 0; i < n; ++i) acc += (double)d2_host[i];

@@ -132,13 +132,16 @@ np.savez(sys.argv[3], pops=pops, fe=fe, nn_idx=nn[0], nn_d2=nn[1], hd_idx=nn[2],
 """
 
 
-def test_session_over_rccl(dens, tmp_path):
-    """The merge path of a multi-GPU session -- segment sweeps, pack, ncclAllReduce(sum / min) in a group
-    call, unpack -- with every device the box has; on a one-GPU box as a one-rank communicator."""
+@pytest.mark.parametrize("nn_merge", ["allgather", "allreduce"])
+def test_session_over_rccl(dens, tmp_path, nn_merge):
+    """The merge path of a multi-GPU session -- segment sweeps, ncclAllReduce(sum) of the populations, the
+    neighbours as an ncclAllGather of position-ordered blocks (default) or an ncclAllReduce(min) of packed words
+    (DC_SESSION_NN_MERGE=allreduce), all in group calls -- with every device the box has; on a one-GPU box as a
+    one-rank communicator."""
     from clustering_amd import capi
     avail = capi.device_count()
     out = str(tmp_path / "r.npz")
-    env = dict(os.environ, DC_SESSION_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, DC_SESSION_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", DC_SESSION_NN_MERGE=nn_merge)
     r = subprocess.run([sys.executable, "-c", RCCL_CHILD, ROOT, str(min(avail, 2)), out], capture_output=True,
                        text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -200,15 +203,16 @@ np.savez(sys.argv[3], pops=pops, fe=fe, nn_idx=nn[0], nn_d2=nn[1], hd_idx=nn[2],
 """
 
 
-@pytest.mark.parametrize("n_dev", [2, 3])
-def test_session_host_merge_of_several_segments(dens, tmp_path, n_dev):
+@pytest.mark.parametrize("n_dev,nn_merge", [(2, "allgather"), (3, "allgather"), (3, "allreduce")])
+def test_session_host_merge_of_several_segments(dens, tmp_path, n_dev, nn_merge):
     """The multi-device flow with its HOST merge (what a session falls back to when RCCL cannot be loaded or its
     communicator cannot be built; the reference's own merge, density_clustering_cuda.cu:171-180, :311-326): n_dev
     "devices" on the one physical GPU -- one host thread, stream, workspace and segment each, sweeping concurrently --
-    partial populations summed and packed neighbour words minimised on the host, results and forest equal to the
-    single-device call-by-call path bit for bit."""
+    partial populations summed, the neighbours merged as gathered position-ordered blocks (default: what the RCCL
+    path does with ncclAllGather) or as minimised packed words (DC_SESSION_NN_MERGE=allreduce); results and forest
+    equal to the single-device call-by-call path bit for bit."""
     out = str(tmp_path / "h.npz")
-    env = dict(os.environ, DC_SESSION_ALLOW_DUPLICATE_DEVICES="1")
+    env = dict(os.environ, DC_SESSION_ALLOW_DUPLICATE_DEVICES="1", DC_SESSION_NN_MERGE=nn_merge)
     r = subprocess.run([sys.executable, "-c", HOST_MERGE_CHILD, ROOT, str(n_dev), out], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
