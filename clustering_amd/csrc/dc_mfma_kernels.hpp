@@ -2564,6 +2564,14 @@ inline uint32_t waves_per_group(int nm) {
   if (forced) return (uint32_t)forced;
   return nm <= 2 ? 1u : 4u;
 }
+// Share floor of the per-wave population sweep by problem size: a share of 1 024 reference tiles is right from about
+// 400 000 rows on (C3), but it left a 100 000-row problem (C2: 3 500 tiles) with three shares = 1 500 waves for the
+// chip's 2 048 wave slots -- 1.10 ms per step against 0.89 ms at 256 tiles per share (128: 1.02 ms, the per-wave
+// set-up takes over).  A twelfth of the reference tiles, between 256 and 1 024.
+inline uint32_t pop_share_floor(uint32_t ref_tiles) {
+  const uint32_t f = ref_tiles / 12u;
+  return f < 256u ? 256u : (f > kPopShareFloor ? kPopShareFloor : f);
+}
 inline uint32_t pick_chunks(uint32_t tiles, int tq, uint32_t target, uint32_t ref_tiles,
                             uint32_t share_floor, size_t /*tile_bytes*/) {
   // DC_WAVE_TARGET / DC_SHARE_FLOOR: measurement overrides of the two tuning constants (both sweeps)
@@ -2690,7 +2698,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
   const uint32_t waves = seg_groups(((n_q + 31) / 32 + TQV - 1) / TQV, q_seg), tiles = waves * TQV;
   if (waves == 0) return;
   const uint32_t wpb = waves_per_group(S);
-  const dim3 grid(grid_x8((waves + wpb - 1) / wpb), pick_chunks(tiles, TQV, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128)),
+  const dim3 grid(grid_x8((waves + wpb - 1) / wpb), pick_chunks(tiles, TQV, kPopWaveTarget, T, pop_share_floor(T), (size_t)S * 1024 + 128)),
       block(64 * wpb);
   // B form of the query rows: its own image for a row range, else the B form of the rows in the
   // reference order (img_q)
