@@ -63,7 +63,21 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-PMC_PROFILES = ("r3_c3_pmc.json", "r2b_c3_pmc.json", "r2_c3_pmc.json", "r1_pruned_pmc.json")   # newest first
+PMC_PROFILES = ("r4_c3_pmc.json",)   # counter summaries of THIS tree's kernels (older ones describe other kernels)
+
+
+def csrc_digest():
+    """sha256 over the kernel and host sources of the product (clustering_amd/csrc, include/): what a counter profile
+    is tied to.  A profile measured on other sources says nothing about the kernels this run times."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in ("clustering_amd/csrc", "include"):
+        base = os.path.join(ROOT, d)
+        for f in sorted(os.listdir(base)):
+            if f.endswith((".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                h.update(f.encode())
+                h.update(open(os.path.join(base, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_counters(kernel, n, d, radii, variant):
@@ -74,6 +88,7 @@ def measured_counters(kernel, n, d, radii, variant):
     commit of the kernels it measured); {} for any other workload or variant."""
     if variant not in ("auto", "pruned"):
         return {}
+    here = csrc_digest()
     for fname in PMC_PROFILES:
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", fname)))
@@ -82,12 +97,17 @@ def measured_counters(kernel, n, d, radii, variant):
         w = prof.get("workload", {})
         if (w.get("n_rows"), w.get("n_cols"), w.get("radii")) != (n, d, list(radii)):
             continue
+        if prof.get("csrc_digest") != here:
+            # REFUSED: the counters were collected on other kernel sources than the ones this run times
+            return {"source": "profiles/" + fname, "source_commit": prof.get("commit"), "stale": True,
+                    "source_digest": prof.get("csrc_digest"), "digest_here": here}
         tag = "pop_pruned_kernel" if kernel == "population_count" else "nn_pruned_kernel"
         for name, e in prof.get("kernels", {}).items():
             if tag in name:
                 return {"traffic": e.get("traffic_bytes"), "mfma_busy": e.get("matrix_pipe_utilisation"),
                         "valu_insts_per_tile_pair": e.get("valu_insts_per_32x32_tile_pair"),
-                        "source": "profiles/" + fname, "source_commit": prof.get("commit")}
+                        "source": "profiles/" + fname, "source_commit": prof.get("commit"), "stale": False,
+                        "source_digest": here, "digest_here": here}
     return {}
 
 
@@ -335,9 +355,13 @@ def main():
                      "frac": algorithmic / PEAK_FP32_TFLOPS, "flop_per_pair_algorithmic": 2 * d}
             r.update({
                 "traffic": pmc.get("traffic"),
-                "traffic_note": "bytes per launch at the L2's memory side (TCC_EA0 read requests x 128 B + write requests x "
+                "traffic_note": ("NOT REPORTED: " + str(pmc.get("source")) + " was measured on other kernel sources (digest "
+                                 + str(pmc.get("source_digest")) + ", this tree " + str(pmc.get("digest_here"))
+                                 + "): regenerate it with scratch/profile_r4.sh. " if pmc.get("stale") else "")
+                                + "bytes per launch at the L2's memory side (TCC_EA0 read requests x 128 B + write requests x "
                                 "64 B, separate rocprofv3 --pmc pass, Infinity-Cache hits included) from "
-                                + str(pmc.get("source")) + " (kernels of commit " + str(pmc.get("source_commit"))
+                                + str(pmc.get("source")) + " (kernel sources of digest " + str(pmc.get("source_digest"))
+                                + ", commit " + str(pmc.get("source_commit"))
                                 + "); algorithmic bytes per launch = N*D*4 + outputs = "
                                 f"{n * d * 4 + n * 16} B: the kernel is compute-bound and re-streams its operand image through L2",
                 "mfma_busy": pmc.get("mfma_busy"),
