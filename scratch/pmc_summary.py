@@ -22,7 +22,7 @@ for _ in [0]:
             disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 out = {}
 for k, cs in tot.items():
-    if "pruned_kernel" not in k and "mfma_kernel" not in k and "shared_kernel" not in k and "msym_kernel" not in k:
+    if "pruned_kernel" not in k and "mfma_kernel" not in k and "shared_kernel" not in k and "msym_kernel" not in k and "mfma32_kernel" not in k:
         continue
     out[k] = {c: v / max(1, len(disp[(k, c)])) for c, v in cs.items()}
     out[k]["dispatches"] = max(len(disp[(k, c)]) for c in cs)
