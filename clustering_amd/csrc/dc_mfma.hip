@@ -189,7 +189,9 @@ static inline size_t image_smem(uint32_t n_cols) { return sizeof(float) * 4 * 33
 // operand image of the (centred, scaled) coordinates in the fp16x2 slot layout (dc_mfma_kernels.hpp), rows
 // in natural order (perm == nullptr) or gathered through perm (an ordered frame list).  One thread
 // writes the 16-byte fragment of one lane of one MFMA of one tile; the threads of MFMA 0, half 0
-// also write the squared norm of their row (norms != nullptr).  b_form: query-side pieces (-2x').
+// also write the squared norm of their row (norms != nullptr).  b_form 1: query-side pieces (-2x'); 2: the A form
+// with the pieces of the row's own |x''|^2 / 2^a in the two constant slots (65504 there for a pad row), the folded
+// reference operand of nn_pruned_kernel.
 __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total, uint32_t n_rows,
                              uint32_t D, uint32_t NM, uint32_t T, const float* __restrict__ means,
                              const uint32_t* __restrict__ perm, int b_form, uint4* __restrict__ img,
@@ -246,9 +248,32 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   const float* x = xs + (size_t)(lane & 31u) * D;
   means = org;
   const Scale sc = load_scale(hdr);   // (the sweep's scale: scale_kernel ran before)
+  const bool fold = b_form == 2;
+  b_form = (b_form == 1) ? 1 : 0;
   const float s1 = b_form ? sc.sb : sc.sa;
   auto col = [&](uint32_t k) -> float { return (x[k] - means[k]) * s1; };   // x'' = 2^k fl(x - mu)
   uint32_t w[4] = {0u, 0u, 0u, 0u};
+  double nrm = 0.0;
+  if ((norms || fold) && m == 0 && h == 0) {
+    // |x''|^2 of the SCALED coordinates (double accumulate, rounded once); a power-of-two scale commutes with it
+    // (four columns per step, their loads issued together; summed in column order)
+    for (uint32_t k0 = 0; k0 < D; k0 += 4) {
+      float xv[4], mv[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t k = min(k0 + j, D - 1u);
+        xv[j] = x[k];
+        mv[j] = means[k];
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (k0 + j < D) {
+          const float v = live ? (xv[j] - mv[j]) * s1 : 0.0f;   // (= col(k))
+          nrm += (double)v * (double)v;
+        }
+    }
+  }
+  if (!live && fold && m == 0 && h == 0) w[0] = 0x7BFFu;   // pad row: 65504 * 2^a, far above every threshold
   if (live) {
     // the 8 consecutive slots of this fragment (slot_value's layout, with ONE division for the first
     // coordinate slot instead of one per slot: the divisions were most of this kernel's time)
@@ -263,6 +288,10 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
       uint32_t v;
       if (s0 + j < (uint32_t)kConstSlots) {
         v = b_form ? 0u : const_a_bits(sc.a);
+        if (fold) {
+          const Pieces pn = split2((float)nrm * sc.cinv);   // (as load_query splits c_q)
+          v = (j == 0) ? pn.hi : pn.mid;
+        }
       } else {
         v = 0u;
         if (G < (uint32_t)kPieceGroups) {
@@ -280,24 +309,6 @@ __global__ void image_kernel(const float* __restrict__ coords, uint32_t n_total,
   }
   img[((size_t)t * NM + m) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);   // pad rows: all zero
   if (norms && m == 0 && h == 0) {
-    // |x''|^2 of the SCALED coordinates (double accumulate, rounded once); a power-of-two scale commutes with it
-    // (four columns per step, their loads issued together; summed in column order)
-    double nrm = 0.0;
-    for (uint32_t k0 = 0; k0 < D; k0 += 4) {
-      float xv[4], mv[4];
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j) {
-        const uint32_t k = min(k0 + j, D - 1u);
-        xv[j] = x[k];
-        mv[j] = means[k];
-      }
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j)
-        if (k0 + j < D) {
-          const float v = live ? (xv[j] - mv[j]) * s1 : 0.0f;   // (= col(k))
-          nrm += (double)v * (double)v;
-        }
-    }
     norms[row] = live ? (float)nrm : INFINITY;   // pad rows can never be "inside"
   }
 }
@@ -1898,8 +1909,9 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                      (float4*)(p + L.off_box_p), d_fe, (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos),
                      (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr);
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
+  // (the per-wave sweep takes the reference norms through the operand image: dc_mfma_kernels.hpp "reference norms folded")
   hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
-                     L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
+                     L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, nn_shared_wanted(n_rows, n_cols) ? 0 : 2,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                      (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
   if (q_mode != kQueryOwnOrder) {

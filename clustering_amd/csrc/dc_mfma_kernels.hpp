@@ -401,12 +401,14 @@ __host__ __device__ inline float next_up(float f) {   // f >= 0 finite; inf / Na
 }
 
 // (doubles: the population rule evaluates these at scales far from the final one)
-__host__ __device__ inline double guard_e0_linear(double M, double thr, int D, int rounded) {   // M, thr: scaled
+__host__ __device__ inline double guard_e0_linear(double M, double thr, int D, int rounded, int folded = 0) {   // M, thr: scaled
   const double u = 5.9604644775390625e-8;
   const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
   const double t = (thr > 0.0) ? thr : 0.0;
   const double cR = rounded ? 2.1 : 0.0;
-  const double cM = 3.0 + 4.1 + 27.0 + 34.0 + 72.4 * (nb - 1) + 0.072 * ns + 2.0 + cR;
+  // folded (nn_pruned_kernel: the reference norm in the constant slots, the query norm outside the accumulator): the ns
+  // MFMAs of small products add to an accumulator of magnitude <= M + d2 instead of ~d2 -- 18 u M each
+  const double cM = 3.0 + 4.1 + 27.0 + 34.0 + 72.4 * (nb - 1) + 0.072 * ns + 2.0 + cR + (folded ? 18.0 * ns : 0.0);
   const double cT = 1.0 + 4.1 + 17.0 + 18.0 * (nb - 1) + 18.0 * ns + 1.0 + cR;
   return 1.25 * u * (cM * M + cT * t);
 }
@@ -414,17 +416,17 @@ __host__ __device__ inline double guard_flush(double M, int D, int g, int a) {
   const double fl_rel = ldexp(1.0, -12 - g) + (g > 0 ? ldexp(1.0, -23 + g) : 0.0);
   return 1.25 * (fl_rel * sqrt((double)D * M) + (g > 0 ? (double)D * ldexp(1.0, -27 + g) : 0.0) + ldexp(1.0, -14 + a));
 }
-__host__ __device__ inline double guard_e0(double M, double thr, int D, int g, int a, int rounded) {
-  return guard_e0_linear(M, thr, D, rounded) + guard_flush(M, D, g, a);
+__host__ __device__ inline double guard_e0(double M, double thr, int D, int g, int a, int rounded, int folded = 0) {
+  return guard_e0_linear(M, thr, D, rounded, folded) + guard_flush(M, D, g, a);
 }
 __host__ __device__ inline double guard_kappa(int D, int rounded) {
   const double u = 5.9604644775390625e-8;
   const int nb = (D + kConstSlots + 15) / 16, ns = nm_for(D) - nb;
   return 1.25 * u * (18.0 * ns + 1.0 + 0.25 * D + 9.0 + (rounded ? 2.1 : 0.0));
 }
-__host__ __device__ inline GuardBand guard_band(float M, float thr, int D, const Scale& sc) {   // M, thr: scaled
+__host__ __device__ inline GuardBand guard_band(float M, float thr, int D, const Scale& sc, bool folded = false) {   // M, thr: scaled
   GuardBand gb;
-  gb.e0 = next_up((float)guard_e0((double)M, (double)thr, D, sc.g, sc.a, sc.rounded));
+  gb.e0 = next_up((float)guard_e0((double)M, (double)thr, D, sc.g, sc.a, sc.rounded, folded ? 1 : 0));
   gb.kappa = next_up((float)guard_kappa(D, sc.rounded));
   return gb;
 }
@@ -1709,6 +1711,42 @@ __device__ __forceinline__ void nn_chain(const s16x8 (&a)[NM], const s16x8 (&b)[
   }
 }
 
+// ---- early-out of the pruned neighbour sweep -----------------------------------------------------------------
+// The K slots are ordered "large products first" (slot_value): the constant and every hi x hi product sit in the
+// first kNnCoarse<NM> MFMAs of a chain, the mid x hi / hi x mid corrections after them.  Each correction is at most
+// 2^-11 (1 + 2^-11) |a_k| * |hi(2 b_k)|, all of them together at most 2^-9 (1 + 2^-10) |a| |b| <= 2^-9 (1 + 2^-10) M
+// (M: the extent max |x'|^2 of the sweep, scaled), and the accumulation of the remaining MFMAs moves the value by
+// less than 2^-16 M on top (the guard band's own bound for it is 18 * 2^-24 M per MFMA).  So after the coarse
+// part every FINAL element is >= coarse - nn_skip_bound(M): when the coarse tile minimum minus that bound is not
+// below the chain's candidate threshold in any lane, the rest of the chain can change neither a running minimum
+// nor a candidate list, and is skipped.  Chains that are not skipped run the very MFMA sequence they always ran.
+template <int NM>
+constexpr int kNnCoarse = (NM <= 2) ? 1 : 2;          // n_cols <= 10: 12 slots; n_cols <= 20: 22 slots (NM <= 4)
+__device__ __forceinline__ float nn_skip_bound(float M_scaled) {
+  return M_scaled * (0.001953125f * 1.01f + 1.52587890625e-05f);   // 2^-9 * 1.01 + 2^-16
+}
+
+// the coarse part of a chain into acc_new, with the tile minimum of acc_old (a coarse accumulator too) in its shadow
+template <int NM, int MI = 0>
+__device__ __forceinline__ void nn_chain_coarse(const s16x8 (&a)[NM], const s16x8 (&b)[NM], const f32x16& c0,
+                                                f32x16& acc_new, const f32x16& acc_old, float& tmin) {
+  constexpr int NB = kNnCoarse<NM>;
+  if constexpr (MI < NB) {
+    if constexpr (MI == 0)
+      acc_new = mfma16(a[0], b[0], c0);
+    else
+      acc_new = mfma16(a[MI], b[MI], acc_new);
+    tile_min<(16 * MI) / NB, (16 * (MI + 1)) / NB>(acc_old, tmin);
+    nn_chain_coarse<NM, MI + 1>(a, b, c0, acc_new, acc_old, tmin);
+  }
+}
+// the rest of a chain (fragments kNnCoarse .. NM-1 of the reference tile: `a_rest`)
+template <int NM, int NR_>
+__device__ __forceinline__ void nn_chain_rest(const s16x8 (&a_rest)[NR_], const s16x8 (&b)[NM], f32x16& acc) {
+#pragma unroll
+  for (int m = kNnCoarse<NM>; m < NM; ++m) acc = mfma16(a_rest[m - kNnCoarse<NM>], b[m], acc);
+}
+
 template <int NM, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -1969,6 +2007,48 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+// ---- reference norms folded into the operands (nn_pruned_kernel) --------------------------------------------------
+// The pruned neighbour sweep takes the REFERENCE row's norm through the two constant slots (A side: the pieces of
+// |y'|^2 / 2^a, image_kernel mode 2; B side: 2^a twice, patched in here) and starts every chain from C = 0, so a
+// reference tile is NM x 16 B per lane and nothing else: no 4 x dwordx4 of norms per tile, no 16 + 16 registers for
+// them.  The accumulator is then acc' = |y'|^2 - 2 x'.y' = d2 - |x'|^2: the QUERY norm c_q stays outside, a per-lane
+// constant that moves into the thresholds (a threshold T on d2 is the threshold T - c_q on acc', rounded up: only
+// ever more candidates).  Pad reference rows carry 65504 * 2^a (~2^31) in slot 0 and nothing else; thresholds are
+// capped at kNnThrCap = 1.25 * 2^30 before c_q comes off (every real acc' + c_q is a d2 <= 4 S M < 2^30), so a pad
+// row is never a candidate, also while a query has no incumbent yet (threshold +inf).  What the band pays: the
+// accumulator no longer collapses to ~d2 after the hi x hi products, the ns later MFMAs truncate their addends at
+// 2^-24 of ~M instead of ~d2: + 18 ns u M in e0 (guard_e0_linear, `folded`).
+constexpr float kNnThrCap = 1342177280.0f;   // 1.25 * 2^30
+__device__ __forceinline__ float round_up(float x) {   // >= x for finite x (one ulp or so); +-inf unchanged
+  return (fabsf(x) < INFINITY) ? x + fabsf(x) * 1.1920929e-7f : x;
+}
+__device__ __forceinline__ float nn_prime(float thr, float cq) { return round_up(fminf(thr, kNnThrCap) - cq); }   // d2 units -> acc' units
+__device__ __forceinline__ float nn_unprime(float v, float cq) { return round_up(v + cq); }                       // acc' units -> d2 units
+template <int NM>
+__device__ __forceinline__ void load_query_folded(const uint4* __restrict__ img_b, uint32_t tile, int lane, int h,
+                                                  bool live, const Scale& sc, s16x8 (&b)[NM]) {
+  const uint4* ip = img_b + (size_t)tile * (NM * 64) + lane;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const uint4 v = ip[m * 64];
+    b[m] = __builtin_bit_cast(s16x8, v);
+  }
+  if (h == 0) {
+    const short one = live ? (short)const_a_bits(sc.a) : (short)0;
+    b[0][0] = one;
+    b[0][1] = one;
+  }
+}
+template <int NM>
+__device__ __forceinline__ void load_tile_folded(const uint4* __restrict__ img, uint32_t t, int lane, s16x8 (&a)[NM]) {
+  const uint4* ip = img + (size_t)t * (NM * 64) + lane;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const uint4 v = ip[m * 64];
+    a[m] = __builtin_bit_cast(s16x8, v);
+  }
+}
+
 template <int NM, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -2024,11 +2104,14 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
-  const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc);   // (the extent the scale was chosen for)
+  const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc, true);   // (the extent the scale was chosen for; folded norms)
   (void)cell2;   // (the first ring's floor: the cell edge of the query's own component, set below)
+  (void)norms_r;   // (the reference norms ride in the operand image)
+  const float skipb = nn_skip_bound(__uint_as_float(hdr[kHdrMused]) * sc.s2);   // (early-out of the chains, see nn_chain_coarse)
 
   s16x8 b[TQ][NM];
-  NnPQr q[TQ];
+  NnPQr q[TQ];   // (m_nn, m_hd in d2 units; bn, bh in the accumulators' units: c_q taken off)
+  float cq[TQ];  // |x'|^2 of the lane's query (scaled units)
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
   float4 qbox[TQ];
@@ -2043,7 +2126,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const bool live = frame != kInvalidFrame;
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? frame : 0u;
-    load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
+    load_query_folded<NM>(img_q, tl, lane, h, live, sc, b[qt]);
+    cq[qt] = live ? norms_q[tl * 32 + c] : 0.0f;
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
     q[qt].m_nn = live ? INFINITY : -INFINITY;   // idle lanes can never trigger the exact path
@@ -2063,8 +2147,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
     }
     q[qt].m_nn = fminf(q[qt].m_nn, q[qt].m_hd);   // (two reads of merge64 a moment apart: keep m_nn <= m_hd)
-    q[qt].bn = nn_band(gb, q[qt].m_nn);
-    q[qt].bh = nn_band(gb, q[qt].m_hd);
+    q[qt].bn = nn_prime(nn_band(gb, q[qt].m_nn), cq[qt]);
+    q[qt].bh = nn_prime(nn_band(gb, q[qt].m_hd), cq[qt]);
     qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
     gbox.x = fminf(gbox.x, qbox[qt].x);
     gbox.y = fmaxf(gbox.y, qbox[qt].y);
@@ -2135,8 +2219,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       const float s_nn = bd_nn * sc.s2, s_hd = bd_hd * sc.s2;
       if (bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
       if (bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
-      Q.bn = nn_band(gb, Q.m_nn);
-      Q.bh = nn_band(gb, Q.m_hd);
+      Q.bn = nn_prime(nn_band(gb, Q.m_nn), cq[qt]);
+      Q.bh = nn_prime(nn_band(gb, Q.m_hd), cq[qt]);
       // published at once: the other shares of this group start while this wave is still sweeping
       if (n_chunks > 1) {
         if (bd_nn < FLT_MAX)
@@ -2206,13 +2290,12 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       // are software-pipelined over two accumulator tiles: while the MFMAs of one chain run, the
       // tile minimum of the previous chain issues in their shadow (a wave issues in order).
       s16x8 a0[NM];
-      float4 n0[4];
       auto entry = [&](uint32_t i) {
         return (uint32_t)__builtin_amdgcn_readfirstlane(list[i < cnt ? i : cnt - 1]);
       };
       // the rest of an epilogue: free-energy classes, band test, parking of the candidates.
       // (t, fr) describe the reference tile the accumulator belongs to.
-      auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t, float2 fr) {
+      auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t, float2 fr) __attribute__((always_inline)) {
         constexpr int qi = decltype(qi_c)::value;
         NnPQr& Q = q[qi];
         // Common path: two compares against the cached candidate thresholds.  "Lower free energy" is
@@ -2249,10 +2332,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           // (the two half-wave lanes of a query see different rows of every tile: what either of them has
           //  found bounds the answer of both, so the running minima are shared whenever they move -- the
           //  records of one sequence over all rows instead of two over half of them each)
-          float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+          float new_nn = fminf(Q.m_nn, nn_unprime(tmin, cq[qi])), new_hd = fminf(Q.m_hd, nn_unprime(hmin, cq[qi]));
           new_nn = fminf(new_nn, __shfl_xor(new_nn, 32, 64));
           new_hd = fminf(new_hd, __shfl_xor(new_hd, 32, 64));
-          const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
+          const float bn = nn_prime(nn_band(gb, new_nn), cq[qi]), bh = nn_prime(nn_band(gb, new_hd), cq[qi]);
           const bool trig = (tmin < bn) | (hmin < bh);
           if (__builtin_amdgcn_ballot_w64(trig) != 0) {
             // park this tile's candidates (values within the band of the running minima); element r
@@ -2314,13 +2397,56 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       float2 frB = make_float2(INFINITY, INFINITY);
       // (fr: the tile's free-energy range, fetched with its operands one tile ahead -- read at the start of the
       //  tile's own chains the scalar load's latency sat in front of the second chain of every tile)
-      auto compute = [&](s16x8 (&a)[NM], float4 (&nv)[4], uint32_t t, uint32_t t_next, float2 fr) {
-        const f32x16 c0 = frag16(nv);
+      // (early-out, two operand buffers only) the fragments behind the coarse part of the tile whose last chain is
+      // still pending: the buffer they came from is being refilled while that chain waits for its test
+      constexpr int kRest = kSingleBuffer<NM> ? 1 : NM - kNnCoarse<NM>;
+      s16x8 a_rest_prev[kRest];
+      // coarse minimum -> skip, or finish the chain and run its epilogue
+      auto settle = [&](f32x16& acc, auto qi_c, float tmin_c, uint32_t t, float2 fr, const s16x8 (&a_rest)[kRest]) __attribute__((always_inline)) {
+        constexpr int qi = decltype(qi_c)::value;
+        const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin_c < thr_c) != 0, 0)) {
+          if constexpr (!kSingleBuffer<NM>) nn_chain_rest<NM, kRest>(a_rest, b[qi], acc);
+          float tmin = INFINITY;
+          tile_min<0, 16>(acc, tmin);
+          finish(acc, qi_c, tmin, t, fr);
+        }
+      };
+      auto compute = [&](s16x8 (&a)[NM], uint32_t t, uint32_t t_next, float2 fr) {
+        f32x16 c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = 0.0f;   // (an inline constant of the first MFMA)
         chains += TQ;
         static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+        if constexpr (!kSingleBuffer<NM>) {
+          s16x8 a_rest[kRest];
+#pragma unroll
+          for (int m = 0; m < kRest; ++m) a_rest[m] = a[kNnCoarse<NM> + m];
+          constexpr_for_pairs<TQ>([&](auto qt_c) {
+            constexpr int qt = decltype(qt_c)::value;
+            constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
+            float tmin = INFINITY;
+            nn_chain_coarse<NM>(a, b[qt], c0, accA, accB, tmin);
+            if constexpr (qt == 0)
+              settle(accB, std::integral_constant<int, qb>{}, tmin, tB, frB, a_rest_prev);
+            else
+              settle(accB, std::integral_constant<int, qb>{}, tmin, t, fr, a_rest);
+            tmin = INFINITY;
+            nn_chain_coarse<NM>(a, b[qt + 1], c0, accB, accA, tmin);
+            settle(accA, std::integral_constant<int, qt>{}, tmin, t, fr, a_rest);
+          });
+#pragma unroll
+          for (int m = 0; m < kRest; ++m) a_rest_prev[m] = a_rest[m];
+          tB = t;
+          frB = fr;
+          return;
+        }
         auto refill = [&](auto mi_c) {
-          if constexpr (kSingleBuffer<NM>)
-            refill_frag<NM, decltype(mi_c)::value>(img_r, norms_r, t_next, lane, h, a, nv);
+          if constexpr (kSingleBuffer<NM>) {
+            constexpr int MI = decltype(mi_c)::value;
+            const uint4 v = img_r[(size_t)t_next * (NM * 64) + MI * 64 + lane];
+            a[MI] = __builtin_bit_cast(s16x8, v);
+          }
         };
         constexpr_for_pairs<TQ>([&](auto qt_c) {
           constexpr int qt = decltype(qt_c)::value;
@@ -2336,44 +2462,45 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
             nn_chain<NM>(a, b[qt + 1], c0, accB, accA, tmin);
           finish(accA, std::integral_constant<int, qt>{}, tmin, t, fr);
         });
-        keep_alive(c0);
         tB = t;
         frB = fr;
       };
       if constexpr (kSingleBuffer<NM>) {
         uint32_t t0 = entry(0);
-        load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+        load_tile_folded<NM>(img_r, t0, lane, a0);
         float2 f0 = ferange_r[t0];
         for (uint32_t i = 0; i < cnt; ++i) {
           const uint32_t t1 = entry(i + 1);
           const float2 f1 = ferange_r[t1];
-          compute(a0, n0, t0, t1, f0);
+          compute(a0, t0, t1, f0);
           t0 = t1;
           f0 = f1;
         }
       } else {
         s16x8 a1[NM];
-        float4 n1[4];
         uint32_t t0 = entry(0), t1;
-        load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+        load_tile_folded<NM>(img_r, t0, lane, a0);
         float2 f0 = ferange_r[t0], f1;
         for (uint32_t i = 0; i < cnt; i += 2) {
           t1 = entry(i + 1);
-          load_tile<NM>(img_r, norms_r, t1, lane, h, a1, n1);
+          load_tile_folded<NM>(img_r, t1, lane, a1);
           f1 = ferange_r[t1];
-          compute(a0, n0, t0, t1, f0);
+          compute(a0, t0, t1, f0);
           if (i + 1 < cnt) {
             t0 = entry(i + 2);
-            load_tile<NM>(img_r, norms_r, t0, lane, h, a0, n0);
+            load_tile_folded<NM>(img_r, t0, lane, a0);
             f0 = ferange_r[t0];
-            compute(a1, n1, t1, t0, f1);
+            compute(a1, t1, t0, f1);
           }
         }
       }
       {  // drain: epilogue of the last pending chain of this round
         float tmin = INFINITY;
         tile_min<0, 16>(accB, tmin);
-        finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
+        if constexpr (!kSingleBuffer<NM>)
+          settle(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB, a_rest_prev);
+        else
+          finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
       }
     }
     flush();                                          // the settle test needs the exact incumbents (in LDS)

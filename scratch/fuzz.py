@@ -12,6 +12,7 @@ t0 = time.time()
 for case in range(n_cases):
     n = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 257, 1000, 3000, 9000, 40000, 150000], p=[.03,.03,.05,.05,.05,.05,.1,.14,.2,.12,.08,.07,.03]))
     d = int(rng.integers(1, 65)) if rng.random() < 0.3 else int(rng.integers(1, 33))
+    if rng.random() < 0.15: d = int(rng.choice([9, 10]))   # the fp32-input matrix-core variant's widths
     kind = rng.integers(0, 8)
     if big:
         n = int(rng.choice([9000, 40000, 150000, 400000]))
@@ -40,13 +41,13 @@ for case in range(n_cases):
             c[rng.integers(0, n, max(1, n // 500))] += np.float32(50.0 * spread)
     ct = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).cuda()
     scale = float(np.sqrt(d)) * (sig_loc if sig_loc is not None else float(c.std(axis=0).mean() if n > 1 else 1.0))
-    radii = [float(x) for x in (scale * rng.uniform(0.05, 1.5, size=int(rng.integers(1, 4))))]
+    radii = [float(x) for x in (scale * rng.uniform(0.05, 1.5, size=int(rng.choice([1, 1, 2, 3, 4, 5, 8]))))]
     lo = int(rng.integers(0, n)); hi = int(rng.integers(lo, n + 1))
     if rng.random() < 0.5: lo, hi = 0, n
     ref_p = dens.calculate_populations_partial(ct, radii, lo, hi, variant="direct")
     fe = dens.calculate_free_energies(dens.calculate_populations_partial(ct, radii[:1], variant="direct")[0].contiguous())
     ref_n = dens.nearest_neighbors_partial(ct, fe, lo, hi, variant="direct")
-    for v in ("pruned", "mfma"):
+    for v in ("pruned", "mfma") + (("mfma32",) if d in (9, 10) else ()):
         p = dens.calculate_populations_partial(ct, radii, lo, hi, variant=v)
         q = dens.nearest_neighbors_partial(ct, fe, lo, hi, variant=v)
         ok = bool((p == ref_p).all()) and all(bool((x.view(torch.int32) == y.view(torch.int32)).all()) for x, y in zip(q, ref_n))
