@@ -1722,6 +1722,8 @@ __device__ __forceinline__ void nn_chain(const s16x8 (&a)[NM], const s16x8 (&b)[
 // nor a candidate list, and is skipped.  Chains that are not skipped run the very MFMA sequence they always ran.
 template <int NM>
 constexpr int kNnCoarse = (NM <= 2) ? 1 : 2;          // n_cols <= 10: 12 slots; n_cols <= 20: 22 slots (NM <= 4)
+template <int NM>
+constexpr bool kNnEarly = !kSingleBuffer<NM> && NM > kNnCoarse<NM>;   // (two operand buffers, and something to skip)
 __device__ __forceinline__ float nn_skip_bound(float M_scaled) {
   return M_scaled * (0.001953125f * 1.01f + 1.52587890625e-05f);   // 2^-9 * 1.01 + 2^-16
 }
@@ -2399,14 +2401,14 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       //  tile's own chains the scalar load's latency sat in front of the second chain of every tile)
       // (early-out, two operand buffers only) the fragments behind the coarse part of the tile whose last chain is
       // still pending: the buffer they came from is being refilled while that chain waits for its test
-      constexpr int kRest = kSingleBuffer<NM> ? 1 : NM - kNnCoarse<NM>;
+      constexpr int kRest = kNnEarly<NM> ? NM - kNnCoarse<NM> : 1;
       s16x8 a_rest_prev[kRest];
       // coarse minimum -> skip, or finish the chain and run its epilogue
       auto settle = [&](f32x16& acc, auto qi_c, float tmin_c, uint32_t t, float2 fr, const s16x8 (&a_rest)[kRest]) __attribute__((always_inline)) {
         constexpr int qi = decltype(qi_c)::value;
         const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin_c < thr_c) != 0, 0)) {
-          if constexpr (!kSingleBuffer<NM>) nn_chain_rest<NM, kRest>(a_rest, b[qi], acc);
+          if constexpr (kNnEarly<NM>) nn_chain_rest<NM, kRest>(a_rest, b[qi], acc);
           float tmin = INFINITY;
           tile_min<0, 16>(acc, tmin);
           finish(acc, qi_c, tmin, t, fr);
@@ -2418,7 +2420,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         for (int r = 0; r < 16; ++r) c0[r] = 0.0f;   // (an inline constant of the first MFMA)
         chains += TQ;
         static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
-        if constexpr (!kSingleBuffer<NM>) {
+        if constexpr (kNnEarly<NM>) {
           s16x8 a_rest[kRest];
 #pragma unroll
           for (int m = 0; m < kRest; ++m) a_rest[m] = a[kNnCoarse<NM> + m];
@@ -2478,16 +2480,21 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         }
       } else {
         s16x8 a1[NM];
+        // (the survivor list is read one tile ahead of its use: the LDS latency sat in front of every tile's loads)
+        auto peek = [&](uint32_t i) { return list[i < cnt ? i : cnt - 1]; };
         uint32_t t0 = entry(0), t1;
+        uint32_t l_next = peek(1);
         load_tile_folded<NM>(img_r, t0, lane, a0);
         float2 f0 = ferange_r[t0], f1;
         for (uint32_t i = 0; i < cnt; i += 2) {
-          t1 = entry(i + 1);
+          t1 = (uint32_t)__builtin_amdgcn_readfirstlane(l_next);
+          l_next = peek(i + 2);
           load_tile_folded<NM>(img_r, t1, lane, a1);
           f1 = ferange_r[t1];
           compute(a0, t0, t1, f0);
           if (i + 1 < cnt) {
-            t0 = entry(i + 2);
+            t0 = (uint32_t)__builtin_amdgcn_readfirstlane(l_next);
+            l_next = peek(i + 3);
             load_tile_folded<NM>(img_r, t0, lane, a0);
             f0 = ferange_r[t0];
             compute(a1, t1, t0, f1);
@@ -2497,7 +2504,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       {  // drain: epilogue of the last pending chain of this round
         float tmin = INFINITY;
         tile_min<0, 16>(accB, tmin);
-        if constexpr (!kSingleBuffer<NM>)
+        if constexpr (kNnEarly<NM>)
           settle(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB, a_rest_prev);
         else
           finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);

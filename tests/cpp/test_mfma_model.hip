@@ -15,6 +15,10 @@
 //      sweeps' (band <= 1: pieces in the middle of the range, scaled mid-piece products); for the
 //      latter also that the whole band of the launch is at most 1, as the two-bit epilogue assumes.
 //
+//  (2b) the folded form of the pruned neighbour sweep (reference norm in the constant slots, C = 0, query norm
+//      outside the accumulator): the same band with the folded extra (18 u M per MFMA of small products), and the
+//      early-out rule: every final element >= the element after the coarse MFMAs - nn_skip_bound(M).
+//
 //  (3) ref_credit (the cross-lane reduction of the symmetric population sweep) against a host count on random strings.
 //
 // Prints a summary and exits 0 when all hold, 1 otherwise.  Built by clustering_amd/csrc/Makefile,
@@ -181,6 +185,108 @@ static int run_gram(bool pop_rule, uint32_t D, float scale, float offset, float 
   return bad;
 }
 
+// ---- (2b) the folded form: acc' = |y'|^2 - 2 x'.y' from C = 0; coarse = the value after kNnCoarse<NM> MFMAs ---------
+template <int NM>
+__global__ void gram_tile_folded(const float* ref, const float* qry, uint32_t D, const float* ny, ScaleExp se,
+                                 float* out, float* out_coarse) {
+  const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+  const Scale sc = make_scale(se);
+  s16x8 a[NM], b[NM];
+  for (int m = 0; m < NM; ++m)
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t s = 16 * m + 8 * h + j;
+      a[m][j] = (short)slot_value(s, D, false, sc, [&](uint32_t k) { return ref[c * D + k]; });
+      b[m][j] = (short)slot_value(s, D, true, sc, [&](uint32_t k) { return qry[c * D + k]; });
+    }
+  if (h == 0) {   // (as image_kernel mode 2 and load_query_folded)
+    const Pieces p = split2(ny[c] * sc.cinv);
+    a[0][0] = (short)p.hi;
+    a[0][1] = (short)p.mid;
+    b[0][0] = (short)const_a_bits(sc.a);
+    b[0][1] = (short)const_a_bits(sc.a);
+  }
+  f32x16 acc;
+  for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+  for (int m = 0; m < NM; ++m) {
+    acc = mfma16(a[m], b[m], acc);
+    if (m + 1 == kNnCoarse<NM> || (NM < kNnCoarse<NM> && m + 1 == NM))
+      for (int g = 0; g < 16; ++g) out_coarse[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + c] = acc[g];
+  }
+  for (int g = 0; g < 16; ++g) out[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + c] = acc[g];
+}
+
+template <int NM>
+static int run_gram_folded(uint32_t D, float scale, float offset, double* worst_ratio, double* worst_skip, int trials) {
+  float *d_ref, *d_qry, *d_ny, *d_out, *d_outc;
+  CHECK(hipMalloc((void**)&d_ref, 32 * D * 4));
+  CHECK(hipMalloc((void**)&d_qry, 32 * D * 4));
+  CHECK(hipMalloc((void**)&d_ny, 128));
+  CHECK(hipMalloc((void**)&d_out, 4096));
+  CHECK(hipMalloc((void**)&d_outc, 4096));
+  std::vector<float> ref(32 * D), qry(32 * D), ny(32), out(1024), outc(1024);
+  const double u = ldexp(1.0, -24);
+  const int nb = ((int)D + kConstSlots + 15) / 16, ns = nm_for((int)D) - nb;
+  int bad = 0;
+  for (int t = 0; t < trials; ++t) {
+    double M = 0;
+    for (int i = 0; i < 32; ++i) {
+      double n1 = 0, n2 = 0;
+      for (uint32_t k = 0; k < D; ++k) {
+        const float base = offset * ((k % 3) - 1.0f);
+        ref[i * D + k] = base + scale * (float)((rand() % 20001) - 10000) * 1e-4f;
+        // (every other trial: queries next to the references -- small d2 against a large |x'|^2)
+        qry[i * D + k] = (t & 1) ? ref[((i * 7) & 31) * D + k] + 1e-3f * scale * (float)((rand() % 2001) - 1000) * 1e-3f
+                                 : base + scale * (float)((rand() % 20001) - 10000) * 1e-4f;
+        n1 += (double)ref[i * D + k] * ref[i * D + k];
+        n2 += (double)qry[i * D + k] * qry[i * D + k];
+      }
+      M = fmax(M, fmax(n1, n2));
+    }
+    const ScaleExp se = pick_scale_nn((float)M);
+    double Ms = 0;
+    for (int i = 0; i < 32; ++i) {
+      double n1 = 0, n2 = 0;
+      for (uint32_t k = 0; k < D; ++k) {
+        ref[i * D + k] = ref[i * D + k] * se.c;
+        qry[i * D + k] = qry[i * D + k] * se.c;
+        n1 += (double)ref[i * D + k] * ref[i * D + k];
+        n2 += (double)qry[i * D + k] * qry[i * D + k];
+      }
+      ny[i] = (float)n1;
+      Ms = fmax(Ms, fmax(n1, n2));
+    }
+    CHECK(hipMemcpy(d_ref, ref.data(), 32 * D * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_qry, qry.data(), 32 * D * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_ny, ny.data(), 128, hipMemcpyHostToDevice));
+    gram_tile_folded<NM><<<1, 64>>>(d_ref, d_qry, D, d_ny, se, d_out, d_outc);
+    CHECK(hipMemcpy(out.data(), d_out, 4096, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(outc.data(), d_outc, 4096, hipMemcpyDeviceToHost));
+    const double skipb = (double)Ms * (0.001953125 * 1.01 + 1.52587890625e-05);   // nn_skip_bound
+    for (int i = 0; i < 32; ++i)
+      for (int j = 0; j < 32; ++j) {
+        long double dot = 0;
+        for (uint32_t k = 0; k < D; ++k) dot += (long double)ref[i * D + k] * (long double)qry[j * D + k];
+        const long double E = (long double)ny[i] - 2.0L * dot;   // = d2 - |x'|^2
+        const double absE = (double)fabsl(E);
+        const double bound = u * (4.1 * Ms + 27.0 * Ms + 17.0 * (2.0 * Ms) + (nb - 1) * 18.0 * (4.02 * Ms) +
+                                  ns * 18.0 * (absE + 0.004 * Ms) + absE) +
+                             guard_flush(Ms, (int)D, se.g, se.a) / 1.25;
+        const double err = (double)fabsl((long double)out[i * 32 + j] - E);
+        if (err / bound > *worst_ratio) *worst_ratio = err / bound;
+        if (err > bound) ++bad;
+        // early-out: the final element is never more than the skip bound below the coarse one
+        // (where the kernel uses it: the coarse MFMAs hold the constant and every hi x hi product)
+        if ((int)D + kConstSlots <= 16 * kNnCoarse<NM>) {
+          const double drop = (double)outc[i * 32 + j] - (double)out[i * 32 + j];
+          if (drop / skipb > *worst_skip) *worst_skip = drop / skipb;
+          if (drop > skipb) ++bad;
+        }
+      }
+  }
+  (void)hipFree(d_ref); (void)hipFree(d_qry); (void)hipFree(d_ny); (void)hipFree(d_out); (void)hipFree(d_outc);
+  return bad;
+}
+
 // ---- (3) the reference-side reduction of the symmetric population sweep ---------------------------------------
 // ref_credit on random strings: row i of the tile must be credited with the number of (query tile, lane of the
 // row's half-wave) whose string has the sign bit of the row's element set.
@@ -325,6 +431,25 @@ int main() {
     bad += run_gram<nm_for(5)>(pr, 5, 1e10f, 3e10f, 1e20f, &worst_ratio, 20);
     printf("fp16x2 gram chain, %s scale: worst error / (MFMA + dropped-product + flush part of the band) = %.3f, violations %d\n",
            pr ? "population" : "neighbour", worst_ratio, bad);
+  }
+  {
+    double wr = 0, ws = 0;
+    int bf = 0;
+    bf += run_gram_folded<nm_for(2)>(2, 1.0f, 0.0f, &wr, &ws, 40);
+    bf += run_gram_folded<nm_for(3)>(3, 0.3f, 1.0f, &wr, &ws, 40);
+    bf += run_gram_folded<nm_for(5)>(5, 1e-12f, 1e-11f, &wr, &ws, 20);
+    bf += run_gram_folded<nm_for(5)>(5, 1e10f, 3e10f, &wr, &ws, 20);
+    bf += run_gram_folded<nm_for(10)>(10, 0.1f, 0.5f, &wr, &ws, 60);
+    bf += run_gram_folded<nm_for(10)>(10, 0.01f, 3.0f, &wr, &ws, 60);
+    bf += run_gram_folded<nm_for(10)>(10, 100.0f, 1000.0f, &wr, &ws, 40);
+    bf += run_gram_folded<nm_for(14)>(14, 0.1f, 0.5f, &wr, &ws, 40);
+    bf += run_gram_folded<nm_for(15)>(15, 0.1f, 0.5f, &wr, &ws, 40);
+    bf += run_gram_folded<nm_for(20)>(20, 0.1f, 2.0f, &wr, &ws, 40);
+    bf += run_gram_folded<nm_for(30)>(30, 0.1f, 0.5f, &wr, &ws, 40);
+    bf += run_gram_folded<nm_for(64)>(64, 0.05f, 2.0f, &wr, &ws, 30);
+    printf("folded neighbour chain: worst error / band part = %.3f, worst (coarse - final) / skip bound = %.3f, violations %d\n",
+           wr, ws, bf);
+    bad += bf;
   }
   const int bad_credit = run_credit<2>(40) + run_credit<4>(40) + run_credit<6>(40);
   printf("reference-side reduction of the symmetric sweep (2, 4, 6 strings): violations %d\n", bad_credit);
