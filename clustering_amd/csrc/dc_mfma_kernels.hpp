@@ -1728,20 +1728,26 @@ __device__ __forceinline__ float nn_skip_bound(float M_scaled) {
   return M_scaled * (0.001953125f * 1.01f + 1.52587890625e-05f);   // 2^-9 * 1.01 + 2^-16
 }
 
-// the coarse part of a chain into acc_new, with the tile minimum of acc_old (a coarse accumulator too) in its shadow
-template <int NM, int MI = 0>
-__device__ __forceinline__ void nn_chain_coarse(const s16x8 (&a)[NM], const s16x8 (&b)[NM], const f32x16& c0,
+// the coarse part of a chain (NB MFMAs; `a` holds at least those fragments) into acc_new, with the tile minimum of
+// acc_old (a coarse accumulator too) in its shadow
+template <int NM, int NB, int NA, int MI = 0>
+__device__ __forceinline__ void nn_chain_coarse(const s16x8 (&a)[NA], const s16x8 (&b)[NM], const f32x16& c0,
                                                 f32x16& acc_new, const f32x16& acc_old, float& tmin) {
-  constexpr int NB = kNnCoarse<NM>;
+  static_assert(NB <= NA && NB <= NM, "coarse fragments");
   if constexpr (MI < NB) {
     if constexpr (MI == 0)
       acc_new = mfma16(a[0], b[0], c0);
     else
       acc_new = mfma16(a[MI], b[MI], acc_new);
     tile_min<(16 * MI) / NB, (16 * (MI + 1)) / NB>(acc_old, tmin);
-    nn_chain_coarse<NM, MI + 1>(a, b, c0, acc_new, acc_old, tmin);
+    nn_chain_coarse<NM, NB, NA, MI + 1>(a, b, c0, acc_new, acc_old, tmin);
   }
 }
+// the MFMAs of the coarse part that hold the constant and every hi x hi product: ceil((n_cols + 2) / 16), and the most
+// an NM can need (n_cols <= (16 NM - 2) / 3)
+__host__ __device__ constexpr int nn_coarse_for(int n_cols) { return (n_cols + kConstSlots + 15) / 16; }
+template <int NM>
+constexpr int kNnCoarseMax = nn_coarse_for((16 * NM - kConstSlots) / kPieceGroups);
 // the rest of a chain (fragments kNnCoarse .. NM-1 of the reference tile: `a_rest`)
 template <int NM, int NR_>
 __device__ __forceinline__ void nn_chain_rest(const s16x8 (&a_rest)[NR_], const s16x8 (&b)[NM], f32x16& acc) {
@@ -2428,13 +2434,13 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
             constexpr int qt = decltype(qt_c)::value;
             constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
             float tmin = INFINITY;
-            nn_chain_coarse<NM>(a, b[qt], c0, accA, accB, tmin);
+            nn_chain_coarse<NM, kNnCoarse<NM>, NM>(a, b[qt], c0, accA, accB, tmin);
             if constexpr (qt == 0)
               settle(accB, std::integral_constant<int, qb>{}, tmin, tB, frB, a_rest_prev);
             else
               settle(accB, std::integral_constant<int, qb>{}, tmin, t, fr, a_rest);
             tmin = INFINITY;
-            nn_chain_coarse<NM>(a, b[qt + 1], c0, accB, accA, tmin);
+            nn_chain_coarse<NM, kNnCoarse<NM>, NM>(a, b[qt + 1], c0, accB, accA, tmin);
             settle(accA, std::integral_constant<int, qt>{}, tmin, t, fr, a_rest);
           });
 #pragma unroll
@@ -2738,10 +2744,27 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
     if (n_chunks > 1)
       hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s, A.merge64, n_rows);
     hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
-    { sweep_timer_mark(1, true, s); hipLaunchKernelGGL((nn_shared_kernel<S, TQV>), dim3(grid_x8(groups), n_chunks), dim3(256), smem, s, coords, n_rows, n_cols, fe,
-                       A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r, A.fe_c, A.coords_c,
-                       A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg, A.full_range, A.cell2, hdr,
-                       chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2, CV); sweep_timer_mark(1, false, s); }
+    {
+      sweep_timer_mark(1, true, s);
+      // (the MFMAs in front of the early-out test: the most this NM can need, or one fewer for its narrowest rows)
+      constexpr int kNbMax = kNnCoarseMax<S>;
+      constexpr int kNbMin = (S > 1) ? nn_coarse_for((16 * (S - 1) - kConstSlots) / kPieceGroups + 1) : kNbMax;
+      auto launch = [&](auto nb_c) {
+        hipLaunchKernelGGL((nn_shared_kernel<S, TQV, decltype(nb_c)::value>), dim3(grid_x8(groups), n_chunks), dim3(256), smem, s, coords,
+                           n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r, A.fe_c,
+                           A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg, A.full_range, A.cell2,
+                           hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2, CV);
+      };
+      if constexpr (kNbMin != kNbMax) {
+        if (nn_coarse_for((int)n_cols) < kNbMax)
+          launch(std::integral_constant<int, kNbMin>{});
+        else
+          launch(std::integral_constant<int, kNbMax>{});
+      } else {
+        launch(std::integral_constant<int, kNbMax>{});
+      }
+      sweep_timer_mark(1, false, s);
+    }
     if (n_chunks > 1 && A.full_range)
       hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
                          (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)(4 * TQV), A.q_seg, nn_idx,

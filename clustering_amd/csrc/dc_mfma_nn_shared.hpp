@@ -44,7 +44,10 @@ inline bool nn_shared_wanted(uint32_t n_rows, uint32_t n_cols) {
   return nm >= 5 && image > ((size_t)96 << 20);
 }
 
-template <int NM, int TQ>
+// NB: the MFMAs of a chain that run before the early-out test (dc_mfma_kernels.hpp "early-out of the pruned
+// neighbour sweep"): nn_coarse_for(n_cols); the fragments behind them are read from the ring only by the chains
+// that go on.
+template <int NM, int TQ, int NB>
 __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ fe, const uint4* __restrict__ img_r,
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
   const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc);   // (the extent the scale was chosen for)
+  const float skipb = nn_skip_bound(__uint_as_float(hdr[kHdrMused]) * sc.s2);
   (void)cell2;   // (the first ring's floor: the cell edge of the query's own component, set below)
 
   s16x8 b[TQ][NM];
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       };
       // the rest of an epilogue: free-energy classes, band test, parking of the candidates.
       // (t, fr) describe the reference tile the accumulator belongs to.
-      auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t, float2 fr) {
+      auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t, float2 fr) __attribute__((always_inline)) {
         constexpr int qi = decltype(qi_c)::value;
         NnPQ& Q = q[qi];
         // Common path: two compares against the cached candidate thresholds.  "Lower free energy" is
@@ -382,31 +386,42 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
           Q.bh = bh;
         }
       };
-      // accB always holds the chain whose epilogue is still pending: query tile TQ-1 of reference
-      // tile tB (or +inf everywhere: no minimum, no candidates)
+      // Chains software-pipelined over two accumulator tiles WITHIN a reference tile: the coarse part of chain q + 1
+      // runs while the coarse minimum of chain q is taken; a chain none of whose lanes can hold a candidate stops
+      // there, the others read the remaining fragments from the ring slot and go on to the epilogue.  (No chain stays
+      // pending across tiles: the slot is refilled at the next window.)
       f32x16 accA, accB;
+      auto settle = [&](f32x16& acc, auto qi_c, float tmin_c, uint32_t t, float2 fr, const uint4* slot) __attribute__((always_inline)) {
+        constexpr int qi = decltype(qi_c)::value;
+        const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin_c < thr_c) != 0, 0)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
-      uint32_t tB = 0;
-      float2 frB = make_float2(INFINITY, INFINITY);
-      auto compute = [&](const s16x8 (&a)[NM], const float4 (&nv)[4], uint32_t t, float2 fr) {
+          for (int m = NB; m < NM; ++m) acc = mfma16(__builtin_bit_cast(s16x8, slot[m * 64 + lane]), b[qi][m], acc);
+          float tmin = INFINITY;
+          tile_min<0, 16>(acc, tmin);
+          finish(acc, qi_c, tmin, t, fr);
+        }
+      };
+      auto compute = [&](const s16x8 (&a)[NB], const float4 (&nv)[4], uint32_t t, float2 fr, const uint4* slot) {
         const f32x16 c0 = frag16(nv);
         chains += TQ;
         static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+        accA = mfma16(a[0], b[0][0], c0);
+#pragma unroll
+        for (int m = 1; m < NB; ++m) accA = mfma16(a[m], b[0][m], accA);
         constexpr_for_pairs<TQ>([&](auto qt_c) {
           constexpr int qt = decltype(qt_c)::value;
-          constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
           float tmin = INFINITY;
-          nn_chain<NM>(a, b[qt], c0, accA, accB, tmin);
-          finish(accB, std::integral_constant<int, qb>{}, tmin, (qt == 0) ? tB : t,
-                 (qt == 0) ? frB : fr);
+          nn_chain_coarse<NM, NB, NB>(a, b[qt + 1], c0, accB, accA, tmin);
+          settle(accA, std::integral_constant<int, qt>{}, tmin, t, fr, slot);
           tmin = INFINITY;
-          nn_chain<NM>(a, b[qt + 1], c0, accB, accA, tmin);
-          finish(accA, std::integral_constant<int, qt>{}, tmin, t, fr);
+          if constexpr (qt + 2 < TQ)
+            nn_chain_coarse<NM, NB, NB>(a, b[qt + 2], c0, accA, accB, tmin);
+          else
+            tile_min<0, 16>(accB, tmin);
+          settle(accB, std::integral_constant<int, qt + 1>{}, tmin, t, fr, slot);
         });
         keep_alive(c0);
-        tB = t;
-        frB = fr;
       };
       if ((uint32_t)wib < total) fetch(entry((uint32_t)wib), (uint32_t)wib);
       for (uint32_t i = 0; i < total; ++i) {
@@ -418,19 +433,14 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
         }
         const uint32_t t = entry(i);
         const uint4* slot = ring + (i % kRing) * kUnits;
-        s16x8 a[NM];
+        s16x8 a[NB];
         float4 nv[4];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) a[m] = __builtin_bit_cast(s16x8, slot[m * 64 + lane]);
+        for (int m = 0; m < NB; ++m) a[m] = __builtin_bit_cast(s16x8, slot[m * 64 + lane]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) nv[g] = reinterpret_cast<const float4*>(slot + NM * 64)[2 * g + h];
         const float2 fr = *reinterpret_cast<const float2*>(slot + NM * 64 + 8);
-        if (wave_live) compute(a, nv, t, fr);
-      }
-      {  // drain: epilogue of the last pending chain of this round
-        float tmin = INFINITY;
-        tile_min<0, 16>(accB, tmin);
-        finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
+        if (wave_live) compute(a, nv, t, fr, slot);
       }
       __syncthreads();   // lists and ring are free for the next round
     }
