@@ -1297,6 +1297,7 @@ struct QuerySel {
   uint32_t i_from, i_to, segment, n_segments;
 };
 static int tq_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 5 ? 4 : 2; }   // = tq_for<NM>
+static int tq_nn_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? DC_NN_TQ_SMALL : tq_of(n_cols); }   // = tq_nn_for<NM>
 static int tq_pop_of(uint32_t n_cols) { return nm_for((int)n_cols) <= 2 ? 6 : tq_of(n_cols); }   // = tq_pop_for<NM>
 // query tiles per group of the population sweep that will run: the unit segments are dealt out in and the
 // query image is built for (pop_shared_kernel: the four waves of a workgroup form one group)
@@ -1864,7 +1865,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   }
   // (query tiles per group: a wave's, or with the shared-operand sweep the workgroup's; the orders are padded so that
   //  every component starts at a whole group -- see pop_pruned_one)
-  const uint32_t tq = (uint32_t)tq_of(n_cols) * (nn_shared_wanted(n_rows, n_cols) ? 4u : 1u), group_rows = 32u * tq;
+  const uint32_t tq = nn_shared_wanted(n_rows, n_cols) ? 4u * (uint32_t)tq_of(n_cols) : (uint32_t)tq_nn_of(n_cols), group_rows = 32u * tq;
   const uint32_t T_r = (n_rows + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
   const uint32_t T_q = (n_q + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
   // ordering key: (cell number over all components, quantised free energy) in whole sort passes
@@ -2061,7 +2062,7 @@ __global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G
 }
 
 static uint32_t nn_group_rows(uint32_t n_rows, uint32_t n_cols) {
-  return 32u * (uint32_t)tq_of(n_cols) * (nn_shared_wanted(n_rows, n_cols) ? 4u : 1u);
+  return 32u * (nn_shared_wanted(n_rows, n_cols) ? 4u * (uint32_t)tq_of(n_cols) : (uint32_t)tq_nn_of(n_cols));
 }
 // tiles of the neighbour sweep's padded order (every component starts at a whole query group)
 static uint32_t nn_order_tiles(uint32_t n_rows, uint32_t n_cols) {

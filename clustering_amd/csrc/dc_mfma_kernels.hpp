@@ -616,6 +616,13 @@ __device__ __forceinline__ f32x16 gram_chain(const s16x8 (&a)[NM], const s16x8 (
 // f(integral_constant<0>), f(integral_constant<2>), ... for the even indices below N (compile-time
 // indices for register arrays inside the pipelined tile bodies)
 template <int N, int I = 0, class F>
+__device__ __forceinline__ void constexpr_for_all(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    constexpr_for_all<N, I + 1>(f);
+  }
+}
+template <int N, int I = 0, class F>
 __device__ __forceinline__ void constexpr_for_pairs(F&& f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>{});
@@ -1719,7 +1726,8 @@ __device__ __forceinline__ void nn_chain(const s16x8 (&a)[NM], const s16x8 (&b)[
 // less than 2^-16 M on top (the guard band's own bound for it is 18 * 2^-24 M per MFMA).  So after the coarse
 // part every FINAL element is >= coarse - nn_skip_bound(M): when the coarse tile minimum minus that bound is not
 // below the chain's candidate threshold in any lane, the rest of the chain can change neither a running minimum
-// nor a candidate list, and is skipped.  Chains that are not skipped run the very MFMA sequence they always ran.
+// nor a candidate list, and is skipped.  Chains that are not skipped run the very MFMA sequence they always ran (the
+// per-wave kernel starts them again from their first MFMA, the shared-operand kernel goes on from the coarse part).
 template <int NM>
 constexpr int kNnCoarse = (NM <= 2) ? 1 : 2;          // n_cols <= 10: 12 slots; n_cols <= 20: 22 slots (NM <= 4)
 template <int NM>
@@ -1748,13 +1756,6 @@ __device__ __forceinline__ void nn_chain_coarse(const s16x8 (&a)[NA], const s16x
 __host__ __device__ constexpr int nn_coarse_for(int n_cols) { return (n_cols + kConstSlots + 15) / 16; }
 template <int NM>
 constexpr int kNnCoarseMax = nn_coarse_for((16 * NM - kConstSlots) / kPieceGroups);
-// the rest of a chain (fragments kNnCoarse .. NM-1 of the reference tile: `a_rest`)
-template <int NM, int NR_>
-__device__ __forceinline__ void nn_chain_rest(const s16x8 (&a_rest)[NR_], const s16x8 (&b)[NM], f32x16& acc) {
-#pragma unroll
-  for (int m = kNnCoarse<NM>; m < NM; ++m) acc = mfma16(a_rest[m - kNnCoarse<NM>], b[m], acc);
-}
-
 template <int NM, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_mfma_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -2115,7 +2116,10 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc, true);   // (the extent the scale was chosen for; folded norms)
   (void)cell2;   // (the first ring's floor: the cell edge of the query's own component, set below)
   (void)norms_r;   // (the reference norms ride in the operand image)
-  const float skipb = nn_skip_bound(__uint_as_float(hdr[kHdrMused]) * sc.s2);   // (early-out of the chains, see nn_chain_coarse)
+  // (early-out of the chains, see nn_chain_coarse: the cached thresholds q[].bn / q[].bh INCLUDE the skip bound -- the
+  //  coarse test compares against them as they are, and the test in front of the candidate path, which only has to let
+  //  every candidate through, uses them too; the exact bands are formed again inside that path)
+  const float skipb = kNnEarly<NM> ? nn_skip_bound(__uint_as_float(hdr[kHdrMused]) * sc.s2) : 0.0f;
 
   s16x8 b[TQ][NM];
   NnPQr q[TQ];   // (m_nn, m_hd in d2 units; bn, bh in the accumulators' units: c_q taken off)
@@ -2155,8 +2159,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
     }
     q[qt].m_nn = fminf(q[qt].m_nn, q[qt].m_hd);   // (two reads of merge64 a moment apart: keep m_nn <= m_hd)
-    q[qt].bn = nn_prime(nn_band(gb, q[qt].m_nn), cq[qt]);
-    q[qt].bh = nn_prime(nn_band(gb, q[qt].m_hd), cq[qt]);
+    q[qt].bn = nn_prime(nn_band(gb, q[qt].m_nn), cq[qt]) + skipb;
+    q[qt].bh = nn_prime(nn_band(gb, q[qt].m_hd), cq[qt]) + skipb;
     qbox[qt] = (tile < TQT) ? box_q[tile] : make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
     gbox.x = fminf(gbox.x, qbox[qt].x);
     gbox.y = fmaxf(gbox.y, qbox[qt].y);
@@ -2227,8 +2231,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       const float s_nn = bd_nn * sc.s2, s_hd = bd_hd * sc.s2;
       if (bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
       if (bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
-      Q.bn = nn_prime(nn_band(gb, Q.m_nn), cq[qt]);
-      Q.bh = nn_prime(nn_band(gb, Q.m_hd), cq[qt]);
+      Q.bn = nn_prime(nn_band(gb, Q.m_nn), cq[qt]) + skipb;
+      Q.bh = nn_prime(nn_band(gb, Q.m_hd), cq[qt]) + skipb;
       // published at once: the other shares of this group start while this wave is still sweeping
       if (n_chunks > 1) {
         if (bd_nn < FLT_MAX)
@@ -2247,7 +2251,6 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
   // ordering pass): a query at that level has no lower-FE neighbour
   const float fe_floor = fkey_inv(~hdr[12]);
-
   // evaluate and empty the candidate list (64 candidates at a time, one per lane)
   auto flush = [&]() {
     nn_wave_flush(cand, qn, qrows, best64, TQ * 32, coords_c, perm_r, n_cols, lane);
@@ -2392,8 +2395,8 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           }
           Q.m_nn = new_nn;
           Q.m_hd = new_hd;
-          Q.bn = bn;
-          Q.bh = bh;
+          Q.bn = bn + skipb;
+          Q.bh = bh + skipb;
         }
       };
       // accB always holds the chain whose epilogue is still pending: query tile TQ-1 of reference
@@ -2405,21 +2408,6 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       float2 frB = make_float2(INFINITY, INFINITY);
       // (fr: the tile's free-energy range, fetched with its operands one tile ahead -- read at the start of the
       //  tile's own chains the scalar load's latency sat in front of the second chain of every tile)
-      // (early-out, two operand buffers only) the fragments behind the coarse part of the tile whose last chain is
-      // still pending: the buffer they came from is being refilled while that chain waits for its test
-      constexpr int kRest = kNnEarly<NM> ? NM - kNnCoarse<NM> : 1;
-      s16x8 a_rest_prev[kRest];
-      // coarse minimum -> skip, or finish the chain and run its epilogue
-      auto settle = [&](f32x16& acc, auto qi_c, float tmin_c, uint32_t t, float2 fr, const s16x8 (&a_rest)[kRest]) __attribute__((always_inline)) {
-        constexpr int qi = decltype(qi_c)::value;
-        const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin_c < thr_c) != 0, 0)) {
-          if constexpr (kNnEarly<NM>) nn_chain_rest<NM, kRest>(a_rest, b[qi], acc);
-          float tmin = INFINITY;
-          tile_min<0, 16>(acc, tmin);
-          finish(acc, qi_c, tmin, t, fr);
-        }
-      };
       auto compute = [&](s16x8 (&a)[NM], uint32_t t, uint32_t t_next, float2 fr) {
         f32x16 c0;
 #pragma unroll
@@ -2427,26 +2415,43 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         chains += TQ;
         static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
         if constexpr (kNnEarly<NM>) {
-          s16x8 a_rest[kRest];
+          // Early-out (see nn_chain_coarse): the coarse minima of the tile's TQ chains are tested TOGETHER -- one scalar
+          // hand-off per reference tile instead of one per chain (C3: 11.1 -> 10.8 ms) --, and a chain that goes on is
+          // computed again from its first MFMA, so no accumulator has to wait for its test and nothing stays pending
+          // across tiles.
+          float tm[TQ], dmin = INFINITY;
+          auto coarse_first = [&](f32x16& acc, const s16x8 (&bq)[NM]) {
+            acc = mfma16(a[0], bq[0], c0);
 #pragma unroll
-          for (int m = 0; m < kRest; ++m) a_rest[m] = a[kNnCoarse<NM> + m];
+            for (int m = 1; m < kNnCoarse<NM>; ++m) acc = mfma16(a[m], bq[m], acc);
+          };
+          coarse_first(accA, b[0]);
           constexpr_for_pairs<TQ>([&](auto qt_c) {
             constexpr int qt = decltype(qt_c)::value;
-            constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
-            float tmin = INFINITY;
-            nn_chain_coarse<NM, kNnCoarse<NM>, NM>(a, b[qt], c0, accA, accB, tmin);
-            if constexpr (qt == 0)
-              settle(accB, std::integral_constant<int, qb>{}, tmin, tB, frB, a_rest_prev);
+            tm[qt] = INFINITY;
+            nn_chain_coarse<NM, kNnCoarse<NM>, NM>(a, b[qt + 1], c0, accB, accA, tm[qt]);
+            tm[qt + 1] = INFINITY;
+            if constexpr (qt + 2 < TQ)
+              nn_chain_coarse<NM, kNnCoarse<NM>, NM>(a, b[qt + 2], c0, accA, accB, tm[qt + 1]);
             else
-              settle(accB, std::integral_constant<int, qb>{}, tmin, t, fr, a_rest);
-            tmin = INFINITY;
-            nn_chain_coarse<NM, kNnCoarse<NM>, NM>(a, b[qt + 1], c0, accB, accA, tmin);
-            settle(accA, std::integral_constant<int, qt>{}, tmin, t, fr, a_rest);
+              tile_min<0, 16>(accB, tm[qt + 1]);
           });
 #pragma unroll
-          for (int m = 0; m < kRest; ++m) a_rest_prev[m] = a_rest[m];
-          tB = t;
-          frB = fr;
+          for (int qi = 0; qi < TQ; ++qi) dmin = fminf(dmin, tm[qi] - ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn));
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmin < 0.0f) != 0, 0)) {
+            constexpr_for_all<TQ>([&](auto qi_c) {
+              constexpr int qi = decltype(qi_c)::value;
+              const float thr_c = (fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn;
+              if (__builtin_amdgcn_ballot_w64(tm[qi] < thr_c) != 0) {
+                f32x16 acc = mfma16(a[0], b[qi][0], c0);
+#pragma unroll
+                for (int m = 1; m < NM; ++m) acc = mfma16(a[m], b[qi][m], acc);
+                float tmin = INFINITY;
+                tile_min<0, 16>(acc, tmin);
+                finish(acc, qi_c, tmin, t, fr);
+              }
+            });
+          }
           return;
         }
         auto refill = [&](auto mi_c) {
@@ -2511,7 +2516,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         float tmin = INFINITY;
         tile_min<0, 16>(accB, tmin);
         if constexpr (kNnEarly<NM>)
-          settle(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB, a_rest_prev);
+          (void)tmin;   // (nothing stays pending across tiles)
         else
           finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
       }
@@ -2623,6 +2628,14 @@ constexpr int tq_for = (NM <= 5) ? 4 : 2;
 // (measured at C3: 23.6 ms against 25.1 ms with four; eight spill; the neighbour sweep loses at six)
 template <int NM>
 constexpr int tq_pop_for = (NM <= 2) ? 6 : tq_for<NM>;
+// the neighbour sweeps: six as well since the early-out (round 4: the chains are short, the per-tile work -- loads,
+// list, the one test -- is shared by six of them; C3 11.0 -> 10.7 ms, 256 registers, no spill.  DC_NN_TQ_SMALL=4:
+// measurements)
+#ifndef DC_NN_TQ_SMALL
+#define DC_NN_TQ_SMALL 6
+#endif
+template <int NM>
+constexpr int tq_nn_for = (NM <= 2) ? DC_NN_TQ_SMALL : tq_for<NM>;   // (dc_mfma.hip tq_nn_of)
 // query tiles per wave of the full sweeps (double-buffered reference operands)
 template <int NM>
 constexpr int tq_full_for = (NM <= 4) ? 4 : (NM <= 8) ? 2 : 1;
@@ -2806,8 +2819,11 @@ void nn_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, c
                         const NnPrunedArgs& A, uint32_t T, const uint32_t* hdr,
                         unsigned long long* chain_counter, uint32_t* nn_idx, float* nn_d2,
                         uint32_t* hd_idx, float* hd_d2, hipStream_t s) {
-  nn_pruned_launch<S, tq_for<S>>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2,
-                                 hd_idx, hd_d2, s);
+  // (the shared-operand sweep keeps tq_for: its workgroup of four waves is one group of 4 * TQ tiles)
+  if (nn_shared_wanted(n_rows, n_cols))
+    nn_pruned_launch<S, tq_for<S>>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2, hd_idx, hd_d2, s);
+  else
+    nn_pruned_launch<S, tq_nn_for<S>>(coords, n_rows, n_cols, fe, A, T, hdr, chain_counter, nn_idx, nn_d2, hd_idx, hd_d2, s);
 }
 
 // pruned population sweep: queries = n_q spatially ordered rows (image/perm/boxes "q"), references =
