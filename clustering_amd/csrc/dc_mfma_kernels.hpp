@@ -2699,13 +2699,14 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // box scans must stay small next to the chains.  Measured on C3 (1M x 10): the full sweeps are
 // fastest at 12 chunks (pop 38.3 -> 35.6 ms, nn 50.2 -> 38.8 ms against one chunk), one eighth of the
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
-constexpr uint32_t kPopWaveTarget = 196608, kNnWaveTarget = 98304, kNnWaveTargetPerWave = 57344;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
+constexpr uint32_t kPopWaveTarget = 49152, kPopSharedWaveTarget = 196608, kNnWaveTarget = 98304, kNnWaveTargetPerWave = 57344;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
 constexpr uint32_t kPopShareFloor = 1024, kNnShareFloor = 900;     //  49152 / 1024: C3 12.30 -> 12.12 ms, one eighth of it 1.82 -> 1.72 ms;
                                                                    //  per-wave neighbour sweep 98304 -> 57344: C3 14.26 -> 14.10 ms, two boxes;
-                                                                   //  round 4, populations 49152 -> 196608: the shared-operand sweeps end with
+                                                                   //  round 4, shared-operand population sweeps 49152 -> 196608: they end with
                                                                    //  fewer half-empty CUs -- one rank of C5 450 -> 409 ms, 1M x 30 x 8 radii
-                                                                   //  154 -> 132, 1M x 16 x 4 radii 91 -> 78, 600k x 40 19.2 -> 17.3 ms; C3 / C2
-                                                                   //  11.76 -> 11.58 / 0.84 -> 0.85 ms)
+                                                                   //  154 -> 132, 1M x 16 x 4 radii 91 -> 78, 600k x 40 19.2 -> 17.3 ms; the
+                                                                   //  per-wave sweep of C3 is box-dependent at 196608 (11.76 -> 11.58 on one,
+                                                                   //  12.1 -> 12.4 ms on another, 56 % more memory-side traffic): it stays)
 // waves per workgroup of the per-wave sweeps (pop_pruned_kernel, nn_pruned_kernel; see nn_pruned_kernel): ONE while a
 // chain has at most two MFMAs -- no slot waits for the slowest wave of a workgroup (1M x 10: neighbours 16.1 -> 15.0 ms,
 // 1M x 3: 5.7 -> 5.3 / populations 6.3 -> 6.05 ms) -- and four beyond that: the four waves of a workgroup sit on one CU
@@ -2901,7 +2902,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
     constexpr int kTQS = tq_shared_for<S, NRV>;
     const uint32_t groups = seg_groups(((n_q + 31) / 32 + 4 * kTQS - 1) / (4 * kTQS), q_seg);
     if (groups == 0) return;
-    const dim3 grid_s(grid_x8(groups), pick_chunks(groups * 4 * kTQS, kTQS, kPopWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
+    const dim3 grid_s(grid_x8(groups), pick_chunks(groups * 4 * kTQS, kTQS, kPopSharedWaveTarget, T, kPopShareFloor, (size_t)S * 1024 + 128));
     const size_t smem_s = (size_t)kRing * kTileUnits<S> * 16 + sizeof(uint32_t) * 4 * shared_wave_words(kTQS, NRV);
     if constexpr (NRV > 1 && kTQS == kMsTQ) {
       if (pop_sym_wanted(false, q_mode, q_seg, n_rows, 1) && pop_msym_wanted()) {
