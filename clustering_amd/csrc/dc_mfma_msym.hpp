@@ -60,6 +60,53 @@ __device__ __attribute__((noinline)) void pop_wave_flush_ms(const uint2* queue, 
   }
 }
 
+// ---- radii that hold nothing of a chain -------------------------------------------------------------------------
+// With ASCENDING radii (delta_r = r_r^2 - r_0^2 >= 0, non-decreasing) a chain whose smallest accumulator value is
+// >= 2 + delta_r has all 1 024 pairs outside radius r -- and outside every smaller one.  The strings of such radii are
+// the all-outside pattern (sign 0, bit 30 set: 0x55555555 -- no count, no band, nothing for the reference side), and
+// their 24 epilogue instructions each need not be issued.  At C5 (radii 0.30 ... 0.65 against a typical intra-cluster
+// distance of 0.62) the smallest radius is empty in 99.5 % of the chains, the two smallest in 87.7 %.
+// What the decision may cost decides its form: the lane minima (8 v_min3) and ONE wave-level compare -- "the first
+// kMsSkip<NR> radii are all empty, or none is skipped" -- with one scalar hand-off and two code variants: one rank of C5
+// 412 -> 397 ms; finer decisions lose what they find (three levels 398, five levels 402 ms without the bookkeeping:
+// about 100 cycles per skipped radius and chain against 150 for a five-way decision; forced skips of two / three radii
+// with no decision at all: 368 / 338 ms).  Radii in any other order: nothing is skipped.
+constexpr uint32_t kAllOutside = 0x55555555u;
+template <int NR>
+constexpr int kMsSkip = NR / 4;   // the leading radii skipped together: 2 of 8, 1 of 4
+template <int NR, int K0>
+__device__ __forceinline__ void mr_begin_k(MrAcc<NR>& e) {
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) e.bits[rr] = (rr < K0) ? kAllOutside : 0u;
+}
+template <int NR, int K0, int R0, int R1>   // elements [R0, R1), both even; radii K0 .. NR-1
+__device__ __forceinline__ void mr_epi_k(const f32x16& acc, const PopDeltas<NR>& dl, MrAcc<NR>& e) {
+  static_assert(R0 % 2 == 0 && R1 % 2 == 0, "elements are handled in pairs");
+#pragma unroll
+  for (int rr = K0; rr < NR; ++rr) {
+#pragma unroll
+    for (int r = R0; r < R1; r += 2) {
+      f32x2 t = {acc[r], acc[r + 1]};
+      if (rr != 0) t = t - f32x2{dl.d[rr], dl.d[rr]};
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.x), 30);
+      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.y), 30);
+    }
+  }
+}
+template <int NM, int NR, int K0, int MI = 0>
+__device__ __forceinline__ void mr_chain_k(const s16x8 (&a)[NM], const s16x8 (&b)[NM], const f32x16& c0,
+                                           f32x16& acc_new, const f32x16& acc_old, const PopDeltas<NR>& dl,
+                                           MrAcc<NR>& e) {
+  if constexpr (MI < NM) {
+    if constexpr (MI == 0)
+      acc_new = mfma16(a[0], b[0], c0);
+    else
+      acc_new = mfma16(a[MI], b[MI], acc_new);
+    mr_epi_k<NR, K0, 2 * ((8 * MI) / NM), 2 * ((8 * (MI + 1)) / NM)>(acc_old, dl, e);
+    mr_chain_k<NM, NR, K0, MI + 1>(a, b, c0, acc_new, acc_old, dl, e);
+  }
+}
+
 template <int NM, int NR>
 __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -105,6 +152,30 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
 #pragma unroll
   for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
   const float far2 = r2max * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
+  // radii that hold nothing of a chain (see mr_chain_k): ascending radii only
+  bool radii_ascending = n_rad >= kMsSkip<NR>;
+#pragma unroll
+  for (int rr = 1; rr < NR; ++rr) radii_ascending &= (rr >= n_rad) || (P.dl.d[rr] >= P.dl.d[rr - 1]);
+  const float skip_thr = 2.0f + P.dl.d[kMsSkip<NR> - 1];   // (d[0] = 0)
+  // (a wave that finds nothing to skip in a whole round of its survivor list -- fewer than a quarter of the chains --
+  //  raises the threshold to +inf: its chains then go straight to the full epilogue.  Measured with radii that never
+  //  skip, 0.50 ... 0.65: 451 -> 460 ms, +2 %, the price of the minima; with C5's radii 412 -> 397 ms.)
+  float skip_thr_now = radii_ascending ? skip_thr : INFINITY;
+  uint32_t skip_hits = 0;
+  // number of leading radii (0 or kMsSkip<NR>) that hold nothing of the chain with accumulator `acc` (wave-uniform)
+  auto skip_count = [&](const f32x16& acc) -> int {
+    float tmin = INFINITY;
+    tile_min<0, 16>(acc, tmin);
+    const bool hit = __builtin_amdgcn_ballot_w64(tmin < skip_thr_now) == 0;
+    skip_hits += hit ? 1u : 0u;
+    return hit ? kMsSkip<NR> : 0;
+  };
+  auto with_skip = [&](int k, auto&& body) __attribute__((always_inline)) {
+    switch (k) {
+      case 0: body(std::integral_constant<int, 0>{}); break;
+      default: body(std::integral_constant<int, kMsSkip<NR>>{}); break;
+    }
+  };
 
   for (uint32_t k = tid; k < (uint32_t)(kMsAccSlots * NR * 64); k += 256) acc[k] = 0ull;
 
@@ -346,12 +417,18 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
           chains += TQ;
           f32x16 acc0 = gram_chain<NM>(a, b[0], c0), acc1;
           MrAcc<NR> e;
-          mr_begin<NR>(e);
-          mr_chain<NM, NR>(a, b[1], c0, acc1, acc0, P.dl, e);
+          with_skip(skip_count(acc0), [&](auto k_c) {
+            constexpr int K0 = decltype(k_c)::value;
+            mr_begin_k<NR, K0>(e);
+            mr_chain_k<NM, NR, K0>(a, b[1], c0, acc1, acc0, P.dl, e);
+          });
           keep_alive(c0);
           finish(std::integral_constant<int, 0>{}, e, t);
-          mr_begin<NR>(e);
-          mr_epi<NR, 0, 16>(acc1, P.dl, e);
+          with_skip(skip_count(acc1), [&](auto k_c) {
+            constexpr int K0 = decltype(k_c)::value;
+            mr_begin_k<NR, K0>(e);
+            mr_epi_k<NR, K0, 0, 16>(acc1, P.dl, e);
+          });
           finish(std::integral_constant<int, 1>{}, e, t);
 #ifndef DC_MS_ABL_NOCREDIT
           if ((t / (4u * TQ)) != group)   // (not the workgroup's own group)
@@ -366,6 +443,9 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
         const uint32_t n_win = (total + kMsWin - 1) / kMsWin, w = n_win - 1u, j = w * kMsWin;
         reduce_window(w, [&](uint32_t k) { return entry(j + k); }, min((uint32_t)kMsWin, total - j));
       }
+      // (the skip test of this wave: worth its compare only where it finds something)
+      if (wave_live && total >= 16u && skip_hits * 4u < (uint32_t)TQ * total) skip_thr_now = INFINITY;
+      skip_hits = 0;
     }
     __syncthreads();   // lists, ring and accumulators are free for the next round
   }

@@ -12,8 +12,12 @@ for n, d, r in [(9000, 30, 0.5), (70000, 30, 0.55), (33, 30, 0.5), (4097, 28, 0.
     if n > 100:
         c[rng.integers(0, n, n // 7)] = c[rng.integers(0, n, n // 7)]
     ct = torch.from_numpy(c).cuda()
-    for n_rad in (3, 4, 8):
+    for n_rad, order in ((3, "any"), (4, "any"), (8, "any"), (8, "ascending"), (4, "ascending"), (5, "ascending"), (8, "wide")):
         radii = [float(x) for x in r * rng.uniform(0.6, 1.25, n_rad)]
+        if order == "ascending":   # (the radii a chain holds nothing of are skipped: dc_mfma_msym.hpp mr_chain_k)
+            radii = sorted(radii)
+        if order == "wide":        # from far below to far above the typical pair distance: every skip count occurs
+            radii = [float(x) for x in r * np.linspace(0.25, 1.6, n_rad)]
         want = dens.calculate_populations_partial(ct, radii, variant="direct")
         got = dens.calculate_populations_partial(ct, radii, variant="pruned")
         assert bool((got == want).all()), (n, d, n_rad, int((got != want).sum()))

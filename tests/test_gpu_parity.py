@@ -581,13 +581,20 @@ for n, d, r in [(9000, 30, 0.5), (5000, 24, 0.45), (3000, 40, 0.6), (20000, 10, 
     assert bool((acc == want[:1]).all()), (n, d, "segments")
     equals_oracle(acc, want_o[:1], (n, d, "segments vs oracle"))
     # several radii in ONE sweep (wide rows only: 5..8 MFMAs per chain), 2..17 radii in any order
-    for n_rad in (2, 4, 5, 8, 9, 17):
+    # (ascending radii: the symmetric sweep leaves out the leading radii a chain holds nothing of -- "wide" runs from far
+    #  below to far above the typical pair distance, so that chains with and without the skip occur)
+    for n_rad, order in ((2, "any"), (4, "any"), (5, "any"), (8, "any"), (9, "any"), (17, "any"), (4, "ascending"),
+                         (8, "ascending"), (8, "wide"), (6, "wide")):
         radii = [float(x) for x in r * rng.uniform(0.5, 1.3, n_rad)]
+        if order == "ascending":
+            radii = sorted(radii)
+        if order == "wide":
+            radii = [float(x) for x in r * np.linspace(0.25, 1.6, n_rad)]
         want_m = dens.calculate_populations_partial(ct, radii, variant="direct")
         got_m = dens.calculate_populations_partial(ct, radii, variant="pruned")
-        assert bool((got_m == want_m).all()), (n, d, n_rad)
+        assert bool((got_m == want_m).all()), (n, d, n_rad, order)
         if n_rad in (4, 8, 17):
-            equals_oracle(got_m, oracle.populations(c, radii), (n, d, n_rad, "multi-radius sweep vs oracle"))
+            equals_oracle(got_m, oracle.populations(c, radii), (n, d, n_rad, order, "multi-radius sweep vs oracle"))
         acc = torch.zeros_like(want_m)
         for g in range(2):
             acc += dens.calculate_populations_segment(ct, radii, g, 2)
