@@ -534,12 +534,15 @@ int density_main(int argc, char** argv) {
       LOG("    calculating free energy and population\n    using radii: ");
       for (float r : o.radii) LOG("%g, ", r);
       LOG("\n    using HIP\n");
-      // all radii in one sweep; free energies per radius from the host formula
+      // all radii in one sweep; free energies per radius from the host formula.  (Ascending: the files are per radius,
+      // and the multi-radius sweep leaves out the small radii a chain holds nothing of -- dc_mfma_msym.hpp mr_chain_k.)
+      std::vector<float> radii = o.radii;
+      std::sort(radii.begin(), radii.end());
       std::vector<std::uint32_t> all;
       std::vector<float> fe_r;
-      for (std::size_t k = 0; k < o.radii.size(); ++k) {
+      for (std::size_t k = 0; k < radii.size(); ++k) {
         if (k == 0) {
-          sweep(o.radii, 0, false, all, fe_r, nn_idx, nn_d2, hd_idx, hd_d2);
+          sweep(radii, 0, false, all, fe_r, nn_idx, nn_d2, hd_idx, hd_d2);
         } else if (!o.free_energy.empty()) {
           // FE of radius k: same formula on that population row (density_clustering.cpp:197-212)
           const std::uint32_t* p = all.data() + k * n_rows;
@@ -551,11 +554,11 @@ int density_main(int argc, char** argv) {
             fe_r[i] = (float)(-std::log((double)q));
           }
         }
-        LOG("    storing results for radius %g\n", o.radii[k]);
+        LOG("    storing results for radius %g\n", radii[k]);
         if (!o.population.empty())
-          write_pops(sprintf_f(o.population, o.radii[k]), all.data() + k * n_rows, n_rows, header, cm);
+          write_pops(sprintf_f(o.population, radii[k]), all.data() + k * n_rows, n_rows, header, cm);
         if (!o.free_energy.empty())
-          write_fes(sprintf_f(o.free_energy, o.radii[k]), fe_r.data(), n_rows, header, cm);
+          write_fes(sprintf_f(o.free_energy, radii[k]), fe_r.data(), n_rows, header, cm);
       }
     } else {
       float radius_lump = 1.0f;

@@ -113,6 +113,7 @@ int get_num_gpus() {
 Pops calculate_populations_per_gpu(const float* coords, std::size_t n_rows, std::size_t n_cols,
                                    std::vector<float> radii, std::size_t i_from, std::size_t i_to,
                                    int i_gpu) {
+  std::sort(radii.begin(), radii.end());   // (results are keyed by radius: see calculate_populations)
   std::vector<std::uint32_t> partial(n_rows * radii.size());
   must(dc_hip_populations(coords, n_rows, n_cols, radii.data(), radii.size(), i_from, i_to, i_gpu,
                           partial.data()),
@@ -141,7 +142,10 @@ Pops calculate_populations_partial(const float* coords, const std::vector<float>
 
 Pops calculate_populations(const float* coords, const std::size_t n_rows, const std::size_t n_cols,
                            std::vector<float> radii) {
-  std::sort(radii.begin(), radii.end(), std::greater<float>());   // density_clustering_cuda.cu:147
+  // (density_clustering_cuda.cu:147 sorts descending for its early break; the result is a map keyed by radius, so the
+  //  order is the library's to choose: ascending lets the multi-radius sweep leave out the small radii a chain holds
+  //  nothing of -- dc_mfma_msym.hpp mr_chain_k)
+  std::sort(radii.begin(), radii.end());
   get_num_gpus();
   // all GPUs, one segment each, partials summed on the devices (density_clustering_cuda.cu:149-180 shards
   // row blocks over OpenMP threads and sums on the host)
