@@ -2399,8 +2399,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           Q.bh = bh + skipb;
         }
       };
-      // accB always holds the chain whose epilogue is still pending: query tile TQ-1 of reference
-      // tile tB (or +inf everywhere: no minimum, no candidates)
+      // Full chains (NM = 1 and the single-buffer instances): accB always holds the chain whose epilogue is still
+      // pending -- query tile TQ-1 of reference tile tB (or +inf everywhere: no minimum, no candidates).  The early-out
+      // form (kNnEarly) keeps nothing pending across tiles and uses accA / accB as its two coarse accumulators.
       f32x16 accA, accB;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
