@@ -1546,14 +1546,20 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     } else {
       s16x8 a1[NM];
       float4 n1[4];
+      // (the survivor list is read one tile ahead of its use, as in nn_pruned_kernel: the LDS latency sat in front of
+      //  every tile's loads)
+      auto peek = [&](uint32_t i) { return list[i < cnt ? i : cnt - 1]; };
       uint32_t e0 = entry(0), e1;
+      uint32_t l_next = peek(1);
       load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
       for (uint32_t i = 0; i < cnt; i += 2) {
-        e1 = entry(i + 1);
+        e1 = (uint32_t)__builtin_amdgcn_readfirstlane(l_next);
+        l_next = peek(i + 2);
         load_tile<NM>(img_r, norms_r, e1, lane, h, a1, n1);
         compute(a0, n0, e0, e1);
         if (i + 1 < cnt) {
-          e0 = entry(i + 2);
+          e0 = (uint32_t)__builtin_amdgcn_readfirstlane(l_next);
+          l_next = peek(i + 3);
           load_tile<NM>(img_r, norms_r, e0, lane, h, a0, n0);
           compute(a1, n1, e1, e0);
         }
@@ -2700,9 +2706,11 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // box scans must stay small next to the chains.  Measured on C3 (1M x 10): the full sweeps are
 // fastest at 12 chunks (pop 38.3 -> 35.6 ms, nn 50.2 -> 38.8 ms against one chunk), one eighth of the
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
-constexpr uint32_t kPopWaveTarget = 49152, kPopSharedWaveTarget = 196608, kNnWaveTarget = 98304, kNnWaveTargetPerWave = 57344;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
+constexpr uint32_t kPopWaveTarget = 49152, kPopSharedWaveTarget = 196608, kNnWaveTarget = 98304, kNnWaveTargetPerWave = 40960;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
 constexpr uint32_t kPopShareFloor = 1024, kNnShareFloor = 900;     //  49152 / 1024: C3 12.30 -> 12.12 ms, one eighth of it 1.82 -> 1.72 ms;
                                                                    //  per-wave neighbour sweep 98304 -> 57344: C3 14.26 -> 14.10 ms, two boxes;
+                                                                   //  round 4, six query tiles per wave: 57344 -> 40960, 8 shares instead of 12
+                                                                   //  at C3, 11.2 -> 11.0 ms on one box;
                                                                    //  round 4, shared-operand population sweeps 49152 -> 196608: they end with
                                                                    //  fewer half-empty CUs -- one rank of C5 450 -> 409 ms, 1M x 30 x 8 radii
                                                                    //  154 -> 132, 1M x 16 x 4 radii 91 -> 78, 600k x 40 19.2 -> 17.3 ms; the
