@@ -71,6 +71,16 @@ def _check_coords(coords):
     return coords.shape[0], coords.shape[1]
 
 
+def _ascending(rad, out):
+    """Several radii go to the library in ASCENDING order (the symmetric multi-radius sweep then leaves out the small
+    radii a tile pair holds nothing of -- INTEGRATION.md section 5); the rows come back in the caller's order.
+    -> (radii for the call, buffer for the call, row permutation or None)"""
+    if rad.size < 2 or bool(np.all(rad[1:] >= rad[:-1])):
+        return rad, out, None
+    order = np.argsort(rad, kind="stable")
+    return np.ascontiguousarray(rad[order]), torch.empty_like(out), torch.from_numpy(order).to(out.device)
+
+
 def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="auto", out=None, stats_valid=False):
     """Per-GPU partial of calculate_populations (density_clustering_cuda.cu:45-137).
 
@@ -85,12 +95,15 @@ def calculate_populations_partial(coords, radii, i_from=0, i_to=None, variant="a
     if out is None:
         out = torch.empty((rad.size, n_rows), dtype=torch.int32, device=coords.device)
     assert out.shape == (rad.size, n_rows) and out.dtype == torch.int32 and out.is_contiguous()
+    rad_call, dst, order = _ascending(rad, out)
     with torch.cuda.device(coords.device):
         ws, ws_bytes = _workspace(coords.device).get(n_rows, n_cols, rad.size)
         rc = capi.lib.dc_hip_populations_dev(
-            _dev(coords), n_rows, n_cols, rad.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
-            i_from, i_to, _dev(out), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
+            _dev(coords), n_rows, n_cols, rad_call.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
+            i_from, i_to, _dev(dst), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
     capi.check(rc, "dc_hip_populations_dev")
+    if order is not None:
+        out[order] = dst
     return out
 
 
@@ -104,12 +117,15 @@ def calculate_populations_segment(coords, radii, segment, n_segments, variant="a
     if out is None:
         out = torch.empty((rad.size, n_rows), dtype=torch.int32, device=coords.device)
     assert out.shape == (rad.size, n_rows) and out.dtype == torch.int32 and out.is_contiguous()
+    rad_call, dst, order = _ascending(rad, out)
     with torch.cuda.device(coords.device):
         ws, ws_bytes = _workspace(coords.device).get(n_rows, n_cols, rad.size)
         rc = capi.lib.dc_hip_populations_segment_dev(
-            _dev(coords), n_rows, n_cols, rad.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
-            segment, n_segments, _dev(out), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
+            _dev(coords), n_rows, n_cols, rad_call.ctypes.data_as(C.POINTER(C.c_float)), rad.size,
+            segment, n_segments, _dev(dst), ws, ws_bytes, _variant(variant, stats_valid), _stream_ptr())
     capi.check(rc, "dc_hip_populations_segment_dev")
+    if order is not None:
+        out[order] = dst
     return out
 
 
