@@ -1910,9 +1910,9 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                      (float4*)(p + L.off_box_p), d_fe, (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos),
                      (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr);
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
-  // (the per-wave sweep takes the reference norms through the operand image: dc_mfma_kernels.hpp "reference norms folded")
+  // (the neighbour sweeps take the reference norms through the operand image: dc_mfma_kernels.hpp "reference norms folded")
   hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
-                     L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, nn_shared_wanted(n_rows, n_cols) ? 0 : 2,
+                     L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 2,
                      (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
                      (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
   if (q_mode != kQueryOwnOrder) {

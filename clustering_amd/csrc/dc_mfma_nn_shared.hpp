@@ -96,12 +96,16 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
 
   // (scaled units, like the accumulators and the running minima taken from them)
   const Scale sc = load_scale(hdr);   // (the neighbour scale: scale_kernel ran before the images were built)
-  const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc);   // (the extent the scale was chosen for)
+  // (reference norms folded into the operand image, query norm outside the accumulator -- dc_mfma_kernels.hpp
+  //  "reference norms folded": q[].m_nn / m_hd in d2 units, q[].bn / bh in the accumulators' units)
+  const GuardBand gb = guard_band(__uint_as_float(hdr[kHdrMused]) * sc.s2, 0.0f, (int)n_cols, sc, true);   // (the extent the scale was chosen for)
   const float skipb = nn_skip_bound(__uint_as_float(hdr[kHdrMused]) * sc.s2);
+  (void)norms_r;
   (void)cell2;   // (the first ring's floor: the cell edge of the query's own component, set below)
 
   s16x8 b[TQ][NM];
   NnPQ q[TQ];
+  float cq[TQ];   // |x'|^2 of the lane's query (scaled units)
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
   float4 qbox[TQ];
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     const bool live = frame != kInvalidFrame;
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     jq[qt] = live ? frame : 0u;
-    load_query<NM>(img_q, tl, lane, h, live ? norms_q[tl * 32 + c] : dead_const(sc), sc, b[qt]);
+    load_query_folded<NM>(img_q, tl, lane, h, live, sc, b[qt]);
+    cq[qt] = live ? norms_q[tl * 32 + c] : 0.0f;
     q[qt].feq = live ? fe[jq[qt]] : -INFINITY;
     q[qt].spos = live ? (full_range ? pos : invpos_r[jq[qt]]) : 0xFFFFFFFFu;
     if (h == 0) jq_tab[qt * 32 + c] = jq[qt];
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       if (g_hd[qt] < FLT_MAX) q[qt].m_hd = s_hd + (gb.e0 + gb.kappa * s_hd);
     }
     q[qt].m_nn = fminf(q[qt].m_nn, q[qt].m_hd);   // (two reads of merge64 a moment apart: keep m_nn <= m_hd)
-    q[qt].bn = nn_band(gb, q[qt].m_nn);
-    q[qt].bh = nn_band(gb, q[qt].m_hd);
+    q[qt].bn = nn_prime(nn_band(gb, q[qt].m_nn), cq[qt]);
+    q[qt].bh = nn_prime(nn_band(gb, q[qt].m_hd), cq[qt]);
     q[qt].bd_nn = FLT_MAX;
     q[qt].bd_hd = FLT_MAX;
     q[qt].bj_nn = n_rows + 1;
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       const float s_nn = Q.bd_nn * sc.s2, s_hd = Q.bd_hd * sc.s2;
       if (Q.bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
       if (Q.bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
-      Q.bn = nn_band(gb, Q.m_nn);
-      Q.bh = nn_band(gb, Q.m_hd);
+      Q.bn = nn_prime(nn_band(gb, Q.m_nn), cq[qt]);
+      Q.bh = nn_prime(nn_band(gb, Q.m_hd), cq[qt]);
       // published at once: the other shares of this group start while this wave is still sweeping
       if (n_chunks > 1) {
         if (Q.bd_nn < FLT_MAX)
@@ -281,14 +286,13 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
         const uint32_t off = i - (w == 0 ? 0u : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
         return (uint32_t)__builtin_amdgcn_readfirstlane(lists[w][off]);
       };
-      // reference tile t -> ring slot, by this wave alone (see pop_shared_kernel): NM fragments of 1 KB, the 32 row
-      // norms (lanes 0..7) and the tile's free-energy range (two dwords)
+      // reference tile t -> ring slot, by this wave alone (see pop_shared_kernel): NM fragments of 1 KB (the row norms
+      // ride in their constant slots) and the tile's free-energy range (two dwords)
       auto fetch = [&](uint32_t t, uint32_t slot_id) {
         const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + slot_id * kUnits));
         const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
 #pragma unroll
         for (int m = 0; m < NM; ++m) lds_dma16(src + m * 64, dst + (uint32_t)m * 1024u);
-        if (lane < 8) lds_dma16(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane, dst + (uint32_t)NM * 1024u);
         if (lane < 2) lds_dma4(reinterpret_cast<const float*>(ferange_r + t) + lane, dst + (uint32_t)NM * 1024u + 128u);
       };
       // the rest of an epilogue: free-energy classes, band test, parking of the candidates.
@@ -330,10 +334,10 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
           // (the two half-wave lanes of a query see different rows of every tile: what either of them has
           //  found bounds the answer of both, so the running minima are shared whenever they move -- the
           //  records of one sequence over all rows instead of two over half of them each)
-          float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
+          float new_nn = fminf(Q.m_nn, nn_unprime(tmin, cq[qi])), new_hd = fminf(Q.m_hd, nn_unprime(hmin, cq[qi]));
           new_nn = fminf(new_nn, __shfl_xor(new_nn, 32, 64));
           new_hd = fminf(new_hd, __shfl_xor(new_hd, 32, 64));
-          const float bn = nn_band(gb, new_nn), bh = nn_band(gb, new_hd);
+          const float bn = nn_prime(nn_band(gb, new_nn), cq[qi]), bh = nn_prime(nn_band(gb, new_hd), cq[qi]);
           const bool trig = (tmin < bn) | (hmin < bh);
           if (__builtin_amdgcn_ballot_w64(trig) != 0) {
             // park this tile's candidates (values within the band of the running minima); element r
@@ -388,40 +392,49 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       };
       // Chains software-pipelined over two accumulator tiles WITHIN a reference tile: the coarse part of chain q + 1
       // runs while the coarse minimum of chain q is taken; a chain none of whose lanes can hold a candidate stops
-      // there, the others read the remaining fragments from the ring slot and go on to the epilogue.  (No chain stays
-      // pending across tiles: the slot is refilled at the next window.)
+      // there, the others are computed in full (remaining fragments from the ring slot) and go on to the epilogue.
+      // (No chain stays pending across tiles: the slot is refilled at the next window.)
       f32x16 accA, accB;
-      auto settle = [&](f32x16& acc, auto qi_c, float tmin_c, uint32_t t, float2 fr, const uint4* slot) __attribute__((always_inline)) {
-        constexpr int qi = decltype(qi_c)::value;
-        const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin_c < thr_c) != 0, 0)) {
+      auto compute = [&](const s16x8 (&a)[NB], uint32_t t, float2 fr, const uint4* slot) {
+        f32x16 c0;
 #pragma unroll
-          for (int m = NB; m < NM; ++m) acc = mfma16(__builtin_bit_cast(s16x8, slot[m * 64 + lane]), b[qi][m], acc);
-          float tmin = INFINITY;
-          tile_min<0, 16>(acc, tmin);
-          finish(acc, qi_c, tmin, t, fr);
-        }
-      };
-      auto compute = [&](const s16x8 (&a)[NB], const float4 (&nv)[4], uint32_t t, float2 fr, const uint4* slot) {
-        const f32x16 c0 = frag16(nv);
+        for (int r = 0; r < 16; ++r) c0[r] = 0.0f;   // (an inline constant of the first MFMA)
         chains += TQ;
         static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+        // the coarse minima of the tile's TQ chains, tested together (one scalar hand-off per tile, as in
+        // nn_pruned_kernel); a chain that goes on starts again from its first MFMA
+        float tm[TQ], dmin = INFINITY;
         accA = mfma16(a[0], b[0][0], c0);
 #pragma unroll
         for (int m = 1; m < NB; ++m) accA = mfma16(a[m], b[0][m], accA);
         constexpr_for_pairs<TQ>([&](auto qt_c) {
           constexpr int qt = decltype(qt_c)::value;
-          float tmin = INFINITY;
-          nn_chain_coarse<NM, NB, NB>(a, b[qt + 1], c0, accB, accA, tmin);
-          settle(accA, std::integral_constant<int, qt>{}, tmin, t, fr, slot);
-          tmin = INFINITY;
+          tm[qt] = INFINITY;
+          nn_chain_coarse<NM, NB, NB>(a, b[qt + 1], c0, accB, accA, tm[qt]);
+          tm[qt + 1] = INFINITY;
           if constexpr (qt + 2 < TQ)
-            nn_chain_coarse<NM, NB, NB>(a, b[qt + 2], c0, accA, accB, tmin);
+            nn_chain_coarse<NM, NB, NB>(a, b[qt + 2], c0, accA, accB, tm[qt + 1]);
           else
-            tile_min<0, 16>(accB, tmin);
-          settle(accB, std::integral_constant<int, qt + 1>{}, tmin, t, fr, slot);
+            tile_min<0, 16>(accB, tm[qt + 1]);
         });
-        keep_alive(c0);
+#pragma unroll
+        for (int qi = 0; qi < TQ; ++qi) dmin = fminf(dmin, tm[qi] - (((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb));
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmin < 0.0f) != 0, 0)) {
+          constexpr_for_all<TQ>([&](auto qi_c) {
+            constexpr int qi = decltype(qi_c)::value;
+            const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
+            if (__builtin_amdgcn_ballot_w64(tm[qi] < thr_c) != 0) {
+              f32x16 acc = mfma16(a[0], b[qi][0], c0);
+#pragma unroll
+              for (int m = 1; m < NB; ++m) acc = mfma16(a[m], b[qi][m], acc);
+#pragma unroll
+              for (int m = NB; m < NM; ++m) acc = mfma16(__builtin_bit_cast(s16x8, slot[m * 64 + lane]), b[qi][m], acc);
+              float tmin = INFINITY;
+              tile_min<0, 16>(acc, tmin);
+              finish(acc, qi_c, tmin, t, fr);
+            }
+          });
+        }
       };
       if ((uint32_t)wib < total) fetch(entry((uint32_t)wib), (uint32_t)wib);
       for (uint32_t i = 0; i < total; ++i) {
@@ -434,13 +447,10 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
         const uint32_t t = entry(i);
         const uint4* slot = ring + (i % kRing) * kUnits;
         s16x8 a[NB];
-        float4 nv[4];
 #pragma unroll
         for (int m = 0; m < NB; ++m) a[m] = __builtin_bit_cast(s16x8, slot[m * 64 + lane]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) nv[g] = reinterpret_cast<const float4*>(slot + NM * 64)[2 * g + h];
         const float2 fr = *reinterpret_cast<const float2*>(slot + NM * 64 + 8);
-        if (wave_live) compute(a, nv, t, fr, slot);
+        if (wave_live) compute(a, t, fr, slot);
       }
       __syncthreads();   // lists and ring are free for the next round
     }
