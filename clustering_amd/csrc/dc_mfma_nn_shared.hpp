@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
       // there, the others are computed in full (remaining fragments from the ring slot) and go on to the epilogue.
       // (No chain stays pending across tiles: the slot is refilled at the next window.)
       f32x16 accA, accB;
-      auto compute = [&](const s16x8 (&a)[NB], uint32_t t, float2 fr, const uint4* slot) {
+      // (i: the tile's place in the round's survivor list -- its index is looked up only by a chain that goes on: the
+      //  look-up is an LDS round trip that sat in front of every tile's operand reads)
+      auto compute = [&](const s16x8 (&a)[NB], uint32_t i, float2 fr, const uint4* slot) {
         f32x16 c0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = 0.0f;   // (an inline constant of the first MFMA)
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
 #pragma unroll
         for (int qi = 0; qi < TQ; ++qi) dmin = fminf(dmin, tm[qi] - (((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb));
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmin < 0.0f) != 0, 0)) {
+          const uint32_t t = entry(i);
           constexpr_for_all<TQ>([&](auto qi_c) {
             constexpr int qi = decltype(qi_c)::value;
             const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
@@ -444,13 +447,12 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
           const uint32_t nxt = i + 4 + (uint32_t)wib;
           if (nxt < total) fetch(entry(nxt), nxt % kRing);
         }
-        const uint32_t t = entry(i);
         const uint4* slot = ring + (i % kRing) * kUnits;
         s16x8 a[NB];
 #pragma unroll
         for (int m = 0; m < NB; ++m) a[m] = __builtin_bit_cast(s16x8, slot[m * 64 + lane]);
         const float2 fr = *reinterpret_cast<const float2*>(slot + NM * 64 + 8);
-        if (wave_live) compute(a, t, fr, slot);
+        if (wave_live) compute(a, i, fr, slot);
       }
       __syncthreads();   // lists and ring are free for the next round
     }
