@@ -47,6 +47,18 @@ inline bool nn_shared_wanted(uint32_t n_rows, uint32_t n_cols) {
 // NB: the MFMAs of a chain that run before the early-out test (dc_mfma_kernels.hpp "early-out of the pruned
 // neighbour sweep"): nn_coarse_for(n_cols); the fragments behind them are read from the ring only by the chains
 // that go on.
+// Only the NB coarse fragments of a tile go through the ring: 97 % of the chains stop after them, and the sweep ran at the
+// memory side's pace (C5: 0.56 TB per launch at 5.7 TB/s).  A chain that goes on loads its remaining fragments straight
+// from the image and waits for them -- one rank of C5 100 -> 87 ms.  (DC_NNS_GLOBAL_REST=0: the whole tile through the
+// ring, as before; measurements.)
+#ifndef DC_NNS_GLOBAL_REST
+#define DC_NNS_GLOBAL_REST 1
+#endif
+#if DC_NNS_GLOBAL_REST
+#define DC_NNS_RING_FRAGS NB
+#else
+#define DC_NNS_RING_FRAGS NM
+#endif
 template <int NM, int TQ, int NB>
 __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -286,13 +298,13 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
         const uint32_t off = i - (w == 0 ? 0u : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
         return (uint32_t)__builtin_amdgcn_readfirstlane(lists[w][off]);
       };
-      // reference tile t -> ring slot, by this wave alone (see pop_shared_kernel): NM fragments of 1 KB (the row norms
-      // ride in their constant slots) and the tile's free-energy range (two dwords)
+      // reference tile t -> ring slot, by this wave alone (see pop_shared_kernel): the coarse fragments of 1 KB each (the
+      // row norms ride in their constant slots) and the tile's free-energy range (two dwords)
       auto fetch = [&](uint32_t t, uint32_t slot_id) {
         const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + slot_id * kUnits));
         const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) lds_dma16(src + m * 64, dst + (uint32_t)m * 1024u);
+        for (int m = 0; m < DC_NNS_RING_FRAGS; ++m) lds_dma16(src + m * 64, dst + (uint32_t)m * 1024u);
         if (lane < 2) lds_dma4(reinterpret_cast<const float*>(ferange_r + t) + lane, dst + (uint32_t)NM * 1024u + 128u);
       };
       // the rest of an epilogue: free-energy classes, band test, parking of the candidates.
@@ -430,8 +442,19 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
               f32x16 acc = mfma16(a[0], b[qi][0], c0);
 #pragma unroll
               for (int m = 1; m < NB; ++m) acc = mfma16(a[m], b[qi][m], acc);
+#if DC_NNS_GLOBAL_REST
+              {
+                const uint4* rest = img_r + (size_t)t * (NM * 64) + lane;
+                s16x8 ar[NM - NB > 0 ? NM - NB : 1];
+#pragma unroll
+                for (int m = NB; m < NM; ++m) ar[m - NB] = __builtin_bit_cast(s16x8, rest[m * 64]);
+#pragma unroll
+                for (int m = NB; m < NM; ++m) acc = mfma16(ar[m - NB], b[qi][m], acc);
+              }
+#else
 #pragma unroll
               for (int m = NB; m < NM; ++m) acc = mfma16(__builtin_bit_cast(s16x8, slot[m * 64 + lane]), b[qi][m], acc);
+#endif
               float tmin = INFINITY;
               tile_min<0, 16>(acc, tmin);
               finish(acc, qi_c, tmin, t, fr);
