@@ -1206,12 +1206,14 @@ static uint32_t data_cookie(const float* d_coords, uint32_t n_rows, uint32_t n_c
 }
 
 // the per-sweep words of a header whose statistics stay (DC_FLAG_STATS_VALID): evaluated-tile counters (words 2..5), the
-// free-energy range (12..13), the fingerprint the guard recomputes (kHdrFp + 2, + 3)
+// free-energy range (12..13), the fingerprint the guard recomputes (kHdrFp + 2, + 3), the extent over the components
+// (a header built from scratch starts from zeros altogether)
 __global__ void sweep_words_reset_kernel(uint32_t* __restrict__ hdr) {
   const uint32_t k = threadIdx.x;
   if (k >= 2u && k <= 5u) hdr[k] = 0u;
   if (k == 12u || k == 13u) hdr[k] = 0u;
   if (k == kHdrFp + 2u || k == kHdrFp + 3u) hdr[k] = 0u;
+  if (k == kHdrMloc) hdr[k] = 0u;   // (the extent over the components: order_rows_kernel of this call forms it again)
 }
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
@@ -1511,7 +1513,6 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   if (prep) {
     // components of the frames for this call's largest radius, their origins and fine grids
     (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
-    (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
     hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn,
                        comp);
     hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
@@ -1888,7 +1889,6 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   // the pass over the free energies finds their range (and raises the flag for NaNs)
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 256u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
                      (uint32_t*)nullptr, hdr);
-  (void)hipMemsetAsync(hdr + kHdrMloc, 0, sizeof(uint32_t), stream);
   const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
   if (reuse_components) {
     // the partition an earlier sweep over these coordinates left in the workspace (DC_FLAG_STATS_VALID: the
