@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdcdensity.so")
 
 DC_OK = 0
-ABI_VERSION = 2               # include/dc_density.h: DC_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 3               # include/dc_density.h: DC_HIP_ABI_VERSION this binding was written against
 FLAG_STATS_VALID = 0x100      # DC_FLAG_STATS_VALID
 VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA, VARIANT_MFMA_PRUNED = 0, 1, 2, 3
 VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA,
@@ -21,13 +21,13 @@ VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA
 SYMBOLS = (
     "dc_hip_last_error", "dc_hip_abi_version", "dc_hip_device_count", "dc_hip_workspace_bytes",
     "dc_hip_populations_dev", "dc_hip_free_energies_dev", "dc_hip_nearest_neighbors_dev",
-    "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_sweep_timing", "dc_hip_last_sweep_ms", "dc_hip_workspace_components_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
+    "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_workspace_mfma_counters_dev", "dc_hip_sweep_timing", "dc_hip_last_sweep_ms", "dc_hip_workspace_components_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs", "dc_hip_radius_min_edge_dev", "dc_hip_radius_forest",
     "dc_hip_populations_segment_dev", "dc_hip_nearest_neighbors_segment_dev",
     "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev", "dc_hip_neighbors_block_rows",
     "dc_hip_neighbors_block_pack_dev", "dc_hip_neighbors_block_unpack_dev", "dc_hip_radius_min_edge_segment_dev",
     "dc_hip_session_open", "dc_hip_session_close", "dc_hip_session_devices", "dc_hip_session_uses_rccl",
-    "dc_hip_session_merge_mode",
+    "dc_hip_session_merge_mode", "dc_hip_session_merge_note",
     "dc_hip_session_counters", "dc_hip_session_populations", "dc_hip_session_free_energies",
     "dc_hip_session_set_free_energies", "dc_hip_session_nearest_neighbors", "dc_hip_session_radius_pairs",
     "dc_hip_session_radius_forest",
@@ -118,6 +118,10 @@ def _load():
     lib.dc_hip_session_uses_rccl.argtypes = [vp]
     lib.dc_hip_session_merge_mode.restype = i32
     lib.dc_hip_session_merge_mode.argtypes = [vp]
+    lib.dc_hip_workspace_mfma_counters_dev.restype = i32
+    lib.dc_hip_workspace_mfma_counters_dev.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
+    lib.dc_hip_session_merge_note.restype = C.c_char_p
+    lib.dc_hip_session_merge_note.argtypes = [vp]
     lib.dc_hip_session_counters.restype = i32
     lib.dc_hip_session_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.dc_hip_session_populations.restype = i32

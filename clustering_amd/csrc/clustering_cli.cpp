@@ -485,7 +485,13 @@ int density_main(int argc, char** argv) {
   // and stay there across pop -> FE -> NN -> sigma2 -> (second pop + NN at the lumping radius) -> forest
   dc_hip_session* session = nullptr;
   auto sess = [&]() {
-    if (!session) must(dc_hip_session_open(coords.data(), n_rows, n_cols, nullptr, n_gpus, &session), "uploading the coordinates");
+    if (!session) {
+      must(dc_hip_session_open(coords.data(), n_rows, n_cols, nullptr, n_gpus, &session), "uploading the coordinates");
+      // which merge runs (density_clustering_cuda.cu:152-180 is never silent about its own): a multi-GPU run that fell
+      // back from RCCL to the host merge is correct and slow -- always said on stderr, every mode under -v
+      if (dc_hip_session_merge_mode(session) == 2) std::cerr << "warning: " << dc_hip_session_merge_note(session) << std::endl;
+      LOG("merge: %s\n", dc_hip_session_merge_note(session));
+    }
     return session;
   };
   std::vector<float> fe;

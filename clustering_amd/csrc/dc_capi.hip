@@ -171,6 +171,17 @@ int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles, 
   return DC_OK;
 }
 
+int dc_hip_workspace_mfma_counters_dev(const void* d_workspace, uint64_t* pop_mfma, uint64_t* nn_mfma, void* stream) {
+  if (!d_workspace) return fail(DC_ERR_INVALID_ARGUMENT, "null workspace");
+  uint32_t h[32];   // header words 6..7 (population sweeps), 26..27 (neighbour sweeps): dc_mfma_kernels.hpp kHdrMfma*
+  hipStream_t s = (hipStream_t)stream;
+  DC_HIP_TRY(hipMemcpyAsync(h, d_workspace, sizeof(h), hipMemcpyDeviceToHost, s));
+  DC_HIP_TRY(hipStreamSynchronize(s));
+  if (pop_mfma) *pop_mfma = ((uint64_t)h[7] << 32) | h[6];
+  if (nn_mfma) *nn_mfma = ((uint64_t)h[27] << 32) | h[26];
+  return DC_OK;
+}
+
 }  // extern "C"
 
 namespace {

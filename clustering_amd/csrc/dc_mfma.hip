@@ -1210,10 +1210,15 @@ static uint32_t data_cookie(const float* d_coords, uint32_t n_rows, uint32_t n_c
 // (a header built from scratch starts from zeros altogether)
 __global__ void sweep_words_reset_kernel(uint32_t* __restrict__ hdr) {
   const uint32_t k = threadIdx.x;
-  if (k >= 2u && k <= 5u) hdr[k] = 0u;
+  if (k >= 2u && k <= 7u) hdr[k] = 0u;                         // (... and the MFMAs the population sweeps issued, 6..7)
+  if (k == kHdrMfmaNn || k == kHdrMfmaNn + 1u) hdr[k] = 0u;   // (the neighbour sweeps')
   if (k == 12u || k == 13u) hdr[k] = 0u;
   if (k == kHdrFp + 2u || k == kHdrFp + 3u) hdr[k] = 0u;
-  if (k == kHdrMloc) hdr[k] = 0u;   // (the extent over the components: order_rows_kernel of this call forms it again)
+  // (the extent over the components: order_rows_kernel of this call forms it again with atomicMax.  INVARIANT: every
+  //  preparation of an order -- prep == true in pop_pruned_one, every nn_pruned_sel -- runs behind a mfma_prepare of the
+  //  SAME API call, which clears the word here or with the header memset; a second preparation on one header without it
+  //  would keep the maximum of the earlier partitions: a wider band, slower, never wrong.)
+  if (k == kHdrMloc) hdr[k] = 0u;
 }
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,

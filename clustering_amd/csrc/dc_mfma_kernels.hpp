@@ -329,6 +329,12 @@ constexpr uint32_t kHdrFp = 14;         // words 14..15: content fingerprint of 
 constexpr uint32_t kHdrCookie = 28;     // whose statistics the header holds (array, shape); 0 after a reset
 constexpr uint32_t kHdrMused = 31;      // the extent max |x - origin|^2 the current sweep's scale was chosen for (float bits)
 constexpr uint32_t kHdrOpen = 30;       // neighbour sweeps: queries listed for the search in other components (nn_open_kernel)
+// MFMA instructions the sweep kernels ISSUED (64-bit counters; bench.py's executed-flop figure: x 32*32*16*2 flop): header
+// words 6..7 for the population sweeps, 26..27 for the neighbour sweeps -- whose early-out leaves most chains at their
+// coarse MFMAs, so chains x NM would overstate it.  Addressed relative to the chain counters the kernels already get
+// (words 2..3 / 4..5): + kMfmaCtrPop / + kMfmaCtrNn 64-bit words.
+constexpr uint32_t kHdrMfmaPop = 6, kHdrMfmaNn = 26;
+constexpr int kMfmaCtrPop = (kHdrMfmaPop - 2) / 2, kMfmaCtrNn = (kHdrMfmaNn - 4) / 2;
 constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: max |x - origin(component of x)|^2 (float bits, with a rounding margin)
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
@@ -1578,7 +1584,10 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
       }
     }
   }
-  if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
+  if (lane == 0 && chain_counter) {
+    atomicAdd(chain_counter, (unsigned long long)chains);
+    atomicAdd(chain_counter + kMfmaCtrPop, (unsigned long long)chains * NM);
+  }
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) flush(qt);
   if constexpr (kWaveWide) flush_wave();
@@ -2263,6 +2272,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     qn = 0;
   };
   uint32_t chains = 0, visited = 0;
+  uint32_t chains_on = 0;   // chains that went on behind the early-out test (computed again in full)
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scans only touch their own boxes)
   // (the tiles of the group's own COMPONENT only -- dc_mfma_kernels.hpp "components": what lies in other components is
@@ -2450,6 +2460,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               constexpr int qi = decltype(qi_c)::value;
               const float thr_c = (fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn;
               if (__builtin_amdgcn_ballot_w64(tm[qi] < thr_c) != 0) {
+                chains_on += 1;
                 f32x16 acc = mfma16(a[0], b[qi][0], c0);
 #pragma unroll
                 for (int m = 1; m < NM; ++m) acc = mfma16(a[m], b[qi][m], acc);
@@ -2558,7 +2569,11 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     }
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
   }
-  if (lane == 0 && chain_counter) atomicAdd(chain_counter, (unsigned long long)chains);
+  if (lane == 0 && chain_counter) {
+    atomicAdd(chain_counter, (unsigned long long)chains);
+    atomicAdd(chain_counter + kMfmaCtrNn, kNnEarly<NM> ? (unsigned long long)chains * kNnCoarse<NM> + (unsigned long long)chains_on * NM
+                                                       : (unsigned long long)chains * NM);
+  }
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {

@@ -156,7 +156,10 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   bool radii_ascending = n_rad >= kMsSkip<NR>;
 #pragma unroll
   for (int rr = 1; rr < NR; ++rr) radii_ascending &= (rr >= n_rad) || (P.dl.d[rr] >= P.dl.d[rr - 1]);
-  const float skip_thr = 2.0f + P.dl.d[kMsSkip<NR> - 1];   // (d[0] = 0)
+  // (rounded UP: fl(2 + d) may lie below 2 + d -- by up to 2^-5 at d ~ 2^19 -- and a chain whose minimum equals it would
+  //  skip radii for which the epilogue's own test, fl(acc - d) >= 2, sends the pair to the band; with t >= next_up(..)
+  //  >= 2 + d the difference is >= 2 exactly, and rounding is monotone: never laxer than the epilogue)
+  const float skip_thr = next_up(2.0f + P.dl.d[kMsSkip<NR> - 1]);   // (d[0] = 0)
   // (a wave that finds nothing to skip in a whole round of its survivor list -- fewer than a quarter of the chains --
   //  raises the threshold to +inf: its chains then go straight to the full epilogue.  Measured with radii that never
   //  skip, 0.50 ... 0.65: 451 -> 460 ms, +2 %, the price of the minima; with C5's radii 412 -> 397 ms.)
@@ -449,7 +452,10 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     }
     __syncthreads();   // lists, ring and accumulators are free for the next round
   }
-  if (lane == 0 && chain_counter && wave_live) atomicAdd(chain_counter, (unsigned long long)chains);
+  if (lane == 0 && chain_counter && wave_live) {
+    atomicAdd(chain_counter, (unsigned long long)chains);
+    atomicAdd(chain_counter + kMfmaCtrPop, (unsigned long long)chains * NM);
+  }
   flush();
 
 #pragma unroll

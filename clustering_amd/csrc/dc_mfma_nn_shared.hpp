@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
   };
 
   uint32_t chains = 0, visited = 0;
+  uint32_t chains_on = 0;   // chains that went on behind the early-out test
   // this wave's share of the reference tiles: t = chunk + u * n_chunks, u = 0 .. U-1 (round-robin, so
   // every share sees every region; the scans only touch their own boxes)
   // (the tiles of the group's own COMPONENT only -- dc_mfma_kernels.hpp "components": what lies in other components is
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
             constexpr int qi = decltype(qi_c)::value;
             const float thr_c = ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn) + skipb;
             if (__builtin_amdgcn_ballot_w64(tm[qi] < thr_c) != 0) {
+              chains_on += 1;
               f32x16 acc = mfma16(a[0], b[qi][0], c0);
 #pragma unroll
               for (int m = 1; m < NB; ++m) acc = mfma16(a[m], b[qi][m], acc);
@@ -520,7 +522,10 @@ __global__ __launch_bounds__(256, 2) void nn_shared_kernel(
     }
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
   }
-  if (lane == 0 && chain_counter && wave_live) atomicAdd(chain_counter, (unsigned long long)chains);
+  if (lane == 0 && chain_counter && wave_live) {
+    atomicAdd(chain_counter, (unsigned long long)chains);
+    atomicAdd(chain_counter + kMfmaCtrNn, (unsigned long long)chains * NB + (unsigned long long)chains_on * NM);
+  }
 
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {

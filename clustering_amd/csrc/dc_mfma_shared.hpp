@@ -375,7 +375,10 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     }
     __syncthreads();   // lists and ring are free for the next round
   }
-  if (lane == 0 && chain_counter && wave_live) atomicAdd(chain_counter, (unsigned long long)chains);
+  if (lane == 0 && chain_counter && wave_live) {
+    atomicAdd(chain_counter, (unsigned long long)chains);
+    atomicAdd(chain_counter + kMfmaCtrPop, (unsigned long long)chains * NM);
+  }
   flush();
 
 #pragma unroll

@@ -126,6 +126,7 @@ struct dc_hip_session {
   size_t n_radii = 0;            // of the populations currently resident
   uint64_t tiles_pop = 0, tiles_nn = 0;
   std::string merge_note;        // why RCCL is not used although there are several devices
+  std::string merge_line;        // dc_hip_session_merge_note: the merge in one line
 };
 
 namespace {
@@ -323,6 +324,25 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
     n_devices = avail;
     devices = nullptr;
   }
+  // DC_SESSION_DEVICES="0,1,..." (hosts that do not choose devices themselves -- the C++ shim, the command line): the
+  // device ordinals of the session; with DC_SESSION_ALLOW_DUPLICATE_DEVICES=1 an ordinal may repeat (tests of the
+  // multi-device flow on a one-GPU box)
+  std::vector<int> env_devices;
+  if (!devices) {
+    const char* list = getenv("DC_SESSION_DEVICES");
+    for (const char* c = list; c && *c;) {
+      char* end = nullptr;
+      const long v = strtol(c, &end, 10);
+      if (end == c) break;
+      env_devices.push_back((int)v);
+      c = (*end == ',') ? end + 1 : end;
+      if (*end != ',' && *end != 0) break;
+    }
+    if (!env_devices.empty()) {
+      devices = env_devices.data();
+      n_devices = (int)env_devices.size();
+    }
+  }
   {
     const char* dup = getenv("DC_SESSION_ALLOW_DUPLICATE_DEVICES");
     if (n_devices > avail && !(devices && dup && dup[0] == '1'))
@@ -399,8 +419,22 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
     if (!s->use_rccl && must_rccl)
       rc = failf(DC_ERR_HIP, "%d devices, DC_SESSION_MERGE=rccl: %s", n_devices, why.c_str());
     s->merge_note = why;   // (empty: RCCL is up; else why the session merges on the host)
+  } else if (rc == DC_OK && n_devices > 1) {
+    s->merge_note = duplicates ? "a device is listed more than once (DC_SESSION_ALLOW_DUPLICATE_DEVICES)" : "DC_SESSION_MERGE=host";
   }
   if (rc == DC_OK && n_devices > 1 && !s->use_rccl) s->host_merge = true;
+  {
+    char line[640];
+    if (s->use_rccl)
+      snprintf(line, sizeof(line), "%d device%s: partial results merge on the devices (RCCL all-reduce / all-gather over xGMI)",
+               n_devices, n_devices == 1 ? "" : "s");
+    else if (s->host_merge)
+      snprintf(line, sizeof(line), "%d devices: partial results merge THROUGH THE HOST over PCIe, not RCCL (%s)", n_devices,
+               s->merge_note.empty() ? "no reason recorded" : s->merge_note.c_str());
+    else
+      snprintf(line, sizeof(line), "one device: nothing to merge");
+    s->merge_line = line;
+  }
   if (rc != DC_OK) {
     const std::string keep = dc_hip_last_error();
     dc_hip_session_close(s);
@@ -416,6 +450,8 @@ int dc_hip_session_merge_mode(const dc_hip_session* s) {
   if (!s) return kMergeNone;
   return s->use_rccl ? kMergeRccl : (s->host_merge ? kMergeHost : kMergeNone);
 }
+
+const char* dc_hip_session_merge_note(const dc_hip_session* s) { return s ? s->merge_line.c_str() : ""; }
 
 int dc_hip_session_counters(const dc_hip_session* s, uint64_t* pop_tiles, uint64_t* nn_tiles) {
   if (!s) return failf(DC_ERR_INVALID_ARGUMENT, "null session");
@@ -546,23 +582,31 @@ int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float*
     return dc_hip_neighbors_pack_dev(d.d_idx, d.d_d2, d.d_idx + n, d.d_d2 + n, n, d.d_words, d.stream);
   });
   if (rc != DC_OK) return rc;
-  std::vector<uint32_t> layout;   // the layout headers of the gathered blocks (checked after the final synchronisation)
   if ((s->use_rccl || s->host_merge) && gather) {
     // ALL-GATHER of position-ordered blocks (density_clustering_cuda.cu:311-326 copies row blocks on the host): half the
     // bytes of the all-reduce(min) below and no reduction
     if ((rc = gather_blocks(s, 4 * block_rows)) != DC_OK) return rc;
+    // every device must have packed under the same layout (order, deal): the G layout headers are compared BEFORE anything
+    // is scattered into the result arrays -- one small copy and synchronisation on device 0 (every device holds the same
+    // gathered blocks) -- so that a mismatch leaves no mis-scattered rows behind
+    {
+      std::vector<uint32_t> layout(G * 8);
+      DevState& d0 = s->dev[0];
+      SESSION_HIP_TRY(hipSetDevice(d0.device));
+      for (size_t g = 0; g < G; ++g)   // (words 0..6 of the header: the last 32 entries of plane 0 of a block)
+        SESSION_HIP_TRY(hipMemcpyAsync(layout.data() + 8 * g, d0.d_blocks + g * 4 * block_rows + (block_rows - 32), 32,
+                                       hipMemcpyDeviceToHost, d0.stream));
+      SESSION_HIP_TRY(hipStreamSynchronize(d0.stream));
+      for (size_t g = 1; g < G; ++g)
+        if (memcmp(layout.data(), layout.data() + 8 * g, 7 * sizeof(uint32_t)) != 0)
+          return failf(DC_ERR_HIP, "neighbour blocks of devices 0 and %zu were packed under different layouts", g);
+    }
     rc = on_every_device(s, [&](int g) -> int {
       DevState& d = s->dev[g];
       return dc_hip_neighbors_block_unpack_dev(d.d_blocks, n, s->n_cols, G, d.d_ws, d.ws_bytes, DC_VARIANT_AUTO, d.d_idx,
                                                d.d_d2, d.d_idx + n, d.d_d2 + n, d.stream);
     });
     if (rc != DC_OK) return rc;
-    layout.resize(G * 8);
-    DevState& d0 = s->dev[0];
-    SESSION_HIP_TRY(hipSetDevice(d0.device));
-    for (size_t g = 0; g < G; ++g)   // (words 0..6 of the header: the last 32 entries of plane 0 of a block)
-      SESSION_HIP_TRY(hipMemcpyAsync(layout.data() + 8 * g, d0.d_blocks + g * 4 * block_rows + (block_rows - 32), 32,
-                                     hipMemcpyDeviceToHost, d0.stream));
   } else if (s->use_rccl || s->host_merge) {
     // DC_SESSION_NN_MERGE=allreduce: every row has one owner; all other devices hold the larger "none" word
     if ((rc = merge_partials(s, [](DevState& d) { return (void*)d.d_words; }, 2 * n, ncclUint64, ncclMin,
@@ -587,9 +631,6 @@ int dc_hip_session_nearest_neighbors(dc_hip_session* s, uint32_t* nn_idx, float*
   if (d2_host) SESSION_HIP_TRY(hipMemcpyAsync(d2_host, d0.d_d2, sizeof(float) * n, hipMemcpyDeviceToHost, d0.stream));
   if (hd_d2) SESSION_HIP_TRY(hipMemcpyAsync(hd_d2, d0.d_d2 + n, sizeof(float) * n, hipMemcpyDeviceToHost, d0.stream));
   if ((rc = sync_all(s, "nearest-neighbour sweep")) != DC_OK) return rc;
-  for (size_t g = 1; g * 8 < layout.size(); ++g)   // every device must have packed under the same layout (order, deal)
-    if (memcmp(layout.data(), layout.data() + 8 * g, 7 * sizeof(uint32_t)) != 0)
-      return failf(DC_ERR_HIP, "neighbour blocks of devices 0 and %zu were packed under different layouts", g);
   if (sigma2) {
     double acc = 0.0;   // frame order, double: density_clustering.cpp:334-343
     for (size_t i = 0; i < n; ++i) acc += (double)d2_host[i];

@@ -46,6 +46,7 @@ struct Resident {
   std::uint64_t fingerprint = 0;
 };
 Resident* g_resident = nullptr;   // (heap object, never destroyed: no HIP calls during static destruction)
+bool g_hdn_invalidate = false;    // HIP::invalidate_neighborhood_cache(): high_density_neighborhood starts from scratch
 
 // fingerprint of the WHOLE buffer (every word enters; four interleaved multiply-xor lanes, one pass at memory
 // bandwidth: ~10 ms for the 40 MB of C3, against the sweeps' 30 ms and the upload's 5): an in-place change of
@@ -87,6 +88,9 @@ dc_hip_session* resident_session(const float* coords, std::size_t n_rows, std::s
   if (r.session) dc_hip_session_close(r.session);
   r = Resident();
   must(dc_hip_session_open(coords, n_rows, n_cols, nullptr, 0, &r.session), "uploading the coordinates");
+  // (the reference's merge, density_clustering_cuda.cu:152-180, always does what it says; a session that could not get
+  //  RCCL on several devices merges through the host -- correct and slow, so say it)
+  if (dc_hip_session_merge_mode(r.session) == 2) std::cerr << "warning: " << dc_hip_session_merge_note(r.session) << std::endl;
   r.coords = coords;
   r.n_rows = n_rows;
   r.n_cols = n_cols;
@@ -290,20 +294,29 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
   // partner lists of ALL frames come from one GPU sweep (radius graph), cached per (coords, max_dist).
   namespace H = Clustering::Density::HIP;
   const std::size_t n_rows = sorted_fe.size();
-  // The reference calls this once per FRAME of a screening pass (density_clustering_common.cpp:37-134), so a cache hit
-  // must cost O(1): the key is the identity of both arrays (address, size) plus a fingerprint of 64 samples of each --
-  // a rewritten buffer or a re-sorted list changes a sample with near certainty; the full-buffer fingerprint of
-  // resident_session decides on every miss.
+  // The reference calls this once per FRAME of a screening pass, i_frame ascending (density_clustering_common.cpp:37-134),
+  // so a cache hit must cost O(1) INSIDE a pass: there the key is the identity of both arrays (address, size) plus a
+  // fingerprint of 64 samples of each.  Whenever a new pass begins -- i_frame does not continue upwards from the previous
+  // call -- or invalidate_neighborhood_cache() was called, EVERY word of both arrays is fingerprinted again (one pass at
+  // memory bandwidth, ~10 ms at C3) and compared with what the cached graph was built from: an in-place edit of a few rows
+  // or a re-sorted order between passes is caught, not "probably" caught.  Precondition that remains
+  // (density_clustering_hip.hpp): coords and sorted_fe are not modified BETWEEN the calls of one ascending pass.
   struct Cache {
     const float* coords = nullptr;
     const FreeEnergy* order = nullptr;
     std::size_t n_rows = 0, n_cols = 0;
     float max_dist = 0.0f;
-    std::uint64_t sample_fp = 0;
+    std::uint64_t sample_fp = 0, full_fp = 0;
+    std::size_t last_i_frame = 0;
+    bool valid = false;
     H::RadiusGraph graph;
     std::vector<std::uint32_t> pos_of;   // frame -> position in sorted_fe
   };
   static Cache cache;
+  if (g_hdn_invalidate) {
+    cache = Cache();
+    g_hdn_invalidate = false;
+  }
   std::uint64_t sample_fp = 1469598103934665603ull;
   {
     const std::uint32_t* w = reinterpret_cast<const std::uint32_t*>(coords);
@@ -317,8 +330,26 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
       sample_fp = (sample_fp ^ e.first ^ ((std::uint64_t)fb << 32)) * 1099511628211ull;
     }
   }
-  if (cache.coords != coords || cache.order != sorted_fe.data() || cache.n_rows != n_rows || cache.n_cols != n_cols ||
-      cache.max_dist != max_dist || cache.sample_fp != sample_fp) {
+  auto full_fp_now = [&]() {
+    std::uint64_t h = full_fingerprint(coords, n_rows * n_cols);
+    for (std::size_t p = 0; p < n_rows; ++p) {
+      std::uint32_t fb;
+      std::memcpy(&fb, &sorted_fe[p].second, sizeof fb);
+      h = (h ^ (std::uint64_t)sorted_fe[p].first ^ ((std::uint64_t)fb << 32)) * 0x100000001B3ull;
+      h ^= h >> 29;
+    }
+    return h;
+  };
+  const bool same_key = cache.valid && cache.coords == coords && cache.order == sorted_fe.data() && cache.n_rows == n_rows &&
+                        cache.n_cols == n_cols && cache.max_dist == max_dist && cache.sample_fp == sample_fp;
+  const bool new_pass = !same_key || i_frame <= cache.last_i_frame;
+  std::uint64_t full_fp = 0;
+  bool hit = same_key;
+  if (new_pass) {
+    full_fp = full_fp_now();
+    hit = same_key && full_fp == cache.full_fp;
+  }
+  if (!hit) {
     cache = Cache();
     std::string err;
     if (!H::build_radius_graph(resident_session(coords, n_rows, n_cols), n_rows, max_dist, &cache.graph, &err)) {
@@ -331,6 +362,8 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
     cache.n_cols = n_cols;
     cache.max_dist = max_dist;
     cache.sample_fp = sample_fp;
+    cache.full_fp = full_fp;
+    cache.valid = true;
     cache.pos_of.assign(n_rows, 0xFFFFFFFFu);
     for (std::size_t p = 0; p < n_rows; ++p) {
       if (sorted_fe[p].first >= n_rows) {
@@ -339,6 +372,11 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
       }
       cache.pos_of[sorted_fe[p].first] = (std::uint32_t)p;
     }
+  }
+  cache.last_i_frame = i_frame;
+  if (i_frame >= n_rows) {
+    std::cerr << "error in high_density_neighborhood: i_frame " << i_frame << " out of range" << std::endl;
+    exit(EXIT_FAILURE);
   }
   std::set<std::size_t> nh;
   const std::size_t frame = sorted_fe[i_frame].first;
@@ -353,6 +391,8 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
 }  // namespace CUDA
 
 namespace HIP {
+
+void invalidate_neighborhood_cache() { CUDA::g_hdn_invalidate = true; }
 
 void release_resident() {
   if (CUDA::g_resident && CUDA::g_resident->session) dc_hip_session_close(CUDA::g_resident->session);

@@ -90,7 +90,12 @@ std::vector<std::size_t> sanitize_state_names(std::vector<std::size_t> clusterin
 
 //! declared in density_clustering_cuda.hpp:56-62, defined nowhere in the reference's CUDA sources; CPU
 //! semantics density_clustering.cpp:292-332.  All ids are positions in sorted_fe.  Served from the GPU
-//! radius graph of the resident trajectory (n_rows = sorted_fe.size()), cached per (coords, max_dist).
+//! radius graph of the resident trajectory (n_rows = sorted_fe.size()), cached per (coords, sorted_fe, max_dist).
+//! The reference calls it once per frame of a screening pass with i_frame ASCENDING: inside such a pass a call costs
+//! O(1) (the arrays are recognised by address, size and 64 sampled words); whenever i_frame does not continue upwards
+//! -- a new pass -- both arrays are fingerprinted in full and a change of any element rebuilds the graph.
+//! PRECONDITION: coords and sorted_fe are not modified between the calls of one ascending pass (the reference's
+//! screening never does); HIP::invalidate_neighborhood_cache() forces the rebuild where a caller must.
 std::set<std::size_t> high_density_neighborhood(const float* coords, const std::size_t n_cols,
                                                 const std::vector<FreeEnergy>& sorted_fe,
                                                 const std::size_t i_frame, const std::size_t limit,
@@ -112,6 +117,8 @@ struct DensityResult {
 //! the whole buffer, so re-using a host buffer for other coordinates is detected).  This drops it and frees
 //! the device memory and the RCCL communicators of all GPUs; call it when the density phase is over.
 void release_resident();
+//! the next CUDA::high_density_neighborhood call rebuilds its radius graph and position table from scratch
+void invalidate_neighborhood_cache();
 //! whole path (pop -> FE -> NN) with coordinates kept resident on the devices between the phases
 DensityResult density_all(const float* coords, std::size_t n_rows, std::size_t n_cols,
                           const std::vector<float>& radii, std::size_t fe_radius_index,

@@ -196,6 +196,19 @@ def evaluated_tiles(device):
     return int(a.value), int(b.value)
 
 
+def issued_mfmas(device):
+    """(pop, nn): v_mfma_f32_32x32x16_f16 instructions the last pruned sweeps on this device's workspace issued, counted by
+    the kernels (dc_hip_workspace_mfma_counters_dev); read right after the sweep of interest, like evaluated_tiles"""
+    ws = _workspace(device)
+    if ws.buf is None:
+        return 0, 0
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    with torch.cuda.device(device):
+        capi.check(capi.lib.dc_hip_workspace_mfma_counters_dev(_dev(ws.buf), C.byref(a), C.byref(b), _stream_ptr()),
+                   "dc_hip_workspace_mfma_counters_dev")
+    return int(a.value), int(b.value)
+
+
 def components_info(coords):
     """of the last pruned population sweep over coords on its device: dict(n_components, extent2_global, extent2_local,
     scale) -- dc_hip_workspace_components_dev"""
@@ -425,6 +438,11 @@ class Session:
     def merge_mode(self):
         """0: one device; 1: RCCL collectives on the devices; 2: through the host (the reference's own merge)"""
         return int(capi.lib.dc_hip_session_merge_mode(self._h))
+
+    @property
+    def merge_note(self):
+        """dc_hip_session_merge_note: which merge runs and, for the host merge, why RCCL is not used"""
+        return capi.lib.dc_hip_session_merge_note(self._h).decode("utf-8", "replace")
 
     def counters(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

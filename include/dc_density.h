@@ -92,8 +92,10 @@ DC_API const char* dc_hip_last_error(void);
  *   1  rounds 1-2 up to the sessions
  *   2  sessions (dc_hip_session_*), segment entry points whose populations are PARTIAL counts of ALL rows
  *      (symmetric one-radius sweeps credit both frames of a pair), dc_hip_session_merge_mode, host-merge
- *      fallback, DC_FLAG_STATS_VALID */
-#define DC_HIP_ABI_VERSION 2
+ *      fallback, DC_FLAG_STATS_VALID
+ *   3  dc_hip_session_merge_note (which merge a multi-device session runs, and why),
+ *      dc_hip_workspace_mfma_counters_dev */
+#define DC_HIP_ABI_VERSION 3
 DC_API int dc_hip_abi_version(void);
 
 /* replaces Clustering::Density::CUDA::get_num_gpus() (density_clustering_cuda.hpp:16-17,
@@ -115,6 +117,12 @@ DC_API size_t dc_hip_workspace_bytes(size_t n_rows, size_t n_cols, size_t n_radi
  * DC_VARIANT_MFMA do not count and report 0).  Synchronises the stream. */
 DC_API int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles,
                                          uint64_t* nn_tiles, void* stream);
+/* ... and the matrix-core instructions (v_mfma_f32_32x32x16_f16: 32*32*16*2 flop each) those sweeps ISSUED, counted by the
+ * kernels themselves: tiles x MFMAs per chain for the population sweeps, fewer for the neighbour sweeps, whose chains
+ * mostly stop after their coarse MFMAs (the executed-flop figure of bench.py's roofline; it equals
+ * SQ_VALU_MFMA_BUSY_CYCLES / 32 of a counter profile).  Synchronises the stream. */
+DC_API int dc_hip_workspace_mfma_counters_dev(const void* d_workspace, uint64_t* pop_mfma, uint64_t* nn_mfma,
+                                              void* stream);
 
 /* diagnostics of the last pruned POPULATION sweep that ran in this workspace (same n_rows, n_cols): the number of
  * components the frames were cut into (sets at least r_max apart in columns 0/1, each measured from its own origin by
@@ -345,6 +353,12 @@ DC_API int dc_hip_session_devices(const dc_hip_session* session);      /* number
 DC_API int dc_hip_session_uses_rccl(const dc_hip_session* session);    /* 1 if partials merge over RCCL */
 /* 0: one device, nothing to merge; 1: RCCL collectives on the devices; 2: through the host */
 DC_API int dc_hip_session_merge_mode(const dc_hip_session* session);
+/* one line saying which merge this session runs and, for the host merge of a multi-device session, WHY RCCL is not
+ * used (library not loadable, communicator not built, DC_SESSION_MERGE=host, duplicate devices) -- the reference's
+ * merge (density_clustering_cuda.cu:152-180) is never silent about what it does, and a multi-GPU run that fell back
+ * to PCIe is correct and slow: the C++ shim prints this line to stderr for mode 2, the command line under -v.
+ * The string lives as long as the session. */
+DC_API const char* dc_hip_session_merge_note(const dc_hip_session* session);
 /* 32x32 frame-pair tiles the last population call / neighbour call evaluated, summed over devices */
 DC_API int dc_hip_session_counters(const dc_hip_session* session, uint64_t* pop_tiles, uint64_t* nn_tiles);
 

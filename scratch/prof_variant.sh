@@ -2,6 +2,8 @@
 # prof_variant.sh <variant> <tag> <program> [args...]: prof_cmd.sh with clustering_amd/lib/variants/<variant>.so as the library
 cd $GRAFT_REPO_ROOT
 cp clustering_amd/lib/libdcdensity.so /tmp/lib_saved.so
+# (whatever ends this script -- a timeout, a kill of prof_cmd.sh -- the product library comes back: ADVICE r4)
+trap 'cp /tmp/lib_saved.so $GRAFT_REPO_ROOT/clustering_amd/lib/libdcdensity.so' EXIT
 cp clustering_amd/lib/variants/$1.so clustering_amd/lib/libdcdensity.so
 shift
 bash scratch/prof_cmd.sh "$@" > /dev/null

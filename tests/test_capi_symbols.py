@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert capi.lib.dc_hip_abi_version() == capi.ABI_VERSION == 2
+    assert capi.lib.dc_hip_abi_version() == capi.ABI_VERSION == 3
     assert capi.lib.dc_hip_last_error() is not None
 
 

@@ -213,6 +213,32 @@ def test_cli_microstates_from_initial_states(tmp_path, oracle):
     assert data_lines(tmp_path / "micro") == [str(int(v)) for v in want]
 
 
+def test_hosts_say_which_merge_ran(tmp_path, oracle):
+    """The reference's merge (density_clustering_cuda.cu:152-180) is never silent about what it does: a multi-device
+    session of the C++ hosts that merges through the host instead of RCCL says so on stderr (forced here with two
+    "devices" on the one GPU), the command line names the merge under -v in every mode."""
+    c = write_coords(tmp_path / "coords", gaussian_blobs(2500, 5, seed=48))
+    pops = oracle.populations(c, [0.1])[0]
+    env = dict(os.environ, DC_SESSION_DEVICES="0,0", DC_SESSION_ALLOW_DUPLICATE_DEVICES="1")
+    cmd = [CLI, "density", "-f", str(tmp_path / "coords"), "-r", "0.1", "-p", str(tmp_path / "pop")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "warning: 2 devices: partial results merge THROUGH THE HOST over PCIe, not RCCL (a device is listed more than once" in r.stderr
+    assert data_lines(tmp_path / "pop") == [str(int(p)) for p in pops]       # (two segments, merged on the host)
+    r = subprocess.run(cmd + ["-v"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "THROUGH THE HOST" not in r.stderr
+    assert "merge: " in r.stdout and ("nothing to merge" in r.stdout or "RCCL" in r.stdout)
+    # the shim (Clustering::Density::CUDA::calculate_populations on its resident session)
+    c2 = gaussian_blobs(600, 10, seed=49)
+    fe = oracle.free_energies(oracle.populations(c2, [0.2])[0])
+    c2.tofile(tmp_path / "c.f32")
+    fe.tofile(tmp_path / "fe.f32")
+    r = subprocess.run([SHIM, str(tmp_path / "c.f32"), "600", "10", str(tmp_path / "fe.f32"), "0.2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "warning: 2 devices: partial results merge THROUGH THE HOST" in r.stderr
+
+
 def test_cli_output_needs_a_mode(tmp_path):
     (tmp_path / "coords").write_text("0 0\n1 1\n0.5 0.5\n")
     r = subprocess.run([CLI, "density", "-f", str(tmp_path / "coords"), "-r", "1", "-o", str(tmp_path / "x")],
@@ -259,6 +285,46 @@ def test_cpp_shim_reference_signatures(tmp_path, oracle):
     foreign = np.where(fe < np.float32(1.0), 1 + np.arange(len(fe)) % 3, 0)
     fline = [l.split() for l in lines if l.startswith("foreign ")][0]
     assert [int(x) for x in fline[2:]] == so.screening(fe, exp[1], 2.0, c, foreign).tolist()
+
+
+def test_shim_neighbourhood_cache_sees_in_place_edits(tmp_path, oracle):
+    """CUDA::high_density_neighborhood (declared density_clustering_cuda.hpp:56-62, CPU semantics density_clustering.cpp:
+    292-332) serves every frame of a screening pass from one cached radius graph.  Between passes the buffers may be
+    rewritten IN PLACE -- one row of the coordinates, two entries of the order -- and the next pass must see it: every
+    pass against the brute-force neighbourhoods of the arrays as they are then (the sampled key missed it)."""
+    from refmath import d2_matrix
+    c = gaussian_blobs(400, 10, seed=51)
+    n, d = c.shape
+    fe = oracle.free_energies(oracle.populations(c, [0.2])[0])
+    c.tofile(tmp_path / "c.f32")
+    fe.tofile(tmp_path / "fe.f32")
+    max_dist = np.float32(0.06)
+    r = subprocess.run([SHIM, str(tmp_path / "c.f32"), str(n), str(d), str(tmp_path / "fe.f32"), "hdn", "%.9g" % max_dist],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.splitlines()]
+    orders = {l[0]: np.array([int(x) for x in l[1:]]) for l in lines if l[0].startswith("order_")}
+    order = orders["order_hdn1"]                              # (std::sort: ties of free energy fall where it puts them)
+    assert sorted(order.tolist()) == list(range(n)) and (np.diff(fe[order]) >= 0).all()
+    moved = int([l for l in lines if l[0] == "moved"][0][1])
+    assert moved == order[3] and (orders["order_hdn2"] == order).all()
+
+    def expect(coords, order):
+        d2 = d2_matrix(coords[order])                          # [position, position]
+        return [sorted(set(np.nonzero(d2[i] < max_dist)[0].tolist()) | {i}) for i in range(n)]
+
+    def got(tag):
+        return [[int(x) for x in l[2:]] for l in lines if l[0] == tag]
+
+    assert got("hdn1") == expect(c, order)
+    c2 = c.copy()
+    c2[moved] += np.float32(100.0)
+    want2 = expect(c2, order)
+    assert want2 != expect(c, order) and got("hdn2") == want2
+    order3 = order.copy()
+    order3[[5, 9]] = order3[[9, 5]]
+    assert (orders["order_hdn3"] == order3).all()
+    assert got("hdn3") == expect(c2, order3) and got("hdn3") != want2
 
 
 def test_cli_refuses_malformed_coordinate_files(tmp_path):

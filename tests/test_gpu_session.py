@@ -192,6 +192,7 @@ c = gaussian_blobs(12000, 10, seed=21)
 torch.cuda.set_device(0)
 with dens.Session(c, devices=[0] * n_dev) as s:
     assert s.n_devices == n_dev and s.merge_mode == 2 and not s.uses_rccl
+    assert "THROUGH THE HOST" in s.merge_note and "more than once" in s.merge_note, s.merge_note
     pops = s.populations([0.2, 0.3])
     fe = s.free_energies(0)
     nn = s.nearest_neighbors()
