@@ -16,6 +16,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -213,6 +215,7 @@ int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const 
   DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_radii * n_rows, s));
   if (i_from == i_to && n_segments == 0) return DC_OK;
   const bool mfma = want_mfma(variant, n_cols);
+  const bool pruned = mfma && variant != DC_VARIANT_MFMA && variant != DC_VARIANT_MFMA32;   // (the pruned sweep will run)
   if ((variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA_PRUNED) && !mfma)
     return fail(DC_ERR_INVALID_ARGUMENT, "MFMA variant does not support n_cols=%zu", n_cols);
   if (variant == DC_VARIANT_MFMA32 && (!mfma || !dc::mfma32_supports(n_cols) || n_segments > 0))
@@ -222,10 +225,11 @@ int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const 
       return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                   dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
     if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
-                                  variant == DC_VARIANT_MFMA, s, stats_valid))
+                                  variant == DC_VARIANT_MFMA, s, stats_valid, pruned))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
   }
   for (size_t r0 = 0; r0 < n_radii; r0 += dc::kMaxRadiiPerLaunch) {
+    const bool comp_clean = pruned && !stats_valid && r0 == 0;   // (the component region: zero-filled with the header)
     const int n_rad = (int)std::min((size_t)dc::kMaxRadiiPerLaunch, n_radii - r0);
     dc::Rad2 rad2;
     for (int r = 0; r < dc::kMaxRadiiPerLaunch; ++r)
@@ -242,10 +246,10 @@ int populations_impl(const float* d_coords, size_t n_rows, size_t n_cols, const 
                           (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
     else if (mfma && n_segments > 0)
       dc::launch_pop_pruned_segment(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)segment,
-                                    (uint32_t)n_segments, rad2, n_rad, out, d_workspace, s);
+                                    (uint32_t)n_segments, rad2, n_rad, out, d_workspace, s, comp_clean);
     else if (mfma)
       dc::launch_pop_pruned(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
-                            (uint32_t)i_to, rad2, n_rad, out, d_workspace, s);
+                            (uint32_t)i_to, rad2, n_rad, out, d_workspace, s, comp_clean);
     if (i_from != i_to && !dc::launch_pop_direct(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, (uint32_t)i_from,
                                (uint32_t)i_to, rad2, n_rad, out,
                                mfma ? (const uint32_t*)d_workspace : nullptr, s))
@@ -288,7 +292,10 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
   // the host
   struct Scratch {
     int device = -1;
-    uint32_t* d_max = nullptr;
+    uint32_t* d_max = nullptr;     // kFeStateWords of state (fe_log_kernel), then the list of flagged (row, pop) pairs
+    uint32_t* h_head = nullptr;    // pinned host memory (max, count) are copied to
+    uint32_t seq = 0;
+    bool dirty = false;            // a call did not run to its end: its slots of the state may not be zero
     float* d_table = nullptr;
     size_t table_cap = 0;
     std::vector<float> table;
@@ -299,24 +306,28 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
   DC_HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(scratch_mutex[dev & 15]);   // (one call at a time per device)
   Scratch& S = scratch[dev & 15];
+  constexpr uint32_t kFlagCap = 4096;
   if (S.device != dev) {   // first use on this device (or a slot shared by devices 16 apart)
     if (S.d_max) (void)hipFree(S.d_max);
     if (S.d_table) (void)hipFree(S.d_table);
+    if (S.h_head) (void)hipHostFree(S.h_head);
     S = Scratch();
     S.device = dev;
-    // [0] max population, [1] number of flagged rows, [2..] flagged (row, pop) pairs
-    DC_HIP_TRY(hipMalloc((void**)&S.d_max, sizeof(uint32_t) * (2 + 2 * 4096)));
+    DC_HIP_TRY(hipMalloc((void**)&S.d_max, sizeof(uint32_t) * (dc::kFeStateWords + 2 * kFlagCap)));
+    DC_HIP_TRY(hipMemset(S.d_max, 0, sizeof(uint32_t) * dc::kFeStateWords));   // (the kernels keep words 0..2 zero between calls)
+    if (hipHostMalloc((void**)&S.h_head, 64, hipHostMallocDefault) != hipSuccess) {   // (then a pageable destination)
+      (void)hipGetLastError();
+      S.h_head = nullptr;
+    }
   }
-  dc::launch_max_u32(d_pops, (uint32_t)n_rows, S.d_max, s);
   // Default: every row's free energy from the device's double log, the rows it cannot vouch for
   // (value within 64 ulp(double) of a float rounding boundary: one in 2^22) recomputed by the host libm
-  // -- one stream synchronisation, no table.  DC_FE_HOST_TABLE=1 (and more flagged rows than the list
-  // holds) takes the table path below: one host log per distinct population.
+  // -- one hand-off to the host (max_pop and the number of listed rows), no table.  DC_FE_HOST_TABLE=1 (and more
+  // flagged rows than the list holds) takes the table path below: one host log per distinct population.
   static const bool host_table = [] {
     const char* v = getenv("DC_FE_HOST_TABLE");
     return v && v[0] == '1';
   }();
-  constexpr uint32_t kFlagCap = 4096;
   // margin around the float rounding boundaries, relative to the value: 64 ulp(double) unless the test
   // suite widens it (DC_FE_REFEREE_TOL) to drive rows through the referee and the overflow path
   static const double tol_rel = [] {
@@ -327,17 +338,23 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
   uint32_t max_pop = 0;
   hipError_t e = hipSuccess;
   if (!host_table) {
-    dc::launch_fe_log(d_pops, (uint32_t)n_rows, S.d_max, d_fe, S.d_max + 1, S.d_max + 2, kFlagCap, tol_rel, s);
-    uint32_t head[2] = {0, 0};   // max_pop, number of flagged rows
-    e = hipMemcpyAsync(head, S.d_max, sizeof(head), hipMemcpyDeviceToHost, s);
+    const uint32_t slot = (S.seq++) & 1u;   // (alternate calls use alternate slots of the state; each clears the other's)
+    if (S.dirty) DC_HIP_TRY(hipMemsetAsync(S.d_max, 0, sizeof(uint32_t) * dc::kFeStateWords, s));
+    S.dirty = true;   // (until this call has run to its end)
+    dc::launch_fe_log(d_pops, (uint32_t)n_rows, S.d_max, slot, d_fe, S.d_max + dc::kFeStateWords, kFlagCap, tol_rel, s);
+    // (max, count) into pinned host memory where there is some: a true asynchronous copy, no staging
+    uint32_t head_local[2] = {0, 0};
+    uint32_t* head = S.h_head ? S.h_head : head_local;   // max_pop, number of flagged rows
+    e = hipMemcpyAsync(head, S.d_max + 2u * slot, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(DC_ERR_HIP, "free energies: %s", hipGetErrorString(e));
+    S.dirty = false;
     max_pop = head[0];
     if (max_pop_out) *max_pop_out = max_pop;
     if (head[1] == 0) return DC_OK;
     if (head[1] <= kFlagCap) {
       std::vector<uint32_t> list(2 * (size_t)head[1]);
-      e = hipMemcpyAsync(list.data(), S.d_max + 2, sizeof(uint32_t) * list.size(), hipMemcpyDeviceToHost, s);
+      e = hipMemcpyAsync(list.data(), S.d_max + dc::kFeStateWords, sizeof(uint32_t) * list.size(), hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipStreamSynchronize(s);
       const float rec = 1.0f / (float)max_pop;
       std::vector<float> fixed(head[1]);
@@ -350,7 +367,8 @@ int dc_hip_free_energies_dev(const uint32_t* d_pops, size_t n_rows, float* d_fe,
       return DC_OK;
     }
   } else {
-    e = hipMemcpyAsync(&max_pop, S.d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    dc::launch_max_u32(d_pops, (uint32_t)n_rows, S.d_max + 4, s);   // (its own word, filled first)
+    e = hipMemcpyAsync(&max_pop, S.d_max + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(DC_ERR_HIP, "max population: %s", hipGetErrorString(e));
     if (max_pop_out) *max_pop_out = max_pop;
@@ -411,7 +429,7 @@ int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, 
     // (the pruned sweep packs reference POSITIONS of the padded order into 30 bits: kQueuePosMask)
     const bool full_sweep = variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA32 || n_rows + dc::kOrderPadRows > ((size_t)1 << 30);
     if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
-                                  full_sweep, s, stats_valid))
+                                  full_sweep, s, stats_valid, !full_sweep))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
     if (variant == DC_VARIANT_MFMA32)
       dc::launch_nn_mfma32(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from, (uint32_t)i_to, d_nn_idx,
@@ -556,7 +574,7 @@ int dc_hip_radius_pairs_dev(const float* d_coords, size_t n_rows, size_t n_cols,
     return fail(DC_ERR_WORKSPACE, "workspace of %zu bytes needed, got %zu",
                 dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
   DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_rows, s));
-  if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, false, s))
+  if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, false, s, false, true))
     return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
   dc::launch_radius_pairs(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, r2, d_pops, (uint2*)d_pairs,
                           (unsigned long long)capacity, d_count, d_workspace, s);
@@ -591,7 +609,7 @@ int dc_hip_radius_min_edge_segment_dev(const float* d_coords, size_t n_rows, siz
                 dc::mfma_workspace_bytes(n_rows, n_cols), d_workspace ? workspace_bytes : 0);
   hipStream_t s = (hipStream_t)stream;
   DC_HIP_TRY(hipMemsetAsync(d_pops, 0, sizeof(uint32_t) * n_rows, s));
-  if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, false, s))
+  if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace, false, s, false, true))
     return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
   dc::launch_radius_min_edge(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, r2, d_comp, d_rank, d_best,
                              d_pops, d_workspace, s, (uint32_t)segment, (uint32_t)n_segments);

@@ -48,9 +48,9 @@ void launch_nn_unpack(const unsigned long long* d_words, uint32_t n_rows, uint32
                       uint32_t* d_hd_idx, float* d_hd_d2, hipStream_t stream);
 // fe of every row with the device's double log; rows whose value sits within 64 ulp(double) of a float
 // rounding boundary go to d_flag_list as (row, pop) pairs (d_flag_count may exceed flag_cap)
-void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, const uint32_t* d_max, float* d_fe,
-                   uint32_t* d_flag_count, uint32_t* d_flag_list, uint32_t flag_cap, double tol_rel,
-                   hipStream_t stream);
+void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_state, uint32_t slot, float* d_fe,
+                   uint32_t* d_flag_list, uint32_t flag_cap, double tol_rel, hipStream_t stream);
+constexpr uint32_t kFeStateWords = 8;   // device state of the free-energy pass in front of its list of flagged rows
 
 // ---- canonical squared distance, compile-time D ----------------------------------------
 // q: this lane's query row (registers); r: reference row (registers, wave-uniform values).

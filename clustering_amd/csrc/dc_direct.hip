@@ -316,13 +316,20 @@ __global__ void fe_gather_kernel(const uint32_t* __restrict__ pops, uint32_t n_r
 // in 2^22 with the margin below -- are listed for the host, which recomputes them with its libm.
 // q, the reciprocal (double division rounded to float = correctly rounded float division, 53 >= 2*24+2)
 // and the final rounding are IEEE operations, identical on both sides.
-__global__ void fe_log_kernel(const uint32_t* __restrict__ pops, uint32_t n_rows,
-                              const uint32_t* __restrict__ max_pop, float* __restrict__ fe,
-                              uint32_t* __restrict__ flag_count, uint2* __restrict__ flag_list,
-                              uint32_t flag_cap, double tol_rel) {
+// state (device, kFeStateWords words): two slots of (max population, number of listed rows) used by alternate calls --
+// slot = call parity.  The slot of the NEXT call is cleared by this call's kernel (its first thread), so that a step needs
+// no fill kernels: max_u32_kernel and the rows' atomicAdd start from zeros.  (A first version cleared its own slot from
+// the last block to finish, found with a ticket behind a __threadfence(): 245 us instead of 7 -- a device-scope release
+// per block is an L2 write-back per block.)
+__global__ void fe_log_kernel(const uint32_t* __restrict__ pops, uint32_t n_rows, uint32_t* __restrict__ state, uint32_t slot,
+                              float* __restrict__ fe, uint2* __restrict__ flag_list, uint32_t flag_cap, double tol_rel) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    state[2u * (slot ^ 1u)] = 0u;
+    state[2u * (slot ^ 1u) + 1u] = 0u;
+  }
   if (i >= n_rows) return;
-  const float rec = (float)(1.0 / (double)(float)(*max_pop));
+  const float rec = (float)(1.0 / (double)(float)(state[2u * slot]));
   const uint32_t pop = pops[i];
   const float q = (float)pop * rec;
   const double y = -log((double)q);
@@ -334,7 +341,7 @@ __global__ void fe_log_kernel(const uint32_t* __restrict__ pops, uint32_t n_rows
     const double up = (double)__uint_as_float(fb + 1u), dn = (double)__uint_as_float(fb - 1u);
     const double tol = tol_rel * fabs(y);   // default 64 ulp(double): device log <= 2 ulp, glibc log <= 1 ulp
     if (fabs(y - 0.5 * ((double)f + up)) < tol || fabs(y - 0.5 * ((double)f + dn)) < tol) {
-      const uint32_t k = atomicAdd(flag_count, 1u);
+      const uint32_t k = atomicAdd(state + 2u * slot + 1u, 1u);
       if (k < flag_cap) flag_list[k] = make_uint2(i, pop);
     }
   }
@@ -483,13 +490,14 @@ void launch_fe_gather(const uint32_t* d_pops, uint32_t n_rows, const float* d_ta
                      n_rows, d_table, d_fe);
 }
 
-void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, const uint32_t* d_max, float* d_fe,
-                   uint32_t* d_flag_count, uint32_t* d_flag_list, uint32_t flag_cap, double tol_rel,
-                   hipStream_t stream) {
-  (void)hipMemsetAsync(d_flag_count, 0, sizeof(uint32_t), stream);
+// (the call's slot of the state is zero on entry: see fe_log_kernel)
+void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_state, uint32_t slot, float* d_fe, uint32_t* d_flag_list,
+                   uint32_t flag_cap, double tol_rel, hipStream_t stream) {
   if (n_rows == 0) return;
-  hipLaunchKernelGGL(fe_log_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_pops, n_rows, d_max,
-                     d_fe, d_flag_count, (uint2*)d_flag_list, flag_cap, tol_rel);
+  const uint32_t grid = min((n_rows + 1023u) / 1024u, 256u);
+  hipLaunchKernelGGL(max_u32_kernel, dim3(grid), dim3(256), 0, stream, d_pops, n_rows, d_state + 2u * slot);
+  hipLaunchKernelGGL(fe_log_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_pops, n_rows, d_state, slot, d_fe,
+                     (uint2*)d_flag_list, flag_cap, tol_rel);
 }
 
 void launch_nn_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const uint32_t* d_hd_idx,

@@ -473,45 +473,6 @@ __global__ void fine_mark_kernel(const float* __restrict__ coords, uint32_t n_ro
   reinterpret_cast<unsigned char*>(comp + kCompBitmap)[(size_t)fx * (kCoarseDim * kFineSub) + fy] = 1;
 }
 
-// box of the occupied sub-cells of every coarse cell (a little wider than the sub-cells: every frame of the cell lies
-// inside whatever the rounding of its sub-cell index did); lo0 > hi0 marks an empty cell.  NB: a frame is assigned to
-// the COARSE cell of its sub-cell (fx / kFineSub), see comp_of_point.
-__global__ void coarse_box_kernel(const uint32_t* __restrict__ hdr, float r_max, uint32_t n_rows,
-                                  uint32_t* __restrict__ comp) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  const CoarseGrid g = coarse_grid(hdr, r_max, n_rows);
-  if (c >= g.ncx * g.ncy) return;
-  const uint32_t cx = c / g.ncy, cy = c % g.ncy;
-  const unsigned char* bm = reinterpret_cast<const unsigned char*>(comp + kCompBitmap);
-  int x0 = kFineSub, x1 = -1, y0 = kFineSub, y1 = -1;
-  for (int sx = 0; sx < kFineSub; ++sx)
-    for (int sy = 0; sy < kFineSub; ++sy)
-      if (bm[(size_t)(cx * kFineSub + sx) * (kCoarseDim * kFineSub) + (cy * kFineSub + sy)]) {
-        x0 = min(x0, sx);
-        x1 = max(x1, sx);
-        y0 = min(y0, sy);
-        y1 = max(y1, sy);
-      }
-  float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
-  if (x1 >= 0) {
-    // (the occupied sub-cells of the whole grid: what the frames cover of the plane, comp[kCompGrid + 2])
-    uint32_t n_sub = 0;
-    for (int sx = 0; sx < kFineSub; ++sx)
-      for (int sy = 0; sy < kFineSub; ++sy)
-        n_sub += bm[(size_t)(cx * kFineSub + sx) * (kCoarseDim * kFineSub) + (cy * kFineSub + sy)] ? 1u : 0u;
-    atomicAdd(comp + kCompGrid + 2, n_sub);
-    const float gf = g.gc / (float)kFineSub, slack = 1.0e-3f * gf;
-    box.x = g.min0 + (float)(cx * kFineSub + x0) * gf - slack;
-    box.y = g.min0 + (float)(cx * kFineSub + x1 + 1) * gf + slack;
-    box.z = g.min1 + (float)(cy * kFineSub + y0) * gf - slack;
-    box.w = g.min1 + (float)(cy * kFineSub + y1 + 1) * gf + slack;
-  }
-  reinterpret_cast<float4*>(comp + kCompCellBox)[c] = box;
-}
-
-__device__ __forceinline__ float4 cell_box(const uint32_t* __restrict__ comp, uint32_t cell) {
-  return reinterpret_cast<const float4*>(comp + kCompCellBox)[cell];
-}
 // coarse cell of a point, through its sub-cell (the same arithmetic as fine_mark_kernel)
 __device__ __forceinline__ uint32_t coarse_cell_of_point(const CoarseGrid& g, float x, float y) {
   const float gf = g.gc / (float)kFineSub;
@@ -525,19 +486,35 @@ __device__ __forceinline__ uint32_t coarse_cell_of_point(const CoarseGrid& g, fl
 // components are at least r_max apart in full dimension as well.  Minimum-label propagation over the (2R + 1)^2
 // neighbourhood with pointer jumping; labels are cell indices (the result does not depend on the order in which the
 // cells were listed).  Writes the component of every cell, the components' origins and fine cell grids.
+__device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell, uint32_t fine_bits,
+                               uint32_t* __restrict__ comp);
+
+// Round 5: ONE launch for what were four -- the boxes of the coarse cells (coarse_box_kernel) are formed here, straight
+// from the occupancy bitmap into the labelling's tables; the column means (mean_kernel: means_out != nullptr) in front; the
+// fine cell grids of the components (fine_grid_kernel) behind, by the first thread.
 __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __restrict__ hdr,
                                                           const float* __restrict__ means, uint32_t D,
                                                           float r_max, uint32_t n_rows, float frames_per_cell,
                                                           uint32_t fine_bits, uint32_t* __restrict__ comp,
-                                                          int force_single, float r_true, uint32_t cookie) {
+                                                          int force_single, float r_true, uint32_t cookie,
+                                                          float* __restrict__ means_out = nullptr,
+                                                          float fine_frames_per_cell = 0.0f) {
   // r_max: the connectivity length rho (what the coarse grid was built for); r_true: the largest radius itself;
   // cookie: whose partition this is (comp_guard_kernel)
   (void)frames_per_cell;
-  (void)fine_bits;
   const float r_conn_param = r_max;
+  if (means_out) {   // column means as the float the centring subtracts (mean_kernel)
+    if (threadIdx.x < D) {
+      const double* sums = reinterpret_cast<const double*>(reinterpret_cast<const char*>(hdr) + kHdrSums);
+      float muf = (float)(sums[threadIdx.x] / (double)n_rows);
+      if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
+      means_out[threadIdx.x] = muf;
+    }
+    __syncthreads();
+  }
   __shared__ uint32_t occ[kMaxOccupied], label[kMaxOccupied];
   __shared__ float4 obox[kMaxOccupied];
-  __shared__ uint32_t n_occ_s, changed_s, n_comp_s;
+  __shared__ uint32_t n_occ_s, changed_s, n_comp_s, n_sub_s;
   // cell -> index in occ[] (0xFFFF: empty) during the labelling: in LDS, kCoarseDim^2 half-words (the look-ups of the
   // neighbourhood went to global memory before: 11 dependent round trips per cell and round, 110 of the kernel's 130 us)
   extern __shared__ uint16_t cell_idx[];
@@ -551,11 +528,41 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   if (tid == 0) {
     n_occ_s = 0;
     n_comp_s = 0;
+    n_sub_s = 0;
   }
   __syncthreads();
+  const float gf_sub = g.gc / (float)kFineSub, slack_sub = 1.0e-3f * gf_sub;
   for (uint32_t c = tid; c < n_cells; c += nt) {
     uint32_t idx = 0xFFFFFFFFu;
-    const float4 bx = cell_box(comp, c);
+    // box of the occupied sub-cells of the cell (a little wider than the sub-cells: every frame of the cell lies inside
+    // whatever the rounding of its sub-cell index did); lo0 > hi0 marks an empty cell.  NB: a frame is assigned to the
+    // COARSE cell of its sub-cell (fx / kFineSub), see coarse_cell_of_point.
+    const uint32_t cx = c / g.ncy, cy = c % g.ncy;
+    uint32_t rows4[kFineSub];
+#pragma unroll
+    for (int sx = 0; sx < kFineSub; ++sx)   // (kFineSub = 4 bytes of a bitmap row: one word)
+      rows4[sx] = comp[kCompBitmap + ((size_t)(cx * kFineSub + sx) * (kCoarseDim * kFineSub) + (size_t)cy * kFineSub) / 4];
+    int x0 = kFineSub, x1 = -1, y0 = kFineSub, y1 = -1;
+    uint32_t n_sub = 0;
+#pragma unroll
+    for (int sx = 0; sx < kFineSub; ++sx)
+#pragma unroll
+      for (int sy = 0; sy < kFineSub; ++sy)
+        if ((rows4[sx] >> (8 * sy)) & 0xFFu) {
+          x0 = min(x0, sx);
+          x1 = max(x1, sx);
+          y0 = min(y0, sy);
+          y1 = max(y1, sy);
+          ++n_sub;
+        }
+    float4 bx = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+    if (x1 >= 0) {
+      atomicAdd(&n_sub_s, n_sub);   // (the occupied sub-cells of the whole grid: what the frames cover of the plane)
+      bx.x = g.min0 + (float)(cx * kFineSub + x0) * gf_sub - slack_sub;
+      bx.y = g.min0 + (float)(cx * kFineSub + x1 + 1) * gf_sub + slack_sub;
+      bx.z = g.min1 + (float)(cy * kFineSub + y0) * gf_sub - slack_sub;
+      bx.w = g.min1 + (float)(cy * kFineSub + y1 + 1) * gf_sub + slack_sub;
+    }
     if (bx.x <= bx.y) {
       idx = atomicAdd(&n_occ_s, 1u);
       if (idx < (uint32_t)kMaxOccupied) {
@@ -692,11 +699,16 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   if (tid == 0) {
     comp[kCompGrid + 0] = __float_as_uint(g.gc);
     comp[kCompGrid + 1] = single ? 0u : n_occ;
+    comp[kCompGrid + 2] = n_sub_s;
     comp[kCompGrid + 3] = g.ncx;
     comp[kCompGrid + 4] = g.ncy;
     comp[kCompGrid + 5] = n_comp;
     comp[kCompGrid + 6] = cookie;
     comp[kCompGrid + 7] = __float_as_uint(r_conn_param);
+  }
+  if (fine_frames_per_cell > 0.0f) {   // the fine cell grids of the components for the sweep that follows
+    __syncthreads();                   // (boxes, counts: this workgroup's own writes)
+    if (tid == 0) fine_grid_body(hdr, n_rows, fine_frames_per_cell, fine_bits, comp);
   }
 }
 
@@ -721,11 +733,17 @@ static size_t components_smem() {
 // A partition left in the workspace by an earlier sweep over the same coordinates serves this sweep too (any partition
 // does: what it cannot see across components, the exact cross passes look at) -- unless the cookie says it belongs to
 // other data: then one component, the column means as its origin.
+// Round 5: the fine cell grids of the sweep that follows are formed in the same launch (fine_frames_per_cell > 0), and the
+// rows-per-component counters of both orders start from zero (order_key_kernel adds to them).
 __global__ __launch_bounds__(1024) void comp_guard_kernel(const uint32_t* __restrict__ hdr, const float* __restrict__ means,
-                                                         uint32_t D, uint32_t* __restrict__ comp, uint32_t cookie) {
-  if (comp[kCompGrid + 6] == cookie) return;
-  for (uint32_t c = threadIdx.x; c < (uint32_t)kCoarseCells; c += blockDim.x) comp[kCompCellComp + c] = 0u;
-  if (threadIdx.x == 0) {
+                                                         uint32_t D, uint32_t* __restrict__ comp, uint32_t cookie,
+                                                         uint32_t n_rows = 0, float fine_frames_per_cell = 0.0f,
+                                                         uint32_t fine_bits = 0) {
+  if (threadIdx.x < 2u * ((uint32_t)kMaxComp + 1u)) comp[kCompStart + threadIdx.x] = 0u;
+  const bool keep = comp[kCompGrid + 6] == cookie;
+  if (!keep)
+    for (uint32_t c = threadIdx.x; c < (uint32_t)kCoarseCells; c += blockDim.x) comp[kCompCellComp + c] = 0u;
+  if (!keep && threadIdx.x == 0) {
     float* a = reinterpret_cast<float*>(comp + kCompOrigin);
     for (uint32_t k = 0; k < D; ++k) a[k] = means[k];
     reinterpret_cast<float4*>(comp + kCompBox)[0] =
@@ -736,14 +754,17 @@ __global__ __launch_bounds__(1024) void comp_guard_kernel(const uint32_t* __rest
     comp[kCompGrid + 5] = 1;
     comp[kCompGrid + 7] = __float_as_uint(1.0f);
   }
+  if (fine_frames_per_cell > 0.0f) {
+    __syncthreads();
+    if (threadIdx.x == 0) fine_grid_body(hdr, n_rows, fine_frames_per_cell, fine_bits, comp);
+  }
 }
 
 // the fine cell grids of the components for one sweep (frames_per_cell is the sweep's own): one cell size for all
 // components (at most 4001 cells per dimension and component), the cells of all components numbered consecutively --
 // fewer than 2^fine_bits of them, so the ordering keys stay short
-__global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell,
-                                 uint32_t fine_bits, uint32_t* __restrict__ comp) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell,
+                               uint32_t fine_bits, uint32_t* __restrict__ comp) {
   const uint32_t n_comp = min(comp[kCompGrid + 5], (uint32_t)kMaxComp);
   const float gmin0 = fkey_inv(~hdr[8]), gmax0 = fkey_inv(hdr[9]), gmin1 = fkey_inv(~hdr[10]), gmax1 = fkey_inv(hdr[11]);
   float cell = auto_cell(hdr, n_rows, frames_per_cell);
@@ -791,6 +812,11 @@ __global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_ro
     off = min(off + nx * ny, (1u << fine_bits) - 1u);
   }
   for (uint32_t c = n_comp; c <= (uint32_t)kMaxComp; ++c) comp[kCompCellOff + c] = off;
+}
+__global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell,
+                                 uint32_t fine_bits, uint32_t* __restrict__ comp) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  fine_grid_body(hdr, n_rows, frames_per_cell, fine_bits, comp);
 }
 
 // ordering key of the pruned population sweeps: (component, cell of the component's fine grid on columns 0/1) for
@@ -1114,8 +1140,17 @@ __global__ __launch_bounds__(256) void order_rows_kernel(
   }
 }
 
+#include "dc_prep.hpp"
 
 }  // namespace
+
+// dynamic LDS of order_rows2_kernel (dc_prep.hpp); beyond 64 KB (wide rows) the launch has to ask for it
+static size_t order_rows_smem_set(uint32_t n_cols) {
+  const size_t bytes = order_rows_smem(n_cols);
+  if (bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(order_rows2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
 
 #define DC_FOR_EACH_S(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 DC_FOR_EACH_S(DC_DECLARE_STEP)
@@ -1208,8 +1243,10 @@ static uint32_t data_cookie(const float* d_coords, uint32_t n_rows, uint32_t n_c
 // the per-sweep words of a header whose statistics stay (DC_FLAG_STATS_VALID): evaluated-tile counters (words 2..5), the
 // free-energy range (12..13), the fingerprint the guard recomputes (kHdrFp + 2, + 3), the extent over the components
 // (a header built from scratch starts from zeros altogether)
-__global__ void sweep_words_reset_kernel(uint32_t* __restrict__ hdr) {
+__global__ void sweep_words_reset_kernel(uint32_t* __restrict__ hdr, int pruned) {
   const uint32_t k = threadIdx.x;
+  if (k == 0u && pruned) hdr[k] = 0u;   // (max |x - mean|^2: order_key_kernel of this call forms it again, like word kHdrMloc)
+  if (k == kHdrFp + 4u || k == kHdrFp + 5u) hdr[k] = 0u;   // (hash of the neighbour sweep's order: order_rows2_kernel adds to it)
   if (k >= 2u && k <= 7u) hdr[k] = 0u;                         // (... and the MFMAs the population sweeps issued, 6..7)
   if (k == kHdrMfmaNn || k == kHdrMfmaNn + 1u) hdr[k] = 0u;   // (the neighbour sweeps')
   if (k == 12u || k == 13u) hdr[k] = 0u;
@@ -1222,18 +1259,29 @@ __global__ void sweep_words_reset_kernel(uint32_t* __restrict__ hdr) {
 }
 
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
-                 bool natural_image, hipStream_t stream, bool stats_valid) {
+                 bool natural_image, hipStream_t stream, bool stats_valid, bool pruned) {
+  // pruned: a pruned sweep follows -- the statistics come from ONE pass (stats_kernel, dc_prep.hpp); the column means and
+  // the extents max |x - mean|^2 / max |x - origin|^2 follow in the passes of its preparation that read the rows anyway
+  // (components_kernel, order_key_kernel).  The full sweeps and the fp32-MFMA instance need means and max norm before
+  // their first image: the three passes of rounds 1 - 4.
   char* p = (char*)d_ws;
   const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
   if (stats_valid) {
     // DC_FLAG_STATS_VALID: means, max norm, flag and bounding box of an earlier sweep over the same coordinates
     // stay; only the per-sweep words start over (evaluated-tile counters: words 2..5; free-energy range: 12..13)
     // (one launch instead of three memsets: a fill is a 4.6 us kernel of its own)
-    hipLaunchKernelGGL(sweep_words_reset_kernel, dim3(1), dim3(64), 0, stream, (uint32_t*)p);
+    hipLaunchKernelGGL(sweep_words_reset_kernel, dim3(1), dim3(64), 0, stream, (uint32_t*)p, pruned ? 1 : 0);
     const size_t total = (size_t)n_rows * n_cols;
     hipLaunchKernelGGL(fingerprint_kernel, dim3((uint32_t)std::min<size_t>(1024, (total + 1023) / 1024)), dim3(256), 0, stream,
                        d_coords, total, (unsigned long long*)(p + 4 * (kHdrFp + 2)));
     hipLaunchKernelGGL(stats_guard_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)p, cookie);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  if (pruned) {
+    // header and component region in ONE fill (the layout puts them side by side), then one pass over the coordinates
+    if (hipMemsetAsync(p, 0, kHdrBytes + sizeof(uint32_t) * kCompWords, stream) != hipSuccess) return -1;
+    hipLaunchKernelGGL(stats_kernel, dim3((uint32_t)std::min<size_t>(512, ((size_t)n_rows * n_cols + 255) / 256)), dim3(256), 0,
+                       stream, d_coords, n_rows, n_cols, (uint32_t*)p, cookie);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (hipMemsetAsync(p, 0, kHdrBytes, stream) != hipSuccess) return -1;
@@ -1327,36 +1375,37 @@ static bool pop_multi_radius(uint32_t n_rows, uint32_t n_cols, int n_rad) {
 }
 
 // r2_scale: the largest squared radius the prepared images have to serve (the radii of the whole call)
+// comp_clean: the component region of the workspace has been zero-filled by this call already (mfma_prepare)
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           const EdgeSink* sink, hipStream_t stream, float r2_scale, bool prep = true);
+                           const EdgeSink* sink, hipStream_t stream, float r2_scale, bool prep = true, bool comp_clean = false);
 
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool comp_clean) {
   if (pop_multi_radius(n_rows, n_cols, n_rad)) {
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, rad2, n_rad, d_pops, d_ws, nullptr, stream,
-                   max_radius2(rad2, n_rad));
+                   max_radius2(rad2, n_rad), true, comp_clean);
     return;
   }
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{i_from, i_to, 0, 0}, single_radius(rad2, r), 1,
                    d_pops + (size_t)r * n_rows, d_ws, nullptr, stream, max_radius2(rad2, n_rad),
-                   r == 0);   // one preparation for all radii
+                   r == 0, comp_clean);   // one preparation for all radii
 }
 
 void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
                                uint32_t segment, uint32_t n_segments, const Rad2& rad2, int n_rad,
-                               uint32_t* d_pops, void* d_ws, hipStream_t stream) {
+                               uint32_t* d_pops, void* d_ws, hipStream_t stream, bool comp_clean) {
   if (pop_multi_radius(n_rows, n_cols, n_rad)) {
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments}, rad2, n_rad, d_pops, d_ws,
-                   nullptr, stream, max_radius2(rad2, n_rad));
+                   nullptr, stream, max_radius2(rad2, n_rad), true, comp_clean);
     return;
   }
   for (int r = 0; r < n_rad; ++r)
     pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments},
                    single_radius(rad2, r), 1, d_pops + (size_t)r * n_rows, d_ws, nullptr, stream,
-                   max_radius2(rad2, n_rad), r == 0);
+                   max_radius2(rad2, n_rad), r == 0, comp_clean);
 }
 
 // positions of the sweep's spatial order -> frame ids, for the pairs actually written; a flagged
@@ -1403,13 +1452,13 @@ void launch_radius_pairs(const float* d_coords, uint32_t n_rows, uint32_t n_cols
   (void)hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream);
   if (d_pairs && capacity) {
     const EdgeSink sink{d_pairs, d_count, capacity, nullptr, nullptr, nullptr};
-    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream, r2);
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, &sink, stream, r2, true, true);
     hipLaunchKernelGGL(edges_to_frames_kernel, dim3(1024), dim3(256), 0, stream, d_pairs,
                        (const unsigned long long*)d_count, capacity,
                        (const uint32_t*)((char*)d_ws + L.off_perm_p));
   } else {
     // counting only: the plain population sweep knows the answer
-    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, nullptr, stream, r2);
+    pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, 0, 0}, one, 1, d_pops, d_ws, nullptr, stream, r2, true, true);
     hipLaunchKernelGGL(pairs_from_pops_kernel, dim3(256), dim3(256), 0, stream, (const uint32_t*)d_pops,
                        n_rows, d_count);
     hipLaunchKernelGGL(halve_kernel, dim3(1), dim3(1), 0, stream, d_count);
@@ -1428,7 +1477,7 @@ void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_c
   // comp / rank arrive per FRAME; pop_pruned_one gathers them into the sweep's order
   const EdgeSink sink{nullptr, nullptr, 0, d_comp, d_rank, d_best};
   pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments}, one, 1, d_pops, d_ws,
-                 &sink, stream, r2);
+                 &sink, stream, r2, true, true);
 }
 
 // the padded order of a sorted (component, fine cell) list: perm[position] = frame or kInvalidFrame, tile_comp[tile]
@@ -1464,7 +1513,7 @@ static bool components_off() {
 
 static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const QuerySel& qs,
                            const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws,
-                           const EdgeSink* sink_in, hipStream_t stream, float r2_scale, bool prep) {
+                           const EdgeSink* sink_in, hipStream_t stream, float r2_scale, bool prep, bool comp_clean) {
   // prep == false: the orderings, images and boxes of the previous call (same coordinates, same query
   // selection) are still in the workspace -- the further radii of one populations call
   const uint32_t i_from = qs.i_from, i_to = qs.i_to;
@@ -1516,36 +1565,42 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     sink = &sink_local;
   }
   if (prep) {
-    // components of the frames for this call's largest radius, their origins and fine grids
-    (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
+    // (round 5: the passes of dc_prep.hpp -- twelve launches for the thirty of rounds 3 - 4, same values)
+    const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
+    uint32_t* start_r = comp + kCompStart, *start_q = comp + kCompStart + (kMaxComp + 1);
+    uint32_t* range_r = comp + kCompRange, *range_q = comp + kCompRange + kCompRangeStride;
+    uint32_t* base_r = comp + kCompBase, *base_q = comp + kCompBase + (kMaxComp + 1);
+    // components of the frames for this call's largest radius, their origins, the column means and the fine grids
+    if (!comp_clean) (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
     hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn,
                        comp);
-    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), components_smem(), stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
-                       components_off() ? 1 : 0, r_max, data_cookie(d_coords, n_rows, n_cols));
-    hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, cell_frames(false),
-                       (uint32_t)fine_bits, comp);
-    // order all frames by (component, fine cell); every component then moves to a whole query group of the padded order
-    hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
-                       (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in, n_rows);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits))
-      return;
-    pad_order(keys_out, vals_sorted, n_rows, 0u, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
-              T_r, stream);
-    // original rows in the reference order: the deferred exact path reads them without a
-    // permutation look-up, and the operand images are built from them with coalesced reads
-    hipLaunchKernelGGL(order_rows_kernel, dim3((32 * T_r + 255) / 256), blk, row_tile_smem(order_rows_kernel, n_cols), stream,
-                       d_coords, n_cols, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p),
-                       (float4*)(p + L.off_box_p), (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr,
-                       (float2*)nullptr, (const uint32_t*)tile_comp, origins, hdr);
-    // the scale follows the components' extents
-    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, fmaxf(r2_scale, 0.0f), n_cols,
-                       (const uint32_t*)comp);
-    hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
-                       L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 0,
-                       (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
-                       (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
+                       components_off() ? 1 : 0, r_max, cookie, (float*)(p + kHdrMeans), cell_frames(false));
+    // order all frames by (component, fine cell): keys, rows per component, the extents, the pad presets ...
+    hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_rows, 32u * T_r) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+                       (const uint32_t*)comp, (uint32_t)fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
+                       start_r, 1, perm_p, tile_comp, 32u * T_r);
+    // ... where the components start, the scale of the sweep (it follows the components' extents) ...
+    hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_r, range_r, base_r, n_rows, group_rows, 1,
+                       fmaxf(r2_scale, 0.0f), n_cols);
+    // ... the sort, whose last pass moves every component to a whole query group of the padded order ...
+    {
+      const SortRemap remap{start_r, base_r, (uint32_t)kMaxComp, tile_comp};
+      if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, key_bits, &remap))
+        return;
+    }
+    // ... and the rows in that order (the deferred exact path reads them without a permutation look-up), the tile boxes
+    // and the operand images: A form of every tile, B form of the query groups of this segment (queries in the
+    // reference order)
+    {
+      const bool ref_queries = q_mode != kQueryOwnOrder;
+      hipLaunchKernelGGL(order_rows2_kernel, dim3((32 * T_r + 255) / 256), blk, order_rows_smem_set(n_cols), stream, d_coords, n_cols,
+                         L.NM, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p), (float4*)(p + L.off_box_p),
+                         (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp,
+                         origins, hdr, (uint4*)(p + L.off_img_p), 0, (float*)(p + L.off_norm_p),
+                         ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg);
+    }
     // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
     // buffers are free again)
     if (sink_in && sink_in->best) {
@@ -1554,30 +1609,21 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
       hipLaunchKernelGGL(gather_u32_kernel, dim3((32 * T_r + 255) / 256), blk, 0, stream, sink_in->rank,
                          (const uint32_t*)perm_p, 32u * T_r, keys_out);
     }
-    if (q_mode != kQueryOwnOrder) {
-      // queries in the reference order: only their B form is missing (of the groups of this segment)
-      const uint32_t tiles_q = seg_groups((T_r + tq - 1) / tq, q_seg) * tq;
-      if (tiles_q > 0)
-        hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
-                           L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                           (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg,
-                           (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
-    }
     if (q_mode == kQueryOwnOrder) {
       // query rows of this call: the same ordering restricted to [i_from, i_to)
-      hipLaunchKernelGGL(compkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr,
-                         r_conn, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in, n_rows);
-      if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_q, p + L.fixed_end, tmp_bytes, stream, key_bits))
+      hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_q, 32u * T_q) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+                         (const uint32_t*)comp, (uint32_t)fine_bits, i_from, i_to, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
+                         start_q, 0, perm_q, tile_comp_q, 32u * T_q);
+      hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_q, range_q, base_q, n_q, group_rows, 0,
+                         0.0f, n_cols);
+      const SortRemap remap{start_q, base_q, (uint32_t)kMaxComp, tile_comp_q};
+      if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, key_bits, &remap))
         return;
-      pad_order(keys_out, vals_sorted, n_q, 0u, group_rows, comp, comp + kCompStart + (kMaxComp + 1),
-                comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
-      hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, image_smem(n_cols), stream, d_coords, n_rows, 32u * T_q, n_cols,
-                         L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                         (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
-                         (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
-      hipLaunchKernelGGL(box_kernel, dim3((T_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
-                         (const uint32_t*)perm_q, 32u * T_q, T_q, (float4*)(p + L.off_box_q),
-                         (const float*)nullptr, (float2*)nullptr);
+      hipLaunchKernelGGL(order_rows2_kernel, dim3((32 * T_q + 255) / 256), blk, order_rows_smem_set(n_cols), stream, d_coords, n_cols,
+                         L.NM, (const uint32_t*)perm_q, T_q, (float*)nullptr, (float4*)(p + L.off_box_q),
+                         (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp_q,
+                         origins, hdr, (uint4*)nullptr, 0, (float*)nullptr, (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), 1u,
+                         QSeg{1u, 0u, 1u});
     }
   }
   (void)kCellFramesHere;
@@ -1598,13 +1644,14 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
 
 static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                           const QuerySel& qs, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
-                          float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components);
+                          float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components, bool comp_clean);
 
 void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                       uint32_t i_from, uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2,
                       uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components) {
+  // (a neighbour call that does not reuse the components follows a mfma_prepare that zero-filled their region)
   nn_pruned_sel(d_coords, n_rows, n_cols, d_fe, QuerySel{i_from, i_to, 0, 0}, d_nn_idx, d_nn_d2,
-                d_hd_idx, d_hd_d2, d_ws, stream, reuse_components);
+                d_hd_idx, d_hd_d2, d_ws, stream, reuse_components, !reuse_components);
 }
 
 void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
@@ -1612,7 +1659,7 @@ void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n
                               uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
                               void* d_ws, hipStream_t stream, bool reuse_components) {
   nn_pruned_sel(d_coords, n_rows, n_cols, d_fe, QuerySel{0, n_rows, segment, n_segments}, d_nn_idx,
-                d_nn_d2, d_hd_idx, d_hd_d2, d_ws, stream, reuse_components);
+                d_nn_d2, d_hd_idx, d_hd_d2, d_ws, stream, reuse_components, !reuse_components);
 }
 
 // Neighbours that lie in ANOTHER component than their query (dc_mfma_kernels.hpp "components"): the matrix-core sweep
@@ -1850,7 +1897,7 @@ __global__ void nn_cross_write_kernel(const uint32_t* __restrict__ hdr, const ui
 
 static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,
                           const QuerySel& qs, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,
-                          float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components) {
+                          float* d_hd_d2, void* d_ws, hipStream_t stream, bool reuse_components, bool comp_clean) {
   const uint32_t i_from = qs.i_from, i_to = qs.i_to;
   const Layout L = make_layout(n_rows, n_cols);
   char* p = (char*)d_ws;
@@ -1895,63 +1942,58 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 256u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
                      (uint32_t*)nullptr, hdr);
   const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
+  uint32_t* start_r = comp + kCompStart, *start_q = comp + kCompStart + (kMaxComp + 1);
+  uint32_t* range_r = comp + kCompRange, *range_q = comp + kCompRange + kCompRangeStride;
+  uint32_t* base_r = comp + kCompBase, *base_q = comp + kCompBase + (kMaxComp + 1);
   if (reuse_components) {
     // the partition an earlier sweep over these coordinates left in the workspace (DC_FLAG_STATS_VALID: the
-    // populations -> neighbours pair) -- checked on the device
+    // populations -> neighbours pair) -- checked on the device; the fine grids of THIS sweep in the same launch
     hipLaunchKernelGGL(comp_guard_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr, (const float*)(p + kHdrMeans),
-                       n_cols, comp, cookie);
+                       n_cols, comp, cookie, n_rows, cell_frames(true), (uint32_t)fine_bits);
   } else {
-    (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
+    if (!comp_clean) (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
     hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn, comp);
-    hipLaunchKernelGGL(coarse_box_kernel, dim3(kCoarseCells / 256), blk, 0, stream, (const uint32_t*)hdr, r_conn, n_rows, comp);
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), components_smem(), stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
-                       components_off() ? 1 : 0, 0.0f, cookie);
+                       components_off() ? 1 : 0, 0.0f, cookie, (float*)(p + kHdrMeans), cell_frames(true));
   }
-  hipLaunchKernelGGL(fine_grid_kernel, dim3(1), dim3(64), 0, stream, (const uint32_t*)hdr, n_rows, cell_frames(true),
-                     (uint32_t)fine_bits, comp);
-  // frames by (component, cell, free energy): ONE sort on a combined key
-  hipLaunchKernelGGL(compkey_kernel, grid_n, blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr, r_conn,
-                     (const uint32_t*)comp, fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, fe_bits);
-  if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_rows, p + L.fixed_end, tmp_bytes, stream, fine_bits + fe_bits))
-    return;
-  pad_order(keys_out, vals_sorted, n_rows, fe_bits, group_rows, comp, comp + kCompStart, comp + kCompRange, perm_p, tile_comp,
-            T_r, stream);
+  // frames by (component, cell, free energy): ONE sort on a combined key, its last pass writes the padded order
+  hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_rows, 32u * T_r) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+                     (const uint32_t*)comp, (uint32_t)fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, (uint32_t)fe_bits, start_r, 1,
+                     perm_p, tile_comp, 32u * T_r);
+  hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_r, range_r, base_r, n_rows, group_rows, 1,
+                     -1.0f, n_cols);   // (the neighbour scale)
+  {
+    const SortRemap remap{start_r, base_r, (uint32_t)kMaxComp, tile_comp};
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, fine_bits + fe_bits, &remap))
+      return;
+  }
   const float* coords_p = (const float*)(p + L.off_coords_p);
-  hipLaunchKernelGGL(order_rows_kernel, dim3((32 * T_r + 255) / 256), blk, row_tile_smem(order_rows_kernel, n_cols), stream,
-                     d_coords, n_cols, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p),
-                     (float4*)(p + L.off_box_p), d_fe, (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos),
-                     (float2*)(p + L.off_ferange_p), (const uint32_t*)tile_comp, origins, hdr);
-  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, stream, hdr, -1.0f, n_cols, (const uint32_t*)comp);   // the neighbour scale
-  // (the neighbour sweeps take the reference norms through the operand image: dc_mfma_kernels.hpp "reference norms folded")
-  hipLaunchKernelGGL(image_kernel, grid_img(T_r), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
-                     L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 2,
-                     (uint4*)(p + L.off_img_p), (float*)(p + L.off_norm_p), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
-                     (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
-  if (q_mode != kQueryOwnOrder) {
-    // queries in the reference order: only their B form is missing (of the groups of this segment)
-    const uint32_t tiles_q = seg_groups((T_r + tq - 1) / tq, q_seg) * tq;
-    if (tiles_q > 0)
-      hipLaunchKernelGGL(image_kernel, grid_img(tiles_q), blk, image_smem(n_cols), stream, coords_p, n_rows, 32u * T_r, n_cols,
-                         L.NM, T_r, (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, 1,
-                         (uint4*)(p + L.off_img_q), (float*)nullptr, (const uint32_t*)p, tq, q_seg,
-                         (const uint32_t*)tile_comp, origins, (const uint32_t*)perm_p);
+  // rows, boxes, free-energy ranges, and the operand images: the neighbour sweeps take the reference norms through the
+  // operand image (dc_mfma_kernels.hpp "reference norms folded": a_form 2), the queries' B form for this segment's groups
+  {
+    const bool ref_queries = q_mode != kQueryOwnOrder;
+    hipLaunchKernelGGL(order_rows2_kernel, dim3((32 * T_r + 255) / 256), blk, order_rows_smem_set(n_cols), stream, d_coords, n_cols,
+                       L.NM, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p), (float4*)(p + L.off_box_p), d_fe,
+                       (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos), (float2*)(p + L.off_ferange_p),
+                       (const uint32_t*)tile_comp, origins, hdr, (uint4*)(p + L.off_img_p), 2, (float*)(p + L.off_norm_p),
+                       ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg);
   }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(compkey_kernel, dim3((n_q + 255) / 256), blk, 0, stream, d_coords, n_cols, (const uint32_t*)hdr,
-                       r_conn, (const uint32_t*)comp, fine_bits, i_from, i_to, keys_in, vals_in, n_rows);
-    if (sort_pairs_u32(keys_in, keys_out, vals_in, vals_sorted, n_q, p + L.fixed_end, tmp_bytes, stream, fine_bits))
+    hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_q, 32u * T_q) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+                       (const uint32_t*)comp, (uint32_t)fine_bits, i_from, i_to, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
+                       start_q, 0, perm_q, tile_comp_q, 32u * T_q);
+    hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_q, range_q, base_q, n_q, group_rows, 0,
+                       0.0f, n_cols);
+    const SortRemap remap{start_q, base_q, (uint32_t)kMaxComp, tile_comp_q};
+    if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, fine_bits, &remap))
       return;
-    pad_order(keys_out, vals_sorted, n_q, 0u, group_rows, comp, comp + kCompStart + (kMaxComp + 1),
-              comp + kCompRange + kCompRangeStride, perm_q, tile_comp_q, T_q, stream);
-    hipLaunchKernelGGL(image_kernel, grid_img(T_q), blk, image_smem(n_cols), stream, d_coords, n_rows, 32u * T_q, n_cols,
-                       L.NM, T_q, (const float*)(p + kHdrMeans), (const uint32_t*)perm_q, 1,
-                       (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), (const uint32_t*)p, 1u, QSeg{1u, 0u, 1u},
-                       (const uint32_t*)tile_comp_q, origins, (const uint32_t*)nullptr);
-    hipLaunchKernelGGL(box_kernel, dim3((T_q + 255) / 256), blk, 0, stream, d_coords, n_cols,
-                       (const uint32_t*)perm_q, 32u * T_q, T_q, (float4*)(p + L.off_box_q),
-                       (const float*)nullptr, (float2*)nullptr);
+    hipLaunchKernelGGL(order_rows2_kernel, dim3((32 * T_q + 255) / 256), blk, order_rows_smem_set(n_cols), stream, d_coords, n_cols,
+                       L.NM, (const uint32_t*)perm_q, T_q, (float*)nullptr, (float4*)(p + L.off_box_q), (const float*)nullptr,
+                       (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp_q, origins, hdr,
+                       (uint4*)nullptr, 0, (float*)nullptr, (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), 1u,
+                       QSeg{1u, 0u, 1u});
   }
   const bool own = q_mode == kQueryOwnOrder;
   const uint32_t n_pos_q = 32u * (own ? T_q : T_r);
@@ -2097,13 +2139,8 @@ void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const 
   const uint32_t rows = (uint32_t)nn_block_rows(n_rows, n_cols, n_segments);
   const Layout L = make_layout(n_rows, n_cols);
   const char* p = (const char*)d_ws;
-  if (pruned) {   // hash of the order the block is packed by (header words kHdrFp + 4..5)
-    unsigned long long* dst = (unsigned long long*)(const_cast<char*>(p) + 4 * (kHdrFp + 4));
-    (void)hipMemsetAsync(dst, 0, 8, stream);
-    const uint32_t n_pos = 32u * nn_order_tiles(n_rows, n_cols);
-    hipLaunchKernelGGL(perm_hash_kernel, dim3(std::min<uint32_t>((n_pos + 255) / 256, 512u)), dim3(256), 0, stream,
-                       (const uint32_t*)(p + L.off_perm_p), n_pos, dst);
-  }
+  // (the hash of the order the block is packed by -- header words kHdrFp + 4..5 -- was formed with the order itself:
+  //  order_rows2_kernel of the neighbour call that ran in this workspace)
   hipLaunchKernelGGL(nn_block_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2, d_hd_idx,
                      d_hd_d2, n_rows, 32u * nn_order_tiles(n_rows, n_cols), pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, seg_block(n_segments), rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block);

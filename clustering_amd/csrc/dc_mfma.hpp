@@ -27,9 +27,11 @@ bool mfma_supports(size_t n_cols);
 // bytes of device scratch (operand images, norms) for a problem size; 0 if unsupported
 size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols);
 // builds the operand images of d_coords in the workspace; returns 0 on success
+// pruned: a pruned sweep follows (one statistics pass; the component region of the workspace is zero-filled with the
+// header unless stats_valid, in which case the statistics of an earlier sweep stay and the sweep clears the region itself)
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
                  bool natural_image,
-                 hipStream_t stream, bool stats_valid = false);
+                 hipStream_t stream, bool stats_valid = false, bool pruned = false);
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
                      void* d_ws, hipStream_t stream);
@@ -41,9 +43,10 @@ void launch_nn_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
                       uint32_t i_to, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2, void* d_ws,
                       hipStream_t stream);
 // population sweep over spatially ordered frames with tile-pair pruning (needs mfma_prepare first)
+// comp_clean: mfma_prepare(pruned) of this call has zero-filled the component region of the workspace
 void launch_pop_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                        uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
-                       void* d_ws, hipStream_t stream);
+                       void* d_ws, hipStream_t stream, bool comp_clean = false);
 // pruned population sweep at squared radius r2 that also lists every unordered frame pair with
 // canonical d2 < r2 (frame ids; d_pairs may be nullptr to count only); needs mfma_prepare first.
 // *d_count: number of pairs found (> capacity: buffer too small), ~0 if the data was flagged.
@@ -99,7 +102,7 @@ void launch_nn_pruned(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
 // "none" for the rows of other segments.
 void launch_pop_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
                                uint32_t segment, uint32_t n_segments, const Rad2& rad2, int n_rad,
-                               uint32_t* d_pops_first_row, void* d_ws, hipStream_t stream);
+                               uint32_t* d_pops_first_row, void* d_ws, hipStream_t stream, bool comp_clean = false);
 void launch_nn_pruned_segment(const float* d_coords, uint32_t n_rows, uint32_t n_cols,
                               const float* d_fe, uint32_t segment, uint32_t n_segments,
                               uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2,
@@ -141,11 +144,23 @@ void sweep_timer_enable(bool on);
 void sweep_timer_mark(int kind, bool begin, hipStream_t s);
 int sweep_timer_read(int kind, float* ms);   // 0 ok, -1 nothing recorded / error
 
-// dc_sort.hip: stable key/value radix sort (rocPRIM Onesweep) on the low key_bits bits of the keys
+// dc_sort.hip: stable key/value radix sort on the low key_bits bits of the keys (8 bits per pass).
+// remap: the LAST pass writes the values only, into a padded order: the sorted list is cut into n_seg segments
+// [seg_start[s], seg_start[s + 1]) (device arrays of n_seg + 1 entries; seg_start[n_seg] = n), segment s lands at
+// positions seg_base[s] + 0, 1, ...; tags[position / 32] = s for every tile whose first position is taken.  Positions
+// nothing lands on keep their contents (the caller presets them); keys_out is not written then.
+constexpr uint32_t kSortMaxSegments = 64;
+struct SortRemap {
+  const uint32_t* seg_start;
+  const uint32_t* seg_base;
+  uint32_t n_seg;
+  uint32_t* tags;
+};
 size_t sort_temp_bytes(size_t n);
-int sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+// keys_in / vals_in are scratch: sorts of three or more passes use them for the passes in between.
+int sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
                    uint32_t* vals_out, size_t n, void* temp, size_t temp_bytes, hipStream_t stream,
-                   unsigned key_bits = 32);
+                   unsigned key_bits = 32, const SortRemap* remap = nullptr);
 constexpr unsigned kCellKeyBits = 24;   // cell keys of the spatial orderings: < 4002^2 < 2^24
 
 }  // namespace dc

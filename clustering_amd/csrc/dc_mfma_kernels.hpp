@@ -140,7 +140,8 @@ constexpr size_t kCompAdj = kCompRange + 2 * kCompRangeStride;         // [kMaxC
 constexpr size_t kCompBox = kCompAdj + 2 * (size_t)kMaxComp;           // [kMaxComp] float4: box of the component in columns 0/1
 constexpr size_t kCompBitmap = kCompBox + 4 * (size_t)kMaxComp;        // occupancy of the sub-cells, one byte each
 constexpr size_t kCompBitmapWords = (size_t)kCoarseCells * kFineSub * kFineSub / 4;
-constexpr size_t kCompWords = kCompBitmap + kCompBitmapWords;
+constexpr size_t kCompBase = kCompBitmap + kCompBitmapWords;           // [2][kMaxComp + 1]: first POSITION of a component in the padded order (reference / query order)
+constexpr size_t kCompWords = kCompBase + 2 * ((size_t)kMaxComp + 1);
 
 // Workspace layout.  Regions used by the population sweep: hdr, img, norms.  The neighbour sweep
 // adds a second operand image with the reference frames ORDERED BY FREE ENERGY (img_s, norms_s),
@@ -178,7 +179,9 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   // (every per-position region is sized for the padded orders)
   const size_t img_bytes = (size_t)16 * 64 * (size_t)L.Tp * L.NM;
   const size_t row_bytes = align256(sizeof(float) * 32 * (size_t)L.Tp);
-  L.off_img = kHdrBytes;
+  // (the component region sits right behind the header: ONE fill zeroes both at the start of a call)
+  L.off_comp = kHdrBytes;
+  L.off_img = align256(L.off_comp + sizeof(uint32_t) * kCompWords);
   L.off_img_b = align256(L.off_img + img_bytes);
   L.off_norm = align256(L.off_img_b + img_bytes);
   L.off_img_s = L.off_norm + row_bytes;
@@ -202,8 +205,7 @@ inline Layout make_layout(size_t n_rows, size_t n_cols) {
   L.off_coords_p = align256(L.off_ferange_p + sizeof(float) * 2 * (size_t)L.Tp);
   L.off_merge64 = align256(L.off_coords_p + sizeof(float) * 32 * (size_t)L.Tp * n_cols);
   L.off_box_t = align256(L.off_merge64 + sizeof(unsigned long long) * 2 * n_rows);
-  L.off_comp = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.Tp + L.Tp / 32 + 64));   // (+ one pad box per share)
-  L.off_tile_comp = align256(L.off_comp + sizeof(uint32_t) * kCompWords);
+  L.off_tile_comp = align256(L.off_box_t + sizeof(float) * 4 * ((size_t)L.Tp + L.Tp / 32 + 64));   // (+ one pad box per share)
   L.off_tile_comp_q = align256(L.off_tile_comp + sizeof(uint32_t) * (size_t)L.Tp);
   L.fixed_end = align256(L.off_tile_comp_q + sizeof(uint32_t) * (size_t)L.Tp);
   return L;

@@ -1,0 +1,401 @@
+// dc_prep.hpp -- the preparation passes of the PRUNED sweeps, round 5 (included by dc_mfma.hip inside namespace
+// dc::{anonymous}, behind the kernels of rounds 1 - 4 it still shares code with).
+//
+// Every rank of a sharded run repeats the preparation of a sweep in full -- statistics, components, ordering keys, the
+// sort, the padded order, the gathered rows, the operand images -- while its sweep shrinks with the rank count: at an
+// eighth of C3 the preparation was 0.72 ms of a 4.06 ms step (round 4), some forty launches of which half ran for the
+// 5 us a launch costs whatever it does.  This file is the same preparation in a dozen launches:
+//   stats_kernel        ONE pass over the coordinates: column sums, bounding box of columns 0/1, the flag for non-finite
+//                       or overflow-prone data, the content fingerprint (colsum + mean + rowstats + a fill before)
+//   fine_mark_kernel    (unchanged) occupancy bitmap of the sub-cells
+//   components_kernel   + the coarse cells' boxes in front, the column means and the fine cell grids behind: one launch
+//                       for four
+//   order_key_kernel    ordering key and value of every row (compkey_kernel's arithmetic) + the rows per component +
+//                       the extents max |x - origin(component)|^2 and max |x - mean|^2 (from order_rows / rowstats) +
+//                       the pad presets of the order
+//   order_meta_kernel   where every component starts in the sorted list and in the padded order (comp_start + comp_ranges)
+//                       and the scale of the sweep (scale_kernel)
+//   the sort            dc_sort.hip: its last pass writes straight into the PADDED order (pad_scatter and a fill before)
+//   order_rows_kernel   rows gathered into the order, tile boxes, free-energy ranges, AND the operand images of the
+//                       tiles -- A form of every tile, B form of the query groups of this launch's segment -- built from
+//                       the rows while they sit in LDS (order_rows + scale + two image launches)
+// The arithmetic of every value is what the kernels of rounds 1 - 4 computed; only who computes it when has changed.
+#pragma once
+
+constexpr float kStatsLimit = 5.0e16f;   // |x_k| beyond this: |x - mean|^2 could pass kNormLimit = 1e36 (64 columns x (2 x 5e16)^2 = 6.4e35)
+
+// ONE pass over the coordinates, element-wise (the thread's column is fixed: the stride is a multiple of n_cols): column
+// sums (double), extent of columns 0/1 (header words 8..11), the flag for non-finite / overflow-prone data (word 1,
+// bit 0), the content fingerprint (kHdrFp), the cookie.  The header was zero-filled before.
+__global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
+                                                    uint32_t* __restrict__ hdr, uint32_t cookie) {
+  __shared__ double part[kMaxCols];
+  __shared__ uint32_t wave_max[4];
+  __shared__ unsigned long long fp_part[4];
+  if (threadIdx.x < (uint32_t)kMaxCols) part[threadIdx.x] = 0.0;
+  __syncthreads();
+  const uint32_t nthreads = gridDim.x * blockDim.x;
+  const uint32_t used = (nthreads / D) * D;
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_rows * D;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(coords);
+  const uint32_t col = id % D;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  uint32_t m_lo = 0, m_hi = 0;
+  unsigned long long fp = 0;
+  bool bad = false;
+  auto take = [&](uint32_t bits, size_t e, double& s) {
+    const float v = __uint_as_float(bits);
+    fp += fp_term(bits, e);
+    const bool fin = fabsf(v) <= kStatsLimit;
+    bad = bad | !fin;
+    if (fin) {
+      s += (double)v;
+      m_lo = max(m_lo, ~fkey(v));
+      m_hi = max(m_hi, fkey(v));
+    }
+  };
+  if (id < used) {
+    size_t e = id;
+    for (; e + 3 * (size_t)used < total; e += 4 * (size_t)used) {   // four loads in flight
+      const uint32_t b0 = w[e], b1 = w[e + used], b2 = w[e + 2 * (size_t)used], b3 = w[e + 3 * (size_t)used];
+      take(b0, e, s0);
+      take(b1, e + used, s1);
+      take(b2, e + 2 * (size_t)used, s2);
+      take(b3, e + 3 * (size_t)used, s3);
+    }
+    for (; e < total; e += used) take(w[e], e, s0);
+    atomicAdd(&part[col], (s0 + s1) + (s2 + s3));
+  }
+  __syncthreads();
+  if (threadIdx.x < D) atomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(hdr) + kHdrSums) + threadIdx.x, part[threadIdx.x]);
+  if (bad) atomicOr(hdr + 1, 1u);
+  const bool c0 = id < used && col == 0u, c1 = id < used && col == 1u;
+  publish_max(hdr + 8, c0 ? m_lo : 0u, wave_max);
+  publish_max(hdr + 9, c0 ? m_hi : 0u, wave_max);
+  publish_max(hdr + 10, c1 ? m_lo : 0u, wave_max);
+  publish_max(hdr + 11, c1 ? m_hi : 0u, wave_max);
+  fp_publish(fp, reinterpret_cast<unsigned long long*>(hdr + kHdrFp), fp_part);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[kHdrCookie] = cookie;   // whose statistics these are (DC_FLAG_STATS_VALID is checked against it)
+    if (D == 1u) {              // (a second column of zeros, as the sweeps treat it)
+      atomicMax(hdr + 10, ~fkey(0.0f));
+      atomicMax(hdr + 11, fkey(0.0f));
+    }
+  }
+}
+
+// ---- one workgroup: coarse boxes -> components -> fine grids ----------------------------------------------------
+// (components_kernel and fine_grid_kernel of dc_mfma.hip do the work; these are their launches fused)
+__device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell, uint32_t fine_bits,
+                               uint32_t* __restrict__ comp);
+
+// Ordering key and value of the rows [i_from, i_to) (compkey_kernel's arithmetic), and in the same pass:
+//   counts[c]     rows of component c among them (LDS, then one atomic per component and block; zero before)
+//   measure       the extents of ALL rows: max |x - origin(component of x)|^2 -> hdr[kHdrMloc], max |x - mean|^2 ->
+//                 hdr[0] (float accumulation with a margin, as order_rows_kernel formed the first one in rounds 3 - 4)
+//   presets       the padded order of n_pos positions: every position kInvalidFrame, every tile the all-pad component
+//                 (the sort's last pass writes the real entries over them)
+__global__ __launch_bounds__(256) void order_key_kernel(
+    const float* __restrict__ coords, uint32_t D, uint32_t* __restrict__ hdr, const uint32_t* __restrict__ comp,
+    uint32_t fine_bits, uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+    uint32_t n_total, const float* __restrict__ fe, uint32_t fe_bits, uint32_t* __restrict__ counts, int measure,
+    uint32_t* __restrict__ perm, uint32_t* __restrict__ tile_comp, uint32_t n_pos) {
+  __shared__ uint32_t cnt_s[kMaxComp];
+  __shared__ float blk_max[2][4];
+  if (threadIdx.x < (uint32_t)kMaxComp) cnt_s[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_pos) perm[j] = kInvalidFrame;
+  if (j < n_pos / 32u) tile_comp[j] = kMaxComp;
+  const uint32_t i = i_from + j;
+  float ext_loc = 0.0f, ext_glob = 0.0f;
+  if (i < i_to) {
+    const float* row = coords + (size_t)i * D;
+    const float x = row[0], y = (D > 1) ? row[1] : 0.0f;
+    const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_total);
+    uint32_t c = 0, bx = 0, by = 0, nby = 1;
+    if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
+      c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
+      const uint32_t* f = comp + kCompFine + 4 * (size_t)c;
+      const float lo0 = __uint_as_float(f[0]), lo1 = __uint_as_float(f[1]);
+      const float c0 = __uint_as_float(f[2]), c1 = __uint_as_float(f[3]);
+      nby = comp[kCompNby + c];
+      const float fx = fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f), fy = fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f);
+      bx = (uint32_t)fx;
+      by = min((uint32_t)fy, nby - 1u);
+    }
+    const uint32_t lo = comp[kCompCellOff + c], hi = comp[kCompCellOff + c + 1];
+    uint32_t key = min(lo + bx * nby + by, hi - (hi > lo ? 1u : 0u));
+    if (fe) {
+      const float fe_lo = fkey_inv(~hdr[12]), fe_hi = fkey_inv(hdr[13]);
+      const float span = fe_hi - fe_lo;
+      float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
+      u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
+      const uint32_t levels = (1u << fe_bits) - 1u;
+      const uint32_t level = (uint32_t)((double)u * (double)levels);
+      key = (key << fe_bits) | level;
+    }
+    keys[j] = key;
+    vals[j] = i;
+    atomicAdd(&cnt_s[min(c, (uint32_t)kMaxComp - 1u)], 1u);
+    if (measure) {
+      const float* a = reinterpret_cast<const float*>(comp + kCompOrigin) + (size_t)c * kMaxCols;
+      const float* mu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(hdr) + kHdrMeans);
+      for (uint32_t k0 = 0; k0 < D; k0 += 4) {   // (four columns per step, their loads issued together)
+        float xv[4], av[4], mv[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+          const uint32_t k = min(k0 + q, D - 1u);
+          xv[q] = row[k];
+          av[q] = a[k];
+          mv[q] = mu[k];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q)
+          if (k0 + q < D) {
+            const float vl = xv[q] - av[q], vg = xv[q] - mv[q];
+            ext_loc += vl * vl;
+            ext_glob += vg * vg;
+          }
+      }
+      ext_loc = ext_loc * 1.0001f + FLT_MIN;
+      ext_glob = ext_glob * 1.0001f + FLT_MIN;
+      if (!(ext_loc <= FLT_MAX)) ext_loc = 0.0f;     // (flagged data: the sweep stands down anyway)
+      if (!(ext_glob <= FLT_MAX)) ext_glob = 0.0f;
+    }
+  }
+  if (measure) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ext_loc = fmaxf(ext_loc, __shfl_xor(ext_loc, off, 64));
+      ext_glob = fmaxf(ext_glob, __shfl_xor(ext_glob, off, 64));
+    }
+    if ((threadIdx.x & 63u) == 0) {
+      blk_max[0][threadIdx.x >> 6] = ext_loc;
+      blk_max[1][threadIdx.x >> 6] = ext_glob;
+    }
+  }
+  __syncthreads();
+  if (measure && threadIdx.x < 2) {
+    const float m = fmaxf(fmaxf(blk_max[threadIdx.x][0], blk_max[threadIdx.x][1]), fmaxf(blk_max[threadIdx.x][2], blk_max[threadIdx.x][3]));
+    uint32_t* dst = threadIdx.x == 0 ? hdr + kHdrMloc : hdr;
+    const uint32_t bits = __float_as_uint(m);
+    if (bits > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, bits);
+  }
+  if (threadIdx.x < (uint32_t)kMaxComp && cnt_s[threadIdx.x] != 0u) atomicAdd(&counts[threadIdx.x], cnt_s[threadIdx.x]);
+}
+
+// One thread: from the rows per component (counts, overwritten) the first sorted index of every component (start), the
+// tile range of every component in the padded order (range; entry kMaxComp: the empty range of the all-pad tiles) and the
+// first position of every component (base) -- comp_start_kernel + comp_ranges_kernel of rounds 3 - 4.  r2max != NaN: also
+// the scale of the sweep that follows (scale_kernel): r2max < 0 the neighbour rule, else the population rule.
+__global__ void order_meta_kernel(uint32_t* __restrict__ hdr, uint32_t* __restrict__ comp, uint32_t* __restrict__ start /* [kMaxComp + 1]: counts in */,
+                                  uint32_t* __restrict__ range /* [kMaxComp + 1][2] */, uint32_t* __restrict__ base /* [kMaxComp + 1] */,
+                                  uint32_t n, uint32_t group_rows, int do_scale, float r2max, uint32_t D) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t run = 0, s = 0;
+  for (int c = 0; c < kMaxComp; ++c) {
+    const uint32_t cnt = start[c];
+    start[c] = run;
+    const uint32_t padded = ((cnt + group_rows - 1) / group_rows) * group_rows;
+    range[2 * c] = s / 32;
+    range[2 * c + 1] = (s + padded) / 32;
+    base[c] = s;
+    run += cnt;
+    s += padded;
+  }
+  start[kMaxComp] = n;   // (= run)
+  base[kMaxComp] = s;
+  range[2 * kMaxComp] = 0;
+  range[2 * kMaxComp + 1] = 0;
+  if (do_scale) {
+    float M = __uint_as_float(hdr[0]);
+    if (comp[kCompGrid + 5] > 1u) M = fminf(__uint_as_float(hdr[kHdrMloc]), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);
+    hdr[kHdrMused] = __float_as_uint(M);
+    hdr[kHdrOpen] = 0u;
+    const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
+    hdr[kHdrScale + 0] = __float_as_uint(e.c);
+    hdr[kHdrScale + 1] = __float_as_uint(e.s2);
+    hdr[kHdrScale + 2] = (uint32_t)e.g;
+    hdr[kHdrScale + 3] = (uint32_t)e.a;
+    hdr[kHdrScale + 4] = (uint32_t)e.rounded;
+  }
+}
+
+// ---- operand image of ONE tile from its rows in LDS (one wave) ------------------------------------------------------
+// rows [32][Dp] original coordinates of the tile's positions, origin [D], frames [32] (kInvalidFrame: a dead row).  form
+// 0: A form, 1: B form (pieces of -2x''), 2: the A form with the pieces of the row's own |x''|^2 / 2^a in the constant
+// slots (nn_pruned_kernel's folded reference operand).  Same values as image_kernel, organised the other way round: a
+// lane takes a (row, column) and forms the column's three pieces ONCE (image_kernel's lanes each formed the eight slots
+// of their fragment, i.e. every column three times over: 250 instructions per fragment, 50 us per image at C3, ALU-bound),
+// parks them as fp16 in an LDS copy of the tile's K rows, and the fragments are copied out 16 bytes per lane.
+// lds_img: [32][img_stride] halves, img_stride = 16 NM + 2 (rows on different banks).
+__device__ __forceinline__ uint32_t img_stride_halves(uint32_t NM) { return 16u * NM + 2u; }
+__device__ __forceinline__ void build_tile_image(const float* __restrict__ rows, uint32_t Dp, const float* __restrict__ origin,
+                                                 const uint32_t* __restrict__ frames, uint32_t D, uint32_t NM, const Scale& sc,
+                                                 int form, unsigned short* __restrict__ lds_img, uint4* __restrict__ img_out,
+                                                 float* __restrict__ norms_out, int lane) {
+  const uint32_t stride = img_stride_halves(NM);
+  const bool b_form = form == 1, fold = form == 2;
+  const float s1 = b_form ? sc.sb : sc.sa;
+  // zero the tile's K rows (padding slots, dead rows)
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(lds_img);
+    for (uint32_t e = (uint32_t)lane; e < 32u * stride / 2u; e += 64u) z[e] = 0u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t r = (uint32_t)lane & 31u;
+  const bool live = frames[r] != kInvalidFrame;
+  double nrm = 0.0;
+  for (uint32_t k = (uint32_t)lane >> 5; k < D; k += 2u) {   // lane: row r, columns of its parity
+    const float v = live ? (rows[r * Dp + k] - origin[k]) * s1 : 0.0f;   // x'' = c fl(x - mu)
+    nrm += (double)v * (double)v;
+    if (live) {
+      const Pieces pc = split2(b_form ? -2.0f * v : v, sc.up, sc.dn);
+      unsigned short* dst = lds_img + r * stride + (uint32_t)kConstSlots + k;
+      dst[0] = (unsigned short)pc.hi;                                     // hi x hi
+      dst[D] = (unsigned short)(b_form ? pc.hi_dn : pc.mid);              // A: mid 2^g   B: hi 2^-g
+      dst[2u * D] = (unsigned short)(b_form ? pc.mid : pc.hi_dn);         // A: hi 2^-g   B: mid 2^g
+    }
+  }
+  {  // the two column parities of a row meet (double, in a fixed order: deterministic)
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)__double_as_longlong(nrm), 32, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((unsigned long long)__double_as_longlong(nrm) >> 32), 32, 64);
+    const double other = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    nrm = (lane < 32) ? nrm + other : other + nrm;
+  }
+  if (lane < 32) {
+    unsigned short* dst = lds_img + r * stride;
+    if (fold) {
+      if (live) {
+        const Pieces pn = split2((float)nrm * sc.cinv);   // (as load_query splits c_q)
+        dst[0] = (unsigned short)pn.hi;
+        dst[1] = (unsigned short)pn.mid;
+      } else {
+        dst[0] = 0x7BFFu;   // pad row: 65504 * 2^a, far above every threshold
+      }
+    } else if (live && !b_form) {
+      dst[0] = (unsigned short)const_a_bits(sc.a);
+      dst[1] = (unsigned short)const_a_bits(sc.a);
+    }
+    if (norms_out) norms_out[r] = live ? (float)nrm : INFINITY;   // pad rows can never be "inside"
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // fragment of lane l of MFMA m: slots 16 m + 8 (l >> 5) .. + 7 of row l & 31
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(lds_img + r * stride) + 4u * ((uint32_t)lane >> 5);
+  for (uint32_t m = 0; m < NM; ++m) {
+    const uint32_t* f = src + 8u * m;
+    img_out[m * 64u + (uint32_t)lane] = make_uint4(f[0], f[1], f[2], f[3]);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// dynamic LDS of order_rows_kernel: the rows of 256 positions + per wave the K rows of one tile + its origin
+static inline size_t order_rows_smem(uint32_t n_cols) {
+  const uint32_t NM = (uint32_t)nm_for((int)n_cols);
+  return sizeof(float) * 256 * (n_cols | 1u) + 4 * (sizeof(unsigned short) * 32 * (16 * NM + 2) + sizeof(float) * n_cols);
+}
+
+// The rows of an order in one pass, 256 positions = 8 tiles per block: gathered from the coordinates (element-wise:
+// 40-byte runs of the source, coalesced stores to coords_o when asked for) and parked in LDS, from where every row's
+// lane takes what the tile boxes and the free-energy ranges need (fe != nullptr: the neighbour sweep's order -- fe_s,
+// invpos, ferange, and the hash of the order for the layout header of the all-gather blocks), and every wave builds the
+// operand images of two of the block's tiles:
+//   img_a != nullptr   A form of every tile (a_form 0 / 2) + the rows' norms
+//   img_b != nullptr   B form of the tiles whose query group (grp_tq tiles) this launch's segment owns (+ norms_b)
+// origin of a tile: origins[tile_comp[t]] (the all-pad tiles: the means).  The scale is in the header (order_meta_kernel).
+__global__ __launch_bounds__(256) void order_rows2_kernel(
+    const float* __restrict__ coords, uint32_t D, uint32_t NM, const uint32_t* __restrict__ perm, uint32_t T,
+    float* __restrict__ coords_o, float4* __restrict__ boxes, const float* __restrict__ fe, float* __restrict__ fe_s,
+    uint32_t* __restrict__ invpos, float2* __restrict__ ferange, const uint32_t* __restrict__ tile_comp,
+    const float* __restrict__ origins, uint32_t* __restrict__ hdr, uint4* __restrict__ img_a, int a_form,
+    float* __restrict__ norms_a, uint4* __restrict__ img_b, float* __restrict__ norms_b, uint32_t grp_tq, QSeg grp) {
+  extern __shared__ float or_tile[];            // [256][D | 1], then per wave: K rows of a tile, origin
+  __shared__ uint32_t s_frame[256];
+  __shared__ unsigned long long fp_part[4];
+  const uint32_t Dp = D | 1u;
+  const uint32_t pos0 = blockIdx.x * 256u, pos = pos0 + threadIdx.x, n_pos = 32u * T;
+  const uint32_t frame = (pos < n_pos) ? perm[pos] : kInvalidFrame;
+  s_frame[threadIdx.x] = frame;
+  __syncthreads();
+  const size_t base = (size_t)pos0 * D, total = (size_t)n_pos * D;
+  // (four elements per thread and step, their loads issued together)
+  for (uint32_t e0 = threadIdx.x; e0 < 256u * D; e0 += 1024u) {
+    float v[4];
+    uint32_t off[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t e = e0 + 256u * j;
+      const uint32_t r = min(e / D, 255u), k = e - (e / D) * D;
+      const uint32_t i = s_frame[r];
+      off[j] = r * Dp + k;
+      v[j] = (e < 256u * D && i != kInvalidFrame) ? coords[(size_t)i * D + k] : 0.0f;   // (pad positions of a padded order)
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t e = e0 + 256u * j;
+      if (e < 256u * D) {
+        or_tile[off[j]] = v[j];
+        if (coords_o && base + e < total) coords_o[base + e] = v[j];
+      }
+    }
+  }
+  __syncthreads();
+  const bool in_range = pos < n_pos, live = frame != kInvalidFrame;
+  const uint32_t t = min(pos >> 5, T - 1);
+  const float* row = or_tile + threadIdx.x * Dp;
+  const float x = live ? row[0] : 0.0f, y = (live && D > 1) ? row[1] : 0.0f;
+  float lo0 = live ? x : INFINITY, hi0 = live ? x : -INFINITY;
+  float lo1 = live ? y : INFINITY, hi1 = live ? y : -INFINITY;
+  float flo = INFINITY, fhi = -INFINITY;
+  if (fe) {
+    const float f = live ? fe[frame] : INFINITY;
+    if (in_range) fe_s[pos] = f;
+    if (live) {
+      invpos[frame] = pos;
+      flo = f;
+      fhi = f;
+    }
+    // hash of the order (header words kHdrFp + 4..5, zero before): what the layout header of a neighbour block carries
+    fp_publish(in_range ? fp_term(frame, pos) : 0ull, reinterpret_cast<unsigned long long*>(hdr + kHdrFp + 4), fp_part);
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    lo0 = fminf(lo0, __shfl_xor(lo0, off, 64));
+    hi0 = fmaxf(hi0, __shfl_xor(hi0, off, 64));
+    lo1 = fminf(lo1, __shfl_xor(lo1, off, 64));
+    hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
+    flo = fminf(flo, __shfl_xor(flo, off, 64));
+    fhi = fmaxf(fhi, __shfl_xor(fhi, off, 64));
+  }
+  if ((pos & 31u) == 0 && in_range) {
+    boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
+    if (ferange) ferange[t] = make_float2(flo, fhi);
+  }
+  // ---- operand images: wave w builds tiles 2 w and 2 w + 1 of the block
+  const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+  unsigned short* lds_img = reinterpret_cast<unsigned short*>(or_tile + 256u * Dp) + (size_t)wv * (32u * img_stride_halves(NM) + 2u * D);
+  float* org = reinterpret_cast<float*>(lds_img + 32u * img_stride_halves(NM));
+  const Scale sc = load_scale(hdr);
+  const float* means = reinterpret_cast<const float*>(reinterpret_cast<const char*>(hdr) + kHdrMeans);
+  for (uint32_t tt = 0; tt < 2u; ++tt) {
+    const uint32_t lt = 2u * (uint32_t)wv + tt, tile = blockIdx.x * 8u + lt;
+    if (tile >= T) break;   // (wave-uniform)
+    const uint32_t tc = tile_comp[tile];
+    const float* o = (tc < (uint32_t)kMaxComp) ? origins + (size_t)tc * kMaxCols : means;
+    for (uint32_t k = (uint32_t)lane; k < D; k += 64u) org[k] = o[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* trows = or_tile + (size_t)lt * 32u * Dp;
+    const uint32_t* tframes = s_frame + lt * 32u;
+    if (img_a)
+      build_tile_image(trows, Dp, org, tframes, D, NM, sc, a_form, lds_img, img_a + (size_t)tile * NM * 64u,
+                       norms_a ? norms_a + (size_t)tile * 32u : nullptr, lane);
+    if (img_b && seg_owns(tile / grp_tq, grp))
+      build_tile_image(trows, Dp, org, tframes, D, NM, sc, 1, lds_img, img_b + (size_t)tile * NM * 64u,
+                       norms_b ? norms_b + (size_t)tile * 32u : nullptr, lane);
+  }
+}

@@ -341,6 +341,20 @@ def test_mfma_accumulate_model_and_gram_band():
     assert "OK" in r.stdout
 
 
+@pytest.mark.gpu
+def test_library_radix_sort_is_a_stable_sort():
+    """The frame orders of the pruned sweeps come from the library's own radix sort (dc_sort.hip, round 5); the ranks of a
+    sharded run must derive the SAME order, so it has to be a stable sort -- checked against std::stable_sort by a small
+    HIP program built from the library's source (tests/cpp/test_sort.hip): sizes around the tile and wave boundaries,
+    1 .. 32 key bits, heavy ties, all-equal keys."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "clustering_amd", "bin", "test_sort")
+    assert os.path.exists(exe), "build the library first (make -C clustering_amd/csrc)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "cases OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _brute_pairs(c, r2):
     """All unordered pairs with canonical d2 < r2 (numpy emulation of the canonical order)."""
     from refmath import d2_matrix
