@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdcdensity.so")
+# DC_LIB_PATH: another build of the SAME library (measurement variants under clustering_amd/lib/variants/) instead of
+# copying it over the product
+LIB_PATH = os.environ.get("DC_LIB_PATH") or os.path.join(_HERE, "lib", "libdcdensity.so")
 
 DC_OK = 0
 ABI_VERSION = 3               # include/dc_density.h: DC_HIP_ABI_VERSION this binding was written against

@@ -429,7 +429,7 @@ int nearest_neighbors_impl(const float* d_coords, size_t n_rows, size_t n_cols, 
     // (the pruned sweep packs reference POSITIONS of the padded order into 30 bits: kQueuePosMask)
     const bool full_sweep = variant == DC_VARIANT_MFMA || variant == DC_VARIANT_MFMA32 || n_rows + dc::kOrderPadRows > ((size_t)1 << 30);
     if (int rc = dc::mfma_prepare(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_workspace,
-                                  full_sweep, s, stats_valid, !full_sweep))
+                                  full_sweep, s, stats_valid, !full_sweep, (stats_valid && !full_sweep) ? d_fe : nullptr))
       return fail(DC_ERR_HIP, "mfma_prepare failed (%d)", rc);
     if (variant == DC_VARIANT_MFMA32)
       dc::launch_nn_mfma32(d_coords, (uint32_t)n_rows, (uint32_t)n_cols, d_fe, (uint32_t)i_from, (uint32_t)i_to, d_nn_idx,

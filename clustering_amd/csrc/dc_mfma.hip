@@ -488,6 +488,7 @@ __device__ __forceinline__ uint32_t coarse_cell_of_point(const CoarseGrid& g, fl
 // cells were listed).  Writes the component of every cell, the components' origins and fine cell grids.
 __device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell, uint32_t fine_bits,
                                uint32_t* __restrict__ comp);
+__device__ void stats_reduce(uint32_t* __restrict__ hdr, const double* __restrict__ table, uint32_t n_rows, uint32_t D);
 
 // Round 5: ONE launch for what were four -- the boxes of the coarse cells (coarse_box_kernel) are formed here, straight
 // from the occupancy bitmap into the labelling's tables; the column means (mean_kernel: means_out != nullptr) in front; the
@@ -497,21 +498,22 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
                                                           float r_max, uint32_t n_rows, float frames_per_cell,
                                                           uint32_t fine_bits, uint32_t* __restrict__ comp,
                                                           int force_single, float r_true, uint32_t cookie,
-                                                          float* __restrict__ means_out = nullptr,
+                                                          const double* __restrict__ stats_table = nullptr,
                                                           float fine_frames_per_cell = 0.0f) {
   // r_max: the connectivity length rho (what the coarse grid was built for); r_true: the largest radius itself;
   // cookie: whose partition this is (comp_guard_kernel)
   (void)frames_per_cell;
   const float r_conn_param = r_max;
-  if (means_out) {   // column means as the float the centring subtracts (mean_kernel)
-    if (threadIdx.x < D) {
-      const double* sums = reinterpret_cast<const double*>(reinterpret_cast<const char*>(hdr) + kHdrSums);
-      float muf = (float)(sums[threadIdx.x] / (double)n_rows);
-      if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
-      means_out[threadIdx.x] = muf;
-    }
-    __syncthreads();
-  }
+#ifdef DC_COMP_STAMPS
+#define DC_STAMP(k) do { if (threadIdx.x == 0) comp[8 + (k)] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define DC_STAMP(k) do {} while (0)
+#endif
+  DC_STAMP(0);
+  // the statistics pass of this call left its column sums and fingerprint shares in a table: sums, fingerprint and the
+  // column means (mean_kernel) into the header first (`means` points there)
+  if (stats_table) stats_reduce(const_cast<uint32_t*>(hdr), stats_table, n_rows, D);
+  DC_STAMP(1);
   __shared__ uint32_t occ[kMaxOccupied], label[kMaxOccupied];
   __shared__ float4 obox[kMaxOccupied];
   __shared__ uint32_t n_occ_s, changed_s, n_comp_s, n_sub_s;
@@ -573,6 +575,7 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
     cell_idx[c] = (uint16_t)min(idx, 0xFFFFu);
   }
   __syncthreads();
+  DC_STAMP(2);
   const uint32_t n_occ = n_occ_s;
   bool single = force_single != 0 || n_occ > (uint32_t)kMaxOccupied || n_occ <= 1u || !(r_max <= FLT_MAX);
   const float r2c = r_max * r_max * 1.0002f;
@@ -629,7 +632,11 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
       if (ch == 0 || iter >= 128) break;
     }
     if (iter >= 128) single = true;   // (not settled: one component is always right)
+#ifdef DC_COMP_STAMPS
+    if (threadIdx.x == 0) comp[8 + 15] = (uint32_t)iter;
+#endif
   }
+  DC_STAMP(3);
   if (!single) {
     // roots = cells that are their own label; component id = rank of the root's cell index
     for (uint32_t i = tid; i < n_occ; i += nt)
@@ -670,6 +677,7 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
     for (uint32_t i = tid; i < n_occ; i += nt) cell_comp[occ[i]] = label[i];
   }
   __syncthreads();
+  DC_STAMP(4);
   // origins, boxes, adjacency
   const float gmin0 = fkey_inv(~hdr[8]), gmax0 = fkey_inv(hdr[9]), gmin1 = fkey_inv(~hdr[10]), gmax1 = fkey_inv(hdr[11]);
   if (tid < n_comp) {
@@ -706,10 +714,12 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
     comp[kCompGrid + 6] = cookie;
     comp[kCompGrid + 7] = __float_as_uint(r_conn_param);
   }
+  DC_STAMP(5);
   if (fine_frames_per_cell > 0.0f) {   // the fine cell grids of the components for the sweep that follows
     __syncthreads();                   // (boxes, counts: this workgroup's own writes)
     if (tid == 0) fine_grid_body(hdr, n_rows, fine_frames_per_cell, fine_bits, comp);
   }
+  DC_STAMP(6);
 }
 
 // row tiles of 256 x (D | 1) floats: 66 560 bytes at D = 64, above the 64 KB a launch gets without asking
@@ -735,12 +745,12 @@ static size_t components_smem() {
 // other data: then one component, the column means as its origin.
 // Round 5: the fine cell grids of the sweep that follows are formed in the same launch (fine_frames_per_cell > 0), and the
 // rows-per-component counters of both orders start from zero (order_key_kernel adds to them).
-__global__ __launch_bounds__(1024) void comp_guard_kernel(const uint32_t* __restrict__ hdr, const float* __restrict__ means,
-                                                         uint32_t D, uint32_t* __restrict__ comp, uint32_t cookie,
-                                                         uint32_t n_rows = 0, float fine_frames_per_cell = 0.0f,
-                                                         uint32_t fine_bits = 0) {
+__device__ void comp_guard_body(const uint32_t* __restrict__ hdr, const float* __restrict__ means, uint32_t D,
+                                uint32_t* __restrict__ comp, uint32_t cookie, uint32_t n_rows, float fine_frames_per_cell,
+                                uint32_t fine_bits) {
   if (threadIdx.x < 2u * ((uint32_t)kMaxComp + 1u)) comp[kCompStart + threadIdx.x] = 0u;
-  const bool keep = comp[kCompGrid + 6] == cookie;
+  if (threadIdx.x < 128u) comp[kCompHash + threadIdx.x] = 0u;   // (shares of the order's hash: order_rows2_kernel adds to them)
+  const bool keep = comp[kCompGrid + 6] == cookie && hdr[kHdrCookie] == cookie;   // (a failed claim: nothing of the workspace is this array's)
   if (!keep)
     for (uint32_t c = threadIdx.x; c < (uint32_t)kCoarseCells; c += blockDim.x) comp[kCompCellComp + c] = 0u;
   if (!keep && threadIdx.x == 0) {
@@ -758,6 +768,12 @@ __global__ __launch_bounds__(1024) void comp_guard_kernel(const uint32_t* __rest
     __syncthreads();
     if (threadIdx.x == 0) fine_grid_body(hdr, n_rows, fine_frames_per_cell, fine_bits, comp);
   }
+}
+__global__ __launch_bounds__(1024) void comp_guard_kernel(const uint32_t* __restrict__ hdr, const float* __restrict__ means,
+                                                         uint32_t D, uint32_t* __restrict__ comp, uint32_t cookie,
+                                                         uint32_t n_rows = 0, float fine_frames_per_cell = 0.0f,
+                                                         uint32_t fine_bits = 0) {
+  comp_guard_body(hdr, means, D, comp, cookie, n_rows, fine_frames_per_cell, fine_bits);
 }
 
 // the fine cell grids of the components for one sweep (frames_per_cell is the sweep's own): one cell size for all
@@ -1144,6 +1160,13 @@ __global__ __launch_bounds__(256) void order_rows_kernel(
 
 }  // namespace
 
+// dynamic LDS of the measuring order_key_kernel (dc_prep.hpp)
+static size_t order_key_smem_set(uint32_t n_cols) {
+  const size_t bytes = order_key_smem(n_cols, true);
+  if (bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(order_key_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
 // dynamic LDS of order_rows2_kernel (dc_prep.hpp); beyond 64 KB (wide rows) the launch has to ask for it
 static size_t order_rows_smem_set(uint32_t n_cols) {
   const size_t bytes = order_rows_smem(n_cols);
@@ -1258,8 +1281,16 @@ __global__ void sweep_words_reset_kernel(uint32_t* __restrict__ hdr, int pruned)
   if (k == kHdrMloc) hdr[k] = 0u;
 }
 
+// DC_POP_CELL_FRAMES / DC_NN_CELL_FRAMES: measurement overrides of the frames per cell of the orderings
+static float cell_frames(bool nn) {
+  static const float v[2] = {[] { const char* e = getenv("DC_POP_CELL_FRAMES"); return (e && e[0]) ? (float)atof(e) : kPopCellFrames; }(),
+                             [] { const char* e = getenv("DC_NN_CELL_FRAMES"); return (e && e[0]) ? (float)atof(e) : kNnCellFrames; }()};
+  return v[nn ? 1 : 0];
+}
+static float nn_cell_frames() { return cell_frames(true); }
+
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
-                 bool natural_image, hipStream_t stream, bool stats_valid, bool pruned) {
+                 bool natural_image, hipStream_t stream, bool stats_valid, bool pruned, const float* d_fe) {
   // pruned: a pruned sweep follows -- the statistics come from ONE pass (stats_kernel, dc_prep.hpp); the column means and
   // the extents max |x - mean|^2 / max |x - origin|^2 follow in the passes of its preparation that read the rows anyway
   // (components_kernel, order_key_kernel).  The full sweeps and the fp32-MFMA instance need means and max norm before
@@ -1268,20 +1299,30 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
   const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
   if (stats_valid) {
     // DC_FLAG_STATS_VALID: means, max norm, flag and bounding box of an earlier sweep over the same coordinates
-    // stay; only the per-sweep words start over (evaluated-tile counters: words 2..5; free-energy range: 12..13)
-    // (one launch instead of three memsets: a fill is a 4.6 us kernel of its own)
-    hipLaunchKernelGGL(sweep_words_reset_kernel, dim3(1), dim3(64), 0, stream, (uint32_t*)p, pruned ? 1 : 0);
+    // stay; the claim is checked on the device (content fingerprint, cookie) and the per-sweep words start over -- two
+    // launches (dc_prep.hpp: claim_pre_kernel / claim_guard_kernel; five in rounds 3 - 4).  d_fe (a pruned neighbour call):
+    // the range of the free energies and the component guard + fine grids of that sweep ride along.
+    const Layout L = make_layout(n_rows, n_cols);
     const size_t total = (size_t)n_rows * n_cols;
-    hipLaunchKernelGGL(fingerprint_kernel, dim3((uint32_t)std::min<size_t>(1024, (total + 1023) / 1024)), dim3(256), 0, stream,
-                       d_coords, total, (unsigned long long*)(p + 4 * (kHdrFp + 2)));
-    hipLaunchKernelGGL(stats_guard_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)p, cookie);
+    const uint32_t B = (uint32_t)std::max<size_t>(1, std::min<size_t>(kClaimBlocks, (total + 1023) / 1024));
+    unsigned long long* tab = (unsigned long long*)(p + L.fixed_end);   // (the sort's temp region: free until the sort)
+    const bool nn_reuse = pruned && d_fe != nullptr;
+    hipLaunchKernelGGL(claim_pre_kernel, dim3(B), dim3(256), 0, stream, d_coords, total, d_fe, n_rows, tab);
+    hipLaunchKernelGGL(claim_guard_kernel, dim3(1), dim3(1024), 0, stream, (uint32_t*)p, cookie, (const unsigned long long*)tab, B,
+                       pruned ? 1 : 0, d_fe != nullptr ? 1 : 0, n_cols, nn_reuse ? (uint32_t*)(p + L.off_comp) : (uint32_t*)nullptr,
+                       n_rows, nn_reuse ? nn_cell_frames() : 0.0f, cell_key_bits(n_rows, kNnCellFrames) + 1u);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (pruned) {
+    const Layout L = make_layout(n_rows, n_cols);
     // header and component region in ONE fill (the layout puts them side by side), then one pass over the coordinates
-    if (hipMemsetAsync(p, 0, kHdrBytes + sizeof(uint32_t) * kCompWords, stream) != hipSuccess) return -1;
-    hipLaunchKernelGGL(stats_kernel, dim3((uint32_t)std::min<size_t>(512, ((size_t)n_rows * n_cols + 255) / 256)), dim3(256), 0,
-                       stream, d_coords, n_rows, n_cols, (uint32_t*)p, cookie);
+    if (hipMemsetAsync(p, 0, L.off_img, stream) != hipSuccess) return -1;   // (a whole number of 256-byte lines: one fill kernel)
+    // (its per-block table: the sort's temp region, free until the sort; components_kernel adds it up)
+    const size_t room = sort_temp_bytes(n_rows + kOrderPadRows) / (sizeof(double) * kStatsRow);
+    const size_t want = ((size_t)n_rows * n_cols + 1023) / 1024;
+    const uint32_t blocks_s = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(kStatsMaxBlocks, want), room));
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks_s), dim3(256), 0, stream, d_coords, n_rows, n_cols, (uint32_t*)p, cookie,
+                       (double*)(p + L.fixed_end));
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (hipMemsetAsync(p, 0, kHdrBytes, stream) != hipSuccess) return -1;
@@ -1493,13 +1534,6 @@ static void pad_order(const uint32_t* keys_sorted, const uint32_t* vals_sorted, 
                      (const uint32_t*)start, (const uint32_t*)range, perm, tile_comp);
 }
 
-// DC_POP_CELL_FRAMES / DC_NN_CELL_FRAMES: measurement overrides of the frames per cell of the orderings
-static float cell_frames(bool nn) {
-  static const float v[2] = {[] { const char* e = getenv("DC_POP_CELL_FRAMES"); return (e && e[0]) ? (float)atof(e) : kPopCellFrames; }(),
-                             [] { const char* e = getenv("DC_NN_CELL_FRAMES"); return (e && e[0]) ? (float)atof(e) : kNnCellFrames; }()};
-  return v[nn ? 1 : 0];
-}
-
 uint32_t seg_block(uint32_t n_segments) { return n_segments <= 1u ? 1u : kSegBlockGroups; }
 
 // DC_POP_COMPONENTS=0: one component whatever the data looks like (measurements, tests)
@@ -1576,9 +1610,9 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                        comp);
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), components_smem(), stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
-                       components_off() ? 1 : 0, r_max, cookie, (float*)(p + kHdrMeans), cell_frames(false));
+                       components_off() ? 1 : 0, r_max, cookie, (const double*)(p + L.fixed_end), cell_frames(false));
     // order all frames by (component, fine cell): keys, rows per component, the extents, the pad presets ...
-    hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_rows, 32u * T_r) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+    hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_rows, 32u * T_r) + 255) / 256, 1024u)), blk, order_key_smem_set(n_cols), stream, d_coords, n_cols, hdr,
                        (const uint32_t*)comp, (uint32_t)fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
                        start_r, 1, perm_p, tile_comp, 32u * T_r);
     // ... where the components start, the scale of the sweep (it follows the components' extents) ...
@@ -1599,7 +1633,8 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                          L.NM, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p), (float4*)(p + L.off_box_p),
                          (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp,
                          origins, hdr, (uint4*)(p + L.off_img_p), 0, (float*)(p + L.off_norm_p),
-                         ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg);
+                         ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg,
+                         (unsigned long long*)(comp + kCompHash));
     }
     // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
     // buffers are free again)
@@ -1611,7 +1646,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     }
     if (q_mode == kQueryOwnOrder) {
       // query rows of this call: the same ordering restricted to [i_from, i_to)
-      hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_q, 32u * T_q) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+      hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_q, 32u * T_q) + 255) / 256, 1024u)), blk, 0, stream, d_coords, n_cols, hdr,
                          (const uint32_t*)comp, (uint32_t)fine_bits, i_from, i_to, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
                          start_q, 0, perm_q, tile_comp_q, 32u * T_q);
       hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_q, range_q, base_q, n_q, group_rows, 0,
@@ -1623,7 +1658,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                          L.NM, (const uint32_t*)perm_q, T_q, (float*)nullptr, (float4*)(p + L.off_box_q),
                          (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp_q,
                          origins, hdr, (uint4*)nullptr, 0, (float*)nullptr, (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), 1u,
-                         QSeg{1u, 0u, 1u});
+                         QSeg{1u, 0u, 1u}, (unsigned long long*)nullptr);
     }
   }
   (void)kCellFramesHere;
@@ -1938,27 +1973,26 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
     if (forced >= 0) fe_bits = std::min((unsigned)forced, fe_bits);
   }
   const float r_conn = -8.0f;   // components: connected over 8 cells of the ordering (no radius in this sweep)
-  // the pass over the free energies finds their range (and raises the flag for NaNs)
-  hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 256u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
-                     (uint32_t*)nullptr, hdr);
   const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
   uint32_t* start_r = comp + kCompStart, *start_q = comp + kCompStart + (kMaxComp + 1);
   uint32_t* range_r = comp + kCompRange, *range_q = comp + kCompRange + kCompRangeStride;
   uint32_t* base_r = comp + kCompBase, *base_q = comp + kCompBase + (kMaxComp + 1);
   if (reuse_components) {
     // the partition an earlier sweep over these coordinates left in the workspace (DC_FLAG_STATS_VALID: the
-    // populations -> neighbours pair) -- checked on the device; the fine grids of THIS sweep in the same launch
-    hipLaunchKernelGGL(comp_guard_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)hdr, (const float*)(p + kHdrMeans),
-                       n_cols, comp, cookie, n_rows, cell_frames(true), (uint32_t)fine_bits);
+    // populations -> neighbours pair): checked on the device, with the range of the free energies and the fine grids of THIS
+    // sweep, by the claim's guard (mfma_prepare: claim_guard_kernel)
   } else {
+    // the pass over the free energies finds their range (and raises the flag for NaNs)
+    hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 256u)), blk, 0, stream, d_fe, n_rows, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, hdr);
     if (!comp_clean) (void)hipMemsetAsync(comp, 0, sizeof(uint32_t) * kCompWords, stream);
     hipLaunchKernelGGL(fine_mark_kernel, grid_n, blk, 0, stream, d_coords, n_rows, n_cols, (const uint32_t*)hdr, r_conn, comp);
     hipLaunchKernelGGL(components_kernel, dim3(1), dim3(1024), components_smem(), stream, (const uint32_t*)hdr,
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kNnCellFrames, fine_bits, comp,
-                       components_off() ? 1 : 0, 0.0f, cookie, (float*)(p + kHdrMeans), cell_frames(true));
+                       components_off() ? 1 : 0, 0.0f, cookie, (const double*)(p + L.fixed_end), cell_frames(true));
   }
   // frames by (component, cell, free energy): ONE sort on a combined key, its last pass writes the padded order
-  hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_rows, 32u * T_r) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+  hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_rows, 32u * T_r) + 255) / 256, 1024u)), blk, order_key_smem_set(n_cols), stream, d_coords, n_cols, hdr,
                      (const uint32_t*)comp, (uint32_t)fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, (uint32_t)fe_bits, start_r, 1,
                      perm_p, tile_comp, 32u * T_r);
   hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_r, range_r, base_r, n_rows, group_rows, 1,
@@ -1977,11 +2011,12 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        L.NM, (const uint32_t*)perm_p, T_r, (float*)(p + L.off_coords_p), (float4*)(p + L.off_box_p), d_fe,
                        (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos), (float2*)(p + L.off_ferange_p),
                        (const uint32_t*)tile_comp, origins, hdr, (uint4*)(p + L.off_img_p), 2, (float*)(p + L.off_norm_p),
-                       ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg);
+                       ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg,
+                         (unsigned long long*)(comp + kCompHash));
   }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(order_key_kernel, dim3((std::max(n_q, 32u * T_q) + 255) / 256), blk, 0, stream, d_coords, n_cols, hdr,
+    hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_q, 32u * T_q) + 255) / 256, 1024u)), blk, 0, stream, d_coords, n_cols, hdr,
                        (const uint32_t*)comp, (uint32_t)fine_bits, i_from, i_to, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
                        start_q, 0, perm_q, tile_comp_q, 32u * T_q);
     hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_q, range_q, base_q, n_q, group_rows, 0,
@@ -1993,7 +2028,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        L.NM, (const uint32_t*)perm_q, T_q, (float*)nullptr, (float4*)(p + L.off_box_q), (const float*)nullptr,
                        (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp_q, origins, hdr,
                        (uint4*)nullptr, 0, (float*)nullptr, (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), 1u,
-                       QSeg{1u, 0u, 1u});
+                       QSeg{1u, 0u, 1u}, (unsigned long long*)nullptr);
   }
   const bool own = q_mode == kQueryOwnOrder;
   const uint32_t n_pos_q = 32u * (own ? T_q : T_r);
@@ -2056,7 +2091,8 @@ __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const 
                                      uint32_t n_rows, uint32_t n_pos /* positions of the padded order */,
                                      uint32_t gsize /* 32 tq, 0: row blocks only */, uint32_t seg,
                                      uint32_t G, uint32_t seg_blk, uint32_t block_rows, const uint32_t* __restrict__ perm,
-                                     const uint32_t* __restrict__ hdr, uint32_t* __restrict__ block) {
+                                     const uint32_t* __restrict__ hdr, uint32_t* __restrict__ block,
+                                     const unsigned long long* __restrict__ order_hash) {
   const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= block_rows) return;
   const bool by_position = gsize != 0u && hdr[1] == 0u;
@@ -2069,7 +2105,11 @@ __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const 
     if (k == 2) w = by_position ? gsize : 0u;
     if (k == 3) w = G;
     if (k == 4) w = by_position ? seg_blk : 0u;
-    if (k == 5 || k == 6) w = by_position ? hdr[kHdrFp + 4 + (k - 5)] : 0u;   // (perm_hash_kernel)
+    if ((k == 5 || k == 6) && by_position) {   // hash of the order: the 64 shares order_rows2_kernel left (wrap-around sum)
+      unsigned long long hsum = 0;
+      for (int q = 0; q < 64; ++q) hsum += order_hash[q];
+      w = (k == 5) ? (uint32_t)hsum : (uint32_t)(hsum >> 32);
+    }
     block[l] = w;
     for (uint32_t c = 1; c < 4; ++c) block[c * (size_t)block_rows + l] = block_none(c, n_rows);
     return;
@@ -2143,7 +2183,8 @@ void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const 
   //  order_rows2_kernel of the neighbour call that ran in this workspace)
   hipLaunchKernelGGL(nn_block_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2, d_hd_idx,
                      d_hd_d2, n_rows, 32u * nn_order_tiles(n_rows, n_cols), pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, seg_block(n_segments), rows,
-                     pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block);
+                     pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block,
+                     (const unsigned long long*)(p + L.off_comp + sizeof(uint32_t) * kCompHash));
 }
 void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t n_cols, uint32_t n_segments,
                             bool pruned, const void* d_ws, uint32_t* d_nn_idx, float* d_nn_d2, uint32_t* d_hd_idx,

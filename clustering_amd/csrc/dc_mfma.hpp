@@ -31,7 +31,9 @@ size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols);
 // header unless stats_valid, in which case the statistics of an earlier sweep stay and the sweep clears the region itself)
 int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,
                  bool natural_image,
-                 hipStream_t stream, bool stats_valid = false, bool pruned = false);
+                 hipStream_t stream, bool stats_valid = false, bool pruned = false, const float* d_fe = nullptr);
+// (d_fe: the free energies of a pruned NEIGHBOUR call that claims DC_FLAG_STATS_VALID -- their range and the component
+//  guard of that sweep are part of the claim's two launches; launch_nn_pruned[_segment](reuse_components) relies on it)
 void launch_pop_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from,
                      uint32_t i_to, const Rad2& rad2, int n_rad, uint32_t* d_pops_first_row,
                      void* d_ws, hipStream_t stream);

@@ -141,7 +141,8 @@ constexpr size_t kCompBox = kCompAdj + 2 * (size_t)kMaxComp;           // [kMaxC
 constexpr size_t kCompBitmap = kCompBox + 4 * (size_t)kMaxComp;        // occupancy of the sub-cells, one byte each
 constexpr size_t kCompBitmapWords = (size_t)kCoarseCells * kFineSub * kFineSub / 4;
 constexpr size_t kCompBase = kCompBitmap + kCompBitmapWords;           // [2][kMaxComp + 1]: first POSITION of a component in the padded order (reference / query order)
-constexpr size_t kCompWords = kCompBase + 2 * ((size_t)kMaxComp + 1);
+constexpr size_t kCompHash = ((kCompBase + 2 * ((size_t)kMaxComp + 1)) + 1) & ~(size_t)1;   // [64] x 64 bits: shares of the hash of the neighbour sweep's order
+constexpr size_t kCompWords = kCompHash + 2 * 64;
 
 // Workspace layout.  Regions used by the population sweep: hdr, img, norms.  The neighbour sweep
 // adds a second operand image with the reference frames ORDERED BY FREE ENERGY (img_s, norms_s),
@@ -336,6 +337,7 @@ constexpr uint32_t kHdrOpen = 30;       // neighbour sweeps: queries listed for 
 // coarse MFMAs, so chains x NM would overstate it.  Addressed relative to the chain counters the kernels already get
 // (words 2..3 / 4..5): + kMfmaCtrPop / + kMfmaCtrNn 64-bit words.
 constexpr uint32_t kHdrMfmaPop = 6, kHdrMfmaNn = 26;
+constexpr uint32_t kHdrStatsBlocks = 25;   // rows of stats_kernel's table that components_kernel has still to add up (dc_prep.hpp)
 constexpr int kMfmaCtrPop = (kHdrMfmaPop - 2) / 2, kMfmaCtrNn = (kHdrMfmaNn - 4) / 2;
 constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: max |x - origin(component of x)|^2 (float bits, with a rounding margin)
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;

@@ -26,9 +26,16 @@ constexpr float kStatsLimit = 5.0e16f;   // |x_k| beyond this: |x - mean|^2 coul
 
 // ONE pass over the coordinates, element-wise (the thread's column is fixed: the stride is a multiple of n_cols): column
 // sums (double), extent of columns 0/1 (header words 8..11), the flag for non-finite / overflow-prone data (word 1,
-// bit 0), the content fingerprint (kHdrFp), the cookie.  The header was zero-filled before.
+// bit 0), the content fingerprint, the cookie.  The header was zero-filled before.
+// Many short blocks (the pass is bound by the latency of its loads: 37 us with 512 blocks of 19 trips, four loads each),
+// and NO same-address atomics at their ends: every block leaves its column sums and its share of the fingerprint in a
+// table [kStatsRow][blocks] doubles (the sort's temp region, free until the sort), which components_kernel -- one
+// workgroup, the next pass but one -- adds up (stats_reduce).  The extent words are raised with publish_max (an atomic
+// only where it would change the word).
+constexpr uint32_t kStatsRow = kMaxCols + 1;   // per block: kMaxCols column sums + the fingerprint share (bits of a double slot)
+constexpr uint32_t kStatsMaxBlocks = 2048;
 __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
-                                                    uint32_t* __restrict__ hdr, uint32_t cookie) {
+                                                    uint32_t* __restrict__ hdr, uint32_t cookie, double* __restrict__ table) {
   __shared__ double part[kMaxCols];
   __shared__ uint32_t wave_max[4];
   __shared__ unsigned long long fp_part[4];
@@ -67,21 +74,213 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ co
     for (; e < total; e += used) take(w[e], e, s0);
     atomicAdd(&part[col], (s0 + s1) + (s2 + s3));
   }
+  // the block's share of the fingerprint (wrap-around sum: any grouping gives the same total)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)fp, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(fp >> 32), off, 64);
+    fp += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0) fp_part[threadIdx.x >> 6] = fp;
   __syncthreads();
-  if (threadIdx.x < D) atomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(hdr) + kHdrSums) + threadIdx.x, part[threadIdx.x]);
+  if (threadIdx.x < D) table[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = part[threadIdx.x];
+  if (threadIdx.x == 0)
+    reinterpret_cast<unsigned long long*>(table)[(size_t)kMaxCols * gridDim.x + blockIdx.x] = fp_part[0] + fp_part[1] + fp_part[2] + fp_part[3];
   if (bad) atomicOr(hdr + 1, 1u);
   const bool c0 = id < used && col == 0u, c1 = id < used && col == 1u;
   publish_max(hdr + 8, c0 ? m_lo : 0u, wave_max);
   publish_max(hdr + 9, c0 ? m_hi : 0u, wave_max);
   publish_max(hdr + 10, c1 ? m_lo : 0u, wave_max);
   publish_max(hdr + 11, c1 ? m_hi : 0u, wave_max);
-  fp_publish(fp, reinterpret_cast<unsigned long long*>(hdr + kHdrFp), fp_part);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     hdr[kHdrCookie] = cookie;   // whose statistics these are (DC_FLAG_STATS_VALID is checked against it)
+    hdr[kHdrStatsBlocks] = gridDim.x;   // (rows of the table still to be added up: stats_reduce clears the word)
     if (D == 1u) {              // (a second column of zeros, as the sweeps treat it)
       atomicMax(hdr + 10, ~fkey(0.0f));
       atomicMax(hdr + 11, fkey(0.0f));
     }
+  }
+}
+// The table of stats_kernel added up by one workgroup (components_kernel calls it first): column sums -> header (kHdrSums),
+// fingerprint -> kHdrFp, column means -> kHdrMeans (mean_kernel's arithmetic).  A header whose statistics are already
+// complete (kHdrStatsBlocks == 0: the statistics of an earlier call, DC_FLAG_STATS_VALID) is left alone.
+__device__ void stats_reduce(uint32_t* __restrict__ hdr, const double* __restrict__ table, uint32_t n_rows, uint32_t D) {
+  const uint32_t nb = hdr[kHdrStatsBlocks];
+  __syncthreads();   // (every thread has read the word before it is cleared)
+  if (nb == 0u) return;
+  // one wave per column (the fingerprint slot is column kMaxCols): lane l adds the blocks l, l + 64, ... in that order, the
+  // lanes meet in a fixed tree -- the same sums on every rank
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  for (uint32_t c = wave; c <= D; c += n_waves) {
+    const uint32_t col = (c == D) ? (uint32_t)kMaxCols : c;
+    if (col == (uint32_t)kMaxCols) {
+      const unsigned long long* t = reinterpret_cast<const unsigned long long*>(table) + (size_t)col * nb;
+      unsigned long long f = 0;
+      for (uint32_t b0 = lane; b0 < nb; b0 += 512u) {   // (eight loads in flight: one per trip was 10 us of latency)
+        unsigned long long v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) v[q] = (b0 + 64u * q < nb) ? t[b0 + 64u * q] : 0ull;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) f += v[q];
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)f, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(f >> 32), off, 64);
+        f += ((unsigned long long)hi << 32) | lo;
+      }
+      if (lane == 0) *reinterpret_cast<unsigned long long*>(hdr + kHdrFp) = f;
+    } else {
+      const double* t = table + (size_t)col * nb;
+      double sum = 0.0;
+      for (uint32_t b0 = lane; b0 < nb; b0 += 512u) {
+        double v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) v[q] = (b0 + 64u * q < nb) ? t[b0 + 64u * q] : 0.0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) sum += v[q];
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const long long bits = __double_as_longlong(sum);
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)((unsigned long long)bits >> 32), off, 64);
+        sum += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      }
+      if (lane == 0) {
+        reinterpret_cast<double*>(reinterpret_cast<char*>(hdr) + kHdrSums)[col] = sum;
+        float muf = (float)(sum / (double)n_rows);   // column means as the float the centring subtracts
+        if (!(fabsf(muf) <= FLT_MAX)) muf = 0.0f;
+        reinterpret_cast<float*>(reinterpret_cast<char*>(hdr) + kHdrMeans)[col] = muf;
+      }
+    }
+  }
+  if (threadIdx.x == 0) hdr[kHdrStatsBlocks] = 0u;
+  __syncthreads();
+}
+
+// ---- DC_FLAG_STATS_VALID: the claim checked in two launches (were five: reset, fingerprint, guard, free-energy range,
+// component guard) ---------------------------------------------------------------------------------------------------
+// claim_pre_kernel: every block leaves its share of the content fingerprint of the coordinates and -- fe != nullptr, a
+// neighbour call -- the extremes of the free energies it saw in a table (no atomics, nothing to clear before):
+//   tab[b] fingerprint share, tab[B + b] = key of the largest finite free energy << 32 | ~key of the smallest, tab[2 B + b] NaN seen
+constexpr uint32_t kClaimBlocks = 1024;
+__global__ __launch_bounds__(256) void claim_pre_kernel(const float* __restrict__ coords, size_t total, const float* __restrict__ fe,
+                                                        uint32_t n_rows, unsigned long long* __restrict__ tab) {
+  __shared__ unsigned long long part[4];
+  __shared__ uint32_t wmax[2][4];
+  __shared__ uint32_t nan_s;
+  if (threadIdx.x == 0) nan_s = 0u;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(coords);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long f = 0;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; e + 3 * stride < total; e += 4 * stride) {   // four loads in flight
+    const uint32_t v0 = w[e], v1 = w[e + stride], v2 = w[e + 2 * stride], v3 = w[e + 3 * stride];
+    f += fp_term(v0, e) + fp_term(v1, e + stride) + fp_term(v2, e + 2 * stride) + fp_term(v3, e + 3 * stride);
+  }
+  for (; e < total; e += stride) f += fp_term(w[e], e);
+  uint32_t inv = 0, top = 0;
+  bool nan = false;
+  if (fe) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += stride) {
+      const float v = fe[i];
+      nan = nan | (v != v);
+      const uint32_t u = __float_as_uint(v);
+      const uint32_t key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+      inv = max(inv, ~key);
+      top = max(top, (fabsf(v) <= FLT_MAX) ? key : 0u);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)f, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(f >> 32), off, 64);
+    f += ((unsigned long long)hi << 32) | lo;
+    inv = max(inv, (uint32_t)__shfl_xor((int)inv, off, 64));
+    top = max(top, (uint32_t)__shfl_xor((int)top, off, 64));
+  }
+  __syncthreads();
+  if (nan) nan_s = 1u;
+  if ((threadIdx.x & 63) == 0) {
+    part[threadIdx.x >> 6] = f;
+    wmax[0][threadIdx.x >> 6] = inv;
+    wmax[1][threadIdx.x >> 6] = top;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t B = gridDim.x;
+    tab[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    const uint32_t i4 = max(max(wmax[0][0], wmax[0][1]), max(wmax[0][2], wmax[0][3]));
+    const uint32_t t4 = max(max(wmax[1][0], wmax[1][1]), max(wmax[1][2], wmax[1][3]));
+    tab[B + blockIdx.x] = ((unsigned long long)t4 << 32) | i4;
+    tab[2 * B + blockIdx.x] = nan_s;
+  }
+}
+// claim_guard_kernel (one workgroup): the shares added up; the claim holds iff cookie (array address, shape) and fingerprint
+// equal what the statistics pass stored -- otherwise the data is flagged (flag word 1: bit 0 = non-finite / overflow-prone
+// coordinates, a statistic: it stays; bit 1 = the claim failed; bit 2 = NaN free energies) and the matrix-core kernels
+// stand down: slow, never wrong.  The per-sweep words of the header start over (sweep_words_reset_kernel); the free-energy
+// range of a neighbour call goes to words 12 / 13 (fe_key_kernel); and, comp != nullptr, the component partition of the
+// workspace is checked for this sweep and its fine grids are formed (comp_guard_kernel).
+__device__ void comp_guard_body(const uint32_t* __restrict__ hdr, const float* __restrict__ means, uint32_t D,
+                                uint32_t* __restrict__ comp, uint32_t cookie, uint32_t n_rows, float fine_frames_per_cell,
+                                uint32_t fine_bits);
+__global__ __launch_bounds__(1024) void claim_guard_kernel(uint32_t* __restrict__ hdr, uint32_t cookie,
+                                                          const unsigned long long* __restrict__ tab, uint32_t B, int pruned,
+                                                          int have_fe, uint32_t D, uint32_t* __restrict__ comp, uint32_t n_rows,
+                                                          float fine_frames_per_cell, uint32_t fine_bits) {
+  __shared__ unsigned long long part[16];
+  __shared__ uint32_t wmax[3][16];
+  unsigned long long f = 0;
+  uint32_t inv = 0, top = 0, nan = 0;
+  for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+    f += tab[b];
+    const unsigned long long x = tab[B + b];
+    inv = max(inv, (uint32_t)x);
+    top = max(top, (uint32_t)(x >> 32));
+    nan |= (uint32_t)tab[2 * B + b];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)f, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(f >> 32), off, 64);
+    f += ((unsigned long long)hi << 32) | lo;
+    inv = max(inv, (uint32_t)__shfl_xor((int)inv, off, 64));
+    top = max(top, (uint32_t)__shfl_xor((int)top, off, 64));
+    nan |= (uint32_t)__shfl_xor((int)nan, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    part[threadIdx.x >> 6] = f;
+    wmax[0][threadIdx.x >> 6] = inv;
+    wmax[1][threadIdx.x >> 6] = top;
+    wmax[2][threadIdx.x >> 6] = nan;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t nw = blockDim.x >> 6;
+    f = 0;
+    inv = top = nan = 0;
+    for (uint32_t k = 0; k < nw; ++k) {
+      f += part[k];
+      inv = max(inv, wmax[0][k]);
+      top = max(top, wmax[1][k]);
+      nan |= wmax[2][k];
+    }
+    const bool same = hdr[kHdrCookie] == cookie && *reinterpret_cast<const unsigned long long*>(hdr + kHdrFp) == f;
+    *reinterpret_cast<unsigned long long*>(hdr + kHdrFp + 2) = f;
+    hdr[1] = (hdr[1] & 1u) | (same ? 0u : 2u) | ((have_fe && nan) ? 4u : 0u);
+    if (!same) hdr[kHdrCookie] = 0u;   // (the component partition in the workspace is not this array's either)
+    // the per-sweep words: evaluated-tile and MFMA counters, the extents this sweep forms again, the order's hash
+    if (pruned) hdr[0] = 0u;
+    for (uint32_t k = 2; k <= 7; ++k) hdr[k] = 0u;
+    hdr[kHdrMfmaNn] = 0u;
+    hdr[kHdrMfmaNn + 1] = 0u;
+    hdr[kHdrMloc] = 0u;
+    hdr[kHdrFp + 4] = 0u;
+    hdr[kHdrFp + 5] = 0u;
+    hdr[12] = have_fe ? inv : 0u;
+    hdr[13] = have_fe ? top : 0u;
+  }
+  if (comp) {
+    __syncthreads();
+    comp_guard_body(hdr, reinterpret_cast<const float*>(reinterpret_cast<const char*>(hdr) + kHdrMeans), D, comp, cookie, n_rows,
+                    fine_frames_per_cell, fine_bits);
   }
 }
 
@@ -96,24 +295,40 @@ __device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows
 //                 hdr[0] (float accumulation with a margin, as order_rows_kernel formed the first one in rounds 3 - 4)
 //   presets       the padded order of n_pos positions: every position kInvalidFrame, every tile the all-pad component
 //                 (the sort's last pass writes the real entries over them)
+static inline size_t order_key_smem(uint32_t n_cols, bool measure) {
+  return measure ? sizeof(float) * ((size_t)kMaxComp + 1) * n_cols : 0;
+}
 __global__ __launch_bounds__(256) void order_key_kernel(
     const float* __restrict__ coords, uint32_t D, uint32_t* __restrict__ hdr, const uint32_t* __restrict__ comp,
     uint32_t fine_bits, uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
     uint32_t n_total, const float* __restrict__ fe, uint32_t fe_bits, uint32_t* __restrict__ counts, int measure,
     uint32_t* __restrict__ perm, uint32_t* __restrict__ tile_comp, uint32_t n_pos) {
+  // A block walks tiles of 256 rows (grid-stride) and ends with ONE atomic per component and extent word: with a block per
+  // tile the 4 000 blocks of C3 queued 10 000 atomics on three counters -- 50 of the pass's 60 us.  A row per lane, read
+  // where it lies (the loads of a wave touch the same 2.5 KB and meet in the vector cache); the origins and the means in LDS.
+  extern __shared__ float org_s[];   // measure: [kMaxComp][D] origins, then the means [D]
   __shared__ uint32_t cnt_s[kMaxComp];
   __shared__ float blk_max[2][4];
   if (threadIdx.x < (uint32_t)kMaxComp) cnt_s[threadIdx.x] = 0u;
+  const uint32_t n_comp = min(comp[kCompGrid + 5], (uint32_t)kMaxComp);
+  if (measure) {
+    const float* origins = reinterpret_cast<const float*>(comp + kCompOrigin);
+    const float* mu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(hdr) + kHdrMeans);
+    for (uint32_t e = threadIdx.x; e < n_comp * D; e += 256u) org_s[e] = origins[(size_t)(e / D) * kMaxCols + (e - (e / D) * D)];
+    for (uint32_t k = threadIdx.x; k < D; k += 256u) org_s[(size_t)kMaxComp * D + k] = mu[k];
+  }
   __syncthreads();
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n_pos) perm[j] = kInvalidFrame;
-  if (j < n_pos / 32u) tile_comp[j] = kMaxComp;
-  const uint32_t i = i_from + j;
+  const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_total);
+  const float fe_lo = fe ? fkey_inv(~hdr[12]) : 0.0f, fe_hi = fe ? fkey_inv(hdr[13]) : 0.0f;
+  const uint32_t n_items = max(i_to - i_from, n_pos);
   float ext_loc = 0.0f, ext_glob = 0.0f;
-  if (i < i_to) {
+  for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n_items; j += gridDim.x * 256u) {
+    if (j < n_pos) perm[j] = kInvalidFrame;
+    if (j < n_pos / 32u) tile_comp[j] = kMaxComp;
+    const uint32_t i = i_from + j;
+    if (i >= i_to) continue;
     const float* row = coords + (size_t)i * D;
     const float x = row[0], y = (D > 1) ? row[1] : 0.0f;
-    const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_total);
     uint32_t c = 0, bx = 0, by = 0, nby = 1;
     if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
       c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
@@ -128,7 +343,6 @@ __global__ __launch_bounds__(256) void order_key_kernel(
     const uint32_t lo = comp[kCompCellOff + c], hi = comp[kCompCellOff + c + 1];
     uint32_t key = min(lo + bx * nby + by, hi - (hi > lo ? 1u : 0u));
     if (fe) {
-      const float fe_lo = fkey_inv(~hdr[12]), fe_hi = fkey_inv(hdr[13]);
       const float span = fe_hi - fe_lo;
       float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
       u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
@@ -140,29 +354,25 @@ __global__ __launch_bounds__(256) void order_key_kernel(
     vals[j] = i;
     atomicAdd(&cnt_s[min(c, (uint32_t)kMaxComp - 1u)], 1u);
     if (measure) {
-      const float* a = reinterpret_cast<const float*>(comp + kCompOrigin) + (size_t)c * kMaxCols;
-      const float* mu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(hdr) + kHdrMeans);
+      const float* a = org_s + (size_t)min(c, n_comp ? n_comp - 1u : 0u) * D;
+      const float* mu = org_s + (size_t)kMaxComp * D;
+      float el = 0.0f, eg = 0.0f;
       for (uint32_t k0 = 0; k0 < D; k0 += 4) {   // (four columns per step, their loads issued together)
-        float xv[4], av[4], mv[4];
+        float xv[4];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-          const uint32_t k = min(k0 + q, D - 1u);
-          xv[q] = row[k];
-          av[q] = a[k];
-          mv[q] = mu[k];
-        }
+        for (uint32_t q = 0; q < 4; ++q) xv[q] = row[min(k0 + q, D - 1u)];
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q)
           if (k0 + q < D) {
-            const float vl = xv[q] - av[q], vg = xv[q] - mv[q];
-            ext_loc += vl * vl;
-            ext_glob += vg * vg;
+            const float vl = xv[q] - a[k0 + q], vg = xv[q] - mu[k0 + q];
+            el += vl * vl;
+            eg += vg * vg;
           }
       }
-      ext_loc = ext_loc * 1.0001f + FLT_MIN;
-      ext_glob = ext_glob * 1.0001f + FLT_MIN;
-      if (!(ext_loc <= FLT_MAX)) ext_loc = 0.0f;     // (flagged data: the sweep stands down anyway)
-      if (!(ext_glob <= FLT_MAX)) ext_glob = 0.0f;
+      el = el * 1.0001f + FLT_MIN;
+      eg = eg * 1.0001f + FLT_MIN;
+      if (el <= FLT_MAX) ext_loc = fmaxf(ext_loc, el);     // (non-finite rows: the data is flagged, the sweep stands down)
+      if (eg <= FLT_MAX) ext_glob = fmaxf(ext_glob, eg);
     }
   }
   if (measure) {
@@ -312,7 +522,8 @@ __global__ __launch_bounds__(256) void order_rows2_kernel(
     float* __restrict__ coords_o, float4* __restrict__ boxes, const float* __restrict__ fe, float* __restrict__ fe_s,
     uint32_t* __restrict__ invpos, float2* __restrict__ ferange, const uint32_t* __restrict__ tile_comp,
     const float* __restrict__ origins, uint32_t* __restrict__ hdr, uint4* __restrict__ img_a, int a_form,
-    float* __restrict__ norms_a, uint4* __restrict__ img_b, float* __restrict__ norms_b, uint32_t grp_tq, QSeg grp) {
+    float* __restrict__ norms_a, uint4* __restrict__ img_b, float* __restrict__ norms_b, uint32_t grp_tq, QSeg grp,
+    unsigned long long* __restrict__ hash_slots) {
   extern __shared__ float or_tile[];            // [256][D | 1], then per wave: K rows of a tile, origin
   __shared__ uint32_t s_frame[256];
   __shared__ unsigned long long fp_part[4];
@@ -359,8 +570,10 @@ __global__ __launch_bounds__(256) void order_rows2_kernel(
       flo = f;
       fhi = f;
     }
-    // hash of the order (header words kHdrFp + 4..5, zero before): what the layout header of a neighbour block carries
-    fp_publish(in_range ? fp_term(frame, pos) : 0ull, reinterpret_cast<unsigned long long*>(hdr + kHdrFp + 4), fp_part);
+    // hash of the order, what the layout header of a neighbour block carries: a wrap-around sum, left in 64 slots of the
+    // component region (zero before; one word took 4 096 same-address 64-bit atomics at C3: ~20 us at the launch's end),
+    // added up by nn_block_pack_kernel
+    fp_publish(in_range ? fp_term(frame, pos) : 0ull, hash_slots + (blockIdx.x & 63u), fp_part);
   }
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) {

@@ -26,7 +26,7 @@ namespace dc {
 
 namespace {
 
-constexpr uint32_t kSortTile = 4096;   // items per block: 4 waves x 16 steps x 64 lanes
+constexpr uint32_t kSortTile = 2048;   // items per block: 4 waves x 8 steps x 64 lanes (4 096: one block per CU at C3, nothing to hide its latencies behind -- 16 us per pass against 11)
 constexpr uint32_t kSortBins = 256;    // 8 bits per pass
 
 __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t mask,
