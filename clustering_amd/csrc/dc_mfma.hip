@@ -488,8 +488,6 @@ __device__ __forceinline__ uint32_t coarse_cell_of_point(const CoarseGrid& g, fl
 // cells were listed).  Writes the component of every cell, the components' origins and fine cell grids.
 __device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell, uint32_t fine_bits,
                                uint32_t* __restrict__ comp);
-__device__ void stats_reduce(uint32_t* __restrict__ hdr, const double* __restrict__ table, uint32_t n_rows, uint32_t D);
-
 // Round 5: ONE launch for what were four -- the boxes of the coarse cells (coarse_box_kernel) are formed here, straight
 // from the occupancy bitmap into the labelling's tables; the column means (mean_kernel: means_out != nullptr) in front; the
 // fine cell grids of the components (fine_grid_kernel) behind, by the first thread.
@@ -510,9 +508,7 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
 #define DC_STAMP(k) do {} while (0)
 #endif
   DC_STAMP(0);
-  // the statistics pass of this call left its column sums and fingerprint shares in a table: sums, fingerprint and the
-  // column means (mean_kernel) into the header first (`means` points there)
-  if (stats_table) stats_reduce(const_cast<uint32_t*>(hdr), stats_table, n_rows, D);
+  (void)stats_table;   // (the statistics table is added up by its own launch: stats_reduce_kernel)
   DC_STAMP(1);
   __shared__ uint32_t occ[kMaxOccupied], label[kMaxOccupied];
   __shared__ float4 obox[kMaxOccupied];
@@ -580,34 +576,70 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   bool single = force_single != 0 || n_occ > (uint32_t)kMaxOccupied || n_occ <= 1u || !(r_max <= FLT_MAX);
   const float r2c = r_max * r_max * 1.0002f;
   if (!single) {
-    const int R = min((int)ceilf(r_max / g.gc) + 1, 5);   // (gc >= r_max / 2: three cells)
+    // cells d apart (in either direction) keep their boxes at least (d - 1) gc - 2 slack apart: beyond R they cannot be
+    // within reach (gc >= r_max / 2: R = 3; round 4 looked one ring further, 81 cells instead of 49)
+    const int R = min((int)floorf((r_max * 1.0002f + 2.0f * slack_sub) / g.gc) + 1, 5);
     for (uint32_t i = tid; i < n_occ; i += nt) label[i] = occ[i];
     __syncthreads();
+    // The neighbourhood of a cell does not change from round to round: the first round tests the boxes and leaves a bit
+    // per neighbouring cell within reach (at most 11 x 11 of them: four words per cell, a thread owns at most two cells),
+    // the later rounds only follow the bits -- a look-up of the cell and its label each (the box tests of every round
+    // were 8 us per round and three rounds at C3: 25 of the kernel's 43 us).
+    static_assert(kMaxOccupied <= 2048, "a thread of the 1024 owns at most two occupied cells");
+    uint32_t nbr[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     int iter = 0;
     for (;; ++iter) {
       if (tid == 0) changed_s = 0;
       __syncthreads();
-      for (uint32_t i = tid; i < n_occ; i += nt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t i = tid + (uint32_t)s * nt;
+        if (i >= n_occ) continue;
         const uint32_t c = occ[i];
         const int cx = (int)(c / g.ncy), cy = (int)(c % g.ncy);
-        const float4 bi = obox[i];
         uint32_t m = label[i];
-        for (int dx = -R; dx <= R; ++dx) {
-          const int nx = cx + dx;
-          if (nx < 0 || nx >= (int)g.ncx) continue;
-          // (the look-ups of one row of the neighbourhood are independent: issued together, not one latency each)
-          uint32_t jj[11];
+        if (iter == 0) {
+          const float4 bi = obox[i];
+          for (int dx = -R; dx <= R; ++dx) {
+            const int nx = cx + dx;
+            if (nx < 0 || nx >= (int)g.ncx) continue;
+            // (the look-ups of one row of the neighbourhood are independent: issued together, not one latency each)
+            uint32_t jj[11];
 #pragma unroll
-          for (int k = 0; k < 11; ++k) {
-            const int ny = cy + k - 5;
-            const bool in = (k - 5 >= -R) && (k - 5 <= R) && ny >= 0 && ny < (int)g.ncy;
-            jj[k] = in ? (uint32_t)cell_idx[(uint32_t)nx * g.ncy + (uint32_t)ny] : 0xFFFFu;
+            for (int k = 0; k < 11; ++k) {
+              const int ny = cy + k - 5;
+              const bool in = (k - 5 >= -R) && (k - 5 <= R) && ny >= 0 && ny < (int)g.ncy;
+              jj[k] = in ? (uint32_t)cell_idx[(uint32_t)nx * g.ncy + (uint32_t)ny] : 0xFFFFu;
+            }
+            uint32_t row_bits = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+              const uint32_t j = jj[k];
+              if (j >= n_occ) continue;
+              if (box_gap2(bi, obox[j]) <= r2c) {
+                m = min(m, label[j]);
+                row_bits |= 1u << k;
+              }
+            }
+            const uint32_t at = (uint32_t)(dx + R) * 11u;   // bit index of the row's first cell
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const int sh = (int)at - 32 * w;
+              if (sh >= 0 && sh < 32) nbr[s][w] |= row_bits << sh;
+              if (sh < 0 && sh > -11) nbr[s][w] |= row_bits >> (-sh);
+            }
           }
+        } else {
 #pragma unroll
-          for (int k = 0; k < 11; ++k) {
-            const uint32_t j = jj[k];
-            if (j >= n_occ) continue;
-            if (box_gap2(bi, obox[j]) <= r2c) m = min(m, label[j]);
+          for (int w = 0; w < 4; ++w) {
+            uint32_t bits = nbr[s][w];
+            while (bits) {
+              const uint32_t idx = 32u * (uint32_t)w + (uint32_t)__builtin_ctz(bits);
+              bits &= bits - 1u;
+              const uint32_t dxi = idx / 11u, k = idx - dxi * 11u;
+              const uint32_t j = cell_idx[(uint32_t)(cx + (int)dxi - R) * g.ncy + (uint32_t)(cy + (int)k - 5)];
+              m = min(m, label[j]);
+            }
           }
         }
         if (m < label[i]) {
@@ -1323,6 +1355,8 @@ int mfma_prepare(const float* d_coords, uint32_t n_rows, uint32_t n_cols, void* 
     const uint32_t blocks_s = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(kStatsMaxBlocks, want), room));
     hipLaunchKernelGGL(stats_kernel, dim3(blocks_s), dim3(256), 0, stream, d_coords, n_rows, n_cols, (uint32_t*)p, cookie,
                        (double*)(p + L.fixed_end));
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(1024), 0, stream, (uint32_t*)p, (const double*)(p + L.fixed_end), n_rows,
+                       n_cols);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (hipMemsetAsync(p, 0, kHdrBytes, stream) != hipSuccess) return -1;
@@ -1598,6 +1632,9 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     sink_local.rank = keys_out;
     sink = &sink_local;
   }
+  // the counts by position of the one-radius symmetric per-wave sweep (the pq region): cleared by this call's preparation
+  const bool pos_clean = prep && sink_in == nullptr && n_rad == 1 && !pop_shared_wanted(n_rows, n_cols, n_rad) &&
+                         pop_sym_wanted(false, q_mode, q_seg, n_rows, n_rad) && tq <= 6u;
   if (prep) {
     // (round 5: the passes of dc_prep.hpp -- twelve launches for the thirty of rounds 3 - 4, same values)
     const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
@@ -1612,12 +1649,14 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                        (const float*)(p + kHdrMeans), n_cols, r_conn, n_rows, kPopCellFrames, fine_bits, comp,
                        components_off() ? 1 : 0, r_max, cookie, (const double*)(p + L.fixed_end), cell_frames(false));
     // order all frames by (component, fine cell): keys, rows per component, the extents, the pad presets ...
-    hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_rows, 32u * T_r) + 255) / 256, 1024u)), blk, order_key_smem_set(n_cols), stream, d_coords, n_cols, hdr,
+    const uint32_t kb_r = std::min<uint32_t>((std::max(n_rows, 32u * T_r) + 255) / 256, 1024u);
+    uint32_t* cnt_tab = (uint32_t*)(p + L.fixed_end);   // (rows per component and block: the sort's temp region, free until the sort)
+    hipLaunchKernelGGL(order_key_kernel, dim3(kb_r), blk, order_key_smem_set(n_cols), stream, d_coords, n_cols, hdr,
                        (const uint32_t*)comp, (uint32_t)fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
-                       start_r, 1, perm_p, tile_comp, 32u * T_r);
+                       cnt_tab, 1, perm_p, tile_comp, 32u * T_r);
     // ... where the components start, the scale of the sweep (it follows the components' extents) ...
-    hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_r, range_r, base_r, n_rows, group_rows, 1,
-                       fmaxf(r2_scale, 0.0f), n_cols);
+    hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(1024), 0, stream, hdr, comp, (const uint32_t*)cnt_tab, kb_r, start_r, range_r,
+                       base_r, n_rows, group_rows, 1, fmaxf(r2_scale, 0.0f), n_cols);
     // ... the sort, whose last pass moves every component to a whole query group of the padded order ...
     {
       const SortRemap remap{start_r, base_r, (uint32_t)kMaxComp, tile_comp};
@@ -1634,7 +1673,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                          (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp,
                          origins, hdr, (uint4*)(p + L.off_img_p), 0, (float*)(p + L.off_norm_p),
                          ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg,
-                         (unsigned long long*)(comp + kCompHash));
+                         (unsigned long long*)(comp + kCompHash), pos_clean ? (uint32_t*)(p + L.off_pq) : (uint32_t*)nullptr, 1u);
     }
     // lightest-outgoing-pair variant: component ids and ranks in the sweep's order (the sort's key
     // buffers are free again)
@@ -1646,11 +1685,12 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     }
     if (q_mode == kQueryOwnOrder) {
       // query rows of this call: the same ordering restricted to [i_from, i_to)
-      hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_q, 32u * T_q) + 255) / 256, 1024u)), blk, 0, stream, d_coords, n_cols, hdr,
+      const uint32_t kb_q = std::min<uint32_t>((std::max(n_q, 32u * T_q) + 255) / 256, 1024u);
+      hipLaunchKernelGGL(order_key_kernel, dim3(kb_q), blk, 0, stream, d_coords, n_cols, hdr,
                          (const uint32_t*)comp, (uint32_t)fine_bits, i_from, i_to, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
-                         start_q, 0, perm_q, tile_comp_q, 32u * T_q);
-      hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_q, range_q, base_q, n_q, group_rows, 0,
-                         0.0f, n_cols);
+                         cnt_tab, 0, perm_q, tile_comp_q, 32u * T_q);
+      hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(1024), 0, stream, hdr, comp, (const uint32_t*)cnt_tab, kb_q, start_q, range_q,
+                         base_q, n_q, group_rows, 0, 0.0f, n_cols);
       const SortRemap remap{start_q, base_q, (uint32_t)kMaxComp, tile_comp_q};
       if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, key_bits, &remap))
         return;
@@ -1658,7 +1698,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                          L.NM, (const uint32_t*)perm_q, T_q, (float*)nullptr, (float4*)(p + L.off_box_q),
                          (const float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp_q,
                          origins, hdr, (uint4*)nullptr, 0, (float*)nullptr, (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), 1u,
-                         QSeg{1u, 0u, 1u}, (unsigned long long*)nullptr);
+                         QSeg{1u, 0u, 1u}, (unsigned long long*)nullptr, (uint32_t*)nullptr, 0u);
     }
   }
   (void)kCellFramesHere;
@@ -1668,7 +1708,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   case SV:                                                                                    \
     if ((DC_STEP_MASK >> (SV - 1)) & 1u)                                                      \
       pop_pruned_step_##SV(d_coords, n_rows, n_cols, d_ws, T_r, n_pos_q, q_mode, q_seg, rad2, n_rad, \
-                           d_pops, sink, stream);                                             \
+                           d_pops, sink, stream, pos_clean);                                  \
     break;
     DC_FOR_EACH_S(X)
 #undef X
@@ -1992,11 +2032,13 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        components_off() ? 1 : 0, 0.0f, cookie, (const double*)(p + L.fixed_end), cell_frames(true));
   }
   // frames by (component, cell, free energy): ONE sort on a combined key, its last pass writes the padded order
-  hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_rows, 32u * T_r) + 255) / 256, 1024u)), blk, order_key_smem_set(n_cols), stream, d_coords, n_cols, hdr,
-                     (const uint32_t*)comp, (uint32_t)fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, (uint32_t)fe_bits, start_r, 1,
+  const uint32_t kb_r = std::min<uint32_t>((std::max(n_rows, 32u * T_r) + 255) / 256, 1024u);
+  uint32_t* cnt_tab = (uint32_t*)(p + L.fixed_end);   // (rows per component and block: the sort's temp region, free until the sort)
+  hipLaunchKernelGGL(order_key_kernel, dim3(kb_r), blk, order_key_smem_set(n_cols), stream, d_coords, n_cols, hdr,
+                     (const uint32_t*)comp, (uint32_t)fine_bits, 0u, n_rows, keys_in, vals_in, n_rows, d_fe, (uint32_t)fe_bits, cnt_tab, 1,
                      perm_p, tile_comp, 32u * T_r);
-  hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_r, range_r, base_r, n_rows, group_rows, 1,
-                     -1.0f, n_cols);   // (the neighbour scale)
+  hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(1024), 0, stream, hdr, comp, (const uint32_t*)cnt_tab, kb_r, start_r, range_r,
+                     base_r, n_rows, group_rows, 1, -1.0f, n_cols);   // (the neighbour scale)
   {
     const SortRemap remap{start_r, base_r, (uint32_t)kMaxComp, tile_comp};
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_p, n_rows, p + L.fixed_end, tmp_bytes, stream, fine_bits + fe_bits, &remap))
@@ -2012,15 +2054,16 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        (float*)(p + L.off_fe_s), (uint32_t*)(p + L.off_invpos), (float2*)(p + L.off_ferange_p),
                        (const uint32_t*)tile_comp, origins, hdr, (uint4*)(p + L.off_img_p), 2, (float*)(p + L.off_norm_p),
                        ref_queries ? (uint4*)(p + L.off_img_q) : (uint4*)nullptr, (float*)nullptr, tq, q_seg,
-                         (unsigned long long*)(comp + kCompHash));
+                         (unsigned long long*)(comp + kCompHash), (uint32_t*)nullptr, 0u);
   }
   if (q_mode == kQueryOwnOrder) {
     // query rows of this call: the cell ordering restricted to [i_from, i_to)
-    hipLaunchKernelGGL(order_key_kernel, dim3(std::min<uint32_t>((std::max(n_q, 32u * T_q) + 255) / 256, 1024u)), blk, 0, stream, d_coords, n_cols, hdr,
+    const uint32_t kb_q = std::min<uint32_t>((std::max(n_q, 32u * T_q) + 255) / 256, 1024u);
+    hipLaunchKernelGGL(order_key_kernel, dim3(kb_q), blk, 0, stream, d_coords, n_cols, hdr,
                        (const uint32_t*)comp, (uint32_t)fine_bits, i_from, i_to, keys_in, vals_in, n_rows, (const float*)nullptr, 0u,
-                       start_q, 0, perm_q, tile_comp_q, 32u * T_q);
-    hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(64), 0, stream, hdr, comp, start_q, range_q, base_q, n_q, group_rows, 0,
-                       0.0f, n_cols);
+                       cnt_tab, 0, perm_q, tile_comp_q, 32u * T_q);
+    hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(1024), 0, stream, hdr, comp, (const uint32_t*)cnt_tab, kb_q, start_q, range_q,
+                       base_q, n_q, group_rows, 0, 0.0f, n_cols);
     const SortRemap remap{start_q, base_q, (uint32_t)kMaxComp, tile_comp_q};
     if (sort_pairs_u32(keys_in, keys_out, vals_in, perm_q, n_q, p + L.fixed_end, tmp_bytes, stream, fine_bits, &remap))
       return;
@@ -2028,7 +2071,7 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
                        L.NM, (const uint32_t*)perm_q, T_q, (float*)nullptr, (float4*)(p + L.off_box_q), (const float*)nullptr,
                        (float*)nullptr, (uint32_t*)nullptr, (float2*)nullptr, (const uint32_t*)tile_comp_q, origins, hdr,
                        (uint4*)nullptr, 0, (float*)nullptr, (uint4*)(p + L.off_img_q), (float*)(p + L.off_norm_q), 1u,
-                       QSeg{1u, 0u, 1u}, (unsigned long long*)nullptr);
+                       QSeg{1u, 0u, 1u}, (unsigned long long*)nullptr, (uint32_t*)nullptr, 0u);
   }
   const bool own = q_mode == kQueryOwnOrder;
   const uint32_t n_pos_q = 32u * (own ? T_q : T_r);

@@ -2898,7 +2898,9 @@ template <int S, int NRV, int TQV>
 void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
                        uint32_t T, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,
                        int n_rad, uint32_t* pops, unsigned long long* chain_counter,
-                       const EdgeSink* sink, hipStream_t s) {
+                       const EdgeSink* sink, hipStream_t s, bool pos_clean = false) {
+  // pos_clean: the counts by position of the one-radius symmetric per-wave sweep (the pq region) were cleared by the
+  // preparation (order_rows2_kernel) -- no fill in front of the sweep
   if (n_q == 0) return;
   // the query groups of this launch: all of them, or one segment's share
   const uint32_t waves = seg_groups(((n_q + 31) / 32 + TQV - 1) / TQV, q_seg), tiles = waves * TQV;
@@ -2973,7 +2975,7 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
       // symmetric sweep: counts by position (the pq region of the workspace: only the full neighbour sweep uses
       // it), then to the frames
       uint32_t* pops_pos = const_cast<uint32_t*>(P.pq);
-      (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T, s);
+      if (!pos_clean) (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T, s);
       { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_pruned_kernel<S, 1, TQV, kSinkNone, true>), grid, block, smem, s, coords, n_rows,
                          n_cols, P.img_p, P.norms_p, P.perm_p, P.box_p, P.coords_p, T, img_q, norms_q,
                          perm_q, box_q, n_q, q_seg, P.hdr, chain_counter, rad2, n_rad, pops,
@@ -3005,16 +3007,16 @@ template <int S, int NRV>
 void pop_pruned_tq(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P, uint32_t T,
                    uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2, int n_rad,
                    uint32_t* pops, unsigned long long* chain_counter, const EdgeSink* sink,
-                   hipStream_t s) {
+                   hipStream_t s, bool pos_clean = false) {
   pop_pruned_launch<S, NRV, tq_pop_for<S>>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2,
-                                       n_rad, pops, chain_counter, sink, s);
+                                       n_rad, pops, chain_counter, sink, s, pos_clean);
 }
 
 template <int S>
 void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Ptrs& P,
                          uint32_t T, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2,
                          int n_rad, uint32_t* pops, unsigned long long* chain_counter,
-                         const EdgeSink* sink, hipStream_t s) {
+                         const EdgeSink* sink, hipStream_t s, bool pos_clean = false) {
   // one radius per sweep (dc_mfma.hip loops over the radii of a call) -- except the shared-operand sweep of wide
   // rows, which takes up to eight (dc_mfma_shared.hpp; S >= 3 only: no instances for the narrow shapes)
   if constexpr (S >= 3 && S <= 8) {
@@ -3027,7 +3029,7 @@ void pop_pruned_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, 
     }
   }
   pop_pruned_tq<S, 1>(coords, n_rows, n_cols, P, T, n_q, q_mode, q_seg, rad2, n_rad, pops,
-                      chain_counter, sink, s);
+                      chain_counter, sink, s, pos_clean);
 }
 
 template <int S>
@@ -3051,7 +3053,7 @@ void nn_dispatch(const float* coords, uint32_t n_rows, uint32_t n_cols, const Pt
                           uint32_t* pops, hipStream_t s);                                        \
   void pop_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, void* d_ws,   \
                             uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg, const Rad2& rad2, \
-                            int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s);     \
+                            int n_rad, uint32_t* pops, const EdgeSink* sink, hipStream_t s, bool pos_clean); \
   void nn_pruned_step_##SV(const float* coords, uint32_t n_rows, uint32_t n_cols, const float* fe, \
                            void* d_ws, uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg, float cell2, \
                            uint32_t* nn_idx, float* nn_d2, uint32_t* hd_idx, float* hd_d2,             \

@@ -21,12 +21,12 @@ void DC_CAT(pop_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint3
 void DC_CAT(pop_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,
                                        void* d_ws, uint32_t T_ref, uint32_t n_q, int q_mode, QSeg q_seg,
                                        const Rad2& rad2, int n_rad, uint32_t* pops,
-                                       const EdgeSink* sink, hipStream_t s) {
+                                       const EdgeSink* sink, hipStream_t s, bool pos_clean) {
   const Layout L = make_layout(n_rows, n_cols);
   // evaluated-chain counter: header word 2..3 (8-byte aligned)
   // (T_ref: tiles of the padded reference order; n_q: positions of the query order)
   pop_pruned_dispatch<DC_STEP>(coords, n_rows, n_cols, ws_ptrs(d_ws, L), T_ref, n_q, q_mode, q_seg,
-                               rad2, n_rad, pops, (unsigned long long*)((char*)d_ws + 8), sink, s);
+                               rad2, n_rad, pops, (unsigned long long*)((char*)d_ws + 8), sink, s, pos_clean);
 }
 
 void DC_CAT(nn_pruned_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32_t n_cols,

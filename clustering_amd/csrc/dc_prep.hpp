@@ -29,10 +29,10 @@ constexpr float kStatsLimit = 5.0e16f;   // |x_k| beyond this: |x - mean|^2 coul
 // bit 0), the content fingerprint, the cookie.  The header was zero-filled before.
 // Many short blocks (the pass is bound by the latency of its loads: 37 us with 512 blocks of 19 trips, four loads each),
 // and NO same-address atomics at their ends: every block leaves its column sums and its share of the fingerprint in a
-// table [kStatsRow][blocks] doubles (the sort's temp region, free until the sort), which components_kernel -- one
-// workgroup, the next pass but one -- adds up (stats_reduce).  The extent words are raised with publish_max (an atomic
-// only where it would change the word).
-constexpr uint32_t kStatsRow = kMaxCols + 1;   // per block: kMaxCols column sums + the fingerprint share (bits of a double slot)
+// table [kStatsRow][blocks] doubles (the sort's temp region, free until the sort), which one workgroup adds up right behind
+// it (stats_reduce_kernel).  The extents of columns 0/1 go the same way (raised with
+// atomicMax on the four header words they cost 20 us at 10^5 rows: a thousand blocks queueing on four addresses).
+constexpr uint32_t kStatsRow = kMaxCols + 3;   // per block: kMaxCols column sums, the fingerprint share, the extents of columns 0 and 1 (64-bit slots)
 constexpr uint32_t kStatsMaxBlocks = 2048;
 __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D,
                                                     uint32_t* __restrict__ hdr, uint32_t cookie, double* __restrict__ table) {
@@ -86,21 +86,33 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ co
   if (threadIdx.x == 0)
     reinterpret_cast<unsigned long long*>(table)[(size_t)kMaxCols * gridDim.x + blockIdx.x] = fp_part[0] + fp_part[1] + fp_part[2] + fp_part[3];
   if (bad) atomicOr(hdr + 1, 1u);
-  const bool c0 = id < used && col == 0u, c1 = id < used && col == 1u;
-  publish_max(hdr + 8, c0 ? m_lo : 0u, wave_max);
-  publish_max(hdr + 9, c0 ? m_hi : 0u, wave_max);
-  publish_max(hdr + 10, c1 ? m_lo : 0u, wave_max);
-  publish_max(hdr + 11, c1 ? m_hi : 0u, wave_max);
+  {  // the block's extents of columns 0 / 1: ~key(min), key(max) each (0: the block saw nothing of the column)
+    const bool c0 = id < used && col == 0u, c1 = id < used && col == 1u;
+    uint32_t e[4] = {c0 ? m_lo : 0u, c0 ? m_hi : 0u, c1 ? m_lo : 0u, c1 ? m_hi : 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) e[q] = max(e[q], (uint32_t)__shfl_xor((int)e[q], off, 64));
+    }
+    __shared__ uint32_t ext_s[4][4];
+    if ((threadIdx.x & 63) == 0)
+      for (int q = 0; q < 4; ++q) ext_s[q][threadIdx.x >> 6] = e[q];
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const uint32_t q = 2u * threadIdx.x;
+      const uint32_t lo = max(max(ext_s[q][0], ext_s[q][1]), max(ext_s[q][2], ext_s[q][3]));
+      const uint32_t hi = max(max(ext_s[q + 1][0], ext_s[q + 1][1]), max(ext_s[q + 1][2], ext_s[q + 1][3]));
+      reinterpret_cast<unsigned long long*>(table)[(size_t)(kMaxCols + 1 + threadIdx.x) * gridDim.x + blockIdx.x] =
+          ((unsigned long long)hi << 32) | lo;
+    }
+  }
+  (void)wave_max;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     hdr[kHdrCookie] = cookie;   // whose statistics these are (DC_FLAG_STATS_VALID is checked against it)
     hdr[kHdrStatsBlocks] = gridDim.x;   // (rows of the table still to be added up: stats_reduce clears the word)
-    if (D == 1u) {              // (a second column of zeros, as the sweeps treat it)
-      atomicMax(hdr + 10, ~fkey(0.0f));
-      atomicMax(hdr + 11, fkey(0.0f));
-    }
   }
 }
-// The table of stats_kernel added up by one workgroup (components_kernel calls it first): column sums -> header (kHdrSums),
+// The table of stats_kernel added up by one workgroup: column sums -> header (kHdrSums), extents -> words 8..11,
 // fingerprint -> kHdrFp, column means -> kHdrMeans (mean_kernel's arithmetic).  A header whose statistics are already
 // complete (kHdrStatsBlocks == 0: the statistics of an earlier call, DC_FLAG_STATS_VALID) is left alone.
 __device__ void stats_reduce(uint32_t* __restrict__ hdr, const double* __restrict__ table, uint32_t n_rows, uint32_t D) {
@@ -110,9 +122,31 @@ __device__ void stats_reduce(uint32_t* __restrict__ hdr, const double* __restric
   // one wave per column (the fingerprint slot is column kMaxCols): lane l adds the blocks l, l + 64, ... in that order, the
   // lanes meet in a fixed tree -- the same sums on every rank
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  for (uint32_t c = wave; c <= D; c += n_waves) {
-    const uint32_t col = (c == D) ? (uint32_t)kMaxCols : c;
-    if (col == (uint32_t)kMaxCols) {
+  for (uint32_t c = wave; c <= D + 2u; c += n_waves) {
+    const uint32_t col = (c >= D) ? (uint32_t)kMaxCols + (c - D) : c;
+    if (col > (uint32_t)kMaxCols) {   // extent of column 0 / 1: (key(max) << 32 | ~key(min)), both maxima
+      const unsigned long long* t = reinterpret_cast<const unsigned long long*>(table) + (size_t)col * nb;
+      uint32_t lo = 0, hi = 0;
+      for (uint32_t b = lane; b < nb; b += 64u) {
+        const unsigned long long v = t[b];
+        lo = max(lo, (uint32_t)v);
+        hi = max(hi, (uint32_t)(v >> 32));
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        lo = max(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+      }
+      if (lane == 0) {
+        const uint32_t which = col - (uint32_t)kMaxCols - 1u;
+        if (which == 1u && D == 1u) {   // (a second column of zeros, as the sweeps treat it)
+          lo = ~fkey(0.0f);
+          hi = fkey(0.0f);
+        }
+        hdr[8 + 2 * which] = lo;
+        hdr[9 + 2 * which] = hi;
+      }
+    } else if (col == (uint32_t)kMaxCols) {
       const unsigned long long* t = reinterpret_cast<const unsigned long long*>(table) + (size_t)col * nb;
       unsigned long long f = 0;
       for (uint32_t b0 = lane; b0 < nb; b0 += 512u) {   // (eight loads in flight: one per trip was 10 us of latency)
@@ -154,6 +188,12 @@ __device__ void stats_reduce(uint32_t* __restrict__ hdr, const double* __restric
   }
   if (threadIdx.x == 0) hdr[kHdrStatsBlocks] = 0u;
   __syncthreads();
+}
+
+// (its own launch, between the statistics pass and fine_mark_kernel, which needs the extents)
+__global__ __launch_bounds__(1024) void stats_reduce_kernel(uint32_t* __restrict__ hdr, const double* __restrict__ table,
+                                                           uint32_t n_rows, uint32_t D) {
+  stats_reduce(hdr, table, n_rows, D);
 }
 
 // ---- DC_FLAG_STATS_VALID: the claim checked in two launches (were five: reset, fingerprint, guard, free-energy range,
@@ -290,7 +330,7 @@ __device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows
                                uint32_t* __restrict__ comp);
 
 // Ordering key and value of the rows [i_from, i_to) (compkey_kernel's arithmetic), and in the same pass:
-//   counts[c]     rows of component c among them (LDS, then one atomic per component and block; zero before)
+//   counts        rows of every component among the block's rows: a table [block][kMaxComp], added up by order_meta_kernel
 //   measure       the extents of ALL rows: max |x - origin(component of x)|^2 -> hdr[kHdrMloc], max |x - mean|^2 ->
 //                 hdr[0] (float accumulation with a margin, as order_rows_kernel formed the first one in rounds 3 - 4)
 //   presets       the padded order of n_pos positions: every position kInvalidFrame, every tile the all-pad component
@@ -309,8 +349,28 @@ __global__ __launch_bounds__(256) void order_key_kernel(
   extern __shared__ float org_s[];   // measure: [kMaxComp][D] origins, then the means [D]
   __shared__ uint32_t cnt_s[kMaxComp];
   __shared__ float blk_max[2][4];
+  // the tables a key goes through, in LDS: component of a coarse cell (a byte each, the grid's ncx * ncy cells), fine grid
+  // of a component -- from global memory they were three dependent round trips per row
+  constexpr uint32_t kCellCap = 8192;
+  __shared__ unsigned char cellc_s[kCellCap];
+  __shared__ uint32_t par_s[kMaxComp][8];   // bits(lo0), bits(lo1), bits(c0), bits(c1), nby, first cell, first cell of the next
   if (threadIdx.x < (uint32_t)kMaxComp) cnt_s[threadIdx.x] = 0u;
   const uint32_t n_comp = min(comp[kCompGrid + 5], (uint32_t)kMaxComp);
+  const uint32_t n_cells = comp[kCompGrid + 3] * comp[kCompGrid + 4];
+  const bool cells_in_lds = n_cells <= kCellCap;
+  if (cells_in_lds)
+    for (uint32_t e = threadIdx.x; e < n_cells; e += 256u) cellc_s[e] = (unsigned char)min(comp[kCompCellComp + e], (uint32_t)kMaxComp - 1u);
+  if (threadIdx.x < (uint32_t)kMaxComp) {
+    const uint32_t c = threadIdx.x;
+    const uint32_t* f = comp + kCompFine + 4 * (size_t)c;
+    par_s[c][0] = f[0];
+    par_s[c][1] = f[1];
+    par_s[c][2] = f[2];
+    par_s[c][3] = f[3];
+    par_s[c][4] = comp[kCompNby + c];
+    par_s[c][5] = comp[kCompCellOff + c];
+    par_s[c][6] = comp[kCompCellOff + c + 1];
+  }
   if (measure) {
     const float* origins = reinterpret_cast<const float*>(comp + kCompOrigin);
     const float* mu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(hdr) + kHdrMeans);
@@ -331,16 +391,16 @@ __global__ __launch_bounds__(256) void order_key_kernel(
     const float x = row[0], y = (D > 1) ? row[1] : 0.0f;
     uint32_t c = 0, bx = 0, by = 0, nby = 1;
     if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
-      c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
-      const uint32_t* f = comp + kCompFine + 4 * (size_t)c;
-      const float lo0 = __uint_as_float(f[0]), lo1 = __uint_as_float(f[1]);
-      const float c0 = __uint_as_float(f[2]), c1 = __uint_as_float(f[3]);
-      nby = comp[kCompNby + c];
+      const uint32_t cell = coarse_cell_of_point(g, x, y);
+      c = min(cells_in_lds ? (uint32_t)cellc_s[min(cell, kCellCap - 1u)] : comp[kCompCellComp + cell], (uint32_t)kMaxComp - 1u);
+      const float lo0 = __uint_as_float(par_s[c][0]), lo1 = __uint_as_float(par_s[c][1]);
+      const float c0 = __uint_as_float(par_s[c][2]), c1 = __uint_as_float(par_s[c][3]);
+      nby = par_s[c][4];
       const float fx = fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f), fy = fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f);
       bx = (uint32_t)fx;
       by = min((uint32_t)fy, nby - 1u);
     }
-    const uint32_t lo = comp[kCompCellOff + c], hi = comp[kCompCellOff + c + 1];
+    const uint32_t lo = par_s[c][5], hi = par_s[c][6];
     uint32_t key = min(lo + bx * nby + by, hi - (hi > lo ? 1u : 0u));
     if (fe) {
       const float span = fe_hi - fe_lo;
@@ -393,26 +453,52 @@ __global__ __launch_bounds__(256) void order_key_kernel(
     const uint32_t bits = __float_as_uint(m);
     if (bits > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, bits);
   }
-  if (threadIdx.x < (uint32_t)kMaxComp && cnt_s[threadIdx.x] != 0u) atomicAdd(&counts[threadIdx.x], cnt_s[threadIdx.x]);
+  // the block's rows per component: a row of the table [block][kMaxComp] (order_meta_kernel adds the rows up: three
+  // atomics per block on the same three words were a third of this pass at C3)
+  if (threadIdx.x < (uint32_t)kMaxComp) counts[(size_t)blockIdx.x * kMaxComp + threadIdx.x] = cnt_s[threadIdx.x];
 }
 
-// One thread: from the rows per component (counts, overwritten) the first sorted index of every component (start), the
-// tile range of every component in the padded order (range; entry kMaxComp: the empty range of the all-pad tiles) and the
-// first position of every component (base) -- comp_start_kernel + comp_ranges_kernel of rounds 3 - 4.  r2max != NaN: also
-// the scale of the sweep that follows (scale_kernel): r2max < 0 the neighbour rule, else the population rule.
-__global__ void order_meta_kernel(uint32_t* __restrict__ hdr, uint32_t* __restrict__ comp, uint32_t* __restrict__ start /* [kMaxComp + 1]: counts in */,
-                                  uint32_t* __restrict__ range /* [kMaxComp + 1][2] */, uint32_t* __restrict__ base /* [kMaxComp + 1] */,
-                                  uint32_t n, uint32_t group_rows, int do_scale, float r2max, uint32_t D) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One workgroup: the rows per component (the table order_key_kernel left: [n_blocks][kMaxComp]) added up, then -- one thread --
+// the first sorted index of every component (start), the tile range of every component in the padded order (range; entry
+// kMaxComp: the empty range of the all-pad tiles) and the first position of every component (base): comp_start_kernel +
+// comp_ranges_kernel of rounds 3 - 4.  do_scale: also the scale of the sweep that follows (scale_kernel): r2max < 0 the
+// neighbour rule, else the population rule.
+__global__ __launch_bounds__(1024) void order_meta_kernel(uint32_t* __restrict__ hdr, uint32_t* __restrict__ comp,
+                                                         const uint32_t* __restrict__ table, uint32_t n_blocks,
+                                                         uint32_t* __restrict__ start /* [kMaxComp + 1] */,
+                                                         uint32_t* __restrict__ range /* [kMaxComp + 1][2] */,
+                                                         uint32_t* __restrict__ base /* [kMaxComp + 1] */, uint32_t n,
+                                                         uint32_t group_rows, int do_scale, float r2max, uint32_t D) {
+  __shared__ uint32_t part[16][kMaxComp];
+  __shared__ uint32_t cnt[kMaxComp];
+  {
+    const uint32_t c = threadIdx.x & 63u, l = threadIdx.x >> 6;   // 16 groups of 64 threads: component c, blocks l, l + 16, ..
+    uint32_t sum = 0;
+    for (uint32_t b0 = l; b0 < n_blocks; b0 += 64u) {   // (four loads in flight)
+      uint32_t v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) v[q] = (b0 + 16u * q < n_blocks) ? table[(size_t)(b0 + 16u * q) * kMaxComp + c] : 0u;
+      sum += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    part[l][c] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)kMaxComp) {
+    uint32_t sum = 0;
+    for (int l = 0; l < 16; ++l) sum += part[l][threadIdx.x];
+    cnt[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   uint32_t run = 0, s = 0;
   for (int c = 0; c < kMaxComp; ++c) {
-    const uint32_t cnt = start[c];
+    const uint32_t k = cnt[c];
     start[c] = run;
-    const uint32_t padded = ((cnt + group_rows - 1) / group_rows) * group_rows;
+    const uint32_t padded = ((k + group_rows - 1) / group_rows) * group_rows;
     range[2 * c] = s / 32;
     range[2 * c + 1] = (s + padded) / 32;
     base[c] = s;
-    run += cnt;
+    run += k;
     s += padded;
   }
   start[kMaxComp] = n;   // (= run)
@@ -523,7 +609,8 @@ __global__ __launch_bounds__(256) void order_rows2_kernel(
     uint32_t* __restrict__ invpos, float2* __restrict__ ferange, const uint32_t* __restrict__ tile_comp,
     const float* __restrict__ origins, uint32_t* __restrict__ hdr, uint4* __restrict__ img_a, int a_form,
     float* __restrict__ norms_a, uint4* __restrict__ img_b, float* __restrict__ norms_b, uint32_t grp_tq, QSeg grp,
-    unsigned long long* __restrict__ hash_slots) {
+    unsigned long long* __restrict__ hash_slots, uint32_t* __restrict__ zero_pos, uint32_t zero_planes) {
+  // (zero_pos: zero_planes arrays of n_pos words cleared by the way -- the counts by position of a symmetric population sweep)
   extern __shared__ float or_tile[];            // [256][D | 1], then per wave: K rows of a tile, origin
   __shared__ uint32_t s_frame[256];
   __shared__ unsigned long long fp_part[4];
@@ -531,6 +618,8 @@ __global__ __launch_bounds__(256) void order_rows2_kernel(
   const uint32_t pos0 = blockIdx.x * 256u, pos = pos0 + threadIdx.x, n_pos = 32u * T;
   const uint32_t frame = (pos < n_pos) ? perm[pos] : kInvalidFrame;
   s_frame[threadIdx.x] = frame;
+  if (zero_pos && pos < n_pos)
+    for (uint32_t z = 0; z < zero_planes; ++z) zero_pos[(size_t)z * n_pos + pos] = 0u;
   __syncthreads();
   const size_t base = (size_t)pos0 * D, total = (size_t)n_pos * D;
   // (four elements per thread and step, their loads issued together)

@@ -23,7 +23,7 @@ python3 - <<'PY'
 import csv, glob, os
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/trace_c2/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "colsum_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "stats_kernel" in r["Kernel_Name"]]
 i0 = idx[-1] - 1
 t0 = int(rows[i0]["Start_Timestamp"]); prev_end = t0
 for r in rows[i0:]:
