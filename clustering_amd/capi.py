@@ -23,7 +23,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA
 SYMBOLS = (
     "dc_hip_last_error", "dc_hip_abi_version", "dc_hip_device_count", "dc_hip_workspace_bytes",
     "dc_hip_populations_dev", "dc_hip_free_energies_dev", "dc_hip_nearest_neighbors_dev",
-    "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_workspace_mfma_counters_dev", "dc_hip_sweep_timing", "dc_hip_last_sweep_ms", "dc_hip_workspace_components_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
+    "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_workspace_mfma_counters_dev", "dc_hip_workspace_layout_status_dev", "dc_hip_sweep_timing", "dc_hip_last_sweep_ms", "dc_hip_workspace_components_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs", "dc_hip_radius_min_edge_dev", "dc_hip_radius_forest",
     "dc_hip_populations_segment_dev", "dc_hip_nearest_neighbors_segment_dev",
     "dc_hip_neighbors_pack_dev", "dc_hip_neighbors_unpack_dev", "dc_hip_neighbors_block_rows",
@@ -122,6 +122,8 @@ def _load():
     lib.dc_hip_session_merge_mode.argtypes = [vp]
     lib.dc_hip_workspace_mfma_counters_dev.restype = i32
     lib.dc_hip_workspace_mfma_counters_dev.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
+    lib.dc_hip_workspace_layout_status_dev.restype = i32
+    lib.dc_hip_workspace_layout_status_dev.argtypes = [vp, C.POINTER(C.c_int), vp]
     lib.dc_hip_session_merge_note.restype = C.c_char_p
     lib.dc_hip_session_merge_note.argtypes = [vp]
     lib.dc_hip_session_counters.restype = i32

@@ -173,6 +173,16 @@ int dc_hip_workspace_counters_dev(const void* d_workspace, uint64_t* pop_tiles, 
   return DC_OK;
 }
 
+int dc_hip_workspace_layout_status_dev(const void* d_workspace, int* mismatch, void* stream) {
+  if (!d_workspace || !mismatch) return fail(DC_ERR_INVALID_ARGUMENT, "null argument");
+  uint32_t w = 0;   // header word 18 (dc_mfma_kernels.hpp kHdrLayoutBad)
+  hipStream_t s = (hipStream_t)stream;
+  DC_HIP_TRY(hipMemcpyAsync(&w, (const char*)d_workspace + 4 * 18, sizeof(w), hipMemcpyDeviceToHost, s));
+  DC_HIP_TRY(hipStreamSynchronize(s));
+  *mismatch = w != 0u ? 1 : 0;
+  return DC_OK;
+}
+
 int dc_hip_workspace_mfma_counters_dev(const void* d_workspace, uint64_t* pop_mfma, uint64_t* nn_mfma, void* stream) {
   if (!d_workspace) return fail(DC_ERR_INVALID_ARGUMENT, "null workspace");
   uint32_t h[32];   // header words 6..7 (population sweeps), 26..27 (neighbour sweeps): dc_mfma_kernels.hpp kHdrMfma*

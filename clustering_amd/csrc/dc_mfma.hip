@@ -2175,7 +2175,26 @@ __global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G
                                        uint32_t n_pos, uint32_t gsize, uint32_t G, uint32_t seg_blk, uint32_t block_rows,
                                        const uint32_t* __restrict__ perm, const uint32_t* __restrict__ hdr,
                                        uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
-                                       uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+                                       uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2,
+                                       uint32_t* __restrict__ layout_bad) {
+  // Every rank must have packed under the SAME layout (words 0..6 of the blocks' headers): compared here, by every
+  // workgroup before it scatters anything -- on a mismatch nothing is written and the workspace's flag is raised
+  // (dc_hip_workspace_layout_status_dev): a host need not synchronise in front of the unpack to look at the headers.
+  {
+    __shared__ uint32_t bad_s;
+    if (threadIdx.x == 0) bad_s = 0u;
+    __syncthreads();
+    const uint32_t payload = block_rows - kBlockHdrRows;
+    for (uint32_t e = threadIdx.x; e < 7u * G; e += blockDim.x) {
+      const uint32_t r = e / 7u, k = e - 7u * r;
+      if (blocks[(size_t)r * 4u * block_rows + payload + k] != blocks[payload + k]) bad_s = 1u;
+    }
+    __syncthreads();
+    if (layout_bad) {   // (no workspace to flag in: the host's own comparison is the check)
+      if (threadIdx.x == 0 && blockIdx.x == 0) *layout_bad = bad_s;   // this unpack's verdict
+      if (bad_s != 0u) return;
+    }
+  }
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const bool by_position = gsize != 0u && hdr[1] == 0u;
   if (p >= (by_position ? n_pos : n_rows)) return;
@@ -2239,7 +2258,8 @@ void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t 
   hipLaunchKernelGGL(nn_block_unpack_kernel, dim3((n_pos + 255) / 256), dim3(256), 0, stream, d_blocks, n_rows, n_pos,
                      pruned ? nn_group_rows(n_rows, n_cols) : 0u, n_segments, seg_block(n_segments), rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr,
-                     d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
+                     d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2,
+                     p ? (uint32_t*)(const_cast<char*>(p) + 4 * kHdrLayoutBad) : (uint32_t*)nullptr);
 }
 
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,

@@ -337,6 +337,7 @@ constexpr uint32_t kHdrOpen = 30;       // neighbour sweeps: queries listed for 
 // coarse MFMAs, so chains x NM would overstate it.  Addressed relative to the chain counters the kernels already get
 // (words 2..3 / 4..5): + kMfmaCtrPop / + kMfmaCtrNn 64-bit words.
 constexpr uint32_t kHdrMfmaPop = 6, kHdrMfmaNn = 26;
+constexpr uint32_t kHdrLayoutBad = 18;     // nn_block_unpack_kernel: the gathered blocks were packed under different layouts (nothing was unpacked)
 constexpr uint32_t kHdrStatsBlocks = 25;   // rows of stats_kernel's table that components_kernel has still to add up (dc_prep.hpp)
 constexpr int kMfmaCtrPop = (kHdrMfmaPop - 2) / 2, kMfmaCtrNn = (kHdrMfmaNn - 4) / 2;
 constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: max |x - origin(component of x)|^2 (float bits, with a rounding margin)

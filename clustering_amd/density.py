@@ -365,23 +365,42 @@ def check_neighbor_block_layout(blocks):
         raise RuntimeError("neighbour blocks of the ranks were packed under different layouts: " + str(hdr.cpu().tolist()))
 
 
-def unpack_neighbor_blocks(coords, blocks, n_segments, variant="auto", out=None):
+def layout_status(device):
+    """True if the last dc_hip_neighbors_block_unpack_dev in this device's workspace REFUSED its blocks (their layout headers
+    differed: nothing was unpacked) -- dc_hip_workspace_layout_status_dev; synchronises"""
+    ws = _workspace(device)
+    if ws.buf is None:
+        return False
+    bad = C.c_int(0)
+    with torch.cuda.device(device):
+        capi.check(capi.lib.dc_hip_workspace_layout_status_dev(_dev(ws.buf), C.byref(bad), _stream_ptr()),
+                   "dc_hip_workspace_layout_status_dev")
+    return bool(bad.value)
+
+
+def unpack_neighbor_blocks(coords, blocks, n_segments, variant="auto", out=None, check=True):
     """blocks int32 [n_segments, 4, block_rows] gathered from all ranks -> (nn_idx, nn_d2, hd_idx, hd_d2) by frame
-    (dc_hip_neighbors_block_unpack_dev); the blocks' layout headers are compared first"""
+    (dc_hip_neighbors_block_unpack_dev).  The unpack kernel compares the blocks' layout headers itself and writes nothing
+    on a mismatch; check=True asks for its verdict right away (one synchronisation) and raises, check=False leaves that to
+    the caller (layout_status, e.g. once after a timed loop)."""
     n_rows, n_cols = _check_coords(coords)
     dev = coords.device
     rows = neighbor_block_rows(n_rows, n_cols, n_segments)
     assert blocks.is_contiguous() and blocks.dtype == torch.int32 and blocks.numel() == n_segments * 4 * rows
-    check_neighbor_block_layout(blocks.view(n_segments, 4, rows))
     if out is None:
         out = (torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev),
                torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev))
     with torch.cuda.device(dev):
         ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
+        if check and not ws_bytes:   # (no workspace for the kernel to flag in -- shapes without a matrix-core sweep: compared here)
+            check_neighbor_block_layout(blocks.view(n_segments, 4, rows))
         rc = capi.lib.dc_hip_neighbors_block_unpack_dev(_dev(blocks), n_rows, n_cols, n_segments, ws, ws_bytes,
                                                         capi.VARIANTS[variant], _dev(out[0]), _dev(out[1]), _dev(out[2]),
                                                         _dev(out[3]), _stream_ptr())
     capi.check(rc, "dc_hip_neighbors_block_unpack_dev")
+    if check and ws_bytes and layout_status(dev):
+        check_neighbor_block_layout(blocks.view(n_segments, 4, rows))   # (raises, with the headers in the message)
+        raise RuntimeError("neighbour blocks of the ranks were packed under different layouts")
     return out
 
 

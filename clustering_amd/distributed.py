@@ -64,8 +64,11 @@ class HipBackend:
     def pack_neighbor_block(self, coords, nn, segment, n_segments):
         return self._d.pack_neighbor_block(coords, nn[0], nn[1], nn[2], nn[3], segment, n_segments, variant=self.variant)
 
-    def unpack_neighbor_blocks(self, coords, blocks, n_segments):
-        return self._d.unpack_neighbor_blocks(coords, blocks, n_segments, variant=self.variant)
+    def unpack_neighbor_blocks(self, coords, blocks, n_segments, check=True):
+        return self._d.unpack_neighbor_blocks(coords, blocks, n_segments, variant=self.variant, check=check)
+
+    def layout_status(self, device):
+        return self._d.layout_status(device)
 
     def pack_neighbors(self, nn_idx, nn_d2, hd_idx, hd_d2):
         return self._d.pack_neighbors(nn_idx, nn_d2, hd_idx, hd_d2)
@@ -80,9 +83,18 @@ class HipBackend:
 class ShardedDensity:
     """pop -> FE -> NN for the rows of this rank, merged across ranks with two collectives."""
 
-    def __init__(self, backend=None, group=None):
+    def __init__(self, backend=None, group=None, check_layout=True):
+        """check_layout: ask the unpack kernel for its verdict on the gathered blocks' layout headers in every step (one
+        synchronisation); False: the caller asks once, with check_layouts() -- a mismatch leaves the neighbour arrays of that
+        step unwritten either way"""
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
+        self.check_layout = check_layout
+
+    def check_layouts(self, device):
+        """raises if the last unpack on this device refused its blocks (ranks derived different orders)"""
+        if hasattr(self.backend, "layout_status") and self.backend.layout_status(device):
+            raise RuntimeError("neighbour blocks of the ranks were packed under different layouts")
 
     def _world(self):
         if dist.is_available() and dist.is_initialized():
@@ -137,7 +149,10 @@ class ShardedDensity:
                 block = self.backend.pack_neighbor_block(coords, nn, rank, world)
                 gathered = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
                 dist.all_gather_into_tensor(gathered.view(-1), block.view(-1), group=self.group)
-                nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.unpack_neighbor_blocks(coords, gathered, world)
+                if hasattr(self.backend, "layout_status"):
+                    nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.unpack_neighbor_blocks(coords, gathered, world, check=self.check_layout)
+                else:
+                    nn_idx, nn_d2, hd_idx, hd_d2 = self.backend.unpack_neighbor_blocks(coords, gathered, world)
             elif hasattr(self.backend, "pack_neighbors"):     # two library kernels instead of a dozen torch ops
                 # (d2 bits << 32 | index): d2 >= 0, so the words order like (d2, index); one owner per row
                 packed = self.backend.pack_neighbors(*nn)

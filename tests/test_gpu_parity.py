@@ -558,8 +558,13 @@ def test_segments_of_a_sharded_run_merge_to_the_full_result(dens, n_rows, n_cols
     assert all(bool((b[0, -H:-H + 8] == blocks[0][0, -H:-H + 8]).all()) for b in blocks), "one layout for all ranks"
     bad = torch.stack(blocks).contiguous()
     bad[1, 0, -H + 5] ^= 1                                  # a rank that derived another order
+    keep = tuple(torch.full((n_rows,), 7, dtype=dt, device="cuda") for dt in (torch.int32, torch.float32, torch.int32, torch.float32))
     with pytest.raises(RuntimeError):
-        dens.unpack_neighbor_blocks(ct, bad, n_seg)
+        dens.unpack_neighbor_blocks(ct, bad, n_seg, out=keep)
+    if n_cols <= 64:      # (the unpack kernel itself refused the blocks: nothing was scattered into the result arrays)
+        assert all(bool((t == 7).all()) for t in keep)
+        dens.unpack_neighbor_blocks(ct, bad, n_seg, out=keep, check=False)     # a host that asks later ...
+        assert dens.layout_status(ct.device) and all(bool((t == 7).all()) for t in keep)
     for got, want in zip(dens.unpack_neighbor_blocks(ct, torch.stack(blocks).contiguous(), n_seg), full_n):
         assert bool((got.view(torch.int32) == want.view(torch.int32)).all())   # dc_hip_neighbors_block_unpack_dev
 
