@@ -94,21 +94,6 @@ __device__ __forceinline__ void fp_publish(unsigned long long v, unsigned long l
   if (threadIdx.x == 0) atomicAdd(dst, part[0] + part[1] + part[2] + part[3]);
   __syncthreads();
 }
-__global__ __launch_bounds__(256) void fingerprint_kernel(const float* __restrict__ coords, size_t total,
-                                                          unsigned long long* __restrict__ dst) {
-  __shared__ unsigned long long part[4];
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(coords);
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  unsigned long long f = 0;
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; e + 3 * stride < total; e += 4 * stride) {   // four loads in flight
-    const uint32_t v0 = w[e], v1 = w[e + stride], v2 = w[e + 2 * stride], v3 = w[e + 3 * stride];
-    f += fp_term(v0, e) + fp_term(v1, e + stride) + fp_term(v2, e + 2 * stride) + fp_term(v3, e + 3 * stride);
-  }
-  for (; e < total; e += stride) f += fp_term(w[e], e);
-  fp_publish(f, dst, part);
-}
-
 // Header pass over the frames in natural order: max |x'|^2 (word 0), non-finite / overflow flag
 // (word 1) and the extent of columns 0/1 (words 8..11: ~key(min col0), key(max col0), ~key(min col1),
 // key(max col1), all maintained with atomicMax).  |x'|^2 is formed exactly as image_kernel forms it,
@@ -168,19 +153,6 @@ __global__ void rowstats_kernel(const float* __restrict__ coords, uint32_t n_row
   publish_max(hdr + 10, m2, wave_max);
   publish_max(hdr + 11, m3, wave_max);
   fp_publish(fp, reinterpret_cast<unsigned long long*>(hdr + kHdrFp), fp_part);
-}
-
-// DC_FLAG_STATS_VALID: the caller says the header still holds the statistics of these coordinates.  If the cookie
-// (array address and shape) or the content fingerprint (recomputed by this call: words kHdrFp + 2..3) says otherwise
-// -- the previous call on this workspace was not a matrix-core sweep over the same array, or the array has been
-// rewritten since -- the data is flagged: the matrix-core kernels stand down and the gated direct kernels answer --
-// slow, never wrong.
-// Flag word 1: bit 0 = non-finite / overflow-prone coordinates (a statistic: it stays), bit 1 = cookie mismatch,
-// bit 2 = NaN free energies (belongs to one neighbour sweep: cleared here).
-__global__ void stats_guard_kernel(uint32_t* __restrict__ hdr, uint32_t cookie) {
-  const bool same = hdr[kHdrCookie] == cookie && hdr[kHdrFp] == hdr[kHdrFp + 2] && hdr[kHdrFp + 1] == hdr[kHdrFp + 3];
-  hdr[1] = (hdr[1] & 1u) | (same ? 0u : 2u);
-  if (!same) hdr[kHdrCookie] = 0u;   // (the component partition in the workspace is not this array's either)
 }
 
 // dynamic LDS of image_kernel: per wave of the 256-thread block the 32 rows of its tile and their origin
@@ -754,15 +726,6 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   DC_STAMP(6);
 }
 
-// row tiles of 256 x (D | 1) floats: 66 560 bytes at D = 64, above the 64 KB a launch gets without asking
-template <typename K>
-static size_t row_tile_smem(K kernel, uint32_t n_cols) {
-  const size_t bytes = sizeof(float) * 256 * (n_cols | 1u);
-  if (bytes > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return bytes;
-}
-
 // dynamic LDS of components_kernel (the cell map); with its static arrays the workgroup needs 81 KB of the CU's 160
 static size_t components_smem() {
   constexpr size_t bytes = sizeof(uint16_t) * kCoarseDim * kCoarseDim;
@@ -801,13 +764,6 @@ __device__ void comp_guard_body(const uint32_t* __restrict__ hdr, const float* _
     if (threadIdx.x == 0) fine_grid_body(hdr, n_rows, fine_frames_per_cell, fine_bits, comp);
   }
 }
-__global__ __launch_bounds__(1024) void comp_guard_kernel(const uint32_t* __restrict__ hdr, const float* __restrict__ means,
-                                                         uint32_t D, uint32_t* __restrict__ comp, uint32_t cookie,
-                                                         uint32_t n_rows = 0, float fine_frames_per_cell = 0.0f,
-                                                         uint32_t fine_bits = 0) {
-  comp_guard_body(hdr, means, D, comp, cookie, n_rows, fine_frames_per_cell, fine_bits);
-}
-
 // the fine cell grids of the components for one sweep (frames_per_cell is the sweep's own): one cell size for all
 // components (at most 4001 cells per dimension and component), the cells of all components numbered consecutively --
 // fewer than 2^fine_bits of them, so the ordering keys stay short
@@ -860,113 +816,6 @@ __device__ void fine_grid_body(const uint32_t* __restrict__ hdr, uint32_t n_rows
     off = min(off + nx * ny, (1u << fine_bits) - 1u);
   }
   for (uint32_t c = n_comp; c <= (uint32_t)kMaxComp; ++c) comp[kCompCellOff + c] = off;
-}
-__global__ void fine_grid_kernel(const uint32_t* __restrict__ hdr, uint32_t n_rows, float frames_per_cell,
-                                 uint32_t fine_bits, uint32_t* __restrict__ comp) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  fine_grid_body(hdr, n_rows, frames_per_cell, fine_bits, comp);
-}
-
-// ordering key of the pruned population sweeps: (component, cell of the component's fine grid on columns 0/1) for
-// the rows [i_from, i_to): keys[j], vals[j] = key, id of row i_from + j
-__global__ void compkey_kernel(const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ hdr,
-                               float r_max, const uint32_t* __restrict__ comp, uint32_t fine_bits, uint32_t i_from,
-                               uint32_t i_to, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                               uint32_t n_total = 0, const float* __restrict__ fe = nullptr, uint32_t fe_bits = 0) {
-  // fe / fe_bits (the neighbour sweep): the cell number moves up by fe_bits and the free energy, quantised linearly
-  // between the smallest and the largest finite value of the data set (header words 12 / 13), fills the low bits --
-  // the order inside a cell only shapes the tiles' free-energy ranges (the kernels read the ranges, they assume no
-  // order), so the quantisation costs a little pruning at worst and saves a second stable sort
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t i = i_from + j;
-  if (i >= i_to) return;
-  const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-  (void)r_max;   // (the grid of the partition in use: its own connectivity length)
-  const CoarseGrid g = coarse_grid(hdr, comp_r_conn(comp), n_total);
-  uint32_t c = 0, bx = 0, by = 0, nby = 1;
-  if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX) {
-    c = comp[kCompCellComp + coarse_cell_of_point(g, x, y)];
-    const uint32_t* f = comp + kCompFine + 4 * (size_t)c;
-    const float lo0 = __uint_as_float(f[0]), lo1 = __uint_as_float(f[1]);
-    const float c0 = __uint_as_float(f[2]), c1 = __uint_as_float(f[3]);
-    nby = comp[kCompNby + c];
-    const float fx = fminf(fmaxf((x - lo0) / c0, 0.0f), 4001.0f), fy = fminf(fmaxf((y - lo1) / c1, 0.0f), 4001.0f);
-    bx = (uint32_t)fx;
-    by = min((uint32_t)fy, nby - 1u);
-  }
-  // cells of all components numbered consecutively (kCompCellOff): fewer than 2^fine_bits keys
-  const uint32_t lo = comp[kCompCellOff + c], hi = comp[kCompCellOff + c + 1];
-  uint32_t key = min(lo + bx * nby + by, hi - (hi > lo ? 1u : 0u));
-  if (fe) {
-    const float fe_lo = fkey_inv(~hdr[12]), fe_hi = fkey_inv(hdr[13]);
-    const float span = fe_hi - fe_lo;
-    float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;
-    u = fminf(fmaxf(u, 0.0f), 1.0f);                                // (+inf -> 1, -inf / NaN -> 0)
-    const uint32_t levels = (1u << fe_bits) - 1u;
-    const uint32_t level = (uint32_t)((double)u * (double)levels);
-    key = (key << fe_bits) | level;
-  }
-  keys[j] = key;
-  vals[j] = i;
-}
-
-// After the sort: where each component starts in the sorted list (a component without frames starts where the next
-// one does) ...
-// component of a (sorted) cell key: the last component whose first cell is not beyond it; key_shift: the cell key sits
-// above key_shift bits of something else (the neighbour sweep's quantised free energy)
-__device__ __forceinline__ uint32_t comp_of_key(const uint32_t* __restrict__ comp, uint32_t key, uint32_t key_shift) {
-  const uint32_t cellk = key >> key_shift, n_comp = comp[kCompGrid + 5];
-  uint32_t c = 0;
-  for (uint32_t k = 1; k < n_comp; ++k) c += (comp[kCompCellOff + k] <= cellk) ? 1u : 0u;
-  return c;
-}
-// (this kernel also presets the padded order: every position kInvalidFrame, every tile the all-pad component)
-__global__ void comp_start_kernel(const uint32_t* __restrict__ keys_sorted, uint32_t n, uint32_t key_shift,
-                                  const uint32_t* __restrict__ comp, uint32_t* __restrict__ start /* [kMaxComp + 1], preset to n */,
-                                  uint32_t* __restrict__ perm, uint32_t* __restrict__ tile_comp, uint32_t T_used) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 32u * T_used) perm[i] = kInvalidFrame;
-  if (i < T_used) tile_comp[i] = kMaxComp;
-  if (i >= n) return;
-  const uint32_t c = comp_of_key(comp, keys_sorted[i], key_shift);
-  const uint32_t prev = (i == 0) ? 0xFFFFFFFFu : comp_of_key(comp, keys_sorted[i - 1], key_shift);
-  if (c != prev) start[c] = i;
-}
-// ... the tile range of every component once each is padded to whole query groups (group_rows positions) ...
-__global__ void comp_ranges_kernel(uint32_t* __restrict__ start, uint32_t n, uint32_t group_rows,
-                                   uint32_t* __restrict__ range /* [kMaxComp + 1][2] */) {
-  if (threadIdx.x != 0) return;
-  // (empty components: their start was never written -- take the next one's)
-  uint32_t next = n;
-  for (int c = kMaxComp - 1; c >= 0; --c) {
-    if (start[c] > next) start[c] = next;   // (preset n; a real start is never beyond the next component's)
-    next = start[c];
-  }
-  start[kMaxComp] = n;
-  uint32_t s = 0;
-  for (int c = 0; c < kMaxComp; ++c) {
-    const uint32_t cnt = start[c + 1] - start[c];
-    const uint32_t padded = ((cnt + group_rows - 1) / group_rows) * group_rows;
-    range[2 * c] = s / 32;
-    range[2 * c + 1] = (s + padded) / 32;
-    s += padded;
-  }
-  range[2 * kMaxComp] = 0;
-  range[2 * kMaxComp + 1] = 0;
-}
-// ... and the padded order itself: sorted entry i of component c goes to position 32 range[c].lo + (i - start[c]);
-// every other position keeps kInvalidFrame, every tile gets its component (preset: kMaxComp, the all-pad tiles)
-__global__ void pad_scatter_kernel(const uint32_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted,
-                                   uint32_t n, uint32_t key_shift, const uint32_t* __restrict__ comp,
-                                   const uint32_t* __restrict__ start,
-                                   const uint32_t* __restrict__ range, uint32_t* __restrict__ perm,
-                                   uint32_t* __restrict__ tile_comp) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t c = comp_of_key(comp, keys_sorted[i], key_shift);
-  const uint32_t pos = 32u * range[2 * c] + (i - start[c]);
-  perm[pos] = vals_sorted[i];
-  if ((pos & 31u) == 0) tile_comp[pos >> 5] = c;
 }
 
 // Frame pairs between ADJACENT components (rho = r_max / 2: components may come closer than the largest radius): the
@@ -1053,137 +902,6 @@ __global__ __launch_bounds__(64) void pop_cross_kernel(
         atomicAdd(&out[(size_t)(pq >> 5) * (stride * 32) + (size_t)rr * 32 + (pq & 31u)], v);
       else
         atomicAdd(&out[(size_t)rr * stride + (by_position ? pq : fq)], v);
-    }
-  }
-}
-
-// bounding box (lo0, hi0, lo1, hi1) of the frames of each tile of an ordered frame list
-__global__ void box_kernel(const float* __restrict__ coords, uint32_t D,
-                           const uint32_t* __restrict__ perm, uint32_t n_used, uint32_t T,
-                           float4* __restrict__ boxes, const float* __restrict__ fe,
-                           float2* __restrict__ ferange) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
-  float lo0 = INFINITY, hi0 = -INFINITY, lo1 = INFINITY, hi1 = -INFINITY;
-  float flo = INFINITY, fhi = -INFINITY;
-  for (uint32_t r = 0; r < 32; ++r) {
-    const uint32_t pos = t * 32 + r;
-    if (pos >= n_used) break;
-    const uint32_t i = perm[pos];
-    if (i == kInvalidFrame) continue;   // (a pad position of the order)
-    const float x = coords[(size_t)i * D], y = (D > 1) ? coords[(size_t)i * D + 1] : 0.0f;
-    lo0 = fminf(lo0, x);
-    hi0 = fmaxf(hi0, x);
-    lo1 = fminf(lo1, y);
-    hi1 = fmaxf(hi1, y);
-    if (fe) {
-      flo = fminf(flo, fe[i]);
-      fhi = fmaxf(fhi, fe[i]);
-    }
-  }
-  boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
-  if (ferange) ferange[t] = make_float2(flo, fhi);
-}
-
-
-// original coordinates gathered into an ordered frame list (the exact path then needs no
-// permutation look-up before it can fetch a row)
-// The rows of an order in one pass (a gather, a box and a free-energy kernel before, which each read the rows
-// again): 256 positions = 8 tiles per block.  The rows are gathered element-wise (40-byte runs of the source,
-// coalesced stores) and parked in LDS, from where every row's lane takes what the tile boxes, the free-energy ranges
-// and the component-wise extent need (hdr[kHdrMloc]: the maximum over the rows of |x - origin(component of the row's
-// tile)|^2, what the sweep's scale and guard band follow when there are several components, scale_kernel).
-// fe == nullptr: a population sweep.
-__global__ __launch_bounds__(256) void order_rows_kernel(
-    const float* __restrict__ coords, uint32_t D, const uint32_t* __restrict__ perm, uint32_t T,
-    float* __restrict__ coords_o, float4* __restrict__ boxes, const float* __restrict__ fe, float* __restrict__ fe_s,
-    uint32_t* __restrict__ invpos, float2* __restrict__ ferange, const uint32_t* __restrict__ tile_comp,
-    const float* __restrict__ origins, uint32_t* __restrict__ hdr) {
-  extern __shared__ float or_tile[];            // [256][D | 1]
-  __shared__ uint32_t s_frame[256];
-  __shared__ float blk_max[4];
-  const uint32_t Dp = D | 1u;
-  const uint32_t pos0 = blockIdx.x * 256u, pos = pos0 + threadIdx.x, n_pos = 32u * T;
-  const uint32_t frame = (pos < n_pos) ? perm[pos] : kInvalidFrame;
-  s_frame[threadIdx.x] = frame;
-  __syncthreads();
-  const size_t base = (size_t)pos0 * D, total = (size_t)n_pos * D;
-  // (four elements per thread and step, their loads issued together: a load per trip of this run-time loop waited for each)
-  for (uint32_t e0 = threadIdx.x; e0 < 256u * D; e0 += 1024u) {
-    float v[4];
-    uint32_t off[4];
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t e = e0 + 256u * j;
-      const uint32_t r = min(e / D, 255u), k = e - (e / D) * D;
-      const uint32_t i = s_frame[r];
-      off[j] = r * Dp + k;
-      v[j] = (e < 256u * D && i != kInvalidFrame) ? coords[(size_t)i * D + k] : 0.0f;   // (pad positions of a padded order)
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t e = e0 + 256u * j;
-      if (e < 256u * D) {
-        or_tile[off[j]] = v[j];
-        if (base + e < total) coords_o[base + e] = v[j];
-      }
-    }
-  }
-  __syncthreads();
-  const bool in_range = pos < n_pos, live = frame != kInvalidFrame;
-  const uint32_t t = min(pos >> 5, T - 1);
-  const float* row = or_tile + threadIdx.x * Dp;
-  const float x = live ? row[0] : 0.0f, y = (live && D > 1) ? row[1] : 0.0f;
-  float lo0 = live ? x : INFINITY, hi0 = live ? x : -INFINITY;
-  float lo1 = live ? y : INFINITY, hi1 = live ? y : -INFINITY;
-  float flo = INFINITY, fhi = -INFINITY;
-  if (fe) {
-    const float f = live ? fe[frame] : INFINITY;
-    if (in_range) fe_s[pos] = f;
-    if (live) {
-      invpos[frame] = pos;
-      flo = f;
-      fhi = f;
-    }
-  }
-  float ext = 0.0f;
-  if (live) {
-    const float* a = origins + (size_t)tile_comp[t] * kMaxCols;
-    for (uint32_t k0 = 0; k0 < D; k0 += 4) {   // (four origin words per step, loaded together)
-      float av[4];
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j) av[j] = a[min(k0 + j, D - 1u)];
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j)
-        if (k0 + j < D) {
-          const float v = row[k0 + j] - av[j];
-          ext += v * v;
-        }
-    }
-    ext = ext * 1.0001f + FLT_MIN;
-  }
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    lo0 = fminf(lo0, __shfl_xor(lo0, off, 64));
-    hi0 = fmaxf(hi0, __shfl_xor(hi0, off, 64));
-    lo1 = fminf(lo1, __shfl_xor(lo1, off, 64));
-    hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
-    flo = fminf(flo, __shfl_xor(flo, off, 64));
-    fhi = fmaxf(fhi, __shfl_xor(fhi, off, 64));
-    ext = fmaxf(ext, __shfl_xor(ext, off, 64));
-  }
-  if ((pos & 31u) == 0 && in_range) {
-    boxes[t] = make_float4(lo0, hi0, lo1, hi1);   // empty tile: (+inf, -inf, ..): infinitely far
-    if (ferange) ferange[t] = make_float2(flo, fhi);
-  }
-  ext = fmaxf(ext, __shfl_xor(ext, 32, 64));
-  if ((threadIdx.x & 63u) == 0) blk_max[threadIdx.x >> 6] = ext;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float m = fmaxf(fmaxf(blk_max[0], blk_max[1]), fmaxf(blk_max[2], blk_max[3]));
-    if (m <= FLT_MAX) {
-      const uint32_t bits = __float_as_uint(m);
-      if (bits > __atomic_load_n(hdr + kHdrMloc, __ATOMIC_RELAXED)) atomicMax(hdr + kHdrMloc, bits);
     }
   }
 }
@@ -1293,24 +1011,6 @@ size_t mfma_workspace_bytes(size_t n_rows, size_t n_cols) {
 // whose statistics / components a workspace holds: the array (address) and its shape
 static uint32_t data_cookie(const float* d_coords, uint32_t n_rows, uint32_t n_cols) {
   return (0x5354A7u ^ (n_rows * 2654435761u) ^ (n_cols * 40503u) ^ (uint32_t)((uintptr_t)d_coords >> 4)) | 1u;
-}
-
-// the per-sweep words of a header whose statistics stay (DC_FLAG_STATS_VALID): evaluated-tile counters (words 2..5), the
-// free-energy range (12..13), the fingerprint the guard recomputes (kHdrFp + 2, + 3), the extent over the components
-// (a header built from scratch starts from zeros altogether)
-__global__ void sweep_words_reset_kernel(uint32_t* __restrict__ hdr, int pruned) {
-  const uint32_t k = threadIdx.x;
-  if (k == 0u && pruned) hdr[k] = 0u;   // (max |x - mean|^2: order_key_kernel of this call forms it again, like word kHdrMloc)
-  if (k == kHdrFp + 4u || k == kHdrFp + 5u) hdr[k] = 0u;   // (hash of the neighbour sweep's order: order_rows2_kernel adds to it)
-  if (k >= 2u && k <= 7u) hdr[k] = 0u;                         // (... and the MFMAs the population sweeps issued, 6..7)
-  if (k == kHdrMfmaNn || k == kHdrMfmaNn + 1u) hdr[k] = 0u;   // (the neighbour sweeps')
-  if (k == 12u || k == 13u) hdr[k] = 0u;
-  if (k == kHdrFp + 2u || k == kHdrFp + 3u) hdr[k] = 0u;
-  // (the extent over the components: order_rows_kernel of this call forms it again with atomicMax.  INVARIANT: every
-  //  preparation of an order -- prep == true in pop_pruned_one, every nn_pruned_sel -- runs behind a mfma_prepare of the
-  //  SAME API call, which clears the word here or with the header memset; a second preparation on one header without it
-  //  would keep the maximum of the earlier partitions: a wider band, slower, never wrong.)
-  if (k == kHdrMloc) hdr[k] = 0u;
 }
 
 // DC_POP_CELL_FRAMES / DC_NN_CELL_FRAMES: measurement overrides of the frames per cell of the orderings
@@ -1553,19 +1253,6 @@ void launch_radius_min_edge(const float* d_coords, uint32_t n_rows, uint32_t n_c
   const EdgeSink sink{nullptr, nullptr, 0, d_comp, d_rank, d_best};
   pop_pruned_one(d_coords, n_rows, n_cols, QuerySel{0, n_rows, segment, n_segments}, one, 1, d_pops, d_ws,
                  &sink, stream, r2, true, true);
-}
-
-// the padded order of a sorted (component, fine cell) list: perm[position] = frame or kInvalidFrame, tile_comp[tile]
-static void pad_order(const uint32_t* keys_sorted, const uint32_t* vals_sorted, uint32_t n, unsigned key_shift,
-                      uint32_t group_rows, const uint32_t* comp, uint32_t* start, uint32_t* range, uint32_t* perm,
-                      uint32_t* tile_comp, uint32_t T_used, hipStream_t stream) {
-  (void)hipMemsetD32Async((hipDeviceptr_t)start, (int)n, kMaxComp + 1, stream);
-  const dim3 blk(256), grid((n + 255) / 256);
-  hipLaunchKernelGGL(comp_start_kernel, dim3((32 * T_used + 255) / 256), blk, 0, stream, keys_sorted, n,
-                     (uint32_t)key_shift, comp, start, perm, tile_comp, T_used);
-  hipLaunchKernelGGL(comp_ranges_kernel, dim3(1), dim3(64), 0, stream, start, n, group_rows, range);
-  hipLaunchKernelGGL(pad_scatter_kernel, grid, blk, 0, stream, keys_sorted, vals_sorted, n, (uint32_t)key_shift, comp,
-                     (const uint32_t*)start, (const uint32_t*)range, perm, tile_comp);
 }
 
 uint32_t seg_block(uint32_t n_segments) { return n_segments <= 1u ? 1u : kSegBlockGroups; }
@@ -2122,13 +1809,6 @@ __device__ __forceinline__ uint32_t block_none(uint32_t c, uint32_t n_rows) {
 // order itself): every rank must have derived the SAME order, or its rows would be scattered to the wrong frames
 // without any sign.  The hosts compare the headers of the gathered blocks (clustering_amd/distributed.py, dc_session.hip).
 constexpr uint32_t kBlockHdrRows = 32, kBlockMagic = 0x6E6E4200u;   // "nnB" | by_position
-__global__ __launch_bounds__(256) void perm_hash_kernel(const uint32_t* __restrict__ perm, uint32_t n_pos,
-                                                        unsigned long long* __restrict__ dst) {
-  __shared__ unsigned long long part[4];
-  unsigned long long f = 0;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pos; p += gridDim.x * blockDim.x) f += fp_term(perm[p], p);
-  fp_publish(f, dst, part);
-}
 __global__ void nn_block_pack_kernel(const uint32_t* __restrict__ nn_idx, const float* __restrict__ nn_d2,
                                      const uint32_t* __restrict__ hd_idx, const float* __restrict__ hd_d2,
                                      uint32_t n_rows, uint32_t n_pos /* positions of the padded order */,

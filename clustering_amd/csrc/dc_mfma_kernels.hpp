@@ -2078,6 +2078,10 @@ __device__ __forceinline__ void load_tile_folded(const uint4* __restrict__ img, 
   }
 }
 
+#ifdef DC_WAVE_STAMPS
+constexpr uint32_t kDbgWaves = 1u << 17;
+__device__ unsigned long long g_wave_dbg[kDbgWaves][6];
+#endif
 template <int NM, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -2112,6 +2116,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;
+#ifdef DC_WAVE_STAMPS
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
   // (the component of the group, its tile range and cell edge: three dependent look-ups, started before everything else)
   const uint32_t my_comp = CV.tile_comp_q[qt0];
   const uint32_t comp_lo = CV.range_r[2 * my_comp], comp_hi = CV.range_r[2 * my_comp + 1];
@@ -2291,9 +2298,17 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
   if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
+#ifdef DC_WAVE_STAMPS
+  const unsigned long long dbg_t1 = wall_clock64();
+  unsigned long long dbg_scan = 0, dbg_flush = 0;
+  uint32_t dbg_rings = 0;
+#endif
   for (;;) {
     for (uint32_t base = u_lo; base < U; base += kListCap) {
       uint32_t cnt = 0;
+#ifdef DC_WAVE_STAMPS
+      const unsigned long long dbg_ts = wall_clock64();
+#endif
       const uint32_t lim = min(U - base, (uint32_t)kListCap);
       auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
       // (box_t: the boxes of this share stored contiguously -- a step of the scan reads 1 KB instead of
@@ -2316,6 +2331,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
         cnt += (uint32_t)__builtin_popcountll(m);
       }
+#ifdef DC_WAVE_STAMPS
+      dbg_scan += wall_clock64() - dbg_ts;
+#endif
       if (cnt == 0) continue;
       visited += cnt;
       // Reference tile data in two register buffers (the loads run one survivor ahead); the chains
@@ -2544,7 +2562,11 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
       }
     }
+#ifdef DC_WAVE_STAMPS
+    { const unsigned long long tf = wall_clock64(); flush(); dbg_flush += wall_clock64() - tf; ++dbg_rings; }
+#else
     flush();                                          // the settle test needs the exact incumbents (in LDS)
+#endif
     if (!(r2_hi <= FLT_MAX) || visited >= U - u_lo)
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
@@ -2574,6 +2596,19 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     }
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
   }
+#ifdef DC_WAVE_STAMPS
+  if (lane == 0) {
+    const uint32_t wid = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (uint32_t)wib;
+    if (wid < kDbgWaves) {
+      g_wave_dbg[wid][0] = dbg_t0;
+      g_wave_dbg[wid][1] = wall_clock64();
+      g_wave_dbg[wid][2] = ((unsigned long long)chains << 32) | wave;
+      g_wave_dbg[wid][3] = dbg_t1;
+      g_wave_dbg[wid][4] = (dbg_scan << 32) | (dbg_flush & 0xFFFFFFFFull);
+      g_wave_dbg[wid][5] = ((unsigned long long)dbg_rings << 32) | chains_on;
+    }
+  }
+#endif
   if (lane == 0 && chain_counter) {
     atomicAdd(chain_counter, (unsigned long long)chains);
     atomicAdd(chain_counter + kMfmaCtrNn, kNnEarly<NM> ? (unsigned long long)chains * kNnCoarse<NM> + (unsigned long long)chains_on * NM

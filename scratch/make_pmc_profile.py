@@ -41,7 +41,7 @@ out = {"note": "rocprofv3 --kernel-trace --pmc, counters in their own passes (SQ
                "matrix_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); "
                "valu_insts_per_32x32_tile_pair divides by the evaluated tile pairs the kernels counted themselves. "
                "A population call sweeps once per radius: per-dispatch values are per radius.",
-       "workload": workload, "csrc_digest": (open('gpurun_out/r4_csrc_digest.txt').read().strip() if __import__('os').path.exists('gpurun_out/r4_csrc_digest.txt') else None),
+       "workload": workload, "csrc_digest": (next((open(f).read().strip() for f in ('gpurun_out/' + tag.split('_')[0] + '_csrc_digest.txt', 'gpurun_out/r4_csrc_digest.txt') if __import__('os').path.exists(f)), None)),
        "commit": subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None,
        "kernels": {}}
 for k in set(sq) | set(mem):

@@ -1,0 +1,41 @@
+"""per-wave durations of nn_pruned_kernel in one segment of eight (a build with -DDC_WAVE_STAMPS, DC_LIB_PATH):
+how much of the launch is its end (slots idle behind the last long waves) and how uneven the waves are"""
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, '.')
+from clustering_amd import density as dens, capi
+from clustering_amd.synth import gaussian_blobs
+n, d, G = 1000000, 10, int(sys.argv[1]) if len(sys.argv) > 1 else 8
+c = torch.from_numpy(gaussian_blobs(n, d)).cuda()
+pops = dens.calculate_populations_partial(c, [0.2])
+fe = dens.calculate_free_energies(pops[0].contiguous())
+dens.sweep_timing(True)
+for seg in ((0, 3) if G > 1 else (0,)):
+    dens.calculate_populations_segment(c, [0.2], seg, G)
+    dens.nearest_neighbors_segment(c, fe, seg, G, stats_valid=True) if G > 1 else dens.nearest_neighbors_partial(c, fe, stats_valid=True)
+    torch.cuda.synchronize()
+    kms = dens.last_sweep_ms("nn", c.device)
+    N = 1 << 17
+    buf = np.zeros((N, 6), dtype=np.uint64)
+    rc = capi.lib.dc_dbg_wave_times(buf.ctypes.data_as(C.c_void_p), C.c_size_t(N))
+    assert rc == 0
+    live = buf[:, 1] > 0
+    t0, t1, ch = buf[live, 0].astype(np.int64), buf[live, 1].astype(np.int64), (buf[live, 2] >> np.uint64(32)).astype(np.int64)
+    dur = (t1 - t0) / 100.0   # us (100 MHz)
+    start, end = (t0 - t0.min()) / 100.0, (t1 - t0.min()) / 100.0
+    span = end.max()
+    slots = 2048
+    print(f"segment {seg}: kernel {kms*1e3:.0f} us, waves {live.sum()}, span {span:.0f} us, sum of wave times / {slots} slots = {dur.sum()/slots:.0f} us "
+          f"(occupancy {dur.sum()/slots/span:.2f}); wave us: mean {dur.mean():.1f} median {np.median(dur):.1f} p90 {np.percentile(dur,90):.1f} p99 {np.percentile(dur,99):.1f} max {dur.max():.1f}; "
+          f"chains/wave mean {ch.mean():.0f} max {ch.max()}; us per chain {dur.sum()/max(ch.sum(),1):.3f}")
+    t_set = (buf[live, 3].astype(np.int64) - t0) / 100.0
+    scan = (buf[live, 4] >> np.uint64(32)).astype(np.int64) / 100.0
+    fl = (buf[live, 4] & np.uint64(0xFFFFFFFF)).astype(np.int64) / 100.0
+    rings = (buf[live, 5] >> np.uint64(32)).astype(np.int64)
+    on = (buf[live, 5] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    print(f"   per wave (mean us): set-up {t_set.mean():.1f}, box scans {scan.mean():.1f}, candidate flushes at ring ends {fl.mean():.1f}, "
+          f"rest (chains + candidate path) {(dur - t_set - scan - fl).mean():.1f}; rings {rings.mean():.2f}, chains that went on {on.sum()/max(ch.sum(),1):.3f}")
+    # how many waves are still running in the last 10 / 20 / 30 % of the span
+    for f in (0.7, 0.8, 0.9):
+        print(f"   running at {f:.0%} of the span: {((start < f*span) & (end > f*span)).sum()} waves")
+    order = np.argsort(-dur)[:5]
+    print("   longest waves: ", [(round(float(dur[i]),1), int(ch[i]), round(float(start[i]),0)) for i in order])
