@@ -2080,7 +2080,7 @@ __device__ __forceinline__ void load_tile_folded(const uint4* __restrict__ img, 
 
 #ifdef DC_WAVE_STAMPS
 constexpr uint32_t kDbgWaves = 1u << 17;
-__device__ unsigned long long g_wave_dbg[kDbgWaves][6];
+__device__ unsigned long long g_wave_dbg[kDbgWaves][10];
 #endif
 template <int NM, int TQ>
 __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
@@ -2118,6 +2118,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   if (qt0 >= TQT) return;
 #ifdef DC_WAVE_STAMPS
   const unsigned long long dbg_t0 = wall_clock64();
+  const unsigned long long dbg_c0 = clock64();
+  unsigned long long dbg_on_cyc = 0, dbg_fl_cyc = 0;
+  uint32_t dbg_cands = 0, dbg_iters = 0, dbg_nfl = 0;   // (dbg_iters: chains that entered the per-element path)
 #endif
   // (the component of the group, its tile range and cell edge: three dependent look-ups, started before everything else)
   const uint32_t my_comp = CV.tile_comp_q[qt0];
@@ -2280,8 +2283,15 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const float fe_floor = fkey_inv(~hdr[12]);
   // evaluate and empty the candidate list (64 candidates at a time, one per lane)
   auto flush = [&]() {
+#ifdef DC_WAVE_STAMPS
+    const unsigned long long tf0 = clock64();
+    ++dbg_nfl;
+#endif
     nn_wave_flush(cand, qn, qrows, best64, TQ * 32, coords_c, perm_r, n_cols, lane);
     qn = 0;
+#ifdef DC_WAVE_STAMPS
+    dbg_fl_cyc += clock64() - tf0;
+#endif
   };
   uint32_t chains = 0, visited = 0;
   uint32_t chains_on = 0;   // chains that went on behind the early-out test (computed again in full)
@@ -2359,6 +2369,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
         const float thr = (fr.x < Q.feq) ? Q.bh : Q.bn;
         const bool rare = tmin < thr;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+#ifdef DC_WAVE_STAMPS
+          ++dbg_iters;
+#endif
           const bool all_lower = fr.y < Q.feq;
           const bool mixed = (fr.x < Q.feq) & !all_lower;
           const bool special = mixed | (t == (Q.spos >> 5));
@@ -2420,6 +2433,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
               const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
               if (have == 0) break;
               const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
+#ifdef DC_WAVE_STAMPS
+              dbg_cands += n_new;
+#endif
               if (qn + n_new > (uint32_t)kWaveQueue) flush();
               if (m != 0) {
                 const int p = __builtin_ctz(m);
@@ -2479,6 +2495,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
 #pragma unroll
           for (int qi = 0; qi < TQ; ++qi) dmin = fminf(dmin, tm[qi] - ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn));
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmin < 0.0f) != 0, 0)) {
+#ifdef DC_WAVE_STAMPS
+            const unsigned long long to0 = clock64();
+#endif
             constexpr_for_all<TQ>([&](auto qi_c) {
               constexpr int qi = decltype(qi_c)::value;
               const float thr_c = (fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn;
@@ -2492,6 +2511,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
                 finish(acc, qi_c, tmin, t, fr);
               }
             });
+#ifdef DC_WAVE_STAMPS
+            dbg_on_cyc += clock64() - to0;
+#endif
           }
           return;
         }
@@ -2606,6 +2628,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       g_wave_dbg[wid][3] = dbg_t1;
       g_wave_dbg[wid][4] = (dbg_scan << 32) | (dbg_flush & 0xFFFFFFFFull);
       g_wave_dbg[wid][5] = ((unsigned long long)dbg_rings << 32) | chains_on;
+      g_wave_dbg[wid][6] = (dbg_on_cyc << 32) | ((clock64() - dbg_c0) & 0xFFFFFFFFull);
+      g_wave_dbg[wid][7] = (dbg_fl_cyc << 32) | dbg_nfl;
+      g_wave_dbg[wid][8] = ((unsigned long long)dbg_iters << 32) | dbg_cands;
     }
   }
 #endif

@@ -77,6 +77,6 @@ void DC_CAT(nn_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32
 // (measurement build: per-wave start / end stamps of nn_pruned_kernel<2, .>, copied out for scratch/wave_times.py)
 extern "C" __attribute__((visibility("default"))) int dc_dbg_wave_times(unsigned long long* out, size_t n_waves) {
   (void)hipDeviceSynchronize();
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::g_wave_dbg), sizeof(unsigned long long) * 6 * n_waves, 0, hipMemcpyDeviceToHost);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::g_wave_dbg), sizeof(unsigned long long) * 10 * n_waves, 0, hipMemcpyDeviceToHost);
 }
 #endif

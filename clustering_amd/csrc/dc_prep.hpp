@@ -401,7 +401,13 @@ __global__ __launch_bounds__(256) void order_key_kernel(
       by = min((uint32_t)fy, nby - 1u);
     }
     const uint32_t lo = par_s[c][5], hi = par_s[c][6];
-    uint32_t key = min(lo + bx * nby + by, hi - (hi > lo ? 1u : 0u));
+    // (the cells of a component are numbered column by column, every other column downwards: consecutive cells are
+    //  always neighbours.  Numbered upwards in every column, a query group that began at the top of one column and ended at
+    //  the bottom of the next had a box as tall as the component -- gap 0 to every tile of two columns, a first ring of
+    //  hundreds of tiles in index order: the handful of such groups were the last waves of every sharded neighbour sweep,
+    //  2 ms each at C3 where the mean wave takes 0.16)
+    const uint32_t by_s = (bx & 1u) ? nby - 1u - by : by;
+    uint32_t key = min(lo + bx * nby + by_s, hi - (hi > lo ? 1u : 0u));
     if (fe) {
       const float span = fe_hi - fe_lo;
       float u = (span > 0.0f && span <= FLT_MAX) ? (fe[i] - fe_lo) / span : 0.0f;

@@ -15,7 +15,7 @@ for seg in ((0, 3) if G > 1 else (0,)):
     torch.cuda.synchronize()
     kms = dens.last_sweep_ms("nn", c.device)
     N = 1 << 17
-    buf = np.zeros((N, 6), dtype=np.uint64)
+    buf = np.zeros((N, 10), dtype=np.uint64)
     rc = capi.lib.dc_dbg_wave_times(buf.ctypes.data_as(C.c_void_p), C.c_size_t(N))
     assert rc == 0
     live = buf[:, 1] > 0
@@ -34,8 +34,36 @@ for seg in ((0, 3) if G > 1 else (0,)):
     on = (buf[live, 5] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     print(f"   per wave (mean us): set-up {t_set.mean():.1f}, box scans {scan.mean():.1f}, candidate flushes at ring ends {fl.mean():.1f}, "
           f"rest (chains + candidate path) {(dur - t_set - scan - fl).mean():.1f}; rings {rings.mean():.2f}, chains that went on {on.sum()/max(ch.sum(),1):.3f}")
+    # the path behind the early-out test (shader cycles, clock64): chains computed again in full, their epilogues, the
+    # parking of candidates and the flushes inside it
+    cyc_tot = (buf[live, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    cyc_on = (buf[live, 6] >> np.uint64(32)).astype(np.int64)
+    cyc_fl = (buf[live, 7] >> np.uint64(32)).astype(np.int64)
+    nfl = (buf[live, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    iters = (buf[live, 8] >> np.uint64(32)).astype(np.int64)
+    cands = (buf[live, 8] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    mhz = cyc_tot.sum() / dur.sum()
+    print(f"   clock64: {mhz:.0f} cycles per us; behind the early-out test {cyc_on.sum()/cyc_tot.sum():.3f} of the wave time "
+          f"({cyc_on.sum()/max(on.sum(),1):.0f} cycles per chain that went on), of which flushes {cyc_fl.sum()/cyc_tot.sum():.3f} "
+          f"({nfl.sum()/max(on.sum(),1):.3f} flushes, {cands.sum()/max(on.sum(),1):.2f} candidates, {iters.sum()/max(on.sum(),1):.2f} chains into the per-element path per such chain; "
+          f"{cyc_fl.sum()/max(nfl.sum(),1):.0f} cycles per flush)")
+    # by launch order (the reference share is the slow grid dimension: the first waves run without any published bound)
+    idx = np.flatnonzero(live)
+    rest = dur - t_set - scan - fl
+    for lo_, hi_ in ((0, 0.1), (0.1, 0.3), (0.3, 0.6), (0.6, 1.0)):
+        m = (idx >= lo_ * idx.max()) & (idx < hi_ * idx.max() + 1)
+        print(f"   waves {lo_:.0%} - {hi_:.0%} of the launch order: us per chain {rest[m].sum()/max(ch[m].sum(),1):.4f}, went on {on[m].sum()/max(ch[m].sum(),1):.3f}, set-up {t_set[m].mean():.1f} us, chains/wave {ch[m].mean():.0f}")
     # how many waves are still running in the last 10 / 20 / 30 % of the span
     for f in (0.7, 0.8, 0.9):
         print(f"   running at {f:.0%} of the span: {((start < f*span) & (end > f*span)).sum()} waves")
     order = np.argsort(-dur)[:5]
     print("   longest waves: ", [(round(float(dur[i]),1), int(ch[i]), round(float(start[i]),0)) for i in order])
+    wv = (buf[live, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    for i in np.argsort(-dur)[:8]:
+        print(f"      wave id {idx[i]} (group {wv[i]}, share {idx[i] // max(1, (idx.max() + 1) // max(1, int(round((idx.max()+1) / max(1, len(np.unique(wv)))))))}): {dur[i]:.0f} us, chains {ch[i]}, went on {on[i]}, "
+              f"rings {rings[i]}, candidates {cands[i]}, flushes {nfl[i]}, per-element path {iters[i]}, behind the test {cyc_on[i]/max(cyc_tot[i],1):.2f} of its time, flush {cyc_fl[i]/max(cyc_tot[i],1):.2f}")
+    # the groups by their total time over all shares
+    tot = {}
+    for g_, d_ in zip(wv, dur): tot[g_] = tot.get(g_, 0.0) + d_
+    top = sorted(tot.items(), key=lambda kv: -kv[1])[:8]
+    print("   groups by wave time over all their shares (us):", [(int(g_), round(t_)) for g_, t_ in top], " mean", round(float(np.mean(list(tot.values())))))
