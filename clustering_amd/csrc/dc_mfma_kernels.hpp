@@ -2197,6 +2197,12 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
+#ifdef DC_WAVE_STAMPS
+  // (after the results of the loop's loads have arrived: the asm statements pin the order)
+  asm volatile("" ::"v"(q[TQ - 1].feq), "v"(g_hd[TQ - 1]), "v"(cq[TQ - 1]), "v"(b[TQ - 1][NM - 1]));
+  const unsigned long long dbg_sA = wall_clock64();
+  asm volatile("" ::"s"(dbg_sA));
+#endif
   // published bounds and the original coordinates of the queries (for the exact path) into LDS
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt)
@@ -2231,6 +2237,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   // tiles of a sweep park every element, and query groups in sparse regions (wide boxes, long first ring)
   // spent a microsecond per chain in the candidate path.
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (query rows: written by the h = 0 lanes)
+#ifdef DC_WAVE_STAMPS
+  const unsigned long long dbg_sB = wall_clock64();
+#endif
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
     const bool live = (livemask[qt] >> lane) & 1;
@@ -2280,6 +2289,9 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   }
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
   // ordering pass): a query at that level has no lower-FE neighbour
+#ifdef DC_WAVE_STAMPS
+  const unsigned long long dbg_sC = wall_clock64();
+#endif
   const float fe_floor = fkey_inv(~hdr[12]);
   // evaluate and empty the candidate list (64 candidates at a time, one per lane)
   auto flush = [&]() {
@@ -2631,6 +2643,7 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
       g_wave_dbg[wid][6] = (dbg_on_cyc << 32) | ((clock64() - dbg_c0) & 0xFFFFFFFFull);
       g_wave_dbg[wid][7] = (dbg_fl_cyc << 32) | dbg_nfl;
       g_wave_dbg[wid][8] = ((unsigned long long)dbg_iters << 32) | dbg_cands;
+      g_wave_dbg[wid][9] = (((dbg_sA - dbg_t0) & 0xFFFFFull) << 40) | (((dbg_sB - dbg_t0) & 0xFFFFFull) << 20) | ((dbg_sC - dbg_t0) & 0xFFFFFull);
     }
   }
 #endif

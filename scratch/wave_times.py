@@ -47,6 +47,14 @@ for seg in ((0, 3) if G > 1 else (0,)):
           f"({cyc_on.sum()/max(on.sum(),1):.0f} cycles per chain that went on), of which flushes {cyc_fl.sum()/cyc_tot.sum():.3f} "
           f"({nfl.sum()/max(on.sum(),1):.3f} flushes, {cands.sum()/max(on.sum(),1):.2f} candidates, {iters.sum()/max(on.sum(),1):.2f} chains into the per-element path per such chain; "
           f"{cyc_fl.sum()/max(nfl.sum(),1):.0f} cycles per flush)")
+    sA = ((buf[live, 9] >> np.uint64(40)) & np.uint64(0xFFFFF)).astype(np.int64) / 100.0
+    sB = ((buf[live, 9] >> np.uint64(20)) & np.uint64(0xFFFFF)).astype(np.int64) / 100.0
+    sC = (buf[live, 9] & np.uint64(0xFFFFF)).astype(np.int64) / 100.0
+    n_groups_dbg = max(1, len(np.unique((buf[live, 2] & np.uint64(0xFFFFFFFF)))))
+    idx = np.flatnonzero(live)
+    share0 = idx < n_groups_dbg
+    print(f"   set-up of a wave (mean us since its start): query operands / norms / free energies / published words loaded {sA.mean():.1f}, "
+          f"query rows staged {sB.mean():.1f}, seeds done {sC.mean():.1f} (first share: {sC[share0].mean():.1f}, others: {sC[~share0].mean():.1f}), first ring's scan starts {t_set.mean():.1f}")
     # by launch order (the reference share is the slow grid dimension: the first waves run without any published bound)
     idx = np.flatnonzero(live)
     rest = dur - t_set - scan - fl
