@@ -1188,6 +1188,10 @@ __device__ __forceinline__ void stage_query_rows(float* __restrict__ dst, const 
   }
 }
 
+#ifdef DC_WAVE_STAMPS
+constexpr uint32_t kPopDbgWaves = 1u << 17;
+__device__ unsigned long long g_pop_dbg[kPopDbgWaves][3];   // start, end, chains << 32 | group (measurement build)
+#endif
 template <int NM, int NR, int TQ, int MODE = kSinkNone, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -1220,6 +1224,9 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
+#ifdef DC_WAVE_STAMPS
+  const unsigned long long dbg_p0 = wall_clock64();
+#endif
   // (the component of the group and its tile range: two dependent look-ups, started before everything else)
   const uint32_t my_comp = CV.tile_comp_q[qt0];
   const uint32_t comp_lo = CV.range_r[2 * my_comp], comp_hi = CV.range_r[2 * my_comp + 1];
@@ -1593,6 +1600,16 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     atomicAdd(chain_counter, (unsigned long long)chains);
     atomicAdd(chain_counter + kMfmaCtrPop, (unsigned long long)chains * NM);
   }
+#ifdef DC_WAVE_STAMPS
+  if (lane == 0) {
+    const uint32_t wid = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (uint32_t)wib;
+    if (wid < kPopDbgWaves) {
+      g_pop_dbg[wid][0] = dbg_p0;
+      g_pop_dbg[wid][1] = wall_clock64();
+      g_pop_dbg[wid][2] = ((unsigned long long)chains << 32) | wave;
+    }
+  }
+#endif
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) flush(qt);
   if constexpr (kWaveWide) flush_wave();

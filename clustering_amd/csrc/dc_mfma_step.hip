@@ -79,4 +79,8 @@ extern "C" __attribute__((visibility("default"))) int dc_dbg_wave_times(unsigned
   (void)hipDeviceSynchronize();
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::g_wave_dbg), sizeof(unsigned long long) * 10 * n_waves, 0, hipMemcpyDeviceToHost);
 }
+extern "C" __attribute__((visibility("default"))) int dc_dbg_pop_wave_times(unsigned long long* out, size_t n_waves) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::g_pop_dbg), sizeof(unsigned long long) * 3 * n_waves, 0, hipMemcpyDeviceToHost);
+}
 #endif

@@ -24,6 +24,7 @@ for seg in ((0, 3) if G > 1 else (0,)):
     start, end = (t0 - t0.min()) / 100.0, (t1 - t0.min()) / 100.0
     span = end.max()
     slots = 2048
+    np.savez_compressed(f"gpurun_out/nn_waves_G{G}_seg{seg}.npz", idx=np.flatnonzero(live), dur=dur, ch=ch, grp=(buf[live, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64), start=start)
     print(f"segment {seg}: kernel {kms*1e3:.0f} us, waves {live.sum()}, span {span:.0f} us, sum of wave times / {slots} slots = {dur.sum()/slots:.0f} us "
           f"(occupancy {dur.sum()/slots/span:.2f}); wave us: mean {dur.mean():.1f} median {np.median(dur):.1f} p90 {np.percentile(dur,90):.1f} p99 {np.percentile(dur,99):.1f} max {dur.max():.1f}; "
           f"chains/wave mean {ch.mean():.0f} max {ch.max()}; us per chain {dur.sum()/max(ch.sum(),1):.3f}")
