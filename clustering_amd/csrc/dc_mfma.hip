@@ -292,7 +292,7 @@ __global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D
                              const uint32_t* __restrict__ comp = nullptr) {
   float M = __uint_as_float(hdr[0]);   // (final: rowstats_kernel ran before)
   // several components (pruned population sweeps): every row is measured from its component's origin (the maximum
-  // over the rows: order_rows_kernel)
+  // over the rows: order_rows2_kernel)
   if (comp && comp[kCompGrid + 5] > 1u) M = fminf(__uint_as_float(hdr[kHdrMloc]), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);
   hdr[kHdrMused] = __float_as_uint(M);
   hdr[kHdrOpen] = 0u;
@@ -374,7 +374,7 @@ __global__ void fe_rank_kernel(const float* __restrict__ fe, const float* __rest
 
 // Upper bound, known on the host, of the bits a cell key needs: the grid has about K = n / frames_per_cell cells
 // (auto_cell), at most 4002 per dimension; (x + 1)(y + 1) with x y <= K and x, y <= 4001 is at most
-// K + 4001 + K / 4001 + 1.  The Onesweep sort costs one pass (~35 us at 10^6 frames) per 8 key bits: C3's population
+// K + 4001 + K / 4001 + 1.  The radix sort (dc_sort.hip) costs one pass (~25 us at 10^6 frames) per 8 key bits: C3's population
 // ordering needs 15 bits, not kCellKeyBits = 24.  (Should a data set ever exceed the bound, the sort would ignore the
 // top bits of its keys: a worse ordering, i.e. less pruning -- never a different result.)
 static unsigned cell_key_bits(uint32_t n_rows, float frames_per_cell) {
@@ -1450,7 +1450,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // Which queries can have a neighbour in ANOTHER component: their incumbent (or, where a lower-energy neighbour is possible
 // at all, their lower-energy incumbent) reaches another component's box.  By FRAME when the queries are the rows of the
 // reference order (every read coalesced: the by-position form spent 145 us on its six scattered reads per query), by
-// position of the query order otherwise.  The component of a frame is looked up as compkey_kernel assigned it.
+// position of the query order otherwise.  The component of a frame is looked up as order_key_kernel assigned it.
 __global__ void nn_open_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D, const float* __restrict__ fe,
                                const uint32_t* __restrict__ invpos_r, const uint32_t* __restrict__ perm_q, uint32_t n_items,
                                const uint32_t* __restrict__ comp, uint32_t group_rows, QSeg q_seg,

@@ -16,7 +16,7 @@
 //   order_meta_kernel   where every component starts in the sorted list and in the padded order (comp_start + comp_ranges)
 //                       and the scale of the sweep (scale_kernel)
 //   the sort            dc_sort.hip: its last pass writes straight into the PADDED order (pad_scatter and a fill before)
-//   order_rows_kernel   rows gathered into the order, tile boxes, free-energy ranges, AND the operand images of the
+//   order_rows2_kernel  rows gathered into the order, tile boxes, free-energy ranges, AND the operand images of the
 //                       tiles -- A form of every tile, B form of the query groups of this launch's segment -- built from
 //                       the rows while they sit in LDS (order_rows + scale + two image launches)
 // The arithmetic of every value is what the kernels of rounds 1 - 4 computed; only who computes it when has changed.
@@ -595,7 +595,7 @@ __device__ __forceinline__ void build_tile_image(const float* __restrict__ rows,
   __builtin_amdgcn_wave_barrier();
 }
 
-// dynamic LDS of order_rows_kernel: the rows of 256 positions + per wave the K rows of one tile + its origin
+// dynamic LDS of order_rows2_kernel: the rows of 256 positions + per wave the K rows of one tile + its origin
 static inline size_t order_rows_smem(uint32_t n_cols) {
   const uint32_t NM = (uint32_t)nm_for((int)n_cols);
   return sizeof(float) * 256 * (n_cols | 1u) + 4 * (sizeof(unsigned short) * 32 * (16 * NM + 2) + sizeof(float) * n_cols);
