@@ -68,21 +68,24 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-PMC_PROFILES = ("r5_c3_pmc.json",)   # counter summaries of THIS tree's kernels (older ones describe other kernels)
+PMC_PROFILES = ("r6_c3_pmc.json",)   # counter summaries of THIS tree's kernels (older ones describe other kernels)
 
 
 def csrc_digest():
-    """sha256 over the kernel and host sources of the product (clustering_amd/csrc, include/): what a counter profile
-    is tied to.  A profile measured on other sources says nothing about the kernels this run times."""
-    import hashlib
-    h = hashlib.sha256()
-    for d in ("clustering_amd/csrc", "include"):
-        base = os.path.join(ROOT, d)
-        for f in sorted(os.listdir(base)):
-            if f.endswith((".hip", ".hpp", ".cpp", ".h", "Makefile")):
-                h.update(f.encode())
-                h.update(open(os.path.join(base, f), "rb").read())
-    return h.hexdigest()[:16]
+    """Digest of the product's sources as they lie in the tree (clustering_amd/csrc/digest.py: csrc + include/,
+    comments left out -- a comment edit does not orphan the profiles).  The library embeds the digest of the sources it
+    was BUILT from (library_digest()); the two differ when the tree was edited after the build."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dc_digest", os.path.join(ROOT, "clustering_amd", "csrc", "digest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_digest()
+
+
+def library_digest():
+    """what the loaded libdcdensity.so says it was built from (dc_hip_build_digest): the binary the timed run executes"""
+    from clustering_amd import capi
+    return capi.lib.dc_hip_build_digest().decode()
 
 
 def measured_counters(kernel, n, d, radii, variant):
@@ -93,7 +96,7 @@ def measured_counters(kernel, n, d, radii, variant):
     commit of the kernels it measured); {} for any other workload or variant."""
     if variant not in ("auto", "pruned"):
         return {}
-    here = csrc_digest()
+    here = library_digest()   # counters describe a BINARY: the one this run loaded
     for fname in PMC_PROFILES:
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", fname)))
@@ -356,10 +359,10 @@ def main():
             "results_equal_default_path": same,
         }
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r5_c3_mfma32_pmc.json")))
-            if prof.get("csrc_digest") == csrc_digest() and (n, d) == (prof.get("n_rows"), prof.get("n_cols")):
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r6_c3_mfma32_pmc.json")))
+            if prof.get("csrc_digest") == library_digest() and (n, d) == (prof.get("n_rows"), prof.get("n_cols")):
                 fp32_inst["mfma_busy"] = prof.get("mfma_busy")
-                fp32_inst["mfma_busy_source"] = "profiles/r5_c3_mfma32_pmc.json (rocprofv3 --pmc, same kernel sources)"
+                fp32_inst["mfma_busy_source"] = "profiles/r6_c3_mfma32_pmc.json (rocprofv3 --pmc, same library digest)"
         except (OSError, ValueError):
             pass
 
@@ -492,6 +495,11 @@ def main():
             "check": {"mean_pop_r0": pop_sum / n, "max_pop_r0": int(out["pops"][0].max().item()),
                       "sigma2": (density.compute_sigma2(out["nn_d2"]) if want_nn else None),
                       "reference_run": "BASELINE.md: mean 7233.1, max 65950, sigma2 0.00704766 at C3"},
+            "library_digest": library_digest(),
+            "source_digest": csrc_digest(),
+            "digest_note": "library_digest = dc_hip_build_digest() of the libdcdensity.so this run loaded (sources it was built "
+                           "from, comments left out); source_digest = the same digest of the tree; counter figures are taken "
+                           "only from profiles whose csrc_digest equals library_digest",
             "roofline": roof,
             "roofline_by_kernel": by_kernel,
             "fp32_mfma_instance": fp32_inst,

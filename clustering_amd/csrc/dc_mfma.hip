@@ -1984,6 +1984,15 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
 
 // ---- DC_VARIANT_MFMA32: the fp32-input MFMA instance (dc_mfma32.hpp) ---------------------------------------------
 bool mfma32_supports(size_t n_cols) { return n_cols == 9 || n_cols == 10; }
+// (DC_MFMA32_STAGGER=0: every wave starts at the first tile of its chunk -- measurements)
+static uint32_t wpb32() {
+  static const uint32_t v = [] { const char* e = getenv("DC_MFMA32_WPB"); const int k = (e && e[0]) ? atoi(e) : 1; return (k == 1 || k == 2 || k == 4) ? (uint32_t)k : 1u; }();
+  return v;
+}
+static uint32_t stagger32() {
+  static const uint32_t v = [] { const char* e = getenv("DC_MFMA32_STAGGER"); return (e && e[0]) ? (uint32_t)atoi(e) : 1u; }();
+  return v;
+}
 
 void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, uint32_t i_from, uint32_t i_to,
                        const Rad2& rad2, int n_rad, uint32_t* d_pops, void* d_ws, hipStream_t stream) {
@@ -1991,18 +2000,29 @@ void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
   char* p = (char*)d_ws;
   float* img = (float*)(p + L.off_img);
   float* norms = (float*)(p + L.off_norm);
+  // (ONE image for all radii of the call, scaled for the largest: the band of a smaller radius is narrower than 1)
+  float r2max = 0.0f;
+  for (int r = 0; r < n_rad; ++r) r2max = std::max(r2max, rad2.v[r]);
   hipLaunchKernelGGL(image32_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords, n_rows, n_cols, L.T,
-                     (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, img, norms);
+                     (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, (const uint32_t*)p, r2max, img, norms);
 #ifdef DC_MFMA32_TQ
   constexpr int kTQ = DC_MFMA32_TQ;
 #else
-  constexpr int kTQ = 4;
+  constexpr int kTQ = 8;
 #endif
-  const dim3 grid(grid_for(i_from, i_to, kTQ)), block(256);
+  // (two waves per SIMD at eight query tiles per wave: 2 048 wave slots; DC_MFMA32_CHUNKS for measurements)
+  static const uint32_t env_chunks = [] { const char* v = getenv("DC_MFMA32_CHUNKS"); return (v && v[0]) ? (uint32_t)atoi(v) : 0u; }();
+  // (waves per workgroup: DC_MFMA32_WPB, measurements)
+  const uint32_t wpb = wpb32();
+  const uint32_t blocks = (grid_for(i_from, i_to, kTQ) * 4u + wpb - 1) / wpb;
+  const uint32_t chunks = env_chunks ? std::min(env_chunks, L.T) : chunks32(blocks * wpb, L.T, 2048u);
+  const dim3 grid(blocks, chunks), block(64 * wpb);
   for (int r = 0; r < n_rad; ++r) {
+    if (chunks > 1)
+      (void)hipMemsetAsync(d_pops + (size_t)r * n_rows + i_from, 0, sizeof(uint32_t) * (size_t)(i_to - i_from), stream);
     sweep_timer_mark(0, true, stream);
     hipLaunchKernelGGL((pop_mfma32_kernel<kS32, kTQ>), grid, block, 0, stream, d_coords, n_rows, n_cols, (const float*)img,
-                       (const float*)norms, (const uint32_t*)p, L.T, i_from, i_to, rad2.v[r], d_pops + (size_t)r * n_rows);
+                       (const float*)norms, (const uint32_t*)p, L.T, i_from, i_to, rad2.v[r], r2max, stagger32(), d_pops + (size_t)r * n_rows);
     sweep_timer_mark(0, false, stream);
   }
 }
@@ -2023,7 +2043,7 @@ void launch_nn_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   float* img_s = (float*)(p + L.off_img_s);
   float* norms_s = (float*)(p + L.off_norm_s);
   hipLaunchKernelGGL(image32_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_cols, L.T, (const float*)(p + kHdrMeans),
-                     (const uint32_t*)nullptr, img, norms);
+                     (const uint32_t*)nullptr, (const uint32_t*)p, -1.0f, img, norms);
   hipLaunchKernelGGL(fe_key_kernel, dim3(std::min<uint32_t>(grid_n.x, 1024u)), blk, 0, stream, d_fe, n_rows, keys_in, vals_in,
                      (uint32_t*)p);
   if (sort_pairs_u32(keys_in, keys_out, vals_in, perm, n_rows, p + L.fixed_end, sort_temp_bytes(n_rows), stream) != 0) return;
@@ -2032,14 +2052,27 @@ void launch_nn_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   hipLaunchKernelGGL(fe_rank_kernel, grid_n, blk, 0, stream, d_fe, (const float*)(p + L.off_fe_s), n_rows,
                      (uint32_t*)(p + L.off_pq));
   hipLaunchKernelGGL(image32_kernel, grid_t, blk, 0, stream, d_coords, n_rows, n_cols, L.T, (const float*)(p + kHdrMeans),
-                     (const uint32_t*)perm, img_s, norms_s);
+                     (const uint32_t*)perm, (const uint32_t*)p, -1.0f, img_s, norms_s);
   constexpr int kTQ = 4;
+  static const uint32_t env_chunks = [] { const char* v = getenv("DC_MFMA32_CHUNKS"); return (v && v[0]) ? (uint32_t)atoi(v) : 0u; }();
+  // ONE wave per workgroup: a workgroup holds its wave slots until its last wave is done, and the waves of this sweep
+  // differ in length (those that start from published bounds skip most of the candidate path)
+  const uint32_t wpb = wpb32();
+  const uint32_t blocks = (grid_for(i_from, i_to, kTQ) * 4u + wpb - 1) / wpb;
+  const uint32_t chunks = env_chunks ? std::min(env_chunks, L.T) : chunks32(blocks * wpb, L.T, 2048u);
+  unsigned long long* merge64 = (unsigned long long*)(p + L.off_merge64);
+  if (chunks > 1)
+    hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, stream, merge64, n_rows);
   sweep_timer_mark(1, true, stream);
-  hipLaunchKernelGGL((nn_mfma32_kernel<kS32, kTQ>), dim3(grid_for(i_from, i_to, kTQ)), blk, 0, stream, d_coords, n_rows, n_cols,
+  const size_t smem = wpb * sizeof(uint32_t) * (2 * kWaveQueue + 4 * kTQ * 32 + kTQ * 32 * (size_t)n_cols);
+  hipLaunchKernelGGL((nn_mfma32_kernel<kS32, kTQ>), dim3(blocks, chunks), dim3(64 * wpb), smem, stream, d_coords, n_rows, n_cols,
                      (const float*)img, (const float*)norms, (const float*)img_s, (const float*)norms_s, (const uint32_t*)perm,
                      (const uint32_t*)(p + L.off_invpos), (const uint32_t*)(p + L.off_pq), (const uint32_t*)p, L.T, i_from, i_to,
-                     d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
+                     stagger32(), merge64, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
   sweep_timer_mark(1, false, stream);
+  if (chunks > 1)
+    hipLaunchKernelGGL(nn32_unpack_kernel, dim3((i_to - i_from + 255) / 256), dim3(256), 0, stream,
+                       (const unsigned long long*)merge64, n_rows, i_from, i_to, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
 }
 
 }  // namespace dc

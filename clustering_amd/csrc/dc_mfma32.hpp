@@ -8,11 +8,26 @@
 // buildable, covered by the parity tests and benchable (bench.py --variant mfma32), for n_cols 9 .. 10 (five K-steps of
 // two columns).  Same classifier idea as the fp16 kernels, with the fp32 band of round 1:
 //     acc = |y'|^2 - 2 x'.y'  (A = centred reference coordinates, B = -2 centred query coordinates, C = |y'|^2)
-//     t   = acc - ((r^2 - eps) - |x'|^2):  sign -> inside, bits(t) <u bits(2 eps) -> band -> canonical re-check
 //     eps = 1.25 u [(4 K + 10) M + (D / 4 + 12) d2cap],  K = 2 S multiply-adds per chain, M = max |x'|^2
 // (the fp32 MFMA is a chain of fmaf: products exact to one rounding each, 2 S + 2 roundings around values <= 4 M).
 // Operand image: img32[(t * S + s) * 64 + l] = y'[32 t + (l & 31)][2 s + (l >> 5)], norms32[32 t + c] = |y'|^2.
+//
+// Round 6 -- what the fp32-input MFMA wants from the code around it (scratch/ub/mfma32_sched.hip, one MI355X, ns per
+// chain and SIMD at two waves per SIMD; five dependent MFMAs alone: 137.4):
+//   * it does not overlap with VALU work at all, so dealing the epilogue to the MFMA slots (the fp16 kernels' software
+//     pipelining) buys nothing and every MFMA <-> VALU alternation costs a few cycles: 48 VALU dealt 208.7, the same 48 in
+//     one clump behind the chains of FOUR query tiles 202.2; the neighbour epilogue (12) 174.1 -> 159.5;
+//   * the epilogue itself: populations keep TWO bits per element like the fp16 kernels (round 2) -- the image is scaled
+//     so that the guard band of the call's largest radius is just below 1 and the threshold is folded as
+//     t = acc - ((S r^2 - 1) - |x''|^2): sign = inside, bit 30 (t >= 2) = outside, neither = band -> canonical re-check:
+//     one v_pk_add_f32 per two elements and one v_alignbit(.., 30) per element, no minimum (24 VALU: 186.4);
+//   * ONE wave-level test per reference tile (the four chains' band strings OR-ed; the neighbour sweep's four tile minima
+//     against cached thresholds) instead of one or two scalar hand-offs per chain.
+// Scaled band: with x'' = fl(c x') every term of the unscaled bound scales by S = c^2; the scaling adds 2 u (M + d2)
+// (rounding of c x'), 2 u thr (fl(c c), fl(S r^2)) and u (M + 2 thr) / 2 (the two subtractions that form the per-query
+// constant): 1.25 u [(4 K + 13) M + (D / 4 + 18) r^2] in data units, and c is the largest scale at which that is < 1.
 constexpr int kS32 = 5;   // K-steps: n_cols 9 .. 10
+constexpr int kClump32 = 4;   // chains (query tiles) whose MFMAs are issued back to back in front of their epilogues
 
 __host__ __device__ inline float guard_eps32(float M, float d2cap, int K, int D) {
   const double u = 5.9604644775390625e-8;
@@ -20,19 +35,37 @@ __host__ __device__ inline float guard_eps32(float M, float d2cap, int K, int D)
   return next_up((float)(1.25 * u * ((4.0 * K + 10.0) * (double)M + (0.25 * D + 12.0) * cap)));
 }
 
-// fp32 operand image of rows in natural order (perm == nullptr) or gathered through perm
+// scale c of the population image: the largest one at which the band of the scaled chain (see the header) stays below 1
+// for squared radii up to r2max.  Every thread of the image pass and of the sweep evaluates this from the same words.
+__host__ __device__ inline float scale32_pop(float M, float r2max, int K, int D) {
+  const double u = 5.9604644775390625e-8;
+  const double cap = (r2max > 0.0f) ? (double)r2max : 0.0;
+  const double eps1 = 1.25 * u * ((4.0 * K + 13.0) * (double)M + (0.25 * D + 18.0) * cap);   // band at scale 1
+  if (!(eps1 > 1.0e-76)) return 1.8446744e19f;                                               // (all rows equal, r = 0: 2^64)
+  const float c = (float)(sqrt((1.0 - 1.0 / 65536.0) / eps1) * (1.0 - 1.0 / 1048576.0));
+  return c < 1.8446744e19f ? c : 1.8446744e19f;   // (M <= 1e36 and r2 <= FLT_MAX keep c above 2^-56: no lower clamp needed)
+}
+
+// fp32 operand image of rows in natural order (perm == nullptr) or gathered through perm; r2max >= 0: scaled by
+// scale32_pop (population sweeps), r2max < 0: unscaled (neighbour sweep, whose band is relative)
 __global__ void image32_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D, uint32_t T,
                                const float* __restrict__ means, const uint32_t* __restrict__ perm,
-                               float* __restrict__ img, float* __restrict__ norms) {
+                               const uint32_t* __restrict__ hdr, float r2max, float* __restrict__ img,
+                               float* __restrict__ norms) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= 32 * T) return;
   const uint32_t t = row >> 5, c = row & 31;
   const bool live = row < n_rows;
   const uint32_t src = live ? (perm ? perm[row] : row) : 0u;
+  const bool scaled = r2max >= 0.0f;
+  const float cs = scaled ? scale32_pop(__uint_as_float(hdr[0]), r2max, 2 * kS32, (int)D) : 1.0f;
   double nrm = 0.0;
   for (uint32_t k = 0; k < 2 * (uint32_t)kS32; ++k) {
     float v = 0.0f;
-    if (live && k < D) v = coords[(size_t)src * D + k] - means[k];
+    if (live && k < D) {
+      v = coords[(size_t)src * D + k] - means[k];
+      if (scaled) v = cs * v;
+    }
     nrm += (double)v * (double)v;
     img[((size_t)t * kS32 + (k >> 1)) * 64 + c + 32 * (k & 1)] = v;
   }
@@ -42,6 +75,9 @@ __global__ void image32_kernel(const float* __restrict__ coords, uint32_t n_rows
 template <int S>
 __device__ __forceinline__ void load_tile32(const float* __restrict__ img, const float* __restrict__ norms, uint32_t t,
                                             int lane, int h, float (&a)[S], float4 (&nv)[4]) {
+#ifdef DC32_NOLOAD
+  if (t > 1) return;
+#endif
   const float* ip = img + (size_t)t * (S * 64) + lane;
 #pragma unroll
   for (int s = 0; s < S; ++s) a[s] = ip[s * 64];
@@ -50,66 +86,97 @@ __device__ __forceinline__ void load_tile32(const float* __restrict__ img, const
   for (int g = 0; g < 4; ++g) nv[g] = np[2 * g];        // rows 8g + 4h .. +3  <->  registers 4g .. 4g+3
 }
 
-// one-radius epilogue state of a chain: sign string and the unsigned minimum of bits(acc - lo)
-struct Pop32Acc {
-  uint32_t bits, tmin;
-};
-template <int R0, int R1>
-__device__ __forceinline__ void pop32_epi(const f32x16& acc, float lo, Pop32Acc& e) {
-#pragma unroll
-  for (int r = R0; r < R1; ++r) {
-    const uint32_t tb = __float_as_uint(acc[r] - lo);
-    e.bits = __builtin_amdgcn_alignbit(e.bits, tb, 31);   // (bits << 1) | sign(t)
-    e.tmin = min(e.tmin, tb);                             // negative t: huge unsigned
-  }
+// where a workgroup starts in its chunk of nt reference tiles: spread evenly over the chunk by workgroup (the four waves of
+// a workgroup keep together: they sit on one CU and share its L1)
+__device__ __forceinline__ uint32_t start32(uint32_t stagger, uint32_t nt) {
+  return stagger ? (uint32_t)(((unsigned long long)blockIdx.x * nt) / gridDim.x) : 0u;
 }
-template <int S, int SI = 0>
-__device__ __forceinline__ void pop32_chain(const float (&a)[S], const float (&b)[S], const f32x16& c0, f32x16& acc_new,
-                                            const f32x16& acc_old, float lo_old, Pop32Acc& e) {
-  if constexpr (SI < S) {
-    if constexpr (SI == 0)
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
-    else
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
-    pop32_epi<(16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, lo_old, e);
-    pop32_chain<S, SI + 1>(a, b, c0, acc_new, acc_old, lo_old, e);
+
+// the chains of NC query tiles against one reference tile, their MFMAs interleaved (five dependent MFMAs per chain)
+// `after(k)`: issued behind the k-th MFMA of the clump -- the loads of the NEXT reference tile, ONE per MFMA: nine loads
+// in front of a tile's first MFMA made every wave wait for the CU's memory pipeline whenever the waves of a CU reached
+// a tile together (they do once nothing desynchronises them: the sweep with FEWER candidate-path excursions was slower)
+struct NoAfter32 { __device__ __forceinline__ void operator()(int) const {} };
+template <int S, int NC, class After = NoAfter32>
+__device__ __forceinline__ void chains32(const float (&a)[S], const float (*b)[S], const f32x16& c0, f32x16 (&acc)[NC],
+                                         const After& after = After{}) {
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[q][s], s == 0 ? c0 : acc[q], 0, 0, 0);
+      if (s * NC + q < S + 4) {
+        after(s * NC + q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+}
+// load k of a reference tile: k < S: fragment k, then the four quarters of the row norms
+template <int S>
+__device__ __forceinline__ void load_tile32_part(const float* __restrict__ img, const float* __restrict__ norms, uint32_t t,
+                                                 int lane, int h, int k, float (&a)[S], float4 (&nv)[4]) {
+  if (k < S)
+    a[k] = img[(size_t)t * (S * 64) + k * 64 + lane];
+  else
+    nv[k - S] = reinterpret_cast<const float4*>(norms + (size_t)t * 32 + 4 * h)[2 * (k - S)];
+}
+
+// two bits per element of t = acc - lo (element r at bits 31 - 2 r, 30 - 2 r: inside_of / band_of / element_of)
+// (nlo: the NEGATED per-query constant in both halves of a register pair; the packed add is spelt out because hipcc
+//  otherwise falls back to sixteen v_sub_f32)
+__device__ __forceinline__ uint32_t pop32_string(const f32x16& acc, f32x2 nlo) {
+  f32x2 t[8];
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 v = {acc[r], acc[r + 1]};
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(t[r / 2]) : "v"(v), "v"(nlo));
   }
+  uint32_t bits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(t[r / 2].x), 30);
+    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(t[r / 2].y), 30);
+  }
+  return bits;
 }
 
 // rare: exact re-check of the band pairs of one accumulator tile (by value: see pop_fix)
 __device__ __attribute__((noinline)) uint32_t pop32_fix(const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
-                                                        float r2, float lo, f32x16 acc, uint32_t wbits, uint32_t jq,
-                                                        uint32_t t, int h) {
-  uint32_t m = 0, out = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    m |= ((__float_as_uint(acc[r] - lo) < wbits) && (tile_row(t, r, h) < n_rows)) ? (1u << r) : 0u;
+                                                        float r2, uint32_t band, uint32_t jq, uint32_t t, int h) {
+  uint32_t m = band, out = 0;   // (band_of(string): element r at bit 31 - 2 r)
   while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
     if (m != 0) {
-      const int r = __builtin_ctz(m);
-      out += (exact_d2(coords, n_cols, jq, tile_row(t, r, h)) < r2) ? 1u : 0u;
-      m &= m - 1;
+      const int r = element_of(31 - __builtin_clz(m));
+      const uint32_t row = tile_row(t, r, h);
+      if (row < n_rows) out += (exact_d2(coords, n_cols, jq, row) < r2) ? 1u : 0u;
+      m &= ~(0x80000000u >> (2 * r));
     }
   }
   return out;
 }
 
+#ifdef DC32_OCC2
+#define DC32_OCC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define DC32_OCC_ATTR
+#endif
 template <int S, int TQ>
-__global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
+__global__ __launch_bounds__(256, 2) DC32_OCC_ATTR void pop_mfma32_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ img,
     const float* __restrict__ norms, const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to,
-    float r2, uint32_t* __restrict__ pops) {
-  static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+    float r2, float r2max, uint32_t stagger, uint32_t* __restrict__ pops) {
+  static_assert(TQ % kClump32 == 0, "query tiles are handled in clumps");
   if (hdr[1] != 0) return;   // non-finite / overflow-prone data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t qt0 = i_from / 32 + wave * TQ;
   if (qt0 * 32 >= i_to) return;   // whole wave leaves; no barriers in this kernel
-  const float eps = guard_eps32(__uint_as_float(hdr[0]), r2, 2 * S, (int)n_cols);
-  const uint32_t wbits = __float_as_uint(2.0f * eps) + 1u;   // band width 2 eps as an unsigned key, + 1 ulp
-  const float r2e = r2 - eps;
+  // scaled units (the image was built with the same scale): inside <=> t < 0, outside <=> t >= 2, else band
+  const float cs = scale32_pop(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
+  const float thr = (cs * cs) * r2 - 1.0f;
 
-  float b[TQ][S], lo[TQ];
+  float b[TQ][S];
+  f32x2 nlo[TQ];
   uint32_t cnt[TQ], jq[TQ];
   uint64_t livemask[TQ];
 #pragma unroll
@@ -121,76 +188,126 @@ __global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
-    lo[qt] = r2e - (live ? norms[tl * 32 + c] : INFINITY);   // threshold of the lane's query; -inf: nothing inside, no band
+    const float lo = thr - (live ? norms[tl * 32 + c] : INFINITY);   // -inf for an idle lane: t = +inf, outside, no band
+    nlo[qt] = f32x2{-lo, -lo};
     cnt[qt] = 0;
   }
-  f32x16 accA, accB;   // ping-pong; B starts as "+inf everywhere" = contributes nothing
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
-  uint32_t tB = 0;
+  // reference tiles [tb, te) of this wave's chunk (gridDim.y chunks: the launcher sizes the grid so that its waves fill
+  // the chip's wave slots a whole number of times; partial counts merge by atomicAdd into zero-filled rows)
+  const uint32_t per = (T + gridDim.y - 1) / gridDim.y, tb = blockIdx.y * per, te = min(T, tb + per);
+  if (tb >= te) return;
+  // Every wave walks its chunk from its OWN starting tile (and wraps around): with all of them starting at the chunk's
+  // first tile the whole chip asks for the same few cache lines at the same moment, tile after tile (see start32)
+  const uint32_t nt = te - tb;
+  uint32_t t = tb + start32(stagger, nt);
   float a0[S], a1[S];
   float4 n0[4], n1[4];
-  load_tile32<S>(img, norms, 0, lane, h, a0, n0);
-  auto finish = [&](const f32x16& acc, auto qi_c, const Pop32Acc& e, uint32_t t) {
-    constexpr int qi = decltype(qi_c)::value;
-    cnt[qi] += __builtin_popcount(e.bits & 0xFFFFu);
-    if (__builtin_expect((__builtin_amdgcn_ballot_w64(e.tmin < wbits) & livemask[qi]) != 0, 0)) {
-      const uint32_t d = pop32_fix(coords, n_rows, n_cols, r2, lo[qi], acc, wbits, jq[qi], t, h);
-      cnt[qi] += ((livemask[qi] >> lane) & 1) ? d : 0u;
+  load_tile32<S>(img, norms, t, lane, h, a0, n0);
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t, float (&an)[S], float4 (&nn)[4], uint32_t t_next) {
+    const f32x16 c0 = frag16(nv);   // (+inf for a pad row: t = +inf)
+#pragma unroll
+    for (int g = 0; g < TQ; g += kClump32) {
+      f32x16 acc[kClump32];
+      if (g == 0)
+        chains32<S, kClump32>(a, &b[g], c0, acc, [&](int k) { load_tile32_part<S>(img, norms, t_next, lane, h, k, an, nn); });
+      else
+        chains32<S, kClump32>(a, &b[g], c0, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      uint32_t bits[kClump32], band = 0;
+#pragma unroll
+      for (int q = 0; q < kClump32; ++q) {
+        bits[q] = pop32_string(acc[q], nlo[g + q]);
+        cnt[g + q] += __builtin_popcount(inside_of(bits[q]));
+        band |= band_of(bits[q]);
+      }
+#ifdef DC32_NORARE
+      if (false) {
+#else
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(band != 0) != 0, 0)) {
+#endif
+#pragma unroll
+        for (int q = 0; q < kClump32; ++q) {
+          const uint32_t bq = band_of(bits[q]);
+          if (__builtin_amdgcn_ballot_w64(bq != 0) != 0) cnt[g + q] += pop32_fix(coords, n_rows, n_cols, r2, bq, jq[g + q], t, h);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-  };
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
-    const f32x16 c0 = frag16(nv);
-    constexpr_for_pairs<TQ>([&](auto qt_c) {
-      constexpr int qt = decltype(qt_c)::value;
-      constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
-      Pop32Acc e{0u, 0xFFFFFFFFu};
-      pop32_chain<S>(a, b[qt], c0, accA, accB, lo[qb], e);
-      finish(accB, std::integral_constant<int, qb>{}, e, (qt == 0) ? tB : t);
-      e = Pop32Acc{0u, 0xFFFFFFFFu};
-      pop32_chain<S>(a, b[qt + 1], c0, accB, accA, lo[qt], e);
-      finish(accA, std::integral_constant<int, qt>{}, e, t);
-    });
     // (every chain in the three-address form: for the chain at which c0 dies hipcc 7.2 otherwise accumulates INTO c0's
     //  registers and copies the tile back afterwards -- and its first v_mov of that copy is issued before the wait states
     //  the last MFMA needs: element 15 of the pending tile was stale, found by the parity test at TQ = 4)
     keep_alive(c0);
-    tB = t;
   };
-  for (uint32_t t = 0; t < T; t += 2) {
-    load_tile32<S>(img, norms, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
-    tile_body(a0, n0, t);
-    if (t + 1 < T) {
-      load_tile32<S>(img, norms, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
-      tile_body(a1, n1, t + 1);
-    }
-  }
-  {  // drain: epilogue of the last pending chain
-    Pop32Acc e{0u, 0xFFFFFFFFu};
-    pop32_epi<0, 16>(accB, lo[TQ - 1], e);
-    finish(accB, std::integral_constant<int, TQ - 1>{}, e, tB);
+  for (uint32_t k = 0; k < nt; k += 2) {
+    const uint32_t t1 = (t + 1 < te) ? t + 1 : tb;
+    tile_body(a0, n0, t, a1, n1, t1);
+    t = (t1 + 1 < te) ? t1 + 1 : tb;
+    if (k + 1 < nt) tile_body(a1, n1, t1, a0, n0, t);
   }
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
-    const uint32_t total = cnt[qt] + (uint32_t)__shfl_xor((int)cnt[qt], 32, 64);
+    uint32_t total = cnt[qt] + (uint32_t)__shfl_xor((int)cnt[qt], 32, 64);
     if (h == 0 && ((livemask[qt] >> lane) & 1)) {
-      // the sweep met the self pair and counted it iff d2(i,i) < rad2; the reference starts at 1 (:132-134)
-      const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
-      pops[jq[qt]] = total + 1u - ((dself < r2) ? 1u : 0u);
+      if (blockIdx.y == 0) {
+        // the sweep met the self pair and counted it iff d2(i,i) < rad2; the reference starts at 1 (:132-134)
+        const float dself = exact_d2(coords, n_cols, jq[qt], jq[qt]);
+        total += 1u - ((dself < r2) ? 1u : 0u);
+      }
+      if (gridDim.y == 1)
+        pops[jq[qt]] = total;
+      else
+        atomicAdd(&pops[jq[qt]], total);
     }
   }
 }
 
-template <int S, int SI = 0>
-__device__ __forceinline__ void nn32_chain(const float (&a)[S], const float (&b)[S], const f32x16& c0, f32x16& acc_new,
-                                           const f32x16& acc_old, float& tmin) {
-  if constexpr (SI < S) {
-    if constexpr (SI == 0)
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
-    else
-      acc_new = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SI], b[SI], acc_new, 0, 0, 0);
-    tile_min<(16 * SI) / S, (16 * (SI + 1)) / S>(acc_old, tmin);
-    nn32_chain<S, SI + 1>(a, b, c0, acc_new, acc_old, tmin);
+// Reference chunks of the fp32-input sweeps: every wave costs the same (all pairs are evaluated), so a launch whose
+// waves do not fill the chip's wave slots a whole number of times idles at its end -- 7 813 waves of four query tiles on
+// 2 048 slots: 3.81 rounds, 5 % lost; on 3 072 (three waves per SIMD) 2.54 rounds, 15 % lost.  The smallest chunk count
+// (<= 16, >= 512 reference tiles per chunk) whose wave count comes within 1.5 % of a whole number of rounds.
+inline uint32_t chunks32(uint32_t waves_q, uint32_t T, uint32_t slots) {
+  uint32_t best = 1;
+  double best_eff = 0.0;
+  for (uint32_t r = 1; r <= 16 && (r == 1 || T / r >= 512u); ++r) {
+    const double x = (double)waves_q * r / slots, eff = x / ceil(x);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = r; }
+    if (eff >= 0.985) return r;
+  }
+  return best;
+}
+
+// candidate elements of one accumulator tile: values below the bands of the query's running minima, the query itself,
+// pad rows and -- for the lower-free-energy minimum -- the frames at or above the query's free energy left out
+// (element r -> bit r of the nn mask, bit 16 + r of the hd mask); by value: see pop_fix
+__device__ __attribute__((noinline)) uint32_t nn32_masks(f32x16 acc, float bn, float bh, uint32_t spos, uint32_t pq,
+                                                         uint32_t n_rows, uint32_t t, int h) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t pos = tile_row(t, r, h);
+    const bool other = (pos != spos) & (pos < n_rows);
+    m |= (other & (acc[r] < bn)) ? (1u << r) : 0u;
+    m |= (other & (pos < pq) & (acc[r] < bh)) ? (0x10000u << r) : 0u;
+  }
+  return m;
+}
+
+// evaluates the parked candidates of a wave, 64 at a time (one per lane): x = sorted position | nn-flag << 30 |
+// hd-flag << 31, y = query slot; the exact incumbents are order-preserving words (d2 bits << 32 | frame id) in LDS, shared
+// by the two half-wave lanes of a query (see nn_wave_flush)
+__device__ __attribute__((noinline)) void nn32_wave_flush(const uint2* queue, uint32_t qn, const float* qrows,
+                                                          unsigned long long* best, uint32_t n_queries,
+                                                          const float* __restrict__ coords, const uint32_t* __restrict__ perm,
+                                                          uint32_t n_cols, int lane) {
+  for (uint32_t k0 = 0; k0 < qn; k0 += 64) {
+    if (k0 + lane < qn) {
+      const uint2 ent = queue[k0 + lane];
+      const uint32_t j = perm[ent.x & kQueuePosMask], qidx = ent.y;
+      const float d2c = dist2_canon_rows(qrows + (size_t)qidx * n_cols, coords + (size_t)j * n_cols, (int)n_cols);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d2c) << 32) | j;
+      if ((ent.x >> 30) & 1u) atomicMin(&best[qidx], key);
+      if ((ent.x >> 31) & 1u) atomicMin(&best[n_queries + qidx], key);
+    }
   }
 }
 
@@ -200,19 +317,38 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ img,
     const float* __restrict__ norms, const float* __restrict__ img_s, const float* __restrict__ norms_s,
     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ invpos, const uint32_t* __restrict__ pq_of,
-    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
-  static_assert(TQ % 2 == 0, "accumulator ping-pong needs an even number of query tiles");
+    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to, uint32_t stagger,
+    unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
+    float* __restrict__ hd_d2) {
+  static_assert(TQ == kClump32, "one clump of chains per reference tile");
+  // dynamic LDS, per wave: candidate list [kWaveQueue] x 8 B, exact incumbents [2][TQ*32] x 8 B, query rows [TQ*32][n_cols]
+  extern __shared__ __attribute__((aligned(16))) float nn32_lds[];
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t wib = threadIdx.x >> 6;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + wib;
   const uint32_t qt0 = i_from / 32 + wave * TQ;
   if (qt0 * 32 >= i_to) return;
   const float M = __uint_as_float(hdr[0]);
   const float eps2 = 2.5f * guard_eps32(M, 4.0f * M, 2 * S, (int)n_cols);   // candidates can be as far apart as 2 sqrt(M)
+  uint32_t* wave_lds = reinterpret_cast<uint32_t*>(nn32_lds) + (size_t)wib * (2 * kWaveQueue + 4 * TQ * 32 + TQ * 32 * n_cols);
+  uint2* cand = reinterpret_cast<uint2*>(wave_lds);
+  unsigned long long* best64 = reinterpret_cast<unsigned long long*>(wave_lds + 2 * kWaveQueue);
+  float* qrows = reinterpret_cast<float*>(wave_lds + 2 * kWaveQueue + 4 * TQ * 32);
+  uint32_t qn = 0;   // parked candidates (wave-uniform)
+#ifdef DC32_STATS
+  uint32_t st_rare = 0, st_trig = 0, st_flush = 0, st_cand = 0, st_tiles = 0;
+  const unsigned long long st_t0 = wall_clock64();
+#endif
 
   float b[TQ][S];
-  NnQ q[TQ];
+  // per query tile and lane: running minima of the MFMA values over this lane's reference rows (acc = |y'|^2 - 2 x'.y' =
+  // d2 - |x'|^2: the minima carry the same offset, the band does not care; idle lanes sit at -inf and never trigger),
+  // the cached candidate thresholds m + eps2 (they only move in the rare path: a value below a running minimum is below
+  // its band), the query's sorted position, the number of frames of lower free energy and the number of reference tiles
+  // that hold one
+  float m_nn[TQ], m_hd[TQ], thr_nn[TQ], thr_hd[TQ];
+  uint32_t spos[TQ], pq[TQ], t_low[TQ];
   uint32_t jq[TQ];
   uint64_t livemask[TQ];
 #pragma unroll
@@ -225,95 +361,157 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
     const uint32_t jl = live ? jq[qt] : (n_rows - 1);
-    q[qt].pq = live ? pq_of[jl] : 0u;
-    q[qt].spos = live ? invpos[jl] : 0xFFFFFFFFu;
-    q[qt].t_self = live ? (q[qt].spos >> 5) : 0xFFFFFFFFu;
-    q[qt].t_full = q[qt].pq >> 5;
-    q[qt].t_part = (q[qt].pq & 31u) ? (q[qt].pq >> 5) : 0xFFFFFFFFu;
-    // acc = |y'|^2 - 2 x'.y' = d2 - |x'|^2: the running minima carry the same offset, the band does not care.
-    // idle lanes start at -inf: they can never trigger the exact path and never change
-    q[qt].m_nn = live ? INFINITY : -INFINITY;
-    q[qt].m_hd = live ? INFINITY : -INFINITY;
-    q[qt].bd_nn = FLT_MAX;
-    q[qt].bd_hd = FLT_MAX;
-    q[qt].bj_nn = n_rows + 1;
-    q[qt].bj_hd = n_rows + 1;
+    pq[qt] = live ? pq_of[jl] : 0u;
+    spos[qt] = live ? invpos[jl] : 0xFFFFFFFFu;
+    t_low[qt] = (pq[qt] + 31u) >> 5;
+    m_nn[qt] = live ? INFINITY : -INFINITY;
+    m_hd[qt] = live ? INFINITY : -INFINITY;
+#ifndef DC32_NOPUB
+    if (gridDim.y > 1 && live) {
+      // what the waves of earlier reference chunks have published for this query (exact d2, FLT_MAX: nothing yet): the
+      // MFMA value of that pair is at most d2 - |x'|^2 + guard, so the running minima may start there instead of at
+      // +inf -- only the first chunk of a query group learns its thresholds from nothing
+      const float d_nn = __uint_as_float((uint32_t)(merge64[jq[qt]] >> 32)), d_hd = __uint_as_float((uint32_t)(merge64[(size_t)n_rows + jq[qt]] >> 32));
+      const float cq = norms[tl * 32 + c], guard = 0.4f * eps2;
+      if (d_hd < FLT_MAX) m_hd[qt] = round_up(round_up(d_hd - cq) + guard);
+      if (d_nn < FLT_MAX) m_nn[qt] = round_up(round_up(d_nn - cq) + guard);
+#ifdef DC32_PUBNN
+      m_hd[qt] = INFINITY;
+#endif
+      m_nn[qt] = fminf(m_nn[qt], m_hd[qt]);
+    }
+#endif
+    thr_nn[qt] = m_nn[qt] + eps2;
+    thr_hd[qt] = m_hd[qt] + eps2;
+    stage_query_rows(qrows + (size_t)qt * 32 * n_cols, nullptr, coords, jl, live, n_cols, lane);
+    if (h == 0) {
+      best64[qt * 32 + c] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | (n_rows + 1);
+      best64[TQ * 32 + qt * 32 + c] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | (n_rows + 1);
+    }
   }
-  (void)norms;
-  f32x16 accA, accB;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;
-  uint32_t tB = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (query rows and incumbents: written by the h = 0 lanes)
+  // reference tiles [tb, te) of this wave's chunk (see chunks32; partial results merge by a 64-bit atomic minimum of
+  // (d2 bits, frame id) -- the lexicographic order of the reference's scan -- in merge64, nn32_unpack_kernel writes them out)
+  const uint32_t per = (T + gridDim.y - 1) / gridDim.y, tb = blockIdx.y * per, te = min(T, tb + per);
+  const uint32_t nt = te > tb ? te - tb : 0u;
+  uint32_t t = nt ? tb + start32(stagger, nt) : 0u;   // (see pop_mfma32_kernel)
   float a0[S], a1[S];
   float4 n0[4], n1[4];
-  load_tile32<S>(img_s, norms_s, 0, lane, h, a0, n0);
-  auto finish = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t) {
+  load_tile32<S>(img_s, norms_s, t, lane, h, a0, n0);
+  auto flush = [&]() {
+#ifdef DC32_STATS
+    ++st_flush; st_cand += qn;
+#endif
+    nn32_wave_flush(cand, qn, qrows, best64, TQ * 32, coords, perm, n_cols, lane);
+    qn = 0;
+  };
+  // a chain whose tile minimum came below its query's threshold: masked minima where the tile holds the query itself or
+  // straddles its free energy, candidates parked for the exact path, running minima and thresholds renewed
+  auto rare_chain = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t) {
     constexpr int qi = decltype(qi_c)::value;
-    NnQ& Q = q[qi];
-    const bool special = (t == Q.t_self) | (t == Q.t_part);
-    float hmin = (t < Q.t_full) ? tmin : INFINITY;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) {
-      const NnMin g = nn_special(acc, t, h, Q.spos, Q.pq);   // valid for every lane, just slower
+#ifdef DC32_STATS
+    ++st_rare;
+#endif
+    const bool special = (t == (spos[qi] >> 5)) | ((t == (pq[qi] >> 5)) & ((pq[qi] & 31u) != 0u));
+    float hmin = (t < (pq[qi] >> 5)) ? tmin : INFINITY;
+    if (__builtin_amdgcn_ballot_w64(special) != 0) {
+      const NnMin g = nn_special(acc, t, h, spos[qi], pq[qi]);   // valid for every lane, just slower
       tmin = g.tmin;
       hmin = g.hmin;
     }
-    const bool trig = (tmin < Q.m_nn + eps2) | (hmin < Q.m_hd + eps2);
-    const float new_nn = fminf(Q.m_nn, tmin), new_hd = fminf(Q.m_hd, hmin);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(trig) != 0, 0)) {
-      const bool live = (livemask[qi] >> lane) & 1;
-      NnBest best{Q.bd_nn, Q.bd_hd, Q.bj_nn, Q.bj_hd};
-      best = nn_fix(coords, perm, n_rows, n_cols, acc, new_nn + eps2, new_hd + eps2, best, jq[qi], Q.spos, Q.pq, t, h);
-      Q.bd_nn = live ? best.bd_nn : Q.bd_nn;
-      Q.bj_nn = live ? best.bj_nn : Q.bj_nn;
-      Q.bd_hd = live ? best.bd_hd : Q.bd_hd;
-      Q.bj_hd = live ? best.bj_hd : Q.bj_hd;
+    const bool trig = (tmin < m_nn[qi] + eps2) | (hmin < m_hd[qi] + eps2);
+    const float new_nn = fminf(m_nn[qi], tmin), new_hd = fminf(m_hd[qi], hmin);
+    if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+#ifdef DC32_STATS
+      ++st_trig;
+#endif
+      uint32_t m = nn32_masks(acc, new_nn + eps2, new_hd + eps2, spos[qi], pq[qi], n_rows, t, h);
+      if (!((livemask[qi] >> lane) & 1)) m = 0;
+      for (;;) {
+        const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
+        if (have == 0) break;
+        const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
+        if (qn + n_new > (uint32_t)kWaveQueue) flush();
+        if (m != 0) {
+          const int r = __builtin_ctz(m | (m >> 16));
+          const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
+          cand[slot] = make_uint2(tile_row(t, r, h) | (((m >> r) & 1u) << 30) | (((m >> (16 + r)) & 1u) << 31), (uint32_t)(qi * 32 + c));
+          m &= ~(0x10001u << r);
+        }
+        qn += n_new;
+      }
+      if (qn >= 64u) flush();
     }
-    Q.m_nn = new_nn;
-    Q.m_hd = new_hd;
+    m_nn[qi] = new_nn;
+    m_hd[qi] = new_hd;
+    thr_nn[qi] = new_nn + eps2;
+    thr_hd[qi] = new_hd + eps2;
   };
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t, float (&an)[S], float4 (&nn)[4], uint32_t t_next) {
     const f32x16 c0 = frag16(nv);
-    constexpr_for_pairs<TQ>([&](auto qt_c) {
-      constexpr int qt = decltype(qt_c)::value;
-      constexpr int qb = (qt == 0) ? TQ - 1 : qt - 1;
-      float tmin = INFINITY;
-      nn32_chain<S>(a, b[qt], c0, accA, accB, tmin);
-      finish(accB, std::integral_constant<int, qb>{}, tmin, (qt == 0) ? tB : t);
-      tmin = INFINITY;
-      nn32_chain<S>(a, b[qt + 1], c0, accB, accA, tmin);
-      finish(accA, std::integral_constant<int, qt>{}, tmin, t);
-    });
-    keep_alive(c0);   // (see pop_mfma32_kernel)
-    tB = t;
-  };
-  for (uint32_t t = 0; t < T; t += 2) {
-    load_tile32<S>(img_s, norms_s, (t + 1 < T) ? t + 1 : t, lane, h, a1, n1);
-    tile_body(a0, n0, t);
-    if (t + 1 < T) {
-      load_tile32<S>(img_s, norms_s, (t + 2 < T) ? t + 2 : t + 1, lane, h, a0, n0);
-      tile_body(a1, n1, t + 1);
+    f32x16 acc[TQ];
+    chains32<S, TQ>(a, b, c0, acc, [&](int k) { load_tile32_part<S>(img_s, norms_s, t_next, lane, h, k, an, nn); });
+    __builtin_amdgcn_sched_barrier(0);
+    // Common path: the raw tile minimum (the query itself included: it only ever makes the test pass) against ONE
+    // threshold per chain -- thr_hd >= thr_nn when the tile holds a frame of lower free energy, thr_nn otherwise; what
+    // the masked minima and the two bands of the old per-chain test could trigger is a subset of this
+    float tm[TQ], dmin = INFINITY;
+#pragma unroll
+    for (int qi = 0; qi < TQ; ++qi) {
+      tm[qi] = INFINITY;
+      tile_min<0, 16>(acc[qi], tm[qi]);
+      dmin = fminf(dmin, tm[qi] - ((t < t_low[qi]) ? thr_hd[qi] : thr_nn[qi]));   // (inf - inf: NaN, ignored by the minimum)
     }
+#ifdef DC32_NORARE
+    if (t < 8) {
+#else
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmin < 0.0f) != 0, 0)) {
+#endif
+      constexpr_for_all<TQ>([&](auto qi_c) {
+        constexpr int qi = decltype(qi_c)::value;
+        const float thr_c = (t < t_low[qi]) ? thr_hd[qi] : thr_nn[qi];
+        if (__builtin_amdgcn_ballot_w64(tm[qi] < thr_c) != 0) rare_chain(acc[qi], qi_c, tm[qi], t);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    keep_alive(c0);   // (see pop_mfma32_kernel)
+  };
+  for (uint32_t k = 0; k < nt; k += 2) {
+    const uint32_t t1 = (t + 1 < te) ? t + 1 : tb;
+    tile_body(a0, n0, t, a1, n1, t1);
+    t = (t1 + 1 < te) ? t1 + 1 : tb;
+    if (k + 1 < nt) tile_body(a1, n1, t1, a0, n0, t);
   }
-  {  // drain: epilogue of the last pending chain
-    float tmin = INFINITY;
-    tile_min<0, 16>(accB, tmin);
-    finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB);
-  }
+  flush();
+#ifdef DC32_STATS
+  if (lane == 0 && (blockIdx.x % 16) == 7)
+    printf("nn32w %u %u %u %llu %llu %u %u\n", blockIdx.y, blockIdx.x, wib, st_t0 / 100, (wall_clock64() - st_t0) / 100, st_rare, st_cand);
+#endif
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
-    NnQ& Q = q[qt];
-    // merge the two half-waves (disjoint reference rows of the same query)
-    float od = __shfl_xor(Q.bd_nn, 32, 64);
-    uint32_t oj = (uint32_t)__shfl_xor((int)Q.bj_nn, 32, 64);
-    lexi_update(oj <= n_rows, Q.bd_nn, Q.bj_nn, od, oj, n_rows);
-    od = __shfl_xor(Q.bd_hd, 32, 64);
-    oj = (uint32_t)__shfl_xor((int)Q.bj_hd, 32, 64);
-    lexi_update(oj <= n_rows, Q.bd_hd, Q.bj_hd, od, oj, n_rows);
     if (h == 0 && ((livemask[qt] >> lane) & 1)) {
-      nn_idx[jq[qt]] = Q.bj_nn;
-      nn_d2[jq[qt]] = Q.bd_nn;
-      hd_idx[jq[qt]] = Q.bj_hd;
-      hd_d2[jq[qt]] = Q.bd_hd;
+      const unsigned long long w_nn = best64[qt * 32 + c], w_hd = best64[TQ * 32 + qt * 32 + c];
+      if (gridDim.y == 1) {
+        nn_idx[jq[qt]] = (uint32_t)w_nn;
+        nn_d2[jq[qt]] = __uint_as_float((uint32_t)(w_nn >> 32));
+        hd_idx[jq[qt]] = (uint32_t)w_hd;
+        hd_d2[jq[qt]] = __uint_as_float((uint32_t)(w_hd >> 32));
+      } else {
+        atomicMin(&merge64[jq[qt]], w_nn);
+        atomicMin(&merge64[(size_t)n_rows + jq[qt]], w_hd);
+      }
     }
   }
+}
+
+__global__ void nn32_unpack_kernel(const unsigned long long* __restrict__ merge64, uint32_t n_rows, uint32_t i_from,
+                                   uint32_t i_to, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2,
+                                   uint32_t* __restrict__ hd_idx, float* __restrict__ hd_d2) {
+  const uint32_t i = i_from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i_to) return;
+  const unsigned long long a = merge64[i], b = merge64[(size_t)n_rows + i];
+  nn_idx[i] = (uint32_t)a;
+  nn_d2[i] = __uint_as_float((uint32_t)(a >> 32));
+  hd_idx[i] = (uint32_t)b;
+  hd_d2[i] = __uint_as_float((uint32_t)(b >> 32));
 }

@@ -2099,7 +2099,13 @@ __device__ __forceinline__ void load_tile_folded(const uint4* __restrict__ img, 
 constexpr uint32_t kDbgWaves = 1u << 17;
 __device__ unsigned long long g_wave_dbg[kDbgWaves][10];
 #endif
-template <int NM, int TQ>
+// COOP (round 6): the waves of a workgroup are consecutive reference SHARES of ONE query group instead of different
+// groups.  They keep one copy of the query rows, of the exact incumbents (best64) and of the published bounds in LDS,
+// and they exchange the running minima that set the candidate thresholds through LDS inside the candidate path (smin:
+// a returning ds_min per query and kind, only in the chains that went on): a threshold one share has learnt is learnt
+// for all of them -- DESIGN.md 4.8 measured 0.45 ms of a rank's 1.6 ms (an eighth of C3) as thresholds learnt again by
+// every one of a group's 34 shares.  Taken when a group has many shares (sharded runs); a share is still a wave.
+template <int NM, int TQ, bool COOP = false>
 __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ fe, const uint4* __restrict__ img_r,
@@ -2127,12 +2133,13 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   uint32_t* lists_all = reinterpret_cast<uint32_t*>(nn_dyn_lds);
   float* qrows_all = nn_dyn_lds + (size_t)wpb * kListCap;
   const uint32_t TQT = (n_q + 31) / 32;
-  const uint32_t blk_unit = xcd_block((seg_groups((TQT + TQ - 1) / TQ, q_seg) + wpb - 1) / wpb);
+  const uint32_t blk_unit = xcd_block(COOP ? seg_groups((TQT + TQ - 1) / TQ, q_seg) : (seg_groups((TQT + TQ - 1) / TQ, q_seg) + wpb - 1) / wpb);
   if (blk_unit == 0xFFFFFFFFu) return;   // (pad block of the grid)
-  const uint32_t wave = seg_group(blk_unit * wpb + wib, q_seg);
-  const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;   // reference tiles dealt round-robin
+  const uint32_t wave = seg_group(COOP ? blk_unit : blk_unit * wpb + wib, q_seg);
+  // reference tiles dealt round-robin (COOP: the workgroup's waves take neighbouring shares)
+  const uint32_t chunk = COOP ? blockIdx.y * wpb + (uint32_t)wib : blockIdx.y, n_chunks = COOP ? gridDim.y * wpb : gridDim.y;
   const uint32_t qt0 = wave * TQ;
-  if (qt0 >= TQT) return;
+  if (qt0 >= TQT) return;   // (COOP: the whole workgroup leaves -- no barrier is ever met by a part of it)
 #ifdef DC_WAVE_STAMPS
   const unsigned long long dbg_t0 = wall_clock64();
   const unsigned long long dbg_c0 = clock64();
@@ -2144,18 +2151,26 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const uint32_t comp_lo = CV.range_r[2 * my_comp], comp_hi = CV.range_r[2 * my_comp + 1];
   const float comp_cell = __uint_as_float(CV.comp[kCompFine + 4 * min(my_comp, (uint32_t)kMaxComp - 1u) + 2]);
   uint32_t* list = lists_all + (size_t)wib * kListCap;
-  float* qrows = qrows_all + (size_t)wib * (TQ * 32) * n_cols;
-  uint32_t* queues = reinterpret_cast<uint32_t*>(qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
-                     (size_t)wib * (TQ * kQueueCap * 64 + 2 * TQ * 32);
+  // COOP layout (fixed offsets first): lists [wpb][kListCap] | candidate lists [wpb][2 kWaveQueue] | best64 [2][TQ*32] x 8 B |
+  // g_pub [2][TQ*32] | smin [2][TQ*32] | query rows [TQ*32][n_cols] -- everything behind the lists once per WORKGROUP
+  uint32_t* coop_base = lists_all + (size_t)wpb * kListCap;
+  float* qrows = COOP ? reinterpret_cast<float*>(coop_base + (size_t)wpb * 2 * kWaveQueue + 8 * TQ * 32)
+                      : qrows_all + (size_t)wib * (TQ * 32) * n_cols;
+  uint32_t* queues = COOP ? coop_base + (size_t)wib * 2 * kWaveQueue
+                          : reinterpret_cast<uint32_t*>(qrows_all + (size_t)wpb * (TQ * 32) * n_cols) +
+                                (size_t)wib * (TQ * kQueueCap * 64 + 2 * TQ * 32);
   // the wave's LDS behind the query rows (TQ * kQueueCap * 64 words): the compact candidate list (kWaveQueue
   // entries of 8 B) and the packed exact incumbents [2][TQ*32] of 8 B
   static_assert(TQ * kQueueCap * 64 >= 2 * kWaveQueue + 4 * TQ * 32, "candidate list + incumbents fit the queue region");
   uint2* cand = reinterpret_cast<uint2*>(queues);
-  unsigned long long* best64 = reinterpret_cast<unsigned long long*>(queues + 2 * kWaveQueue);
+  unsigned long long* best64 = reinterpret_cast<unsigned long long*>(COOP ? coop_base + (size_t)wpb * 2 * kWaveQueue : queues + 2 * kWaveQueue);
   // exact incumbents other reference chunks had published when this wave started (FLT_MAX: none), [2][TQ*32] -- kept in
   // LDS like the wave's own incumbents: neither is touched inside the chains, and as registers they were live (and
   // partly spilled) across the whole sweep
-  float* g_pub = reinterpret_cast<float*>(queues + TQ * kQueueCap * 64);   // (2 * TQ * 32 words behind the queue region)
+  float* g_pub = COOP ? reinterpret_cast<float*>(coop_base + (size_t)wpb * 2 * kWaveQueue + 4 * TQ * 32)
+                      : reinterpret_cast<float*>(queues + TQ * kQueueCap * 64);   // (2 * TQ * 32 words behind the queue region)
+  // COOP: the group's running minima (ordered-integer keys of m_nn / m_hd in d2 units), [2][TQ*32]
+  uint32_t* smin = coop_base + (size_t)wpb * 2 * kWaveQueue + 6 * TQ * 32;
   uint32_t qn = 0;   // queued candidates (wave-uniform)
 
   // (scaled units, like the accumulators and the running minima taken from them)
@@ -2220,88 +2235,173 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
   const unsigned long long dbg_sA = wall_clock64();
   asm volatile("" ::"s"(dbg_sA));
 #endif
-  // published bounds and the original coordinates of the queries (for the exact path) into LDS
+  if constexpr (COOP) {
+    // one copy per workgroup: published bounds, exact incumbents, running minima (wave 0), query rows (all waves)
+    if (wib == 0 && h == 0) {
 #pragma unroll
-  for (int qt = 0; qt < TQ; ++qt)
-    if (h == 0) {
-      g_pub[qt * 32 + c] = g_nn[qt];
-      g_pub[TQ * 32 + qt * 32 + c] = g_hd[qt];
+      for (int qt = 0; qt < TQ; ++qt) {
+        g_pub[qt * 32 + c] = g_nn[qt];
+        g_pub[TQ * 32 + qt * 32 + c] = g_hd[qt];
+        best64[qt * 32 + c] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | (n_rows + 1);
+        best64[TQ * 32 + qt * 32 + c] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | (n_rows + 1);
+        smin[qt * 32 + c] = fkey(q[qt].m_nn);
+        smin[TQ * 32 + qt * 32 + c] = fkey(q[qt].m_hd);
+      }
     }
-  if (full_range && qt0 + TQ <= TQT) {
-    // (the rows of the wave's tiles are one contiguous piece of the ordered copy: twenty loads per lane in flight, all
-    //  of them at ten columns)
-    const float* src = coords_c + (size_t)qt0 * 32 * n_cols;
-    const uint32_t total = (uint32_t)TQ * 32u * n_cols;
-    for (uint32_t e0 = (uint32_t)lane; e0 < total; e0 += 1280u) {
-      float v[20];
+    if (full_range && qt0 + TQ <= TQT) {
+      const float* src = coords_c + (size_t)qt0 * 32 * n_cols;
+      const uint32_t total = (uint32_t)TQ * 32u * n_cols, nthr = blockDim.x;
+      for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 8u * nthr) {
+        float v[8];
 #pragma unroll
-      for (uint32_t j = 0; j < 20; ++j) v[j] = (e0 + 64u * j < total) ? src[e0 + 64u * j] : 0.0f;
+        for (uint32_t j = 0; j < 8; ++j) v[j] = (e0 + nthr * j < total) ? src[e0 + nthr * j] : 0.0f;
 #pragma unroll
-      for (uint32_t j = 0; j < 20; ++j)
-        if (e0 + 64u * j < total) qrows[e0 + 64u * j] = v[j];
+        for (uint32_t j = 0; j < 8; ++j)
+          if (e0 + nthr * j < total) qrows[e0 + nthr * j] = v[j];
+      }
+    } else {
+#pragma unroll
+      for (int qt = 0; qt < TQ; ++qt) {
+        if (((uint32_t)qt % wpb) != (uint32_t)wib) continue;
+        const uint32_t tile = qt0 + qt, tl = tile < TQT ? tile : TQT - 1;
+        stage_query_rows(qrows + (size_t)qt * 32 * n_cols, full_range ? coords_c + (size_t)tl * 32 * n_cols : nullptr, coords,
+                         jq[qt], (livemask[qt] >> lane) & 1, n_cols, lane);
+      }
     }
-  } else {
-#pragma unroll
-    for (int qt = 0; qt < TQ; ++qt) {
-      const uint32_t tile = qt0 + qt, tl = tile < TQT ? tile : TQT - 1;
-      stage_query_rows(qrows + (size_t)qt * 32 * n_cols, full_range ? coords_c + (size_t)tl * 32 * n_cols : nullptr, coords,
-                       jq[qt], (livemask[qt] >> lane) & 1, n_cols, lane);
-    }
-  }
-  // Seeds: the frames next to each query in the sweep's order (same cell, neighbouring free energy; the
-  // ones before it have a lower free energy) are evaluated exactly before the first ring.  They are
-  // ordinary candidates; what they buy is finite running minima from the start -- without them the first
-  // tiles of a sweep park every element, and query groups in sparse regions (wide boxes, long first ring)
-  // spent a microsecond per chain in the candidate path.
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (query rows: written by the h = 0 lanes)
+    __syncthreads();
 #ifdef DC_WAVE_STAMPS
-  const unsigned long long dbg_sB = wall_clock64();
+    const unsigned long long dbg_sB = wall_clock64();
 #endif
+    if (blockIdx.y == 0) {
+      // Seeds (see below), dealt to the waves of the group's FIRST workgroup: wave w looks at the frames w + 1, w + 1 + wpb,
+      // ... positions away; the results meet in LDS and are published at once
 #pragma unroll
-  for (int qt = 0; qt < TQ; ++qt) {
-    const bool live = (livemask[qt] >> lane) & 1;
-    NnPQr& Q = q[qt];
-    float bd_nn = FLT_MAX, bd_hd = FLT_MAX;          // exact incumbents of this query (canonical d2, frame id)
-    uint32_t bj_nn = n_rows + 1, bj_hd = n_rows + 1;
-    // (only the first reference share: the later ones start from what the earlier ones published)
-    if (live && chunk == 0) {
-      const float* qrow = qrows + (qt * 32 + c) * n_cols;
-      for (int k = 1; k <= kSeedNeighbours; ++k) {
-        const long long p2 = (long long)Q.spos + (h ? -k : k);
-        if (p2 >= 0 && p2 < (long long)CV.n_pos && perm_r[p2] != kInvalidFrame) {
-          const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)p2 * n_cols, 1, (int)n_cols);
-          const uint32_t j = perm_r[p2];
-          lexi_update(true, bd_nn, bj_nn, d2c, j, n_rows);
-          lexi_update(fe_c[p2] < Q.feq, bd_hd, bj_hd, d2c, j, n_rows);
+      for (int qt = 0; qt < TQ; ++qt) {
+        const bool live = (livemask[qt] >> lane) & 1;
+        float bd_nn = FLT_MAX, bd_hd = FLT_MAX;
+        uint32_t bj_nn = n_rows + 1, bj_hd = n_rows + 1;
+        if (live) {
+          const float* qrow = qrows + (qt * 32 + c) * n_cols;
+          for (int k = 1 + wib; k <= kSeedNeighbours; k += (int)wpb) {
+            const long long p2 = (long long)q[qt].spos + (h ? -k : k);
+            if (p2 >= 0 && p2 < (long long)CV.n_pos && perm_r[p2] != kInvalidFrame) {
+              const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)p2 * n_cols, 1, (int)n_cols);
+              const uint32_t j = perm_r[p2];
+              lexi_update(true, bd_nn, bj_nn, d2c, j, n_rows);
+              lexi_update(fe_c[p2] < q[qt].feq, bd_hd, bj_hd, d2c, j, n_rows);
+            }
+          }
+          const float s_nn = bd_nn * sc.s2, s_hd = bd_hd * sc.s2;
+          const unsigned long long w_nn = ((unsigned long long)__float_as_uint(bd_nn) << 32) | bj_nn;
+          const unsigned long long w_hd = ((unsigned long long)__float_as_uint(bd_hd) << 32) | bj_hd;
+          if (bd_nn < FLT_MAX) {
+            atomicMin(&best64[qt * 32 + c], w_nn);
+            atomicMin(&smin[qt * 32 + c], fkey(s_nn + (gb.e0 + gb.kappa * s_nn)));
+            atomicMin(&merge64[jq[qt]], w_nn);
+          }
+          if (bd_hd < FLT_MAX) {
+            atomicMin(&best64[TQ * 32 + qt * 32 + c], w_hd);
+            atomicMin(&smin[TQ * 32 + qt * 32 + c], fkey(s_hd + (gb.e0 + gb.kappa * s_hd)));
+            atomicMin(&merge64[(size_t)n_rows + jq[qt]], w_hd);
+          }
         }
       }
-      // (the two half-wave lanes looked at the frames after / before the query: merge, then both hold the result)
-      {
-        float od = __shfl_xor(bd_nn, 32, 64);
-        uint32_t oj = (uint32_t)__shfl_xor((int)bj_nn, 32, 64);
-        lexi_update(oj <= n_rows, bd_nn, bj_nn, od, oj, n_rows);
-        od = __shfl_xor(bd_hd, 32, 64);
-        oj = (uint32_t)__shfl_xor((int)bj_hd, 32, 64);
-        lexi_update(oj <= n_rows, bd_hd, bj_hd, od, oj, n_rows);
-      }
-      const float s_nn = bd_nn * sc.s2, s_hd = bd_hd * sc.s2;
-      if (bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
-      if (bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
-      Q.bn = nn_prime(nn_band(gb, Q.m_nn), cq[qt]) + skipb;
-      Q.bh = nn_prime(nn_band(gb, Q.m_hd), cq[qt]) + skipb;
-      // published at once: the other shares of this group start while this wave is still sweeping
-      if (n_chunks > 1) {
-        if (bd_nn < FLT_MAX)
-          atomicMin(&merge64[jq[qt]], ((unsigned long long)__float_as_uint(bd_nn) << 32) | bj_nn);
-        if (bd_hd < FLT_MAX)
-          atomicMin(&merge64[(size_t)n_rows + jq[qt]],
-                    ((unsigned long long)__float_as_uint(bd_hd) << 32) | bj_hd);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt) {
+      NnPQr& Q = q[qt];
+      if ((livemask[qt] >> lane) & 1) {
+        Q.m_hd = fminf(Q.m_hd, fkey_inv(smin[TQ * 32 + qt * 32 + c]));
+        Q.m_nn = fminf(fminf(Q.m_nn, fkey_inv(smin[qt * 32 + c])), Q.m_hd);
+        Q.bn = nn_prime(nn_band(gb, Q.m_nn), cq[qt]) + skipb;
+        Q.bh = nn_prime(nn_band(gb, Q.m_hd), cq[qt]) + skipb;
       }
     }
-    // the exact incumbents of the wave's queries live in LDS as order-preserving words (see nn_wave_flush)
-    if (h == 0) {
-      best64[qt * 32 + c] = ((unsigned long long)__float_as_uint(bd_nn) << 32) | bj_nn;
-      best64[TQ * 32 + qt * 32 + c] = ((unsigned long long)__float_as_uint(bd_hd) << 32) | bj_hd;
+  } else {
+    // published bounds and the original coordinates of the queries (for the exact path) into LDS
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt)
+      if (h == 0) {
+        g_pub[qt * 32 + c] = g_nn[qt];
+        g_pub[TQ * 32 + qt * 32 + c] = g_hd[qt];
+      }
+    if (full_range && qt0 + TQ <= TQT) {
+      // (the rows of the wave's tiles are one contiguous piece of the ordered copy: twenty loads per lane in flight, all
+      //  of them at ten columns)
+      const float* src = coords_c + (size_t)qt0 * 32 * n_cols;
+      const uint32_t total = (uint32_t)TQ * 32u * n_cols;
+      for (uint32_t e0 = (uint32_t)lane; e0 < total; e0 += 1280u) {
+        float v[20];
+#pragma unroll
+        for (uint32_t j = 0; j < 20; ++j) v[j] = (e0 + 64u * j < total) ? src[e0 + 64u * j] : 0.0f;
+#pragma unroll
+        for (uint32_t j = 0; j < 20; ++j)
+          if (e0 + 64u * j < total) qrows[e0 + 64u * j] = v[j];
+      }
+    } else {
+#pragma unroll
+      for (int qt = 0; qt < TQ; ++qt) {
+        const uint32_t tile = qt0 + qt, tl = tile < TQT ? tile : TQT - 1;
+        stage_query_rows(qrows + (size_t)qt * 32 * n_cols, full_range ? coords_c + (size_t)tl * 32 * n_cols : nullptr, coords,
+                         jq[qt], (livemask[qt] >> lane) & 1, n_cols, lane);
+      }
+    }
+    // Seeds: the frames next to each query in the sweep's order (same cell, neighbouring free energy; the
+    // ones before it have a lower free energy) are evaluated exactly before the first ring.  They are
+    // ordinary candidates; what they buy is finite running minima from the start -- without them the first
+    // tiles of a sweep park every element, and query groups in sparse regions (wide boxes, long first ring)
+    // spent a microsecond per chain in the candidate path.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (query rows: written by the h = 0 lanes)
+#ifdef DC_WAVE_STAMPS
+    const unsigned long long dbg_sB = wall_clock64();
+#endif
+#pragma unroll
+    for (int qt = 0; qt < TQ; ++qt) {
+      const bool live = (livemask[qt] >> lane) & 1;
+      NnPQr& Q = q[qt];
+      float bd_nn = FLT_MAX, bd_hd = FLT_MAX;          // exact incumbents of this query (canonical d2, frame id)
+      uint32_t bj_nn = n_rows + 1, bj_hd = n_rows + 1;
+      // (only the first reference share: the later ones start from what the earlier ones published)
+      if (live && chunk == 0) {
+        const float* qrow = qrows + (qt * 32 + c) * n_cols;
+        for (int k = 1; k <= kSeedNeighbours; ++k) {
+          const long long p2 = (long long)Q.spos + (h ? -k : k);
+          if (p2 >= 0 && p2 < (long long)CV.n_pos && perm_r[p2] != kInvalidFrame) {
+            const float d2c = dist2_canon_rt(qrow, 1, coords_c + (size_t)p2 * n_cols, 1, (int)n_cols);
+            const uint32_t j = perm_r[p2];
+            lexi_update(true, bd_nn, bj_nn, d2c, j, n_rows);
+            lexi_update(fe_c[p2] < Q.feq, bd_hd, bj_hd, d2c, j, n_rows);
+          }
+        }
+        // (the two half-wave lanes looked at the frames after / before the query: merge, then both hold the result)
+        {
+          float od = __shfl_xor(bd_nn, 32, 64);
+          uint32_t oj = (uint32_t)__shfl_xor((int)bj_nn, 32, 64);
+          lexi_update(oj <= n_rows, bd_nn, bj_nn, od, oj, n_rows);
+          od = __shfl_xor(bd_hd, 32, 64);
+          oj = (uint32_t)__shfl_xor((int)bj_hd, 32, 64);
+          lexi_update(oj <= n_rows, bd_hd, bj_hd, od, oj, n_rows);
+        }
+        const float s_nn = bd_nn * sc.s2, s_hd = bd_hd * sc.s2;
+        if (bd_nn < FLT_MAX) Q.m_nn = fminf(Q.m_nn, s_nn + (gb.e0 + gb.kappa * s_nn));
+        if (bd_hd < FLT_MAX) Q.m_hd = fminf(Q.m_hd, s_hd + (gb.e0 + gb.kappa * s_hd));
+        Q.bn = nn_prime(nn_band(gb, Q.m_nn), cq[qt]) + skipb;
+        Q.bh = nn_prime(nn_band(gb, Q.m_hd), cq[qt]) + skipb;
+        // published at once: the other shares of this group start while this wave is still sweeping
+        if (n_chunks > 1) {
+          if (bd_nn < FLT_MAX)
+            atomicMin(&merge64[jq[qt]], ((unsigned long long)__float_as_uint(bd_nn) << 32) | bj_nn);
+          if (bd_hd < FLT_MAX)
+            atomicMin(&merge64[(size_t)n_rows + jq[qt]],
+                      ((unsigned long long)__float_as_uint(bd_hd) << 32) | bj_hd);
+        }
+      }
+      // the exact incumbents of the wave's queries live in LDS as order-preserving words (see nn_wave_flush)
+      if (h == 0) {
+        best64[qt * 32 + c] = ((unsigned long long)__float_as_uint(bd_nn) << 32) | bj_nn;
+        best64[TQ * 32 + qt * 32 + c] = ((unsigned long long)__float_as_uint(bd_hd) << 32) | bj_hd;
+      }
     }
   }
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
@@ -2425,6 +2525,14 @@ __global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
           //  found bounds the answer of both, so the running minima are shared whenever they move -- the
           //  records of one sequence over all rows instead of two over half of them each)
           float new_nn = fminf(Q.m_nn, nn_unprime(tmin, cq[qi])), new_hd = fminf(Q.m_hd, nn_unprime(hmin, cq[qi]));
+          if constexpr (COOP) {
+            // what the other shares of the group have learnt in the meantime, and what this chain adds to it (a returning
+            // ds_min per kind; idle lanes carry -inf on both sides)
+            const uint32_t o_nn = atomicMin(&smin[qi * 32 + c], fkey(new_nn));
+            const uint32_t o_hd = atomicMin(&smin[TQ * 32 + qi * 32 + c], fkey(new_hd));
+            new_nn = fminf(new_nn, fkey_inv(o_nn));
+            new_hd = fminf(new_hd, fkey_inv(o_hd));
+          }
           new_nn = fminf(new_nn, __shfl_xor(new_nn, 32, 64));
           new_hd = fminf(new_hd, __shfl_xor(new_hd, 32, 64));
           const float bn = nn_prime(nn_band(gb, new_nn), cq[qi]), bh = nn_prime(nn_band(gb, new_hd), cq[qi]);
@@ -2817,6 +2925,7 @@ struct NnPrunedArgs {     // regions of the neighbour sweep's (cell, free energy
 // fastest at 12 chunks (pop 38.3 -> 35.6 ms, nn 50.2 -> 38.8 ms against one chunk), one eighth of the
 // rows (one rank of an 8-GPU run) at 17..64 (pop) / 34 (nn) chunks.
 constexpr uint32_t kPopWaveTarget = 49152, kPopSharedWaveTarget = 196608, kNnWaveTarget = 98304, kNnWaveTargetPerWave = 40960;   // (round 3, with the component-wise scans: pop 98304 / 512 ->
+constexpr uint32_t kNnCoopMinShares = 16;   // shares per group from which the neighbour sweep's shares are waves of one workgroup
 constexpr uint32_t kPopShareFloor = 1024, kNnShareFloor = 900;     //  49152 / 1024: C3 12.30 -> 12.12 ms, one eighth of it 1.82 -> 1.72 ms;
                                                                    //  per-wave neighbour sweep 98304 -> 57344: C3 14.26 -> 14.10 ms, two boxes;
                                                                    //  round 4, six query tiles per wave: 57344 -> 40960, 8 shares instead of 12
@@ -2914,7 +3023,34 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
   }
   const uint32_t waves = seg_groups(((A.n_q + 31) / 32 + TQV - 1) / TQV, A.q_seg), tiles = waves * TQV;
   if (waves == 0) return;
-  const uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTargetPerWave, T, kNnShareFloor, (size_t)S * 1024 + 128);
+  uint32_t n_chunks = pick_chunks(tiles, TQV, kNnWaveTargetPerWave, T, kNnShareFloor, (size_t)S * 1024 + 128);
+  // Many shares per group (a rank of a sharded run: 34 at an eighth of C3): the shares of a group as the waves of ONE
+  // workgroup that learn their thresholds together (nn_pruned_kernel<.., COOP>); DC_NN_COOP = 0 / 1 forces either form
+  static const int coop_env = [] { const char* v = getenv("DC_NN_COOP"); return (v && v[0]) ? atoi(v) : -1; }();
+  constexpr uint32_t kCoopWaves = 4;
+  const bool coop = (coop_env >= 0) ? (coop_env != 0 && n_chunks >= kCoopWaves) : (n_chunks >= kNnCoopMinShares);
+  if (coop) {
+    n_chunks = (n_chunks + kCoopWaves - 1) / kCoopWaves * kCoopWaves;
+    const size_t smem_c = sizeof(uint32_t) * (kCoopWaves * (kListCap + 2 * kWaveQueue) + 8 * TQV * 32) +
+                          sizeof(float) * TQV * 32 * (size_t)n_cols;
+    hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s, A.merge64, n_rows);
+    hipLaunchKernelGGL(box_by_share_kernel, dim3((T + 255) / 256), dim3(256), 0, s, A.box_r, T, n_chunks, A.box_t);
+    sweep_timer_mark(1, true, s);
+    hipLaunchKernelGGL((nn_pruned_kernel<S, TQV, true>), dim3(grid_x8(waves), n_chunks / kCoopWaves), dim3(64 * kCoopWaves), smem_c, s,
+                       coords, n_rows, n_cols, fe, A.img_r, A.norms_r, A.perm_r, A.box_r, (const float4*)A.box_t, A.ferange_r,
+                       A.fe_c, A.coords_c, A.invpos_r, T, A.img_q, A.norms_q, A.perm_q, A.box_q, A.n_q, A.q_seg,
+                       A.full_range, A.cell2, hdr, chain_counter, A.merge64, nn_idx, nn_d2, hd_idx, hd_d2, CV);
+    sweep_timer_mark(1, false, s);
+    if (A.full_range)
+      hipLaunchKernelGGL(nn_merge_unpack_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s,
+                         (const unsigned long long*)A.merge64, A.invpos_r, n_rows, (uint32_t)TQV, A.q_seg,
+                         nn_idx, nn_d2, hd_idx, hd_d2);
+    else
+      hipLaunchKernelGGL(nn_merge_unpack_kernel, dim3((A.n_q + 255) / 256), dim3(256), 0, s,
+                         (const unsigned long long*)A.merge64, A.perm_q, A.n_q, n_rows, (uint32_t)TQV, A.q_seg,
+                         nn_idx, nn_d2, hd_idx, hd_d2);
+    return;
+  }
   // query rows (original coordinates) + candidate queues, per wave
   const uint32_t wpb = waves_per_group(S);
   const size_t smem = wpb * (sizeof(uint32_t) * kListCap + sizeof(float) * TQV * 32 * (size_t)n_cols +

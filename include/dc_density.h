@@ -94,9 +94,15 @@ DC_API const char* dc_hip_last_error(void);
  *      (symmetric one-radius sweeps credit both frames of a pair), dc_hip_session_merge_mode, host-merge
  *      fallback, DC_FLAG_STATS_VALID
  *   3  dc_hip_session_merge_note (which merge a multi-device session runs, and why),
- *      dc_hip_workspace_mfma_counters_dev */
-#define DC_HIP_ABI_VERSION 3
+ *      dc_hip_workspace_mfma_counters_dev, dc_hip_workspace_layout_status_dev
+ *   4  dc_hip_build_digest (which sources this binary was built from) */
+#define DC_HIP_ABI_VERSION 4
 DC_API int dc_hip_abi_version(void);
+
+/* digest of the sources this library was built from (clustering_amd/csrc + include/, comments left out:
+ * clustering_amd/csrc/digest.py; 16 hex digits, embedded by the Makefile).  What a measurement is tied to: bench.py
+ * prints it as "library_digest" and refuses counter profiles (profiles/ *_pmc.json) taken on another one. */
+DC_API const char* dc_hip_build_digest(void);
 
 /* replaces Clustering::Density::CUDA::get_num_gpus() (density_clustering_cuda.hpp:16-17,
  * density_clustering_cuda.cu:32-43).  Returns the device count (>= 0) or a negative status;

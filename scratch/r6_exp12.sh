@@ -1,0 +1,9 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; cd $R; O=$R/gpurun_out
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -k "fp32_mfma" 2>&1 | tail -2
+for cfg in "1 1" "0 1" "1 4" "0 4"; do set -- $cfg
+  DC_MFMA32_STAGGER=$1 DC_MFMA32_WPB=$2 timeout 300 python3 bench.py --variant mfma32 --steps 2 --warmup 1 --cpu-sample 0 --no-full-sweep > $O/r6_exp12.json 2> $O/r6_exp12.err
+  python3 -c "
+import json;d=json.loads(open('$O/r6_exp12.json').read().strip().split('\n')[-1]);r=d['roofline_by_kernel'];print('stagger=$1 wpb=$2', 'pop %.1f ms %.4f' % (r['population_count']['launch_ms'], r['population_count']['frac']), 'nn %.1f ms %.4f' % (r['nearest_neighbor_search']['launch_ms'], r['nearest_neighbor_search']['frac']), d['check']['mean_pop_r0'], d['check']['sigma2'])"
+done
+DC_MFMA32_CHUNKS=3 timeout 600 python3 scratch/fuzz32.py 12 120 2>&1 | tail -2

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 6, experiment 3: fp32-input MFMA sweeps with reference chunks (tail), TQ = 8 (pop), parked candidates (nn)
+R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; cd $R; O=$R/gpurun_out
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -k "fp32_mfma" > $O/r6_exp3_tests.txt 2>&1; tail -3 $O/r6_exp3_tests.txt
+for ch in 0 1 5 11 16; do
+  DC_MFMA32_CHUNKS=$ch timeout 300 python3 bench.py --variant mfma32 --steps 2 --warmup 1 --cpu-sample 0 --no-full-sweep > $O/r6_exp3_$ch.json 2> $O/r6_exp3_$ch.err
+  python3 -c "
+import json;d=json.loads(open('$O/r6_exp3_$ch.json').read().strip().split('\n')[-1]);r=d['roofline_by_kernel'];print('chunks=$ch', 'pop %.1f ms %.4f' % (r['population_count']['launch_ms'], r['population_count']['frac']), 'nn %.1f ms %.4f' % (r['nearest_neighbor_search']['launch_ms'], r['nearest_neighbor_search']['frac']), d['check']['mean_pop_r0'], d['check']['sigma2'])"
+done

@@ -22,8 +22,59 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert capi.lib.dc_hip_abi_version() == capi.ABI_VERSION == 3
+    assert capi.lib.dc_hip_abi_version() == capi.ABI_VERSION == 4
     assert capi.lib.dc_hip_last_error() is not None
+
+
+def _digest_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dc_digest", os.path.join(ROOT, "clustering_amd", "csrc", "digest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_library_carries_the_digest_of_the_sources_it_was_built_from():
+    """dc_hip_build_digest(): what bench.py ties its line and the counter profiles to.  A library older than the sources
+    in the tree fails here (rebuild: __graft_entry__.build())."""
+    from clustering_amd import capi
+    assert capi.lib.dc_hip_build_digest().decode() == _digest_module().source_digest()
+
+
+def test_digest_ignores_comments_and_sees_code(tmp_path):
+    """a comment edit of dc_prep.hpp leaves the digest alone (no profile regeneration), a code edit changes it"""
+    import shutil
+    dg = _digest_module()
+    src = os.path.join(ROOT, "clustering_amd", "csrc")
+    a, inc = tmp_path / "csrc", tmp_path / "include"
+    a.mkdir()
+    shutil.copytree(os.path.join(ROOT, "include"), inc)
+    for f in os.listdir(src):
+        if f.endswith(dg.EXTS) or f == "Makefile":
+            shutil.copy(os.path.join(src, f), a / f)
+    base = dg.source_digest((str(a), str(inc)))
+    assert base == dg.source_digest()
+    prep = a / "dc_prep.hpp"
+    text = prep.read_text()
+    prep.write_text("// a remark\n" + text.replace("\n", "   // trailing remark\n", 1) + "/* block\n comment */\n")
+    assert dg.source_digest((str(a), str(inc))) == base
+    prep.write_text(text + "\nstatic const int dc_digest_probe = 1;\n")
+    assert dg.source_digest((str(a), str(inc))) != base
+    prep.write_text(text.replace('"', "'", 0) + 'static const char* dc_probe = "// not a comment";\n')
+    assert dg.source_digest((str(a), str(inc))) != base
+
+
+def test_make_rebuilds_the_sweeps_when_the_preparation_header_changes():
+    """header dependencies come from the compiler (-MMD): a touched dc_prep.hpp must rebuild dc_mfma.o"""
+    import subprocess
+    csrc = os.path.join(ROOT, "clustering_amd", "csrc")
+    if not os.path.exists(os.path.join(ROOT, "clustering_amd", "lib", "obj", "dc_mfma.d")):
+        import pytest
+        pytest.skip("no dependency files: the library was not built by this Makefile in this tree")
+    out = subprocess.run(["make", "-n", "-W", "dc_prep.hpp", "../lib/libdcdensity.so"], cwd=csrc, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "-o ../lib/obj/dc_mfma.o" in out.stdout
+    assert "-o ../lib/obj/dc_sort.o" not in out.stdout   # (dc_sort.hip does not include it)
 
 
 def test_no_device_is_a_status_not_a_crash():
