@@ -1984,13 +1984,8 @@ void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, con
 
 // ---- DC_VARIANT_MFMA32: the fp32-input MFMA instance (dc_mfma32.hpp) ---------------------------------------------
 bool mfma32_supports(size_t n_cols) { return n_cols == 9 || n_cols == 10; }
-// (DC_MFMA32_STAGGER=0: every wave starts at the first tile of its chunk -- measurements)
 static uint32_t wpb32() {
   static const uint32_t v = [] { const char* e = getenv("DC_MFMA32_WPB"); const int k = (e && e[0]) ? atoi(e) : 1; return (k == 1 || k == 2 || k == 4) ? (uint32_t)k : 1u; }();
-  return v;
-}
-static uint32_t stagger32() {
-  static const uint32_t v = [] { const char* e = getenv("DC_MFMA32_STAGGER"); return (e && e[0]) ? (uint32_t)atoi(e) : 1u; }();
   return v;
 }
 
@@ -2021,8 +2016,8 @@ void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
     if (chunks > 1)
       (void)hipMemsetAsync(d_pops + (size_t)r * n_rows + i_from, 0, sizeof(uint32_t) * (size_t)(i_to - i_from), stream);
     sweep_timer_mark(0, true, stream);
-    hipLaunchKernelGGL((pop_mfma32_kernel<kS32, kTQ>), grid, block, 0, stream, d_coords, n_rows, n_cols, (const float*)img,
-                       (const float*)norms, (const uint32_t*)p, L.T, i_from, i_to, rad2.v[r], r2max, stagger32(), d_pops + (size_t)r * n_rows);
+    hipLaunchKernelGGL((pop_mfma32_kernel<kS32, kTQ>), grid, block, wpb * sizeof(float) * 2 * kNormBatch32 * 32, stream, d_coords, n_rows, n_cols, (const float*)img,
+                       (const float*)norms, (const uint32_t*)p, L.T, i_from, i_to, rad2.v[r], r2max, d_pops + (size_t)r * n_rows);
     sweep_timer_mark(0, false, stream);
   }
 }
@@ -2064,11 +2059,11 @@ void launch_nn_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, c
   if (chunks > 1)
     hipLaunchKernelGGL(nn_merge_fill_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, stream, merge64, n_rows);
   sweep_timer_mark(1, true, stream);
-  const size_t smem = wpb * sizeof(uint32_t) * (2 * kWaveQueue + 4 * kTQ * 32 + kTQ * 32 * (size_t)n_cols);
+  const size_t smem = wpb * sizeof(uint32_t) * (2 * kNormBatch32 * 32 + 2 * kWaveQueue + 4 * kTQ * 32 + kTQ * 32 * (size_t)n_cols);
   hipLaunchKernelGGL((nn_mfma32_kernel<kS32, kTQ>), dim3(blocks, chunks), dim3(64 * wpb), smem, stream, d_coords, n_rows, n_cols,
                      (const float*)img, (const float*)norms, (const float*)img_s, (const float*)norms_s, (const uint32_t*)perm,
                      (const uint32_t*)(p + L.off_invpos), (const uint32_t*)(p + L.off_pq), (const uint32_t*)p, L.T, i_from, i_to,
-                     stagger32(), merge64, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
+                     merge64, d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2);
   sweep_timer_mark(1, false, stream);
   if (chunks > 1)
     hipLaunchKernelGGL(nn32_unpack_kernel, dim3((i_to - i_from + 255) / 256), dim3(256), 0, stream,

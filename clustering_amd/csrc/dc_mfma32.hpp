@@ -10,7 +10,7 @@
 //     acc = |y'|^2 - 2 x'.y'  (A = centred reference coordinates, B = -2 centred query coordinates, C = |y'|^2)
 //     eps = 1.25 u [(4 K + 10) M + (D / 4 + 12) d2cap],  K = 2 S multiply-adds per chain, M = max |x'|^2
 // (the fp32 MFMA is a chain of fmaf: products exact to one rounding each, 2 S + 2 roundings around values <= 4 M).
-// Operand image: img32[(t * S + s) * 64 + l] = y'[32 t + (l & 31)][2 s + (l >> 5)], norms32[32 t + c] = |y'|^2.
+// Operand image: img32[(t * 64 + l) * 8 + s] = y'[32 t + (l & 31)][2 s + (l >> 5)], norms32[32 t + c] = |y'|^2.
 //
 // Round 6 -- what the fp32-input MFMA wants from the code around it (scratch/ub/mfma32_sched.hip, one MI355X, ns per
 // chain and SIMD at two waves per SIMD; five dependent MFMAs alone: 137.4):
@@ -27,6 +27,8 @@
 // (rounding of c x'), 2 u thr (fl(c c), fl(S r^2)) and u (M + 2 thr) / 2 (the two subtractions that form the per-query
 // constant): 1.25 u [(4 K + 13) M + (D / 4 + 18) r^2] in data units, and c is the largest scale at which that is < 1.
 constexpr int kS32 = 5;   // K-steps: n_cols 9 .. 10
+constexpr int kLane32 = 8;    // floats per lane and tile in the operand image (S of them used: one dwordx4 + one dword)
+constexpr int kNormBatch32 = 8;   // tiles whose row norms one LDS-DMA of a wave fetches (64 lanes x 16 B = 8 x 32 floats)
 constexpr int kClump32 = 4;   // chains (query tiles) whose MFMAs are issued back to back in front of their epilogues
 
 __host__ __device__ inline float guard_eps32(float M, float d2cap, int K, int D) {
@@ -67,58 +69,51 @@ __global__ void image32_kernel(const float* __restrict__ coords, uint32_t n_rows
       if (scaled) v = cs * v;
     }
     nrm += (double)v * (double)v;
-    img[((size_t)t * kS32 + (k >> 1)) * 64 + c + 32 * (k & 1)] = v;
+    img[((size_t)t * 64 + c + 32 * (k & 1)) * kLane32 + (k >> 1)] = v;   // (lane-contiguous: see load_frag32)
   }
   norms[row] = live ? (float)nrm : INFINITY;   // pad rows: never inside, never a candidate
 }
 
+// What a reference tile costs a wave besides its chains is the ISSUE of its loads: a vector-memory instruction among
+// fp32 MFMAs costs about 37 cycles wherever it stands (nine of them per tile -- five fragments, four quarters of the row
+// norms -- were 330 of a tile's 2 x 1 280 MFMA cycles at four query tiles per wave; dealt one per MFMA instead of in
+// front of the tile: 190 -> 215 ms).  So the image keeps a lane's S fragments side by side (one dwordx4 + one dword),
+// and the row norms -- the same 16 values for all lanes of a half-wave -- come through a wave-private LDS ring that ONE
+// LDS-DMA per kNormBatch32 tiles fills (ds_read_b128 costs next to nothing among MFMAs): 2 1/8 instead of 9 per tile.
 template <int S>
-__device__ __forceinline__ void load_tile32(const float* __restrict__ img, const float* __restrict__ norms, uint32_t t,
-                                            int lane, int h, float (&a)[S], float4 (&nv)[4]) {
-#ifdef DC32_NOLOAD
-  if (t > 1) return;
-#endif
-  const float* ip = img + (size_t)t * (S * 64) + lane;
-#pragma unroll
-  for (int s = 0; s < S; ++s) a[s] = ip[s * 64];
-  const float4* np = reinterpret_cast<const float4*>(norms + (size_t)t * 32 + 4 * h);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) nv[g] = np[2 * g];        // rows 8g + 4h .. +3  <->  registers 4g .. 4g+3
+__device__ __forceinline__ void load_frag32(const float* __restrict__ img, uint32_t t, int lane, float (&a)[S]) {
+  static_assert(S == 5, "one dwordx4 and one dword per lane");
+  const float* ip = img + ((size_t)t * 64 + lane) * kLane32;
+  const float4 v = *reinterpret_cast<const float4*>(ip);
+  a[0] = v.x;
+  a[1] = v.y;
+  a[2] = v.z;
+  a[3] = v.w;
+  a[4] = ip[4];
 }
-
-// where a workgroup starts in its chunk of nt reference tiles: spread evenly over the chunk by workgroup (the four waves of
-// a workgroup keep together: they sit on one CU and share its L1)
-__device__ __forceinline__ uint32_t start32(uint32_t stagger, uint32_t nt) {
-  return stagger ? (uint32_t)(((unsigned long long)blockIdx.x * nt) / gridDim.x) : 0u;
-}
+// the wave's ring of row norms: two batches of kNormBatch32 tiles; batch i of the chunk (tiles tb + 8 i ...) in slot i & 1
+struct Norms32 {
+  float* ring;          // [2][kNormBatch32 * 32] floats of LDS, private to the wave
+  const float* norms;   // + 32 * first tile of the chunk
+  __device__ __forceinline__ void fetch(uint32_t batch, int lane) const {   // (runs past the chunk's last tile by up to 7 tiles: inside the workspace, never read)
+    lds_dma16(norms + (size_t)batch * (kNormBatch32 * 32) + 4 * lane,
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + (batch & 1u) * (kNormBatch32 * 32))));   // (wave-uniform: M0)
+  }
+  __device__ __forceinline__ void read(uint32_t k, int h, float4 (&nv)[4]) const {   // tile k of the chunk
+    const float4* np = reinterpret_cast<const float4*>(ring + (k & (2 * kNormBatch32 - 1)) * 32 + 4 * h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) nv[g] = np[2 * g];        // rows 8g + 4h .. +3  <->  registers 4g .. 4g+3
+  }
+};
 
 // the chains of NC query tiles against one reference tile, their MFMAs interleaved (five dependent MFMAs per chain)
-// `after(k)`: issued behind the k-th MFMA of the clump -- the loads of the NEXT reference tile, ONE per MFMA: nine loads
-// in front of a tile's first MFMA made every wave wait for the CU's memory pipeline whenever the waves of a CU reached
-// a tile together (they do once nothing desynchronises them: the sweep with FEWER candidate-path excursions was slower)
-struct NoAfter32 { __device__ __forceinline__ void operator()(int) const {} };
-template <int S, int NC, class After = NoAfter32>
-__device__ __forceinline__ void chains32(const float (&a)[S], const float (*b)[S], const f32x16& c0, f32x16 (&acc)[NC],
-                                         const After& after = After{}) {
+template <int S, int NC>
+__device__ __forceinline__ void chains32(const float (&a)[S], const float (*b)[S], const f32x16& c0, f32x16 (&acc)[NC]) {
 #pragma unroll
   for (int s = 0; s < S; ++s)
 #pragma unroll
-    for (int q = 0; q < NC; ++q) {
+    for (int q = 0; q < NC; ++q)
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[q][s], s == 0 ? c0 : acc[q], 0, 0, 0);
-      if (s * NC + q < S + 4) {
-        after(s * NC + q);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-}
-// load k of a reference tile: k < S: fragment k, then the four quarters of the row norms
-template <int S>
-__device__ __forceinline__ void load_tile32_part(const float* __restrict__ img, const float* __restrict__ norms, uint32_t t,
-                                                 int lane, int h, int k, float (&a)[S], float4 (&nv)[4]) {
-  if (k < S)
-    a[k] = img[(size_t)t * (S * 64) + k * 64 + lane];
-  else
-    nv[k - S] = reinterpret_cast<const float4*>(norms + (size_t)t * 32 + 4 * h)[2 * (k - S)];
 }
 
 // two bits per element of t = acc - lo (element r at bits 31 - 2 r, 30 - 2 r: inside_of / band_of / element_of)
@@ -155,17 +150,13 @@ __device__ __attribute__((noinline)) uint32_t pop32_fix(const float* __restrict_
   return out;
 }
 
-#ifdef DC32_OCC2
-#define DC32_OCC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
-#define DC32_OCC_ATTR
-#endif
 template <int S, int TQ>
-__global__ __launch_bounds__(256, 2) DC32_OCC_ATTR void pop_mfma32_kernel(
+__global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ img,
     const float* __restrict__ norms, const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to,
-    float r2, float r2max, uint32_t stagger, uint32_t* __restrict__ pops) {
+    float r2, float r2max, uint32_t* __restrict__ pops) {
   static_assert(TQ % kClump32 == 0, "query tiles are handled in clumps");
+  extern __shared__ __attribute__((aligned(16))) float pop32_lds[];   // per wave: the ring of row norms (Norms32)
   if (hdr[1] != 0) return;   // non-finite / overflow-prone data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -187,7 +178,7 @@ __global__ __launch_bounds__(256, 2) DC32_OCC_ATTR void pop_mfma32_kernel(
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
-    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
+    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * 64 + lane) * kLane32 + s];
     const float lo = thr - (live ? norms[tl * 32 + c] : INFINITY);   // -inf for an idle lane: t = +inf, outside, no band
     nlo[qt] = f32x2{-lo, -lo};
     cnt[qt] = 0;
@@ -196,22 +187,21 @@ __global__ __launch_bounds__(256, 2) DC32_OCC_ATTR void pop_mfma32_kernel(
   // the chip's wave slots a whole number of times; partial counts merge by atomicAdd into zero-filled rows)
   const uint32_t per = (T + gridDim.y - 1) / gridDim.y, tb = blockIdx.y * per, te = min(T, tb + per);
   if (tb >= te) return;
-  // Every wave walks its chunk from its OWN starting tile (and wraps around): with all of them starting at the chunk's
-  // first tile the whole chip asks for the same few cache lines at the same moment, tile after tile (see start32)
   const uint32_t nt = te - tb;
-  uint32_t t = tb + start32(stagger, nt);
+  const Norms32 N{pop32_lds + (size_t)(threadIdx.x >> 6) * (2 * kNormBatch32 * 32), norms + (size_t)tb * 32};
+  N.fetch(0, lane);
+  N.fetch(1, lane);
   float a0[S], a1[S];
   float4 n0[4], n1[4];
-  load_tile32<S>(img, norms, t, lane, h, a0, n0);
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t, float (&an)[S], float4 (&nn)[4], uint32_t t_next) {
+  load_frag32<S>(img, tb, lane, a0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the first two batches of norms have landed)
+  N.read(0, h, n0);
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);   // (+inf for a pad row: t = +inf)
 #pragma unroll
     for (int g = 0; g < TQ; g += kClump32) {
       f32x16 acc[kClump32];
-      if (g == 0)
-        chains32<S, kClump32>(a, &b[g], c0, acc, [&](int k) { load_tile32_part<S>(img, norms, t_next, lane, h, k, an, nn); });
-      else
-        chains32<S, kClump32>(a, &b[g], c0, acc);
+      chains32<S, kClump32>(a, &b[g], c0, acc);
       __builtin_amdgcn_sched_barrier(0);
       uint32_t bits[kClump32], band = 0;
 #pragma unroll
@@ -220,11 +210,7 @@ __global__ __launch_bounds__(256, 2) DC32_OCC_ATTR void pop_mfma32_kernel(
         cnt[g + q] += __builtin_popcount(inside_of(bits[q]));
         band |= band_of(bits[q]);
       }
-#ifdef DC32_NORARE
-      if (false) {
-#else
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(band != 0) != 0, 0)) {
-#endif
 #pragma unroll
         for (int q = 0; q < kClump32; ++q) {
           const uint32_t bq = band_of(bits[q]);
@@ -238,11 +224,18 @@ __global__ __launch_bounds__(256, 2) DC32_OCC_ATTR void pop_mfma32_kernel(
     //  the last MFMA needs: element 15 of the pending tile was stale, found by the parity test at TQ = 4)
     keep_alive(c0);
   };
+  // (tile k of the chunk: its fragments and norms were asked for during tile k - 1; every kNormBatch32 tiles the batch
+  //  after the next one is ordered -- the slot it lands in was read for the last time a tile ago)
   for (uint32_t k = 0; k < nt; k += 2) {
-    const uint32_t t1 = (t + 1 < te) ? t + 1 : tb;
-    tile_body(a0, n0, t, a1, n1, t1);
-    t = (t1 + 1 < te) ? t1 + 1 : tb;
-    if (k + 1 < nt) tile_body(a1, n1, t1, a0, n0, t);
+    load_frag32<S>(img, tb + min(k + 1, nt - 1), lane, a1);
+    N.read(k + 1, h, n1);
+    tile_body(a0, n0, tb + k);
+    if (k + 1 < nt) {
+      if (((k + 2) & (kNormBatch32 - 1)) == 0) N.fetch((k + 2) / kNormBatch32 + 1, lane);
+      load_frag32<S>(img, tb + min(k + 2, nt - 1), lane, a0);
+      N.read(k + 2, h, n0);
+      tile_body(a1, n1, tb + k + 1);
+    }
   }
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
@@ -317,11 +310,12 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ img,
     const float* __restrict__ norms, const float* __restrict__ img_s, const float* __restrict__ norms_s,
     const uint32_t* __restrict__ perm, const uint32_t* __restrict__ invpos, const uint32_t* __restrict__ pq_of,
-    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to, uint32_t stagger,
+    const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to,
     unsigned long long* __restrict__ merge64, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2, uint32_t* __restrict__ hd_idx,
     float* __restrict__ hd_d2) {
   static_assert(TQ == kClump32, "one clump of chains per reference tile");
-  // dynamic LDS, per wave: candidate list [kWaveQueue] x 8 B, exact incumbents [2][TQ*32] x 8 B, query rows [TQ*32][n_cols]
+  // dynamic LDS, per wave: the ring of row norms (Norms32), candidate list [kWaveQueue] x 8 B, exact incumbents
+  // [2][TQ*32] x 8 B, query rows [TQ*32][n_cols]
   extern __shared__ __attribute__((aligned(16))) float nn32_lds[];
   if (hdr[1] != 0) return;
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
@@ -331,15 +325,13 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
   if (qt0 * 32 >= i_to) return;
   const float M = __uint_as_float(hdr[0]);
   const float eps2 = 2.5f * guard_eps32(M, 4.0f * M, 2 * S, (int)n_cols);   // candidates can be as far apart as 2 sqrt(M)
-  uint32_t* wave_lds = reinterpret_cast<uint32_t*>(nn32_lds) + (size_t)wib * (2 * kWaveQueue + 4 * TQ * 32 + TQ * 32 * n_cols);
+  uint32_t* wave_lds = reinterpret_cast<uint32_t*>(nn32_lds) + (size_t)wib * (2 * kNormBatch32 * 32 + 2 * kWaveQueue + 4 * TQ * 32 + TQ * 32 * n_cols);
+  float* norm_ring = reinterpret_cast<float*>(wave_lds);
+  wave_lds += 2 * kNormBatch32 * 32;
   uint2* cand = reinterpret_cast<uint2*>(wave_lds);
   unsigned long long* best64 = reinterpret_cast<unsigned long long*>(wave_lds + 2 * kWaveQueue);
   float* qrows = reinterpret_cast<float*>(wave_lds + 2 * kWaveQueue + 4 * TQ * 32);
   uint32_t qn = 0;   // parked candidates (wave-uniform)
-#ifdef DC32_STATS
-  uint32_t st_rare = 0, st_trig = 0, st_flush = 0, st_cand = 0, st_tiles = 0;
-  const unsigned long long st_t0 = wall_clock64();
-#endif
 
   float b[TQ][S];
   // per query tile and lane: running minima of the MFMA values over this lane's reference rows (acc = |y'|^2 - 2 x'.y' =
@@ -359,14 +351,13 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
-    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * S + s) * 64 + lane];
+    for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * 64 + lane) * kLane32 + s];
     const uint32_t jl = live ? jq[qt] : (n_rows - 1);
     pq[qt] = live ? pq_of[jl] : 0u;
     spos[qt] = live ? invpos[jl] : 0xFFFFFFFFu;
     t_low[qt] = (pq[qt] + 31u) >> 5;
     m_nn[qt] = live ? INFINITY : -INFINITY;
     m_hd[qt] = live ? INFINITY : -INFINITY;
-#ifndef DC32_NOPUB
     if (gridDim.y > 1 && live) {
       // what the waves of earlier reference chunks have published for this query (exact d2, FLT_MAX: nothing yet): the
       // MFMA value of that pair is at most d2 - |x'|^2 + guard, so the running minima may start there instead of at
@@ -375,12 +366,8 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
       const float cq = norms[tl * 32 + c], guard = 0.4f * eps2;
       if (d_hd < FLT_MAX) m_hd[qt] = round_up(round_up(d_hd - cq) + guard);
       if (d_nn < FLT_MAX) m_nn[qt] = round_up(round_up(d_nn - cq) + guard);
-#ifdef DC32_PUBNN
-      m_hd[qt] = INFINITY;
-#endif
       m_nn[qt] = fminf(m_nn[qt], m_hd[qt]);
     }
-#endif
     thr_nn[qt] = m_nn[qt] + eps2;
     thr_hd[qt] = m_hd[qt] + eps2;
     stage_query_rows(qrows + (size_t)qt * 32 * n_cols, nullptr, coords, jl, live, n_cols, lane);
@@ -394,14 +381,15 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
   // (d2 bits, frame id) -- the lexicographic order of the reference's scan -- in merge64, nn32_unpack_kernel writes them out)
   const uint32_t per = (T + gridDim.y - 1) / gridDim.y, tb = blockIdx.y * per, te = min(T, tb + per);
   const uint32_t nt = te > tb ? te - tb : 0u;
-  uint32_t t = nt ? tb + start32(stagger, nt) : 0u;   // (see pop_mfma32_kernel)
+  const Norms32 N{norm_ring, norms_s + (size_t)(nt ? tb : 0u) * 32};
+  N.fetch(0, lane);
+  N.fetch(1, lane);
   float a0[S], a1[S];
   float4 n0[4], n1[4];
-  load_tile32<S>(img_s, norms_s, t, lane, h, a0, n0);
+  load_frag32<S>(img_s, nt ? tb : 0u, lane, a0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the first two batches of norms have landed)
+  N.read(0, h, n0);
   auto flush = [&]() {
-#ifdef DC32_STATS
-    ++st_flush; st_cand += qn;
-#endif
     nn32_wave_flush(cand, qn, qrows, best64, TQ * 32, coords, perm, n_cols, lane);
     qn = 0;
   };
@@ -409,9 +397,6 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
   // straddles its free energy, candidates parked for the exact path, running minima and thresholds renewed
   auto rare_chain = [&](const f32x16& acc, auto qi_c, float tmin, uint32_t t) {
     constexpr int qi = decltype(qi_c)::value;
-#ifdef DC32_STATS
-    ++st_rare;
-#endif
     const bool special = (t == (spos[qi] >> 5)) | ((t == (pq[qi] >> 5)) & ((pq[qi] & 31u) != 0u));
     float hmin = (t < (pq[qi] >> 5)) ? tmin : INFINITY;
     if (__builtin_amdgcn_ballot_w64(special) != 0) {
@@ -422,9 +407,6 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     const bool trig = (tmin < m_nn[qi] + eps2) | (hmin < m_hd[qi] + eps2);
     const float new_nn = fminf(m_nn[qi], tmin), new_hd = fminf(m_hd[qi], hmin);
     if (__builtin_amdgcn_ballot_w64(trig) != 0) {
-#ifdef DC32_STATS
-      ++st_trig;
-#endif
       uint32_t m = nn32_masks(acc, new_nn + eps2, new_hd + eps2, spos[qi], pq[qi], n_rows, t, h);
       if (!((livemask[qi] >> lane) & 1)) m = 0;
       for (;;) {
@@ -447,10 +429,10 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     thr_nn[qi] = new_nn + eps2;
     thr_hd[qi] = new_hd + eps2;
   };
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t, float (&an)[S], float4 (&nn)[4], uint32_t t_next) {
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
     const f32x16 c0 = frag16(nv);
     f32x16 acc[TQ];
-    chains32<S, TQ>(a, b, c0, acc, [&](int k) { load_tile32_part<S>(img_s, norms_s, t_next, lane, h, k, an, nn); });
+    chains32<S, TQ>(a, b, c0, acc);
     __builtin_amdgcn_sched_barrier(0);
     // Common path: the raw tile minimum (the query itself included: it only ever makes the test pass) against ONE
     // threshold per chain -- thr_hd >= thr_nn when the tile holds a frame of lower free energy, thr_nn otherwise; what
@@ -462,11 +444,7 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
       tile_min<0, 16>(acc[qi], tm[qi]);
       dmin = fminf(dmin, tm[qi] - ((t < t_low[qi]) ? thr_hd[qi] : thr_nn[qi]));   // (inf - inf: NaN, ignored by the minimum)
     }
-#ifdef DC32_NORARE
-    if (t < 8) {
-#else
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmin < 0.0f) != 0, 0)) {
-#endif
       constexpr_for_all<TQ>([&](auto qi_c) {
         constexpr int qi = decltype(qi_c)::value;
         const float thr_c = (t < t_low[qi]) ? thr_hd[qi] : thr_nn[qi];
@@ -476,17 +454,18 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     __builtin_amdgcn_sched_barrier(0);
     keep_alive(c0);   // (see pop_mfma32_kernel)
   };
-  for (uint32_t k = 0; k < nt; k += 2) {
-    const uint32_t t1 = (t + 1 < te) ? t + 1 : tb;
-    tile_body(a0, n0, t, a1, n1, t1);
-    t = (t1 + 1 < te) ? t1 + 1 : tb;
-    if (k + 1 < nt) tile_body(a1, n1, t1, a0, n0, t);
+  for (uint32_t k = 0; k < nt; k += 2) {   // (see pop_mfma32_kernel)
+    load_frag32<S>(img_s, tb + min(k + 1, nt - 1), lane, a1);
+    N.read(k + 1, h, n1);
+    tile_body(a0, n0, tb + k);
+    if (k + 1 < nt) {
+      if (((k + 2) & (kNormBatch32 - 1)) == 0) N.fetch((k + 2) / kNormBatch32 + 1, lane);
+      load_frag32<S>(img_s, tb + min(k + 2, nt - 1), lane, a0);
+      N.read(k + 2, h, n0);
+      tile_body(a1, n1, tb + k + 1);
+    }
   }
   flush();
-#ifdef DC32_STATS
-  if (lane == 0 && (blockIdx.x % 16) == 7)
-    printf("nn32w %u %u %u %llu %llu %u %u\n", blockIdx.y, blockIdx.x, wib, st_t0 / 100, (wall_clock64() - st_t0) / 100, st_rare, st_cand);
-#endif
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
     if (h == 0 && ((livemask[qt] >> lane) & 1)) {
