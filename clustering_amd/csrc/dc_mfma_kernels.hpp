@@ -2106,7 +2106,7 @@ __device__ unsigned long long g_wave_dbg[kDbgWaves][10];
 // for all of them -- DESIGN.md 4.8 measured 0.45 ms of a rank's 1.6 ms (an eighth of C3) as thresholds learnt again by
 // every one of a group's 34 shares.  Taken when a group has many shares (sharded runs); a share is still a wave.
 template <int NM, int TQ, bool COOP = false>
-__global__ __launch_bounds__(256, 2) void nn_pruned_kernel(
+__global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const float* __restrict__ fe, const uint4* __restrict__ img_r,
     const float* __restrict__ norms_r, const uint32_t* __restrict__ perm_r,
@@ -3027,7 +3027,7 @@ void nn_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, con
   // Many shares per group (a rank of a sharded run: 34 at an eighth of C3): the shares of a group as the waves of ONE
   // workgroup that learn their thresholds together (nn_pruned_kernel<.., COOP>); DC_NN_COOP = 0 / 1 forces either form
   static const int coop_env = [] { const char* v = getenv("DC_NN_COOP"); return (v && v[0]) ? atoi(v) : -1; }();
-  constexpr uint32_t kCoopWaves = 4;
+  static const uint32_t kCoopWaves = [] { const char* v = getenv("DC_NN_COOP_WAVES"); const int k = (v && v[0]) ? atoi(v) : 4; return (k == 2 || k == 4 || k == 8) ? (uint32_t)k : 4u; }();
   const bool coop = (coop_env >= 0) ? (coop_env != 0 && n_chunks >= kCoopWaves) : (n_chunks >= kNnCoopMinShares);
   if (coop) {
     n_chunks = (n_chunks + kCoopWaves - 1) / kCoopWaves * kCoopWaves;

@@ -82,14 +82,23 @@ __device__ __forceinline__ void mr_begin_k(MrAcc<NR>& e) {
 template <int NR, int K0, int R0, int R1>   // elements [R0, R1), both even; radii K0 .. NR-1
 __device__ __forceinline__ void mr_epi_k(const f32x16& acc, const PopDeltas<NR>& dl, MrAcc<NR>& e) {
   static_assert(R0 % 2 == 0 && R1 % 2 == 0, "elements are handled in pairs");
+  // (the subtraction of the next element pair in front of the current pair's two v_alignbit: see mr_epi)
 #pragma unroll
   for (int rr = K0; rr < NR; ++rr) {
+    if (rr == 0) {
 #pragma unroll
-    for (int r = R0; r < R1; r += 2) {
-      f32x2 t = {acc[r], acc[r + 1]};
-      if (rr != 0) t = t - f32x2{dl.d[rr], dl.d[rr]};
-      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.x), 30);
-      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.y), 30);
+      for (int r = R0; r < R1; ++r) e.bits[0] = __builtin_amdgcn_alignbit(e.bits[0], __float_as_uint(acc[r]), 30);
+    } else if constexpr (R1 > R0) {
+      const f32x2 d2 = {dl.d[rr], dl.d[rr]};
+      f32x2 t = f32x2{acc[R0], acc[R0 + 1]} - d2;
+#pragma unroll
+      for (int r = R0; r < R1; r += 2) {
+        f32x2 tn = t;
+        if (r + 2 < R1) tn = f32x2{acc[r + 2], acc[r + 3]} - d2;
+        e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.x), 30);
+        e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.y), 30);
+        t = tn;
+      }
     }
   }
 }
@@ -122,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   __shared__ uint32_t lists[4][kShareSub];
   __shared__ uint32_t list_cnt[4];
   __shared__ float4 wave_box[4];
+  __shared__ uint32_t flush_flag[2];   // "some wave's queue is filling up": all four flush at the next window (parity of the window)
   __shared__ __attribute__((aligned(16))) uint32_t stage[4][2][16];   // per wave: the row sums of a unit's two radii (lanes 15/31/47/63)
   // dynamic LDS: operand ring [kMsRing][kTileUnits] x 16 B, the accumulators [kMsAccSlots][NR][64] x 8 B, then per wave
   // the compact queue of deferred exact evaluations [kWaveQueue] x 8 B, the positions of its queries [TQ*32] and their
@@ -153,7 +163,11 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   for (int rr = 1; rr < NR; ++rr) r2max = fmaxf(r2max, rad2.v[rr]);
   const float far2 = r2max * 1.0001f;   // boxes at least this far apart (squared) hold no pair inside
   // radii that hold nothing of a chain (see mr_chain_k): ascending radii only
+#ifdef DC_MS_ABL_NOSKIP
+  bool radii_ascending = false;
+#else
   bool radii_ascending = n_rad >= kMsSkip<NR>;
+#endif
 #pragma unroll
   for (int rr = 1; rr < NR; ++rr) radii_ascending &= (rr >= n_rad) || (P.dl.d[rr] >= P.dl.d[rr - 1]);
   // (rounded UP: fl(2 + d) may lie below 2 + d -- by up to 2^-5 at d ~ 2^19 -- and a chain whose minimum equals it would
@@ -181,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   };
 
   for (uint32_t k = tid; k < (uint32_t)(kMsAccSlots * NR * 64); k += 256) acc[k] = 0ull;
+  if (tid < 2) flush_flag[tid] = 0u;
 
   s16x8 b[TQ][NM];
   uint32_t cnt_q[TQ][NR], jq[TQ];
@@ -222,8 +237,11 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   }
 
   uint32_t sb[NR][TQ];   // strings of the two chains on the current reference tile
+  uint32_t next_par = 0;  // parity of the window after the current one
   auto flush = [&]() {
+#ifndef DC_MS_ABL_NOFLUSH
     pop_wave_flush_ms<NR>(queue, qn, jq_tab, fix_tab, TQ * 32, coords_r, coords_r, n_cols, rad2, lane, pops_pos, 4u * TQ, group);
+#endif
     qn = 0;
   };
   // the rest of an epilogue: query-side counts, band test, parking of the band pairs
@@ -258,7 +276,12 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
         }
         qn += n_new;
       }
-      if (qn >= 64u) flush();
+      // The exact evaluations of a wave are a few microseconds of memory latency during which its three partners end up
+      // waiting at the next window barrier: a wave whose queue is filling asks for a flush of ALL four at the next window
+      // (one stall instead of four; ablation: the flushes cost 24 of 393 ms, a flush batch itself 2 - 3 us); it only
+      // flushes on its own when the queue is about to overflow.
+      if (qn >= 40u && lane == 0) flush_flag[next_par] = 1u;
+      if (qn >= 96u) flush();
     }
   };
   // reference side of the pending tile: per radius the two strings added bit-sliced (2-bit counts at the elements'
@@ -394,6 +417,14 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
           __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the window starting at i
           __syncthreads();                      // ... and every wave's adds to the previous window's accumulators have landed
           fetch_window(i + kMsWin);
+          {
+            const uint32_t par = (i / kMsWin) & 1u;
+            next_par = par ^ 1u;
+            if (flush_flag[par] != 0u) {        // (a late reader may miss a flag wave 0 has already cleared: a flush is never needed, only wanted)
+              if (qn != 0u) flush();
+              if (tid == 0) flush_flag[par] = 0u;
+            }
+          }
 #ifndef DC_MS_ABL_NOREDUCE
           if (i >= (uint32_t)kMsWin) {
             const uint32_t j = i - kMsWin;

@@ -59,14 +59,25 @@ __device__ __forceinline__ void mr_begin(MrAcc<NR>& e) { pop_epi_begin<NR>(e); }
 template <int NR, int R0, int R1>   // elements [R0, R1), both even
 __device__ __forceinline__ void mr_epi(const f32x16& acc, const PopDeltas<NR>& dl, MrAcc<NR>& e) {
   static_assert(R0 % 2 == 0 && R1 % 2 == 0, "elements are handled in pairs");
+  // (source order: the packed subtraction of the NEXT element pair stands in front of the two v_alignbit of the current
+  //  one, and the scheduler keeps it there -- a v_alignbit that reads the result of the v_pk_add_f32 right before it costs
+  //  an s_nop, one per pair and radius: a hundred per reference tile of the eight-radius sweeps, round 6)
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
+    if (rr == 0) {
 #pragma unroll
-    for (int r = R0; r < R1; r += 2) {
-      f32x2 t = {acc[r], acc[r + 1]};
-      if (rr != 0) t = t - f32x2{dl.d[rr], dl.d[rr]};
-      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.x), 30);
-      e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.y), 30);
+      for (int r = R0; r < R1; ++r) e.bits[0] = __builtin_amdgcn_alignbit(e.bits[0], __float_as_uint(acc[r]), 30);
+    } else if constexpr (R1 > R0) {
+      const f32x2 d2 = {dl.d[rr], dl.d[rr]};
+      f32x2 t = f32x2{acc[R0], acc[R0 + 1]} - d2;
+#pragma unroll
+      for (int r = R0; r < R1; r += 2) {
+        f32x2 tn = t;
+        if (r + 2 < R1) tn = f32x2{acc[r + 2], acc[r + 3]} - d2;
+        e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.x), 30);
+        e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(t.y), 30);
+        t = tn;
+      }
     }
   }
 }

@@ -1,0 +1,5 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; cd $R
+for v in ms_base ms_noflush ms_noskip ms_nocredit ms_noreduce; do
+  echo -n "$v: "; DC_LIB_PATH=$R/clustering_amd/lib/variants/r6_$v.so timeout 900 python3 scratch/c5_bench.py --pop-only --reps 2 2>/dev/null | tail -1
+done
