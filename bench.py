@@ -219,7 +219,9 @@ def main():
     coords_np = gaussian_blobs(n, d)            # same seed on every rank: coordinates are replicated
     coords = torch.from_numpy(coords_np).to(dev)
     backend = HipBackend(args.variant)
-    job = ShardedDensity(backend, check_layout=False)   # (the layout verdict of the unpacks is asked for once, after the timed loop)
+    # (the layout verdict of an unpack is that of the LAST unpack only: asked for after the last timed step and after every
+    #  instrumented step below -- inside the timed loop it would add a host synchronisation per step)
+    job = ShardedDensity(backend, check_layout=False)
     lo, hi = shard_rows(n, world, rank)
 
     def barrier():
@@ -257,6 +259,8 @@ def main():
             marks.append((name, e))
         job.run(coords, args.radii, 0, want_nn, mark=mark)
         torch.cuda.synchronize()
+        if world > 1:
+            job.check_layouts(dev)
         span = {}
         for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
             span[name] = a.elapsed_time(b)

@@ -474,11 +474,7 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
   // cookie: whose partition this is (comp_guard_kernel)
   (void)frames_per_cell;
   const float r_conn_param = r_max;
-#ifdef DC_COMP_STAMPS
-#define DC_STAMP(k) do { if (threadIdx.x == 0) comp[8 + (k)] = (uint32_t)wall_clock64(); } while (0)
-#else
 #define DC_STAMP(k) do {} while (0)
-#endif
   DC_STAMP(0);
   (void)stats_table;   // (the statistics table is added up by its own launch: stats_reduce_kernel)
   DC_STAMP(1);
@@ -636,9 +632,6 @@ __global__ __launch_bounds__(1024) void components_kernel(const uint32_t* __rest
       if (ch == 0 || iter >= 128) break;
     }
     if (iter >= 128) single = true;   // (not settled: one component is always right)
-#ifdef DC_COMP_STAMPS
-    if (threadIdx.x == 0) comp[8 + 15] = (uint32_t)iter;
-#endif
   }
   DC_STAMP(3);
   if (!single) {
@@ -1283,12 +1276,9 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   uint32_t* comp = (uint32_t*)(p + L.off_comp);
   uint32_t* tile_comp = (uint32_t*)(p + L.off_tile_comp);
   uint32_t* tile_comp_q = (uint32_t*)(p + L.off_tile_comp_q);
-  uint32_t* vals_sorted = (uint32_t*)(p + L.off_invpos);   // (a region of the full neighbour sweep: free here)
   const float* origins = (const float*)(comp + kCompOrigin);
   constexpr float kCellFramesHere = kPopCellFrames;
   const dim3 blk(256), grid_n((n_rows + 255) / 256);
-  auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
-  const float* coords_p = (const float*)(p + L.off_coords_p);
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
   int q_mode = full ? kQueryAll : kQueryOwnOrder;
@@ -1299,7 +1289,8 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
     q_seg = QSeg{qs.n_segments, qs.segment, seg_block(qs.n_segments)};
   }
   // The orders are PADDED: every component of the frames (dc_mfma_kernels.hpp "components") starts at a whole query
-  // group; the sort's input carries kMaxComp * (group_rows - 1) extra (key, kInvalidFrame) entries for that.
+  // group; the sort's last pass writes its values straight to the padded positions (SortRemap: segment starts -> bases),
+  // the pad positions in between keep the kInvalidFrame that order_meta_kernel's presets left there.
   const uint32_t tq = pop_group_tiles(n_rows, n_cols, sink_in != nullptr, n_rad), group_rows = 32u * tq;
   const uint32_t T_r = (n_rows + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
   const uint32_t T_q = (n_q + (uint32_t)kMaxComp * (group_rows - 1u) + 31u) / 32u;
@@ -1672,10 +1663,8 @@ static void nn_pruned_sel(const float* d_coords, uint32_t n_rows, uint32_t n_col
   uint32_t* comp = (uint32_t*)(p + L.off_comp);
   uint32_t* tile_comp = (uint32_t*)(p + L.off_tile_comp);
   uint32_t* tile_comp_q = (uint32_t*)(p + L.off_tile_comp_q);
-  uint32_t* vals_sorted = (uint32_t*)(p + L.off_pq);   // (a region of the full neighbour sweep: free here)
   const float* origins = (const float*)(comp + kCompOrigin);
   const dim3 blk(256), grid_n((n_rows + 255) / 256);
-  auto grid_img = [&](uint32_t tiles) { return dim3((uint32_t)(((size_t)tiles * L.NM * 64 + 255) / 256)); };
   const size_t tmp_bytes = sort_temp_bytes(n_rows + kOrderPadRows);
   const bool full = (i_from == 0 && i_to == n_rows);
   uint32_t n_q = i_to - i_from;
@@ -1871,7 +1860,7 @@ __global__ void nn_block_unpack_kernel(const uint32_t* __restrict__ blocks /* [G
     }
     __syncthreads();
     if (layout_bad) {   // (no workspace to flag in: the host's own comparison is the check)
-      if (threadIdx.x == 0 && blockIdx.x == 0) *layout_bad = bad_s;   // this unpack's verdict
+      if (threadIdx.x == 0 && blockIdx.x == 0) *layout_bad = bad_s;   // THIS unpack's verdict (the next unpack or sweep in the workspace replaces it)
       if (bad_s != 0u) return;
     }
   }
@@ -1921,8 +1910,8 @@ void launch_nn_block_pack(const uint32_t* d_nn_idx, const float* d_nn_d2, const 
   const uint32_t rows = (uint32_t)nn_block_rows(n_rows, n_cols, n_segments);
   const Layout L = make_layout(n_rows, n_cols);
   const char* p = (const char*)d_ws;
-  // (the hash of the order the block is packed by -- header words kHdrFp + 4..5 -- was formed with the order itself:
-  //  order_rows2_kernel of the neighbour call that ran in this workspace)
+  // (the hash of the order the block is packed by -- 64 shares in the component region, kCompHash -- was formed with the
+  //  order itself: order_rows2_kernel of the neighbour call that ran in this workspace)
   hipLaunchKernelGGL(nn_block_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d_nn_idx, d_nn_d2, d_hd_idx,
                      d_hd_d2, n_rows, 32u * nn_order_tiles(n_rows, n_cols), pruned ? nn_group_rows(n_rows, n_cols) : 0u, segment, n_segments, seg_block(n_segments), rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr, d_block,
@@ -1939,7 +1928,9 @@ void launch_nn_block_unpack(const uint32_t* d_blocks, uint32_t n_rows, uint32_t 
                      pruned ? nn_group_rows(n_rows, n_cols) : 0u, n_segments, seg_block(n_segments), rows,
                      pruned ? (const uint32_t*)(p + L.off_perm_p) : nullptr, pruned ? (const uint32_t*)p : nullptr,
                      d_nn_idx, d_nn_d2, d_hd_idx, d_hd_d2,
-                     p ? (uint32_t*)(const_cast<char*>(p) + 4 * kHdrLayoutBad) : (uint32_t*)nullptr);
+                     // (the verdict word lives in the header of a PRUNED sweep's workspace, whose size the caller's entry point
+                     //  has checked; any other workspace is never written)
+                     (pruned && p) ? (uint32_t*)(const_cast<char*>(p) + 4 * kHdrLayoutBad) : (uint32_t*)nullptr);
 }
 
 void launch_nn_mfma(const float* d_coords, uint32_t n_rows, uint32_t n_cols, const float* d_fe,

@@ -1188,10 +1188,6 @@ __device__ __forceinline__ void stage_query_rows(float* __restrict__ dst, const 
   }
 }
 
-#ifdef DC_WAVE_STAMPS
-constexpr uint32_t kPopDbgWaves = 1u << 17;
-__device__ unsigned long long g_pop_dbg[kPopDbgWaves][3];   // start, end, chains << 32 | group (measurement build)
-#endif
 template <int NM, int NR, int TQ, int MODE = kSinkNone, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
@@ -1224,9 +1220,6 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
   const uint32_t chunk = blockIdx.y, n_chunks = gridDim.y;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;    // whole wave leaves; no block-level barriers in this kernel
-#ifdef DC_WAVE_STAMPS
-  const unsigned long long dbg_p0 = wall_clock64();
-#endif
   // (the component of the group and its tile range: two dependent look-ups, started before everything else)
   const uint32_t my_comp = CV.tile_comp_q[qt0];
   const uint32_t comp_lo = CV.range_r[2 * my_comp], comp_hi = CV.range_r[2 * my_comp + 1];
@@ -1600,16 +1593,6 @@ __global__ __launch_bounds__(256, 2) void pop_pruned_kernel(
     atomicAdd(chain_counter, (unsigned long long)chains);
     atomicAdd(chain_counter + kMfmaCtrPop, (unsigned long long)chains * NM);
   }
-#ifdef DC_WAVE_STAMPS
-  if (lane == 0) {
-    const uint32_t wid = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (uint32_t)wib;
-    if (wid < kPopDbgWaves) {
-      g_pop_dbg[wid][0] = dbg_p0;
-      g_pop_dbg[wid][1] = wall_clock64();
-      g_pop_dbg[wid][2] = ((unsigned long long)chains << 32) | wave;
-    }
-  }
-#endif
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) flush(qt);
   if constexpr (kWaveWide) flush_wave();
@@ -2095,10 +2078,6 @@ __device__ __forceinline__ void load_tile_folded(const uint4* __restrict__ img, 
   }
 }
 
-#ifdef DC_WAVE_STAMPS
-constexpr uint32_t kDbgWaves = 1u << 17;
-__device__ unsigned long long g_wave_dbg[kDbgWaves][10];
-#endif
 // COOP (round 6): the waves of a workgroup are consecutive reference SHARES of ONE query group instead of different
 // groups.  They keep one copy of the query rows, of the exact incumbents (best64) and of the published bounds in LDS,
 // and they exchange the running minima that set the candidate thresholds through LDS inside the candidate path (smin:
@@ -2140,12 +2119,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
   const uint32_t chunk = COOP ? blockIdx.y * wpb + (uint32_t)wib : blockIdx.y, n_chunks = COOP ? gridDim.y * wpb : gridDim.y;
   const uint32_t qt0 = wave * TQ;
   if (qt0 >= TQT) return;   // (COOP: the whole workgroup leaves -- no barrier is ever met by a part of it)
-#ifdef DC_WAVE_STAMPS
-  const unsigned long long dbg_t0 = wall_clock64();
-  const unsigned long long dbg_c0 = clock64();
-  unsigned long long dbg_on_cyc = 0, dbg_fl_cyc = 0;
-  uint32_t dbg_cands = 0, dbg_iters = 0, dbg_nfl = 0;   // (dbg_iters: chains that entered the per-element path)
-#endif
   // (the component of the group, its tile range and cell edge: three dependent look-ups, started before everything else)
   const uint32_t my_comp = CV.tile_comp_q[qt0];
   const uint32_t comp_lo = CV.range_r[2 * my_comp], comp_hi = CV.range_r[2 * my_comp + 1];
@@ -2229,12 +2202,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
     gbox.z = fminf(gbox.z, qbox[qt].z);
     gbox.w = fmaxf(gbox.w, qbox[qt].w);
   }
-#ifdef DC_WAVE_STAMPS
-  // (after the results of the loop's loads have arrived: the asm statements pin the order)
-  asm volatile("" ::"v"(q[TQ - 1].feq), "v"(g_hd[TQ - 1]), "v"(cq[TQ - 1]), "v"(b[TQ - 1][NM - 1]));
-  const unsigned long long dbg_sA = wall_clock64();
-  asm volatile("" ::"s"(dbg_sA));
-#endif
   if constexpr (COOP) {
     // one copy per workgroup: published bounds, exact incumbents, running minima (wave 0), query rows (all waves)
     if (wib == 0 && h == 0) {
@@ -2269,9 +2236,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
       }
     }
     __syncthreads();
-#ifdef DC_WAVE_STAMPS
-    const unsigned long long dbg_sB = wall_clock64();
-#endif
     if (blockIdx.y == 0) {
       // Seeds (see below), dealt to the waves of the group's FIRST workgroup: wave w looks at the frames w + 1, w + 1 + wpb,
       // ... positions away; the results meet in LDS and are published at once
@@ -2353,9 +2317,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
     // tiles of a sweep park every element, and query groups in sparse regions (wide boxes, long first ring)
     // spent a microsecond per chain in the candidate path.
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (query rows: written by the h = 0 lanes)
-#ifdef DC_WAVE_STAMPS
-    const unsigned long long dbg_sB = wall_clock64();
-#endif
 #pragma unroll
     for (int qt = 0; qt < TQ; ++qt) {
       const bool live = (livemask[qt] >> lane) & 1;
@@ -2406,21 +2367,11 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
   }
   // lowest free energy of the whole data set (header word 12, ordered-integer key, written by the
   // ordering pass): a query at that level has no lower-FE neighbour
-#ifdef DC_WAVE_STAMPS
-  const unsigned long long dbg_sC = wall_clock64();
-#endif
   const float fe_floor = fkey_inv(~hdr[12]);
   // evaluate and empty the candidate list (64 candidates at a time, one per lane)
   auto flush = [&]() {
-#ifdef DC_WAVE_STAMPS
-    const unsigned long long tf0 = clock64();
-    ++dbg_nfl;
-#endif
     nn_wave_flush(cand, qn, qrows, best64, TQ * 32, coords_c, perm_r, n_cols, lane);
     qn = 0;
-#ifdef DC_WAVE_STAMPS
-    dbg_fl_cyc += clock64() - tf0;
-#endif
   };
   uint32_t chains = 0, visited = 0;
   uint32_t chains_on = 0;   // chains that went on behind the early-out test (computed again in full)
@@ -2437,17 +2388,9 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
   float r2_lo = -1.0f;                                     // rings: r2_lo <= gap2 < r2_hi
   float r2_hi = fmaxf(dgx * dgx + dgy * dgy, cell2);
   if (!(r2_hi > 0.0f)) r2_hi = FLT_MIN;
-#ifdef DC_WAVE_STAMPS
-  const unsigned long long dbg_t1 = wall_clock64();
-  unsigned long long dbg_scan = 0, dbg_flush = 0;
-  uint32_t dbg_rings = 0;
-#endif
   for (;;) {
     for (uint32_t base = u_lo; base < U; base += kListCap) {
       uint32_t cnt = 0;
-#ifdef DC_WAVE_STAMPS
-      const unsigned long long dbg_ts = wall_clock64();
-#endif
       const uint32_t lim = min(U - base, (uint32_t)kListCap);
       auto tile_of = [&](uint32_t u) { return chunk + u * n_chunks; };
       // (box_t: the boxes of this share stored contiguously -- a step of the scan reads 1 KB instead of
@@ -2470,9 +2413,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
         if (ok) list[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = t;
         cnt += (uint32_t)__builtin_popcountll(m);
       }
-#ifdef DC_WAVE_STAMPS
-      dbg_scan += wall_clock64() - dbg_ts;
-#endif
       if (cnt == 0) continue;
       visited += cnt;
       // Reference tile data in two register buffers (the loads run one survivor ahead); the chains
@@ -2498,9 +2438,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
         const float thr = (fr.x < Q.feq) ? Q.bh : Q.bn;
         const bool rare = tmin < thr;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
-#ifdef DC_WAVE_STAMPS
-          ++dbg_iters;
-#endif
           const bool all_lower = fr.y < Q.feq;
           const bool mixed = (fr.x < Q.feq) & !all_lower;
           const bool special = mixed | (t == (Q.spos >> 5));
@@ -2570,9 +2507,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
               const uint64_t have = __builtin_amdgcn_ballot_w64(m != 0);
               if (have == 0) break;
               const uint32_t n_new = (uint32_t)__builtin_popcountll(have);
-#ifdef DC_WAVE_STAMPS
-              dbg_cands += n_new;
-#endif
               if (qn + n_new > (uint32_t)kWaveQueue) flush();
               if (m != 0) {
                 const int p = __builtin_ctz(m);
@@ -2632,9 +2566,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
 #pragma unroll
           for (int qi = 0; qi < TQ; ++qi) dmin = fminf(dmin, tm[qi] - ((fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn));
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(dmin < 0.0f) != 0, 0)) {
-#ifdef DC_WAVE_STAMPS
-            const unsigned long long to0 = clock64();
-#endif
             constexpr_for_all<TQ>([&](auto qi_c) {
               constexpr int qi = decltype(qi_c)::value;
               const float thr_c = (fr.x < q[qi].feq) ? q[qi].bh : q[qi].bn;
@@ -2648,9 +2579,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
                 finish(acc, qi_c, tmin, t, fr);
               }
             });
-#ifdef DC_WAVE_STAMPS
-            dbg_on_cyc += clock64() - to0;
-#endif
           }
           return;
         }
@@ -2721,11 +2649,7 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
           finish(accB, std::integral_constant<int, TQ - 1>{}, tmin, tB, frB);
       }
     }
-#ifdef DC_WAVE_STAMPS
-    { const unsigned long long tf = wall_clock64(); flush(); dbg_flush += wall_clock64() - tf; ++dbg_rings; }
-#else
     flush();                                          // the settle test needs the exact incumbents (in LDS)
-#endif
     if (!(r2_hi <= FLT_MAX) || visited >= U - u_lo)
       break;   // every reference tile of this wave's share has been visited
     // settled: every unvisited frame is >= sqrt(r2_hi) away; the exact incumbents decide
@@ -2755,23 +2679,6 @@ __global__ __launch_bounds__(COOP ? 512 : 256, COOP ? 1 : 2) void nn_pruned_kern
     }
     if (!(r2_hi < 1.0e37f)) r2_hi = INFINITY;
   }
-#ifdef DC_WAVE_STAMPS
-  if (lane == 0) {
-    const uint32_t wid = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (uint32_t)wib;
-    if (wid < kDbgWaves) {
-      g_wave_dbg[wid][0] = dbg_t0;
-      g_wave_dbg[wid][1] = wall_clock64();
-      g_wave_dbg[wid][2] = ((unsigned long long)chains << 32) | wave;
-      g_wave_dbg[wid][3] = dbg_t1;
-      g_wave_dbg[wid][4] = (dbg_scan << 32) | (dbg_flush & 0xFFFFFFFFull);
-      g_wave_dbg[wid][5] = ((unsigned long long)dbg_rings << 32) | chains_on;
-      g_wave_dbg[wid][6] = (dbg_on_cyc << 32) | ((clock64() - dbg_c0) & 0xFFFFFFFFull);
-      g_wave_dbg[wid][7] = (dbg_fl_cyc << 32) | dbg_nfl;
-      g_wave_dbg[wid][8] = ((unsigned long long)dbg_iters << 32) | dbg_cands;
-      g_wave_dbg[wid][9] = (((dbg_sA - dbg_t0) & 0xFFFFFull) << 40) | (((dbg_sB - dbg_t0) & 0xFFFFFull) << 20) | ((dbg_sC - dbg_t0) & 0xFFFFFull);
-    }
-  }
-#endif
   if (lane == 0 && chain_counter) {
     atomicAdd(chain_counter, (unsigned long long)chains);
     atomicAdd(chain_counter + kMfmaCtrNn, kNnEarly<NM> ? (unsigned long long)chains * kNnCoarse<NM> + (unsigned long long)chains_on * NM

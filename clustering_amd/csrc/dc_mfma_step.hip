@@ -1,5 +1,6 @@
 // dc_mfma_step.hip -- instantiates the MFMA sweeps for ONE MFMA count per tile pair (compile with
-// -DDC_STEP=n, n = nm_for(n_cols) = ceil((6 n_cols + 3) / 16)); see dc_mfma_kernels.hpp.
+// -DDC_STEP=n, n = nm_for(n_cols) = ceil((3 n_cols + 2) / 16): three piece products per column and two constant slots on
+// the K axis, 16 slots per MFMA); see dc_mfma_kernels.hpp.
 #include "dc_mfma_kernels.hpp"
 
 #ifndef DC_STEP
@@ -73,14 +74,3 @@ void DC_CAT(nn_mfma_step_, DC_STEP)(const float* coords, uint32_t n_rows, uint32
 
 }  // namespace dc
 
-#if defined(DC_WAVE_STAMPS) && DC_STEP == 2
-// (measurement build: per-wave start / end stamps of nn_pruned_kernel<2, .>, copied out for scratch/wave_times.py)
-extern "C" __attribute__((visibility("default"))) int dc_dbg_wave_times(unsigned long long* out, size_t n_waves) {
-  (void)hipDeviceSynchronize();
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::g_wave_dbg), sizeof(unsigned long long) * 10 * n_waves, 0, hipMemcpyDeviceToHost);
-}
-extern "C" __attribute__((visibility("default"))) int dc_dbg_pop_wave_times(unsigned long long* out, size_t n_waves) {
-  (void)hipDeviceSynchronize();
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::g_pop_dbg), sizeof(unsigned long long) * 3 * n_waves, 0, hipMemcpyDeviceToHost);
-}
-#endif

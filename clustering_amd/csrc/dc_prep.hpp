@@ -120,7 +120,8 @@ __device__ void stats_reduce(uint32_t* __restrict__ hdr, const double* __restric
   __syncthreads();   // (every thread has read the word before it is cleared)
   if (nb == 0u) return;
   // one wave per column (the fingerprint slot is column kMaxCols): lane l adds the blocks l, l + 64, ... in that order, the
-  // lanes meet in a fixed tree -- the same sums on every rank
+  // lanes meet in a fixed tree.  (The table's entries themselves are sums of LDS double atomics in arrival order:
+  // the column sums are reproducible to rounding, not bit for bit -- they only set the origin, which no result depends on.)
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   for (uint32_t c = wave; c <= D + 2u; c += n_waves) {
     const uint32_t col = (c >= D) ? (uint32_t)kMaxCols + (c - D) : c;
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(1024) void claim_guard_kernel(uint32_t* __restrict_
     *reinterpret_cast<unsigned long long*>(hdr + kHdrFp + 2) = f;
     hdr[1] = (hdr[1] & 1u) | (same ? 0u : 2u) | ((have_fe && nan) ? 4u : 0u);
     if (!same) hdr[kHdrCookie] = 0u;   // (the component partition in the workspace is not this array's either)
-    // the per-sweep words: evaluated-tile and MFMA counters, the extents this sweep forms again, the order's hash
+    // the per-sweep words: evaluated-tile and MFMA counters, the extents this sweep forms again, the verdict of the last
+    // block unpack (kHdrLayoutBad = kHdrFp + 4) and the spare word behind it
     if (pruned) hdr[0] = 0u;
     for (uint32_t k = 2; k <= 7; ++k) hdr[k] = 0u;
     hdr[kHdrMfmaNn] = 0u;
@@ -463,6 +465,11 @@ __global__ __launch_bounds__(256) void order_key_kernel(
   // atomics per block on the same three words were a third of this pass at C3)
   if (threadIdx.x < (uint32_t)kMaxComp) counts[(size_t)blockIdx.x * kMaxComp + threadIdx.x] = cnt_s[threadIdx.x];
 }
+
+// (what the kernels of this file assume about the component count: a wave's lane indexes a component -- part[l][threadIdx & 63],
+//  table[b * kMaxComp + c] --, order_key_kernel keeps components in an unsigned char, and the sort's remapped last pass takes
+//  kMaxComp segments)
+static_assert(kMaxComp == 64 && kMaxComp <= (int)kSortMaxSegments && kMaxComp <= 256, "order_key_kernel / order_meta_kernel / SortRemap are written for 64 components");
 
 // One workgroup: the rows per component (the table order_key_kernel left: [n_blocks][kMaxComp]) added up, then -- one thread --
 // the first sorted index of every component (start), the tile range of every component in the padded order (range; entry

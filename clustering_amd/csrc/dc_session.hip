@@ -320,25 +320,33 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
   const int avail = dc_hip_device_count();
   if (avail < 0) return avail;
   if (avail == 0) return failf(DC_ERR_NO_DEVICE, "no HIP device found");
+  const bool caller_chose_count = n_devices > 0;
   if (n_devices <= 0) {
     n_devices = avail;
     devices = nullptr;
   }
   // DC_SESSION_DEVICES="0,1,..." (hosts that do not choose devices themselves -- the C++ shim, the command line): the
   // device ordinals of the session; with DC_SESSION_ALLOW_DUPLICATE_DEVICES=1 an ordinal may repeat (tests of the
-  // multi-device flow on a one-GPU box)
+  // multi-device flow on a one-GPU box).  The list never overrides a caller's choice silently: a caller that passed an
+  // explicit device list keeps it, a caller that asked for N devices (`--ngpus N`) gets the list only if it names
+  // exactly N, and a malformed list is an error, not a shorter list.
   std::vector<int> env_devices;
   if (!devices) {
     const char* list = getenv("DC_SESSION_DEVICES");
     for (const char* c = list; c && *c;) {
       char* end = nullptr;
       const long v = strtol(c, &end, 10);
-      if (end == c) break;
+      if (end == c || (*end != ',' && *end != 0) || v < 0 || v > 4096)
+        return failf(DC_ERR_INVALID_ARGUMENT, "DC_SESSION_DEVICES=\"%s\": expected a comma-separated list of device ordinals", list);
       env_devices.push_back((int)v);
       c = (*end == ',') ? end + 1 : end;
-      if (*end != ',' && *end != 0) break;
+      if (*end == ',' && *c == 0)
+        return failf(DC_ERR_INVALID_ARGUMENT, "DC_SESSION_DEVICES=\"%s\": trailing comma", list);
     }
     if (!env_devices.empty()) {
+      if (caller_chose_count && (int)env_devices.size() != n_devices)
+        return failf(DC_ERR_INVALID_ARGUMENT, "%d devices requested, but DC_SESSION_DEVICES=\"%s\" names %d: unset one of them",
+                     n_devices, list, (int)env_devices.size());
       devices = env_devices.data();
       n_devices = (int)env_devices.size();
     }

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <functional>
 #include <iostream>
+#include <mutex>
 
 namespace Clustering {
 namespace Density {
@@ -301,6 +302,11 @@ std::set<std::size_t> high_density_neighborhood(const float* coords, const std::
   // memory bandwidth, ~10 ms at C3) and compared with what the cached graph was built from: an in-place edit of a few rows
   // or a re-sorted order between passes is caught, not "probably" caught.  Precondition that remains
   // (density_clustering_hip.hpp): coords and sorted_fe are not modified BETWEEN the calls of one ascending pass.
+  // Cost of any OTHER access pattern: a caller that repeats a frame, walks downwards or interleaves two passes pays the
+  // full fingerprint (O(N D), ~10 ms at C3) on every such call -- safe, not fast; only the reference's ascending loop is
+  // O(1) per call.  One caller at a time: the cache is process-wide, calls are serialised by a mutex.
+  static std::mutex cache_mutex;
+  std::lock_guard<std::mutex> cache_lock(cache_mutex);
   struct Cache {
     const float* coords = nullptr;
     const FreeEnergy* order = nullptr;

@@ -96,6 +96,8 @@ std::vector<std::size_t> sanitize_state_names(std::vector<std::size_t> clusterin
 //! -- a new pass -- both arrays are fingerprinted in full and a change of any element rebuilds the graph.
 //! PRECONDITION: coords and sorted_fe are not modified between the calls of one ascending pass (the reference's
 //! screening never does); HIP::invalidate_neighborhood_cache() forces the rebuild where a caller must.
+//! Any other access pattern (a repeated or descending i_frame, two interleaved passes) is correct but pays the full
+//! fingerprint, O(N D), on every such call.  The cache is process-wide; calls are serialised by a mutex.
 std::set<std::size_t> high_density_neighborhood(const float* coords, const std::size_t n_cols,
                                                 const std::vector<FreeEnergy>& sorted_fe,
                                                 const std::size_t i_frame, const std::size_t limit,

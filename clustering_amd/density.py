@@ -381,15 +381,17 @@ def layout_status(device):
 def unpack_neighbor_blocks(coords, blocks, n_segments, variant="auto", out=None, check=True):
     """blocks int32 [n_segments, 4, block_rows] gathered from all ranks -> (nn_idx, nn_d2, hd_idx, hd_d2) by frame
     (dc_hip_neighbors_block_unpack_dev).  The unpack kernel compares the blocks' layout headers itself and writes nothing
-    on a mismatch; check=True asks for its verdict right away (one synchronisation) and raises, check=False leaves that to
-    the caller (layout_status, e.g. once after a timed loop)."""
+    on a mismatch; check=True asks for its verdict right away (one synchronisation) and raises.  check=False leaves that to
+    the caller: layout_status() BEFORE the next call into the workspace -- the verdict word describes the last unpack only,
+    the next unpack or sweep replaces it -- and on a mismatch the returned arrays hold whatever they held before (zeros
+    here: a refused unpack must not hand out uninitialised memory as neighbours)."""
     n_rows, n_cols = _check_coords(coords)
     dev = coords.device
     rows = neighbor_block_rows(n_rows, n_cols, n_segments)
     assert blocks.is_contiguous() and blocks.dtype == torch.int32 and blocks.numel() == n_segments * 4 * rows
     if out is None:
-        out = (torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev),
-               torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.float32, device=dev))
+        buf = (torch.empty if check else torch.zeros)((4, n_rows), dtype=torch.int32, device=dev)   # (one fill, not four)
+        out = (buf[0], buf[1].view(torch.float32), buf[2], buf[3].view(torch.float32))
     with torch.cuda.device(dev):
         ws, ws_bytes = _workspace(dev).get(n_rows, n_cols, 1)
         if check and not ws_bytes:   # (no workspace for the kernel to flag in -- shapes without a matrix-core sweep: compared here)

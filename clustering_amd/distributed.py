@@ -85,14 +85,16 @@ class ShardedDensity:
 
     def __init__(self, backend=None, group=None, check_layout=True):
         """check_layout: ask the unpack kernel for its verdict on the gathered blocks' layout headers in every step (one
-        synchronisation); False: the caller asks once, with check_layouts() -- a mismatch leaves the neighbour arrays of that
-        step unwritten either way"""
+        synchronisation).  False: the caller asks with check_layouts() after a step and BEFORE the next one -- the verdict
+        word is that of the last unpack only, the next step's sweeps and unpack replace it; a refused unpack writes
+        nothing (the step's neighbour arrays are zeros then)"""
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
         self.check_layout = check_layout
 
     def check_layouts(self, device):
-        """raises if the last unpack on this device refused its blocks (ranks derived different orders)"""
+        """raises if the LAST unpack on this device refused its blocks (ranks derived different orders); earlier steps are
+        not covered (dc_hip_workspace_layout_status_dev)"""
         if hasattr(self.backend, "layout_status") and self.backend.layout_status(device):
             raise RuntimeError("neighbour blocks of the ranks were packed under different layouts")
 

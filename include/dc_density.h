@@ -241,9 +241,13 @@ DC_API int dc_hip_neighbors_block_unpack_dev(const uint32_t* d_blocks, size_t n_
                                              size_t workspace_bytes, int variant, uint32_t* d_nn_idx,
                                              float* d_nn_d2, uint32_t* d_hd_idx, float* d_hd_d2, void* stream);
 /* The unpack compares the layout headers of the gathered blocks ON THE DEVICE before it scatters anything: on a mismatch
- * (a rank derived another order) nothing is written and a flag is raised in the workspace header, which stays up until the
- * next sweep in that workspace.  This reads it (synchronises the stream): *mismatch = 1 if the last unpack refused its
- * blocks.  A host may ask after every step or once after many (bench.py). */
+ * (a rank derived another order) NOTHING is written -- the output arrays keep whatever they held -- and a word of the
+ * workspace header records the verdict of THAT unpack (pruned variants only; with any other variant the workspace is not
+ * touched and the host compares the headers itself).  The word describes the LAST unpack only: the next unpack, and the
+ * preparation of the next sweep in the workspace, overwrite it.  This call reads it (synchronises the stream): *mismatch =
+ * 1 if the last unpack refused its blocks.  A host that wants every step covered asks after every step, before the next
+ * call into the workspace (clustering_amd.distributed does unless told otherwise; bench.py asks after its instrumented
+ * steps and after the last timed one). */
 DC_API int dc_hip_workspace_layout_status_dev(const void* d_workspace, int* mismatch, void* stream);
 
 /* replaces Clustering::Density::compute_sigma2 (density_clustering.cpp:334-343): mean of the nearest-

@@ -1,4 +1,4 @@
-"""phases of components_kernel (a build with -DDC_COMP_STAMPS: wall_clock64 stamps in words 8.. of the component region)"""
+"""phases of components_kernel (`git apply -p0 scratch/r6_wave_stamps.patch`, then a build with -DDC_COMP_STAMPS: wall_clock64 stamps in words 8.. of the component region)"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from clustering_amd import density as dens

@@ -1,4 +1,4 @@
-"""per-wave durations of pop_pruned_kernel (a -DDC_WAVE_STAMPS build, DC_LIB_PATH): occupancy of the wave slots and the
+"""per-wave durations of pop_pruned_kernel (a -DDC_WAVE_STAMPS build, DC_LIB_PATH; the stamps are no longer in the product sources: `git apply -p0 scratch/r6_wave_stamps.patch` first): occupancy of the wave slots and the
 longest waves of a launch, for all rows (G = 1) or one segment of eight"""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.')

@@ -1,4 +1,4 @@
-"""per-wave durations of nn_pruned_kernel in one segment of eight (a build with -DDC_WAVE_STAMPS, DC_LIB_PATH):
+"""per-wave durations of nn_pruned_kernel in one segment of eight (a build with -DDC_WAVE_STAMPS, DC_LIB_PATH; the stamps are no longer in the product sources: `git apply -p0 scratch/r6_wave_stamps.patch` first):
 how much of the launch is its end (slots idle behind the last long waves) and how uneven the waves are"""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.')
