@@ -58,7 +58,12 @@ for k in set(sq) | set(mem):
         e['clock_ghz'] = cyc / (sum(ds) / len(ds)) / 1e9
         e['matrix_pipe_utilisation'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc)
         n_disp = workload.get('dispatches_per_call', {}).get(key, 1)
-        e['valu_insts_per_32x32_tile_pair'] = e['SQ_INSTS_VALU'] * n_disp / chains[key]
+        # (the unpruned sweeps -- pop_mfma_kernel / nn_mfma_kernel / *_mfma32_kernel -- evaluate EVERY tile pair: ceil(N/32)^2,
+        #  not the pruned sweeps' count: round 5 divided them by the wrong one, 7x too high)
+        unpruned = ('_mfma_kernel' in k) or ('_mfma32_kernel' in k)
+        t_all = ((workload['n_rows'] + 31) // 32) ** 2
+        e['tile_pairs_per_dispatch'] = t_all if unpruned else chains[key] / n_disp
+        e['valu_insts_per_32x32_tile_pair'] = e['SQ_INSTS_VALU'] / e['tile_pairs_per_dispatch']
     if 'TCC_EA0_RDREQ_sum' in e:
         e['traffic_bytes'] = e['TCC_EA0_RDREQ_sum'] * 128 + e['TCC_EA0_WRREQ_sum'] * 64
         if ds:

@@ -732,7 +732,8 @@ print("FORMS " + json.dumps(out))
 @pytest.mark.gpu
 def test_sweep_forms_agree():
     """The population sweep has a symmetric form (every pair of query groups once, both frames credited) and a
-    one-sided one, workgroups of one or four waves, and a symmetric shared-operand sweep for one or several radii:
+    one-sided one, workgroups of one or four waves, and a symmetric shared-operand sweep for one or several radii; the
+    neighbour sweep runs its reference shares as single waves or as the waves of one workgroup (COOP, round 6):
     every combination, in its own process (the switches are read once), reproduces the ORACLE on the shapes up to
     20 000 rows (populations of every radius, neighbour indices and d2 bits) and gives the same populations (plain and
     position-weighted checksums), the same sums over three segments, and the same neighbours -- on shapes with an even
@@ -744,7 +745,11 @@ def test_sweep_forms_agree():
     cases = [(1152, 10, [0.2]), (1344, 10, [0.3, 0.15]), (40000, 10, [0.2]), (9000, 3, [0.05]), (20000, 16, [0.4, 0.3, 0.5]),
              (12000, 30, [0.6])]
     envs = [{}, {"DC_POP_SYM": "0"}, {"DC_WAVES_PER_GROUP": "4"}, {"DC_WAVES_PER_GROUP": "1"},
-            {"DC_POP_SHARED": "1", "DC_POP_SHARED_SYM": "2"}, {"DC_POP_SHARED": "1", "DC_POP_SHARED_SYM": "0", "DC_NN_SHARED": "1"}]
+            {"DC_POP_SHARED": "1", "DC_POP_SHARED_SYM": "2"}, {"DC_POP_SHARED": "1", "DC_POP_SHARED_SYM": "0", "DC_NN_SHARED": "1"},
+            # round 6: the neighbour sweep's shares as the waves of one workgroup (COOP) -- forced on, with share floors that
+            # give these small shapes many reference shares -- in workgroups of 4, 2 and 8 waves
+            {"DC_NN_COOP": "1", "DC_SHARE_FLOOR": "16"}, {"DC_NN_COOP": "1", "DC_SHARE_FLOOR": "40", "DC_NN_COOP_WAVES": "2"},
+            {"DC_NN_COOP": "1", "DC_SHARE_FLOOR": "8", "DC_NN_COOP_WAVES": "8"}, {"DC_NN_COOP": "0", "DC_SHARE_FLOOR": "16"}]
     results = []
     for extra in envs:
         env = dict(os.environ, **extra)

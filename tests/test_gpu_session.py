@@ -237,3 +237,20 @@ def test_duplicate_devices_need_the_test_switch(dens):
         pytest.skip("switch set in the environment")
     with pytest.raises(capi.DensityLibraryError):
         dens.Session(c, devices=[0, 0])
+
+
+@pytest.mark.parametrize("env_list,n_devices,ok", [("0", 0, True), ("0", 1, True), ("0,x", 0, False), ("0,", 0, False),
+                                                   ("-1", 0, False), ("0,0", 1, False), ("7,", 1, False)])
+def test_session_device_list_from_the_environment_never_overrides_silently(dens, monkeypatch, env_list, n_devices, ok):
+    """DC_SESSION_DEVICES (for hosts that do not choose devices themselves): a malformed list is an argument error, not a
+    shorter list, and a caller that asked for N devices gets the list only if it names N"""
+    from clustering_amd import capi
+    monkeypatch.setenv("DC_SESSION_DEVICES", env_list)
+    monkeypatch.delenv("DC_SESSION_ALLOW_DUPLICATE_DEVICES", raising=False)
+    c = gaussian_blobs(256, 5, seed=1)
+    if ok:
+        with dens.Session(c, n_devices=n_devices) as s:
+            assert s.n_rows == 256
+    else:
+        with pytest.raises(capi.DensityLibraryError):
+            dens.Session(c, n_devices=n_devices)
