@@ -1986,11 +1986,22 @@ void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
   char* p = (char*)d_ws;
   float* img = (float*)(p + L.off_img);
   float* norms = (float*)(p + L.off_norm);
+  // the frames in the order of their 2-D cells (cell32_key_kernel; about 64 frames per cell of the bounding box of columns
+  // 0 / 1, at most 256 x 256 cells: 16-bit keys, two passes of the library's sort)
+  uint32_t* keys_in = (uint32_t*)(p + L.off_keys_in);
+  uint32_t* keys_out = (uint32_t*)(p + L.off_keys_out);
+  uint32_t* vals_in = (uint32_t*)(p + L.off_vals_in);
+  uint32_t* perm = (uint32_t*)(p + L.off_perm);
+  uint32_t G = 1, g_bits = 0;
+  while (G < 256u && (size_t)(2u * G) * (2u * G) * 64u <= (size_t)n_rows) { G *= 2u; ++g_bits; }
+  hipLaunchKernelGGL(cell32_key_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, d_coords, n_rows, n_cols,
+                     (const uint32_t*)p, G, keys_in, vals_in);
+  if (sort_pairs_u32(keys_in, keys_out, vals_in, perm, n_rows, p + L.fixed_end, sort_temp_bytes(n_rows), stream, 2u * g_bits) != 0) return;
   // (ONE image for all radii of the call, scaled for the largest: the band of a smaller radius is narrower than 1)
   float r2max = 0.0f;
   for (int r = 0; r < n_rad; ++r) r2max = std::max(r2max, rad2.v[r]);
   hipLaunchKernelGGL(image32_kernel, dim3((32 * L.T + 255) / 256), dim3(256), 0, stream, d_coords, n_rows, n_cols, L.T,
-                     (const float*)(p + kHdrMeans), (const uint32_t*)nullptr, (const uint32_t*)p, r2max, img, norms);
+                     (const float*)(p + kHdrMeans), (const uint32_t*)perm, (const uint32_t*)p, r2max, img, norms);
 #ifdef DC_MFMA32_TQ
   constexpr int kTQ = DC_MFMA32_TQ;
 #else
@@ -2000,7 +2011,7 @@ void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
   static const uint32_t env_chunks = [] { const char* v = getenv("DC_MFMA32_CHUNKS"); return (v && v[0]) ? (uint32_t)atoi(v) : 0u; }();
   // (waves per workgroup: DC_MFMA32_WPB, measurements)
   const uint32_t wpb = wpb32();
-  const uint32_t blocks = (grid_for(i_from, i_to, kTQ) * 4u + wpb - 1) / wpb;
+  const uint32_t blocks = ((L.T + kTQ - 1) / kTQ + wpb - 1) / wpb;   // (all positions: the rows of a range are scattered over the order)
   const uint32_t chunks = env_chunks ? std::min(env_chunks, L.T) : chunks32(blocks * wpb, L.T, 2048u);
   const dim3 grid(blocks, chunks), block(64 * wpb);
   for (int r = 0; r < n_rad; ++r) {
@@ -2008,7 +2019,7 @@ void launch_pop_mfma32(const float* d_coords, uint32_t n_rows, uint32_t n_cols, 
       (void)hipMemsetAsync(d_pops + (size_t)r * n_rows + i_from, 0, sizeof(uint32_t) * (size_t)(i_to - i_from), stream);
     sweep_timer_mark(0, true, stream);
     hipLaunchKernelGGL((pop_mfma32_kernel<kS32, kTQ>), grid, block, wpb * sizeof(float) * 2 * kNormBatch32 * 32, stream, d_coords, n_rows, n_cols, (const float*)img,
-                       (const float*)norms, (const uint32_t*)p, L.T, i_from, i_to, rad2.v[r], r2max, d_pops + (size_t)r * n_rows);
+                       (const float*)norms, (const uint32_t*)perm, (const uint32_t*)p, L.T, i_from, i_to, rad2.v[r], r2max, d_pops + (size_t)r * n_rows);
     sweep_timer_mark(0, false, stream);
   }
 }

@@ -48,6 +48,22 @@ __host__ __device__ inline float scale32_pop(float M, float r2max, int K, int D)
   return c < 1.8446744e19f ? c : 1.8446744e19f;   // (M <= 1e36 and r2 <= FLT_MAX keep c above 2^-56: no lower clamp needed)
 }
 
+// Spatial order of the fp32 population sweep (round 6): the frames by the cell of a G x G grid on columns 0 / 1 (their
+// extents: header words 8..11).  Every pair is still evaluated on the matrix pipe -- what the order buys is that most
+// 32 x 32 chains then hold NO pair within the radius, which one tile minimum per chain shows (pop_mfma32_kernel).
+__global__ void cell32_key_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D, const uint32_t* __restrict__ hdr,
+                                  uint32_t G, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const float lo0 = fkey_inv(~hdr[8]), hi0 = fkey_inv(hdr[9]), lo1 = fkey_inv(~hdr[10]), hi1 = fkey_inv(hdr[11]);
+  auto cell = [&](float v, float lo, float hi) -> uint32_t {
+    const float u = (hi > lo) ? (v - lo) / (hi - lo) * (float)G : 0.0f;
+    return (u >= 0.0f) ? min((uint32_t)fminf(u, 1.0e6f), G - 1u) : 0u;   // (NaN / -inf: cell 0 -- flagged data never reaches the sweep)
+  };
+  keys[i] = cell(coords[(size_t)i * D], lo0, hi0) * G + ((D > 1) ? cell(coords[(size_t)i * D + 1], lo1, hi1) : 0u);
+  vals[i] = i;
+}
+
 // fp32 operand image of rows in natural order (perm == nullptr) or gathered through perm; r2max >= 0: scaled by
 // scale32_pop (population sweeps), r2max < 0: unscaled (neighbour sweep, whose band is relative)
 __global__ void image32_kernel(const float* __restrict__ coords, uint32_t n_rows, uint32_t D, uint32_t T,
@@ -136,14 +152,15 @@ __device__ __forceinline__ uint32_t pop32_string(const f32x16& acc, f32x2 nlo) {
 }
 
 // rare: exact re-check of the band pairs of one accumulator tile (by value: see pop_fix)
-__device__ __attribute__((noinline)) uint32_t pop32_fix(const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
-                                                        float r2, uint32_t band, uint32_t jq, uint32_t t, int h) {
-  uint32_t m = band, out = 0;   // (band_of(string): element r at bit 31 - 2 r)
+__device__ __attribute__((noinline)) uint32_t pop32_fix(const float* __restrict__ coords, const uint32_t* __restrict__ perm,
+                                                        uint32_t n_rows, uint32_t n_cols, float r2, uint32_t band, uint32_t jq,
+                                                        uint32_t t, int h) {
+  uint32_t m = band, out = 0;   // (band_of(string): element r at bit 31 - 2 r; jq: the query's FRAME, the tile's rows are positions)
   while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
     if (m != 0) {
       const int r = element_of(31 - __builtin_clz(m));
       const uint32_t row = tile_row(t, r, h);
-      if (row < n_rows) out += (exact_d2(coords, n_cols, jq, row) < r2) ? 1u : 0u;
+      if (row < n_rows) out += (exact_d2(coords, n_cols, jq, perm[row]) < r2) ? 1u : 0u;
       m &= ~(0x80000000u >> (2 * r));
     }
   }
@@ -153,15 +170,17 @@ __device__ __attribute__((noinline)) uint32_t pop32_fix(const float* __restrict_
 template <int S, int TQ>
 __global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols, const float* __restrict__ img,
-    const float* __restrict__ norms, const uint32_t* __restrict__ hdr, uint32_t T, uint32_t i_from, uint32_t i_to,
-    float r2, float r2max, uint32_t* __restrict__ pops) {
+    const float* __restrict__ norms, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ hdr, uint32_t T,
+    uint32_t i_from, uint32_t i_to, float r2, float r2max, uint32_t* __restrict__ pops) {
   static_assert(TQ % kClump32 == 0, "query tiles are handled in clumps");
   extern __shared__ __attribute__((aligned(16))) float pop32_lds[];   // per wave: the ring of row norms (Norms32)
   if (hdr[1] != 0) return;   // non-finite / overflow-prone data: the gated direct kernel runs instead
   const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
   const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const uint32_t qt0 = i_from / 32 + wave * TQ;
-  if (qt0 * 32 >= i_to) return;   // whole wave leaves; no barriers in this kernel
+  // (queries and references are POSITIONS of the spatial order -- perm: position -> frame; the rows [i_from, i_to) of a
+  //  row range are wherever the order put them)
+  const uint32_t qt0 = wave * TQ;
+  if (qt0 >= T) return;   // whole wave leaves; no barriers in this kernel
   // scaled units (the image was built with the same scale): inside <=> t < 0, outside <=> t >= 2, else band
   const float cs = scale32_pop(__uint_as_float(hdr[0]), r2max, 2 * S, (int)n_cols);
   const float thr = (cs * cs) * r2 - 1.0f;
@@ -170,12 +189,14 @@ __global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
   f32x2 nlo[TQ];
   uint32_t cnt[TQ], jq[TQ];
   uint64_t livemask[TQ];
+  uint64_t any_live = 0;
 #pragma unroll
   for (int qt = 0; qt < TQ; ++qt) {
-    const uint32_t tile = qt0 + qt;
-    jq[qt] = tile * 32 + c;
-    const bool live = (tile < T) && (jq[qt] >= i_from) && (jq[qt] < i_to);
+    const uint32_t tile = qt0 + qt, pos = tile * 32 + c;
+    jq[qt] = (tile < T && pos < n_rows) ? perm[pos] : 0xFFFFFFFFu;
+    const bool live = (jq[qt] >= i_from) && (jq[qt] < i_to);   // (0xFFFFFFFF: beyond every range)
     livemask[qt] = __builtin_amdgcn_ballot_w64(live);
+    any_live |= livemask[qt];
     const uint32_t tl = tile < T ? tile : T - 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) b[qt][s] = -2.0f * img[((size_t)tl * 64 + lane) * kLane32 + s];
@@ -183,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
     nlo[qt] = f32x2{-lo, -lo};
     cnt[qt] = 0;
   }
+  if (any_live == 0) return;   // (a row range: none of this wave's positions belongs to it)
   // reference tiles [tb, te) of this wave's chunk (gridDim.y chunks: the launcher sizes the grid so that its waves fill
   // the chip's wave slots a whole number of times; partial counts merge by atomicAdd into zero-filled rows)
   const uint32_t per = (T + gridDim.y - 1) / gridDim.y, tb = blockIdx.y * per, te = min(T, tb + per);
@@ -196,25 +218,37 @@ __global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
   load_frag32<S>(img, tb, lane, a0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the first two batches of norms have landed)
   N.read(0, h, n0);
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
+  // `prefetch`: the loads of the NEXT tile, issued right behind the first clump's MFMAs -- the results of a clump cannot
+  // be read for some twenty issue slots anyway (the compiler pads them with s_nop), and there the loads' own issue cost
+  // disappears as well
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t, auto&& prefetch) {
     const f32x16 c0 = frag16(nv);   // (+inf for a pad row: t = +inf)
 #pragma unroll
     for (int g = 0; g < TQ; g += kClump32) {
       f32x16 acc[kClump32];
       chains32<S, kClump32>(a, &b[g], c0, acc);
       __builtin_amdgcn_sched_barrier(0);
-      uint32_t bits[kClump32], band = 0;
+      prefetch(g / kClump32);   // (part 0: the fragments, part 1: the row norms)
+      __builtin_amdgcn_sched_barrier(0);
+      // Most chains of a spatially ordered sweep hold no pair inside or in the band: the smallest t of the lane's 16
+      // elements says so (8 v_min3 + 2 per chain against the 27 of the strings), ONE wave-level test for the clump.
+      float tm[kClump32], dmin = INFINITY;
 #pragma unroll
       for (int q = 0; q < kClump32; ++q) {
-        bits[q] = pop32_string(acc[q], nlo[g + q]);
-        cnt[g + q] += __builtin_popcount(inside_of(bits[q]));
-        band |= band_of(bits[q]);
+        tm[q] = INFINITY;
+        tile_min<0, 16>(acc[q], tm[q]);
+        tm[q] += nlo[g + q].x;                 // smallest t = acc - lo of the lane (+inf: idle lane, pad rows)
+        dmin = fminf(dmin, tm[q]);
       }
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(band != 0) != 0, 0)) {
+      if (__builtin_amdgcn_ballot_w64(dmin < 2.0f) != 0) {
 #pragma unroll
         for (int q = 0; q < kClump32; ++q) {
-          const uint32_t bq = band_of(bits[q]);
-          if (__builtin_amdgcn_ballot_w64(bq != 0) != 0) cnt[g + q] += pop32_fix(coords, n_rows, n_cols, r2, bq, jq[g + q], t, h);
+          if (__builtin_amdgcn_ballot_w64(tm[q] < 2.0f) == 0) continue;   // (every pair of this chain is outside)
+          const uint32_t bits = pop32_string(acc[q], nlo[g + q]);
+          cnt[g + q] += __builtin_popcount(inside_of(bits));
+          const uint32_t bq = band_of(bits);
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(bq != 0) != 0, 0))
+            cnt[g + q] += pop32_fix(coords, perm, n_rows, n_cols, r2, bq, jq[g + q], t, h);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -227,14 +261,18 @@ __global__ __launch_bounds__(256, 2) void pop_mfma32_kernel(
   // (tile k of the chunk: its fragments and norms were asked for during tile k - 1; every kNormBatch32 tiles the batch
   //  after the next one is ordered -- the slot it lands in was read for the last time a tile ago)
   for (uint32_t k = 0; k < nt; k += 2) {
-    load_frag32<S>(img, tb + min(k + 1, nt - 1), lane, a1);
-    N.read(k + 1, h, n1);
-    tile_body(a0, n0, tb + k);
+    tile_body(a0, n0, tb + k, [&](int part) {
+      if (part == 0) load_frag32<S>(img, tb + min(k + 1, nt - 1), lane, a1);
+      if (part == TQ / kClump32 - 1) N.read(k + 1, h, n1);
+    });
     if (k + 1 < nt) {
-      if (((k + 2) & (kNormBatch32 - 1)) == 0) N.fetch((k + 2) / kNormBatch32 + 1, lane);
-      load_frag32<S>(img, tb + min(k + 2, nt - 1), lane, a0);
-      N.read(k + 2, h, n0);
-      tile_body(a1, n1, tb + k + 1);
+      tile_body(a1, n1, tb + k + 1, [&](int part) {
+        if (part == 0) {
+          if (((k + 2) & (kNormBatch32 - 1)) == 0) N.fetch((k + 2) / kNormBatch32 + 1, lane);
+          load_frag32<S>(img, tb + min(k + 2, nt - 1), lane, a0);
+        }
+        if (part == TQ / kClump32 - 1) N.read(k + 2, h, n0);
+      });
     }
   }
 #pragma unroll
@@ -429,10 +467,12 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     thr_nn[qi] = new_nn + eps2;
     thr_hd[qi] = new_hd + eps2;
   };
-  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t) {
+  auto tile_body = [&](const float (&a)[S], const float4 (&nv)[4], uint32_t t, auto&& prefetch) {
     const f32x16 c0 = frag16(nv);
     f32x16 acc[TQ];
     chains32<S, TQ>(a, b, c0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch();   // (the next tile's loads in the issue slots that wait for the chains' results: see pop_mfma32_kernel)
     __builtin_amdgcn_sched_barrier(0);
     // Common path: the raw tile minimum (the query itself included: it only ever makes the test pass) against ONE
     // threshold per chain -- thr_hd >= thr_nn when the tile holds a frame of lower free energy, thr_nn otherwise; what
@@ -455,14 +495,16 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     keep_alive(c0);   // (see pop_mfma32_kernel)
   };
   for (uint32_t k = 0; k < nt; k += 2) {   // (see pop_mfma32_kernel)
-    load_frag32<S>(img_s, tb + min(k + 1, nt - 1), lane, a1);
-    N.read(k + 1, h, n1);
-    tile_body(a0, n0, tb + k);
+    tile_body(a0, n0, tb + k, [&]() {
+      load_frag32<S>(img_s, tb + min(k + 1, nt - 1), lane, a1);
+      N.read(k + 1, h, n1);
+    });
     if (k + 1 < nt) {
-      if (((k + 2) & (kNormBatch32 - 1)) == 0) N.fetch((k + 2) / kNormBatch32 + 1, lane);
-      load_frag32<S>(img_s, tb + min(k + 2, nt - 1), lane, a0);
-      N.read(k + 2, h, n0);
-      tile_body(a1, n1, tb + k + 1);
+      tile_body(a1, n1, tb + k + 1, [&]() {
+        if (((k + 2) & (kNormBatch32 - 1)) == 0) N.fetch((k + 2) / kNormBatch32 + 1, lane);
+        load_frag32<S>(img_s, tb + min(k + 2, nt - 1), lane, a0);
+        N.read(k + 2, h, n0);
+      });
     }
   }
   flush();
