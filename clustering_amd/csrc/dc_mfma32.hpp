@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256, 2) void nn_mfma32_kernel(
     f32x16 acc[TQ];
     chains32<S, TQ>(a, b, c0, acc);
     __builtin_amdgcn_sched_barrier(0);
-    prefetch();   // (the next tile's loads in the issue slots that wait for the chains' results: see pop_mfma32_kernel)
+    prefetch();   // (the next tile's loads in the issue slots that wait for the chains' results: see pop_mfma32_kernel; in
+                  //  front of the chains instead: 172.6 against 173.0 ms, the same)
     __builtin_amdgcn_sched_barrier(0);
     // Common path: the raw tile minimum (the query itself included: it only ever makes the test pass) against ONE
     // threshold per chain -- thr_hd >= thr_nn when the tile holds a frame of lower free energy, thr_nn otherwise; what
