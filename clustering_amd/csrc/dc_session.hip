@@ -320,7 +320,7 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
   const int avail = dc_hip_device_count();
   if (avail < 0) return avail;
   if (avail == 0) return failf(DC_ERR_NO_DEVICE, "no HIP device found");
-  const bool caller_chose_count = n_devices > 0;
+  const bool caller_chose_count = n_devices > 0 && n_devices != avail;   // (a count equal to the devices present is what hosts pass for "all of them")
   if (n_devices <= 0) {
     n_devices = avail;
     devices = nullptr;
@@ -328,8 +328,8 @@ int dc_hip_session_open(const float* coords, size_t n_rows, size_t n_cols, const
   // DC_SESSION_DEVICES="0,1,..." (hosts that do not choose devices themselves -- the C++ shim, the command line): the
   // device ordinals of the session; with DC_SESSION_ALLOW_DUPLICATE_DEVICES=1 an ordinal may repeat (tests of the
   // multi-device flow on a one-GPU box).  The list never overrides a caller's choice silently: a caller that passed an
-  // explicit device list keeps it, a caller that asked for N devices (`--ngpus N`) gets the list only if it names
-  // exactly N, and a malformed list is an error, not a shorter list.
+  // explicit device list keeps it, a caller that asked for N devices other than all of them gets the list only if it
+  // names exactly N, and a malformed list is an error, not a shorter list.
   std::vector<int> env_devices;
   if (!devices) {
     const char* list = getenv("DC_SESSION_DEVICES");

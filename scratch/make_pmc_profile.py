@@ -11,6 +11,9 @@ mem = json.loads(subprocess.check_output(['python3', 'scratch/pmc_summary.py'] +
 bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
 if 'roofline_pop' in bench:
     chains = {'pop': bench['roofline_pop']['tile_pairs'], 'nn': bench['roofline_nn']['tile_pairs']}
+    # (scratch/c5_bench.py also runs ONE full one-radius population sweep for the free energies -- another kernel, its own count)
+    if 'full sweep' in bench.get('evaluated_fraction', {}):
+        chains['pop_full'] = bench['evaluated_fraction']['full sweep'] * float(workload['n_rows']) ** 2 / 1024.0
 elif 'pop_tiles' in bench:   # scratch/spread_bench.py
     chains = {'pop': bench['pop_tiles'], 'nn': bench['nn_tiles']}
 else:
@@ -50,6 +53,8 @@ for k in set(sq) | set(mem):
     if mk:
         e.update({c: v for c, v in mem[mk[0]].items() if c != 'dispatches' or 'dispatches' not in e})
     key = 'pop' if 'pop_' in k else 'nn'
+    if key == 'pop' and 'pop_full' in chains and 'msym' not in k:
+        key = 'pop_full'
     ds = dur.get(k, [])
     if ds:
         e['duration_ms_under_counters'] = 1e3 * sum(ds) / len(ds)

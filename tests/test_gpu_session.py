@@ -240,10 +240,11 @@ def test_duplicate_devices_need_the_test_switch(dens):
 
 
 @pytest.mark.parametrize("env_list,n_devices,ok", [("0", 0, True), ("0", 1, True), ("0,x", 0, False), ("0,", 0, False),
-                                                   ("-1", 0, False), ("0,0", 1, False), ("7,", 1, False)])
+                                                   ("-1", 0, False), ("0,0", 3, False), ("7,", 1, False)])
 def test_session_device_list_from_the_environment_never_overrides_silently(dens, monkeypatch, env_list, n_devices, ok):
     """DC_SESSION_DEVICES (for hosts that do not choose devices themselves): a malformed list is an argument error, not a
-    shorter list, and a caller that asked for N devices gets the list only if it names N"""
+    shorter list, and a caller that asked for N devices -- other than all that are present, which is what hosts pass for
+    "all of them" -- gets the list only if it names N"""
     from clustering_amd import capi
     monkeypatch.setenv("DC_SESSION_DEVICES", env_list)
     monkeypatch.delenv("DC_SESSION_ALLOW_DUPLICATE_DEVICES", raising=False)
