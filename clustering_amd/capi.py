@@ -9,11 +9,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DC_LIB_PATH: another build of the SAME library (measurement variants under clustering_amd/lib/variants/) instead of
-# copying it over the product
-LIB_PATH = os.environ.get("DC_LIB_PATH") or os.path.join(_HERE, "lib", "libdcdensity.so")
+# copying it over the product.  DC_CANON_ORDER=avx: the build with the summation order of a reference compiled
+# with -DCPU_ACCELERATION=AVX (`make -C clustering_amd/csrc CANON=avx` -> clustering_amd/lib_avx/; dc_hip_canon_order())
+CANON_ORDER = os.environ.get("DC_CANON_ORDER", "sse2")
+if CANON_ORDER not in ("sse2", "avx"):
+    raise ImportError(f"DC_CANON_ORDER={CANON_ORDER!r}: expected 'sse2' (the reference's default build) or 'avx'")
+LIB_PATH = os.environ.get("DC_LIB_PATH") or os.path.join(_HERE, "lib_avx" if CANON_ORDER == "avx" else "lib", "libdcdensity.so")
 
 DC_OK = 0
-ABI_VERSION = 4               # include/dc_density.h: DC_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 5               # include/dc_density.h: DC_HIP_ABI_VERSION this binding was written against
 FLAG_STATS_VALID = 0x100      # DC_FLAG_STATS_VALID
 VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA, VARIANT_MFMA_PRUNED = 0, 1, 2, 3
 VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA,
@@ -21,7 +25,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "direct": VARIANT_DIRECT, "mfma": VARIANT_MFMA
 
 # every symbol include/dc_density.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = (
-    "dc_hip_last_error", "dc_hip_abi_version", "dc_hip_build_digest", "dc_hip_device_count", "dc_hip_workspace_bytes",
+    "dc_hip_last_error", "dc_hip_abi_version", "dc_hip_build_digest", "dc_hip_canon_order", "dc_hip_device_count", "dc_hip_workspace_bytes",
     "dc_hip_populations_dev", "dc_hip_free_energies_dev", "dc_hip_nearest_neighbors_dev",
     "dc_hip_sigma2_dev", "dc_hip_workspace_counters_dev", "dc_hip_workspace_mfma_counters_dev", "dc_hip_workspace_layout_status_dev", "dc_hip_sweep_timing", "dc_hip_last_sweep_ms", "dc_hip_workspace_components_dev", "dc_hip_populations", "dc_hip_nearest_neighbors", "dc_hip_density_all",
     "dc_hip_radius_pairs_dev", "dc_hip_radius_pairs", "dc_hip_radius_min_edge_dev", "dc_hip_radius_forest",
@@ -57,6 +61,11 @@ def _load():
             "the library (python -c 'import __graft_entry__ as g; g.build()')")
     lib.dc_hip_build_digest.restype = C.c_char_p
     lib.dc_hip_build_digest.argtypes = []
+    lib.dc_hip_canon_order.restype = C.c_char_p
+    lib.dc_hip_canon_order.argtypes = []
+    if "DC_LIB_PATH" not in os.environ and lib.dc_hip_canon_order().decode() != CANON_ORDER:
+        raise DensityLibraryError(f"{LIB_PATH} reproduces the {lib.dc_hip_canon_order().decode()!r} summation order, "
+                                  f"DC_CANON_ORDER asks for {CANON_ORDER!r}: rebuild it")
     lib.dc_hip_device_count.restype = i32
     lib.dc_hip_workspace_bytes.restype = sz
     lib.dc_hip_workspace_bytes.argtypes = [sz, sz, sz]

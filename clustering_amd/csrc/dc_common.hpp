@@ -52,7 +52,92 @@ void launch_fe_log(const uint32_t* d_pops, uint32_t n_rows, uint32_t* d_state, u
                    uint32_t* d_flag_list, uint32_t flag_cap, double tol_rel, hipStream_t stream);
 constexpr uint32_t kFeStateWords = 8;   // device state of the free-energy pass in front of its list of flagged rows
 
-// ---- canonical squared distance, compile-time D ----------------------------------------
+// ---- canonical squared distance ------------------------------------------------------------------------------------
+// Order of operations = SURVEY.md Appendix B = what the reference binary computes (density_clustering.cpp:171-176,
+// 263-268 under -O3 -ffast-math).  WHICH order that is depends on how the reference was built (CMakeLists.txt:57-83):
+//   default / -DCPU_ACCELERATION=SSE*   four lane sums a_l, (a0 + a2) + (a1 + a3), then a PAIR tail and a scalar tail
+//   -DCPU_ACCELERATION=AVX (-mavx)      eight lane sums a_l, b_i = a_i + a_{i+4}, (b0 + b2) + (b1 + b3); if four or more
+//                                       columns remain: their squares q, s += (q0 + q2) + (q1 + q3); then up to three
+//                                       SCALAR additions -- read off the code g++ 11.4 emits for the reference's loop shape
+//                                       with the reference's flags and pinned against it for D = 1 .. 40, 48, 63 .. 65, 100
+//                                       (the probe of the test suite, built with -mavx)
+// The library is built for ONE of them: `make` = the default order, `make CANON=avx` = the AVX order into
+// clustering_amd/lib_avx/ (same file name, same ABI; dc_hip_canon_order() says which; DC_CANON_ORDER=avx makes the Python
+// host bind that build).  Every exact path of every kernel goes through the three functions below; the guard bands of
+// the matrix-core classifiers bound the summation order generically ((D / 4 + 9) u d2) and cover either.
+#ifdef DC_CANON_AVX
+#define DC_CANON_ORDER_NAME "avx"
+// the AVX order over a sequence of squares p(0) .. p(D-1) (sq: k -> p(k))
+template <class Sq>
+__device__ __forceinline__ float canon_sum_avx(Sq&& sq, int D) {
+  float s = 0.0f;
+  int k = 0;
+  const int V8 = 8 * (D / 8);
+  if (V8 != 0) {
+    // lane accumulators start at +0; 0 + p == p exactly (p is a square: never -0)
+    float a0 = sq(0), a1 = sq(1), a2 = sq(2), a3 = sq(3), a4 = sq(4), a5 = sq(5), a6 = sq(6), a7 = sq(7);
+    for (int k0 = 8; k0 < V8; k0 += 8) {
+      a0 = a0 + sq(k0 + 0);
+      a1 = a1 + sq(k0 + 1);
+      a2 = a2 + sq(k0 + 2);
+      a3 = a3 + sq(k0 + 3);
+      a4 = a4 + sq(k0 + 4);
+      a5 = a5 + sq(k0 + 5);
+      a6 = a6 + sq(k0 + 6);
+      a7 = a7 + sq(k0 + 7);
+    }
+    const float b0 = a0 + a4, b1 = a1 + a5, b2 = a2 + a6, b3 = a3 + a7;
+    s = (b0 + b2) + (b1 + b3);
+    k = V8;
+  }
+  if (D - k >= 4) {
+    const float t = (sq(k) + sq(k + 2)) + (sq(k + 1) + sq(k + 3));
+    s = s + t;   // (no eight-lane part: 0 + t == t exactly)
+    k += 4;
+  }
+  for (; k < D; ++k) s = s + sq(k);
+  return s;
+}
+template <int D>
+__device__ __forceinline__ float dist2_canon(const float (&q)[D], const float (&r)[D]) {
+  float p[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const float c = q[k] - r[k];
+    p[k] = c * c;
+  }
+  float s = 0.0f;
+  constexpr int V8 = 8 * (D / 8);
+  if constexpr (V8 != 0) {
+    float a[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) a[l] = p[l];
+#pragma unroll
+    for (int k0 = 8; k0 < V8; k0 += 8)
+#pragma unroll
+      for (int l = 0; l < 8; ++l) a[l] = a[l] + p[k0 + l];
+    const float b0 = a[0] + a[4], b1 = a[1] + a[5], b2 = a[2] + a[6], b3 = a[3] + a[7];
+    s = (b0 + b2) + (b1 + b3);
+  }
+  constexpr int K4 = (D - V8 >= 4) ? V8 + 4 : V8;
+  if constexpr (D - V8 >= 4) {
+    const float t = (p[V8] + p[V8 + 2]) + (p[V8 + 1] + p[V8 + 3]);
+    s = (V8 != 0) ? s + t : t;
+  }
+#pragma unroll
+  for (int k = K4; k < D; ++k) s = (k == 0) ? p[0] : s + p[k];
+  return s;
+}
+__device__ __forceinline__ float dist2_canon_rt(const float* x, int sx, const float* y, int sy, int D) {
+  return canon_sum_avx([&](int k) {
+    const float c = x[k * sx] - y[k * sy];
+    return c * c;
+  }, D);
+}
+__device__ __forceinline__ float dist2_canon_rows(const float* x, const float* y, int D) { return dist2_canon_rt(x, 1, y, 1, D); }
+#else
+#define DC_CANON_ORDER_NAME "sse2"
+// ---- the default order: compile-time D -----------------------------------------------------------------------------
 // q: this lane's query row (registers); r: reference row (registers, wave-uniform values).
 // Order of operations = SURVEY.md Appendix B = what the reference binary computes
 // (density_clustering.cpp:171-176, 263-268 under -O3 -ffast-math, SSE2).
@@ -155,5 +240,7 @@ __device__ __forceinline__ float dist2_canon_rows(const float* x, const float* y
   if (D - k == 1) s = s + sq(k);
   return s;
 }
+
+#endif   // DC_CANON_AVX
 
 }  // namespace dc

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   __shared__ uint32_t list_cnt[4];
   __shared__ float4 wave_box[4];
   __shared__ uint32_t flush_flag[2];   // "some wave's queue is filling up": all four flush at the next window (parity of the window)
-  __shared__ __attribute__((aligned(16))) uint32_t stage[4][2][16];   // per wave: the row sums of a unit's two radii (lanes 15/31/47/63)
+  __shared__ __attribute__((aligned(16))) uint32_t stage[4][(kMsWin * (NR / 2) + 3) / 4][2][16];   // per wave and unit of a window: the row sums of the unit's two radii (lanes 15/31/47/63)
   // dynamic LDS: operand ring [kMsRing][kTileUnits] x 16 B, the accumulators [kMsAccSlots][NR][64] x 8 B, then per wave
   // the compact queue of deferred exact evaluations [kWaveQueue] x 8 B, the positions of its queries [TQ*32] and their
   // exact-path counts [NR][TQ*32]
@@ -305,24 +305,42 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   // reduce the accumulators of a retired window: its (tile, pair of radii) units are dealt to the four waves;
   // entry_of(k): the k-th reference tile of the window, n_tiles of them
   const uint32_t my_byte = ref_credit_byte(lane);   // byte (of the 16 a row-end lane stages) with the count of reference row lane & 31
+  // (round 6: the wave's units of a window -- up to kMsUnits = ceil(kMsWin * NR / 2 / 4) -- go through the reducer TOGETHER,
+  //  phase by phase: all accumulator reads, then the byte sums, then the staged gather, then the atomics.  One unit after the
+  //  other was three dependent LDS round trips per unit, 16 % of a C5 rank's sweep.)
+  constexpr uint32_t kMsUnits = (kMsWin * (NR / 2) + 3) / 4;
   auto reduce_window = [&](uint32_t win, auto&& entry_of, uint32_t n_tiles) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u32x4 LdsU4;
     typedef __attribute__((address_space(3))) unsigned char LdsU8;
     constexpr uint32_t kPairs = NR / 2;
-    for (uint32_t p = (uint32_t)wib; p < n_tiles * kPairs; p += 4u) {
-      const uint32_t which = p / kPairs, rr0 = 2u * (p % kPairs);
-      const uint32_t slot = (win & 1u) * kMsWin + which;
-      uint32_t cnt2 = 0;   // lanes 0..31: count of reference row `lane` for radius rr0; lanes 32..63: for radius rr0 + 1
-      bool nz_u[2] = {false, false};
+    const uint32_t n_units = n_tiles * kPairs;
+    unsigned long long v[kMsUnits][2];
+    uint32_t which[kMsUnits], rr0[kMsUnits];
+    bool have[kMsUnits], nz_u[kMsUnits][2];
+    // phase 1: the lane's fields of every unit and radius
+#pragma unroll
+    for (uint32_t j = 0; j < kMsUnits; ++j) {
+      const uint32_t p = (uint32_t)wib + 4u * j;
+      have[j] = p < n_units;
+      which[j] = have[j] ? p / kPairs : 0u;
+      rr0[j] = have[j] ? 2u * (p % kPairs) : 0u;
+      const uint32_t slot = (win & 1u) * kMsWin + which[j];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        v[j][u] = have[j] ? acc[(size_t)slot * (NR * 64) + (size_t)(rr0[j] + u) * 64 + lane] : 0ull;
+    }
+    // phase 2: fields -> bytes -> sums over the 16 lanes of a row, left by the row-end lanes in the unit's stage
+    bool any = false;
+#pragma unroll
+    for (uint32_t j = 0; j < kMsUnits; ++j) {
+      const uint32_t slot = (win & 1u) * kMsWin + which[j];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        unsigned long long* a_lane = acc + (size_t)slot * (NR * 64) + (size_t)(rr0 + u) * 64 + lane;
-        const unsigned long long v = *a_lane;
-        const uint32_t A = (uint32_t)v, B = (uint32_t)(v >> 32);
-        const bool nz = __builtin_amdgcn_ballot_w64((A | B) != 0u) != 0;
-        if (nz) {
-          *a_lane = 0ull;
+        const uint32_t A = (uint32_t)v[j][u], B = (uint32_t)(v[j][u] >> 32);
+        nz_u[j][u] = __builtin_amdgcn_ballot_w64((A | B) != 0u) != 0;
+        if (nz_u[j][u]) {
+          acc[(size_t)slot * (NR * 64) + (size_t)(rr0[j] + u) * 64 + lane] = 0ull;
           uint32_t W[4] = {A & 0x0F0F0F0Fu, B & 0x0F0F0F0Fu, (A >> 4) & 0x0F0F0F0Fu, (B >> 4) & 0x0F0F0F0Fu};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {   // bytes <= 8 -> <= 128 over the 16 lanes of a row
@@ -331,30 +349,37 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
             W[e] += dpp_take<0x114>(W[e]);         // row_shr:4
             W[e] += dpp_take<0x118>(W[e]);         // row_shr:8
           }
-          if ((lane & 15) == 15) ((LdsU4*)stage[wib][u])[lane >> 4] = u32x4{W[0], W[1], W[2], W[3]};
-          nz_u[u] = true;
+          if ((lane & 15) == 15) ((LdsU4*)stage[wib][j][u])[lane >> 4] = u32x4{W[0], W[1], W[2], W[3]};
+          any = true;
         }
       }
-      if (!(nz_u[0] | nz_u[1])) continue;   // (wave-uniform)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: its LDS operations execute in order)
-      __builtin_amdgcn_wave_barrier();
-      {
-        // lane L: radius rr0 + (L >> 5), reference row L & 31: the row lies in half hh = bit 2 of the row index; the sums
-        // of that half's 32 query lanes are the row-end lanes 2 hh and 2 hh + 1
-        const int u = lane >> 5;
-        const uint32_t hh = my_byte >> 4, byte = my_byte & 15u;
-        const volatile LdsU8* st = (const volatile LdsU8*)stage[wib][u];
-        cnt2 = (uint32_t)st[(2u * hh) * 16u + byte] + (uint32_t)st[(2u * hh + 1u) * 16u + byte];
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (!((lane >> 5) ? nz_u[1] : nz_u[0])) cnt2 = 0u;   // (a unit that was all zero staged nothing: stale bytes)
-      const uint32_t t = entry_of(which);
+    }
+    if (!any) return;   // (wave-uniform)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: its LDS operations execute in order)
+    __builtin_amdgcn_wave_barrier();
+    // phase 3: lane L: radius rr0 + (L >> 5), reference row L & 31 -- the row lies in half hh = bit 2 of the row index; the
+    // sums of that half's 32 query lanes are the row-end lanes 2 hh and 2 hh + 1
+    uint32_t cnt2[kMsUnits];
+#pragma unroll
+    for (uint32_t j = 0; j < kMsUnits; ++j) {
+      const int u = lane >> 5;
+      const uint32_t hh = my_byte >> 4, byte = my_byte & 15u;
+      const volatile LdsU8* st = (const volatile LdsU8*)stage[wib][j][u];
+      cnt2[j] = (uint32_t)st[(2u * hh) * 16u + byte] + (uint32_t)st[(2u * hh + 1u) * 16u + byte];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // phase 4: one 256-byte atomic per unit
+#pragma unroll
+    for (uint32_t j = 0; j < kMsUnits; ++j) {
+      if (!(nz_u[j][0] | nz_u[j][1])) continue;   // (wave-uniform: nothing staged for this unit)
+      uint32_t c2 = ((lane >> 5) ? nz_u[j][1] : nz_u[j][0]) ? cnt2[j] : 0u;   // (a radius that was all zero staged nothing: stale bytes)
+      const uint32_t t = entry_of(which[j]);
 #ifdef DC_MS_ABL_NOATOMIC
-      if (cnt2 == 0xFFFFFFFFu)
+      if (c2 == 0xFFFFFFFFu)
 #else
-      if (cnt2 != 0u && rr0 + (uint32_t)(lane >> 5) < (uint32_t)n_rad && 32u * t + (uint32_t)(lane & 31) < CV.n_pos)
+      if (c2 != 0u && rr0[j] + (uint32_t)(lane >> 5) < (uint32_t)n_rad && 32u * t + (uint32_t)(lane & 31) < CV.n_pos)
 #endif
-        atomicAdd(&pops_pos[(size_t)t * (NR * 32) + (size_t)(rr0 + (lane >> 5)) * 32 + (uint32_t)(lane & 31)], cnt2);
+        atomicAdd(&pops_pos[(size_t)t * (NR * 32) + (size_t)(rr0[j] + (lane >> 5)) * 32 + (uint32_t)(lane & 31)], c2);
     }
   };
 

@@ -95,14 +95,23 @@ DC_API const char* dc_hip_last_error(void);
  *      fallback, DC_FLAG_STATS_VALID
  *   3  dc_hip_session_merge_note (which merge a multi-device session runs, and why),
  *      dc_hip_workspace_mfma_counters_dev, dc_hip_workspace_layout_status_dev
- *   4  dc_hip_build_digest (which sources this binary was built from) */
-#define DC_HIP_ABI_VERSION 4
+ *   4  dc_hip_build_digest (which sources this binary was built from)
+ *   5  dc_hip_canon_order (which summation order of the reference's distance loop this binary reproduces) */
+#define DC_HIP_ABI_VERSION 5
 DC_API int dc_hip_abi_version(void);
 
 /* digest of the sources this library was built from (clustering_amd/csrc + include/, comments left out:
  * clustering_amd/csrc/digest.py; 16 hex digits, embedded by the Makefile).  What a measurement is tied to: bench.py
  * prints it as "library_digest" and refuses counter profiles (profiles/ *_pmc.json) taken on another one. */
 DC_API const char* dc_hip_build_digest(void);
+
+/* The summation order of the canonical squared distance this library was built for: "sse2" -- the reference's DEFAULT
+ * build (density_clustering.cpp:171-176, 263-268 under CMakeLists.txt:37-45: four lane sums, a pair tail) -- or "avx" --
+ * a reference built with -DCPU_ACCELERATION=AVX (CMakeLists.txt:73-76: eight lane sums, a four-column step, scalar tails).
+ * Integer results are bit-exact against the reference build of the SAME order; the two orders differ in the last bit of
+ * some distances, i.e. in a few frames on a radius.  `make -C clustering_amd/csrc CANON=avx` builds the other library
+ * into clustering_amd/lib_avx/ (same file name, same ABI). */
+DC_API const char* dc_hip_canon_order(void);
 
 /* replaces Clustering::Density::CUDA::get_num_gpus() (density_clustering_cuda.hpp:16-17,
  * density_clustering_cuda.cu:32-43).  Returns the device count (>= 0) or a negative status;

@@ -58,6 +58,32 @@ static inline float dco_sq(float x, float y) {
   return c * c;
 }
 
+#ifdef DCO_CANON_AVX
+/* The order of an AVX build of the reference (CMakeLists.txt:73-76: -DCPU_ACCELERATION=AVX adds -mavx): eight lane sums,
+ * b_i = a_i + a_{i+4}, (b0 + b2) + (b1 + b3); a four-column step (q0 + q2) + (q1 + q3) added to that if four or more
+ * columns remain; then up to three scalar additions.  Read off what g++ emits for the reference's loop shape under its
+ * own flags plus -mavx (fastmath_probe.cpp) and pinned against that build in tests/test_oracle.py. */
+static inline float dist2_canonical(const float* x, const float* y, size_t D) {
+  float s = 0.0f;
+  size_t k = 0;
+  const size_t V8 = 8 * (D / 8);
+  if (V8 != 0) {
+    float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t k0 = 0; k0 < V8; k0 += 8)
+      for (int l = 0; l < 8; ++l) a[l] = a[l] + dco_sq(x[k0 + l], y[k0 + l]);
+    const float b0 = a[0] + a[4], b1 = a[1] + a[5], b2 = a[2] + a[6], b3 = a[3] + a[7];
+    s = (b0 + b2) + (b1 + b3);
+    k = V8;
+  }
+  if (D - k >= 4) {
+    const float t = (dco_sq(x[k], y[k]) + dco_sq(x[k + 2], y[k + 2])) + (dco_sq(x[k + 1], y[k + 1]) + dco_sq(x[k + 3], y[k + 3]));
+    s = s + t;
+    k += 4;
+  }
+  for (; k < D; ++k) s = s + dco_sq(x[k], y[k]);
+  return s;
+}
+#else
 static inline float dist2_canonical(const float* x, const float* y, size_t D) {
   if (D <= 3) {
     float s = dco_sq(x[0], y[0]);
@@ -82,6 +108,7 @@ static inline float dist2_canonical(const float* x, const float* y, size_t D) {
   if (D - k == 1) s = s + dco_sq(x[k], y[k]);
   return s;
 }
+#endif /* DCO_CANON_AVX */
 #else
 /* timing-only build: the reference's loop shape, compiler picks the order */
 static inline float dist2_canonical(const float* x, const float* y, size_t D) {

@@ -22,7 +22,8 @@ _u64p = C.POINTER(C.c_uint64)
 def build(force=False):
     """Compile the oracle, its timing build and the fast-math probe (gcc only)."""
     want = [os.path.join(_BUILD, n) for n in
-            ("libdc_oracle.so", "libdc_oracle_fast.so", "libfastmath_probe.so", "libscreening_oracle.so")]
+            ("libdc_oracle.so", "libdc_oracle_fast.so", "libfastmath_probe.so", "libscreening_oracle.so",
+             "libdc_oracle_avx.so", "libfastmath_probe_avx.so")]
     srcs = [os.path.join(_HERE, n) for n in ("dc_oracle.c", "fastmath_probe.cpp", "screening_oracle.cpp",
                                              "Makefile")]
     stale = force or any(not os.path.exists(w) for w in want)
@@ -39,10 +40,12 @@ def _ptr(a, t):
 
 
 class Oracle:
-    """One loaded build of dc_oracle.c (canonical by default, ``fast=True`` = timing build)."""
+    """One loaded build of dc_oracle.c (canonical by default, ``fast=True`` = timing build, ``order="avx"`` = the
+    summation order of a reference built with -DCPU_ACCELERATION=AVX, for libraries built with `make CANON=avx`)."""
 
-    def __init__(self, fast=False):
-        name = "libdc_oracle_fast.so" if fast else "libdc_oracle.so"
+    def __init__(self, fast=False, order="sse2"):
+        assert order in ("sse2", "avx") and not (fast and order != "sse2")
+        name = "libdc_oracle_fast.so" if fast else ("libdc_oracle_avx.so" if order == "avx" else "libdc_oracle.so")
         path = os.path.join(_BUILD, name)
         if not os.path.exists(path):
             build()
@@ -175,10 +178,12 @@ class ScreeningOracle:
 
 
 class Probe:
-    """oracle/fastmath_probe.cpp: the reference's loop shape under the reference's flags."""
+    """oracle/fastmath_probe.cpp: the reference's loop shape under the reference's flags (``order="avx"``: with the
+    -mavx that -DCPU_ACCELERATION=AVX adds)."""
 
-    def __init__(self):
-        path = os.path.join(_BUILD, "libfastmath_probe.so")
+    def __init__(self, order="sse2"):
+        assert order in ("sse2", "avx")
+        path = os.path.join(_BUILD, "libfastmath_probe_avx.so" if order == "avx" else "libfastmath_probe.so")
         if not os.path.exists(path):
             build()
         self.lib = L = C.CDLL(path)

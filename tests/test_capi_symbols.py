@@ -22,8 +22,27 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert capi.lib.dc_hip_abi_version() == capi.ABI_VERSION == 4
+    assert capi.lib.dc_hip_abi_version() == capi.ABI_VERSION == 5
     assert capi.lib.dc_hip_last_error() is not None
+
+
+def test_the_two_builds_say_which_summation_order_they_reproduce():
+    """libdcdensity.so = the reference's default build ("sse2"), lib_avx/libdcdensity.so = a reference built with
+    -DCPU_ACCELERATION=AVX ("avx"); same ABI, same symbols, same source digest"""
+    import ctypes
+    from clustering_amd import capi
+    if "DC_LIB_PATH" not in os.environ:
+        assert capi.lib.dc_hip_canon_order().decode() == capi.CANON_ORDER
+    other = os.path.join(ROOT, "clustering_amd", "lib_avx", "libdcdensity.so")
+    assert os.path.exists(other), "build() makes both libraries"
+    lib = ctypes.CDLL(other)
+    lib.dc_hip_canon_order.restype = ctypes.c_char_p
+    lib.dc_hip_build_digest.restype = ctypes.c_char_p
+    assert lib.dc_hip_canon_order().decode() == "avx"
+    assert lib.dc_hip_abi_version() == capi.ABI_VERSION
+    assert lib.dc_hip_build_digest().decode() == _digest_module().source_digest()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
 
 
 def _digest_module():

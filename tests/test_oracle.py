@@ -53,6 +53,51 @@ def test_dist2_is_gcc_fastmath_order(oracle, probe, D):
         assert bits(oracle.dist2(c[j], c[i])) == bits(want[i, j])  # bitwise symmetric
 
 
+def _avx_order_d2(x, y):
+    """numpy restatement of the AVX order (independent of dc_oracle.c): eight lane sums, b_i = a_i + a_{i+4}, (b0 + b2) +
+    (b1 + b3); a four-column step (q0 + q2) + (q1 + q3); up to three scalar additions"""
+    f = np.float32
+    p = [f(f(a - b) * f(a - b)) for a, b in zip(x, y)]
+    D, s, k = len(p), f(0.0), 0
+    if D >= 8:
+        a = [f(0.0)] * 8
+        for k0 in range(0, 8 * (D // 8), 8):
+            a = [f(a[l] + p[k0 + l]) for l in range(8)]
+        b = [f(a[i] + a[i + 4]) for i in range(4)]
+        s, k = f(f(b[0] + b[2]) + f(b[1] + b[3])), 8 * (D // 8)
+    if D - k >= 4:
+        s, k = f(s + f(f(p[k] + p[k + 2]) + f(p[k + 1] + p[k + 3]))), k + 4
+    for kk in range(k, D):
+        s = f(s + p[kk])
+    return s
+
+
+@pytest.mark.parametrize("D", list(range(1, 33)) + [40, 63, 64, 65])
+def test_dist2_avx_order_is_gcc_fastmath_avx_order(D):
+    """The summation order of a reference built with -DCPU_ACCELERATION=AVX (CMakeLists.txt:73-76), which the library
+    reproduces when built with `make CANON=avx`: oracle (order="avx") == what g++ -O3 -ffast-math -mavx gives the
+    reference's loop shape == an independent numpy restatement, bit for bit."""
+    from oracle.oracle import Oracle, Probe
+    o, pr = Oracle(order="avx"), Probe(order="avx")
+    rng = np.random.default_rng(300 + D)
+    c = (rng.normal(0, 1, (40, D)) * rng.choice([1e-3, 1.0, 50.0])).astype(np.float32)
+    got = pr.pairwise_d2(c)
+    for i, j in [(0, 1), (5, 33), (39, 3), (7, 8), (20, 21)]:
+        want = _avx_order_d2(c[i], c[j])
+        assert bits(got[i, j]) == bits(want) == bits(got[j, i])
+        assert bits(o.dist2(c[i], c[j])) == bits(want) and bits(o.dist2(c[j], c[i])) == bits(want)
+    full = np.array([[o.dist2(c[i], c[j]) if i != j else 0.0 for j in range(40)] for i in range(40)], dtype=np.float32)
+    assert (bits(full) == bits(got)).all()
+
+
+def test_avx_and_default_orders_differ_only_in_rounding():
+    """the two orders are different roundings of the same sum: populations near a radius may differ by a frame or two"""
+    from oracle.oracle import Oracle
+    c = gaussian_blobs(3000, 10, seed=5)
+    a, b = Oracle().populations(c, [0.2]), Oracle(order="avx").populations(c, [0.2])
+    assert abs(a.astype(np.int64) - b.astype(np.int64)).max() <= 2 and a.sum() > 0
+
+
 @pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 7, 10, 12, 30])
 def test_oracle_vs_numpy_emulation(oracle, D):
     c = gaussian_blobs(700, D, seed=7 + D)
