@@ -29,7 +29,9 @@ pop_tiles = dens.evaluated_tiles(c.device)[0]
 pop_mfma = dens.issued_mfmas(c.device)[0]
 comp_info = dens.components_info(c)
 if a.pop_only:
-    print(json.dumps({'pop_8_radii_ms': pop_ms, 'tile_pairs': pop_tiles}))
+    pl = torch.stack([x.to(torch.int64) for x in p])
+    w = torch.arange(1, pl.shape[1] + 1, device=pl.device, dtype=torch.int64) % 1000003
+    print(json.dumps({'pop_8_radii_ms': pop_ms, 'tile_pairs': pop_tiles, 'sum': int(pl.sum().item()), 'wsum': int((pl * w).sum().item())}))
     sys.exit(0)
 # FE needs the populations of all rows: one full single-radius sweep here (a real run all-reduces the segments)
 pf, full_ms = timed(lambda: dens.calculate_populations_partial(c, [a.radii[len(a.radii) // 2]]))
