@@ -10,11 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DC_LIB_PATH: another build of the SAME library (measurement variants under clustering_amd/lib/variants/) instead of
 # copying it over the product.  DC_CANON_ORDER=avx: the build with the summation order of a reference compiled
-# with -DCPU_ACCELERATION=AVX (`make -C clustering_amd/csrc CANON=avx` -> clustering_amd/lib_avx/; dc_hip_canon_order())
+# with -DCPU_ACCELERATION=AVX (`make -C clustering_amd/csrc CANON=avx` -> clustering_amd/lib_avx/; dc_hip_canon_order());
+# DC_CANON_ORDER=fma: that of a -DNATIVE_COMPILATION build on an AVX2 + FMA host (CANON=fma -> clustering_amd/lib_fma/)
 CANON_ORDER = os.environ.get("DC_CANON_ORDER", "sse2")
-if CANON_ORDER not in ("sse2", "avx"):
-    raise ImportError(f"DC_CANON_ORDER={CANON_ORDER!r}: expected 'sse2' (the reference's default build) or 'avx'")
-LIB_PATH = os.environ.get("DC_LIB_PATH") or os.path.join(_HERE, "lib_avx" if CANON_ORDER == "avx" else "lib", "libdcdensity.so")
+_CANON_DIRS = {"sse2": "lib", "avx": "lib_avx", "fma": "lib_fma"}
+if CANON_ORDER not in _CANON_DIRS:
+    raise ImportError(f"DC_CANON_ORDER={CANON_ORDER!r}: expected 'sse2' (the reference's default build), 'avx' or 'fma'")
+LIB_PATH = os.environ.get("DC_LIB_PATH") or os.path.join(_HERE, _CANON_DIRS[CANON_ORDER], "libdcdensity.so")
 
 DC_OK = 0
 ABI_VERSION = 5               # include/dc_density.h: DC_HIP_ABI_VERSION this binding was written against

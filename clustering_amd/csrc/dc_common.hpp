@@ -61,30 +61,51 @@ constexpr uint32_t kFeStateWords = 8;   // device state of the free-energy pass 
 //                                       SCALAR additions -- read off the code g++ 11.4 emits for the reference's loop shape
 //                                       with the reference's flags and pinned against it for D = 1 .. 40, 48, 63 .. 65, 100
 //                                       (the probe of the test suite, built with -mavx)
-// The library is built for ONE of them: `make` = the default order, `make CANON=avx` = the AVX order into
-// clustering_amd/lib_avx/ (same file name, same ABI; dc_hip_canon_order() says which; DC_CANON_ORDER=avx makes the Python
-// host bind that build).  Every exact path of every kernel goes through the three functions below; the guard bands of
+//   NATIVE_COMPILATION (-march=native) on a host with AVX2 + FMA, g++'s generic / Intel tunings (haswell ... icelake-
+//                                       server, x86-64-v3: all the same code; the Zen tunings unroll differently and are NOT
+//                                       covered): the AVX shape with FUSED multiply-adds in the eight-lane loop and in the
+//                                       scalar tail (one rounding each), the four-column step unfused -- pinned the same way
+//                                       (the probe built with -mavx2 -mfma)
+// The library is built for ONE of them: `make` = the default order, `make CANON=avx` / `make CANON=fma` = the other two into
+// clustering_amd/lib_avx/ and lib_fma/ (same file name, same ABI; dc_hip_canon_order() says which; DC_CANON_ORDER=avx / fma
+// makes the Python host bind that build).  Every exact path of every kernel goes through the three functions below; the guard bands of
 // the matrix-core classifiers bound the summation order generically ((D / 4 + 9) u d2) and cover either.
+#if defined(DC_CANON_FMA) && !defined(DC_CANON_AVX)
+#define DC_CANON_AVX 1   // (the FMA order has the AVX order's shape)
+#endif
 #ifdef DC_CANON_AVX
+// DC_CANON_ACC(a, c): one more column on a lane sum or on the scalar tail.  -mavx: a + c * c, two roundings; with FMA
+// (-march=native on a host with AVX2 + FMA, g++'s generic / Intel tunings: `make CANON=fma`) ONE rounding -- the eight-lane
+// loop is vfmadd231ps, the scalar tail vfmadd231ss; the four-column step stays a plain multiply followed by additions.
+#ifdef DC_CANON_FMA
+#define DC_CANON_ORDER_NAME "fma"
+#define DC_CANON_ACC(a, c) __builtin_fmaf((c), (c), (a))
+#else
 #define DC_CANON_ORDER_NAME "avx"
-// the AVX order over a sequence of squares p(0) .. p(D-1) (sq: k -> p(k))
-template <class Sq>
-__device__ __forceinline__ float canon_sum_avx(Sq&& sq, int D) {
+#define DC_CANON_ACC(a, c) ((a) + (c) * (c))
+#endif
+// the AVX order over a sequence of differences c(0) .. c(D-1) (df: k -> x_k - y_k)
+template <class Df>
+__device__ __forceinline__ float canon_sum_avx(Df&& df, int D) {
+  auto sq = [&](int k) {
+    const float c = df(k);
+    return c * c;
+  };
   float s = 0.0f;
   int k = 0;
   const int V8 = 8 * (D / 8);
   if (V8 != 0) {
-    // lane accumulators start at +0; 0 + p == p exactly (p is a square: never -0)
+    // lane accumulators start at +0; 0 + p == p exactly (p is a square: never -0), and fma(c, c, 0) is the rounded square
     float a0 = sq(0), a1 = sq(1), a2 = sq(2), a3 = sq(3), a4 = sq(4), a5 = sq(5), a6 = sq(6), a7 = sq(7);
     for (int k0 = 8; k0 < V8; k0 += 8) {
-      a0 = a0 + sq(k0 + 0);
-      a1 = a1 + sq(k0 + 1);
-      a2 = a2 + sq(k0 + 2);
-      a3 = a3 + sq(k0 + 3);
-      a4 = a4 + sq(k0 + 4);
-      a5 = a5 + sq(k0 + 5);
-      a6 = a6 + sq(k0 + 6);
-      a7 = a7 + sq(k0 + 7);
+      a0 = DC_CANON_ACC(a0, df(k0 + 0));
+      a1 = DC_CANON_ACC(a1, df(k0 + 1));
+      a2 = DC_CANON_ACC(a2, df(k0 + 2));
+      a3 = DC_CANON_ACC(a3, df(k0 + 3));
+      a4 = DC_CANON_ACC(a4, df(k0 + 4));
+      a5 = DC_CANON_ACC(a5, df(k0 + 5));
+      a6 = DC_CANON_ACC(a6, df(k0 + 6));
+      a7 = DC_CANON_ACC(a7, df(k0 + 7));
     }
     const float b0 = a0 + a4, b1 = a1 + a5, b2 = a2 + a6, b3 = a3 + a7;
     s = (b0 + b2) + (b1 + b3);
@@ -95,44 +116,38 @@ __device__ __forceinline__ float canon_sum_avx(Sq&& sq, int D) {
     s = s + t;   // (no eight-lane part: 0 + t == t exactly)
     k += 4;
   }
-  for (; k < D; ++k) s = s + sq(k);
+  for (; k < D; ++k) s = DC_CANON_ACC(s, df(k));   // (s == +0 at the first of D <= 3 columns: the rounded square either way)
   return s;
 }
 template <int D>
 __device__ __forceinline__ float dist2_canon(const float (&q)[D], const float (&r)[D]) {
-  float p[D];
+  float c[D];
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    const float c = q[k] - r[k];
-    p[k] = c * c;
-  }
+  for (int k = 0; k < D; ++k) c[k] = q[k] - r[k];
   float s = 0.0f;
   constexpr int V8 = 8 * (D / 8);
   if constexpr (V8 != 0) {
     float a[8];
 #pragma unroll
-    for (int l = 0; l < 8; ++l) a[l] = p[l];
+    for (int l = 0; l < 8; ++l) a[l] = c[l] * c[l];
 #pragma unroll
     for (int k0 = 8; k0 < V8; k0 += 8)
 #pragma unroll
-      for (int l = 0; l < 8; ++l) a[l] = a[l] + p[k0 + l];
+      for (int l = 0; l < 8; ++l) a[l] = DC_CANON_ACC(a[l], c[k0 + l]);
     const float b0 = a[0] + a[4], b1 = a[1] + a[5], b2 = a[2] + a[6], b3 = a[3] + a[7];
     s = (b0 + b2) + (b1 + b3);
   }
   constexpr int K4 = (D - V8 >= 4) ? V8 + 4 : V8;
   if constexpr (D - V8 >= 4) {
-    const float t = (p[V8] + p[V8 + 2]) + (p[V8 + 1] + p[V8 + 3]);
+    const float t = (c[V8] * c[V8] + c[V8 + 2] * c[V8 + 2]) + (c[V8 + 1] * c[V8 + 1] + c[V8 + 3] * c[V8 + 3]);
     s = (V8 != 0) ? s + t : t;
   }
 #pragma unroll
-  for (int k = K4; k < D; ++k) s = (k == 0) ? p[0] : s + p[k];
+  for (int k = K4; k < D; ++k) s = (k == 0) ? c[0] * c[0] : DC_CANON_ACC(s, c[k]);
   return s;
 }
 __device__ __forceinline__ float dist2_canon_rt(const float* x, int sx, const float* y, int sy, int D) {
-  return canon_sum_avx([&](int k) {
-    const float c = x[k * sx] - y[k * sy];
-    return c * c;
-  }, D);
+  return canon_sum_avx([&](int k) { return x[k * sx] - y[k * sy]; }, D);
 }
 __device__ __forceinline__ float dist2_canon_rows(const float* x, const float* y, int D) { return dist2_canon_rt(x, 1, y, 1, D); }
 #else

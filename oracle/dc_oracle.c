@@ -58,7 +58,18 @@ static inline float dco_sq(float x, float y) {
   return c * c;
 }
 
+#if defined(DCO_CANON_FMA) && !defined(DCO_CANON_AVX)
+#define DCO_CANON_AVX 1 /* the FMA order has the AVX order's shape */
+#endif
 #ifdef DCO_CANON_AVX
+/* one more column on a lane sum or on the scalar tail: -mavx two roundings; a -march=native build on an AVX2 + FMA host
+ * (CMakeLists.txt:53-56; g++'s generic / Intel tunings) ONE -- vfmadd231ps in the eight-lane loop, vfmadd231ss in the
+ * tail, the four-column step unfused: read off the probe built with -mavx2 -mfma and pinned against it. */
+#ifdef DCO_CANON_FMA
+#define DCO_ACC(a, x, y) fmaf((x) - (y), (x) - (y), (a))
+#else
+#define DCO_ACC(a, x, y) ((a) + dco_sq((x), (y)))
+#endif
 /* The order of an AVX build of the reference (CMakeLists.txt:73-76: -DCPU_ACCELERATION=AVX adds -mavx): eight lane sums,
  * b_i = a_i + a_{i+4}, (b0 + b2) + (b1 + b3); a four-column step (q0 + q2) + (q1 + q3) added to that if four or more
  * columns remain; then up to three scalar additions.  Read off what g++ emits for the reference's loop shape under its
@@ -70,7 +81,7 @@ static inline float dist2_canonical(const float* x, const float* y, size_t D) {
   if (V8 != 0) {
     float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (size_t k0 = 0; k0 < V8; k0 += 8)
-      for (int l = 0; l < 8; ++l) a[l] = a[l] + dco_sq(x[k0 + l], y[k0 + l]);
+      for (int l = 0; l < 8; ++l) a[l] = DCO_ACC(a[l], x[k0 + l], y[k0 + l]);
     const float b0 = a[0] + a[4], b1 = a[1] + a[5], b2 = a[2] + a[6], b3 = a[3] + a[7];
     s = (b0 + b2) + (b1 + b3);
     k = V8;
@@ -80,7 +91,7 @@ static inline float dist2_canonical(const float* x, const float* y, size_t D) {
     s = s + t;
     k += 4;
   }
-  for (; k < D; ++k) s = s + dco_sq(x[k], y[k]);
+  for (; k < D; ++k) s = DCO_ACC(s, x[k], y[k]);
   return s;
 }
 #else

@@ -23,7 +23,7 @@ def build(force=False):
     """Compile the oracle, its timing build and the fast-math probe (gcc only)."""
     want = [os.path.join(_BUILD, n) for n in
             ("libdc_oracle.so", "libdc_oracle_fast.so", "libfastmath_probe.so", "libscreening_oracle.so",
-             "libdc_oracle_avx.so", "libfastmath_probe_avx.so")]
+             "libdc_oracle_avx.so", "libfastmath_probe_avx.so", "libdc_oracle_fma.so", "libfastmath_probe_fma.so")]
     srcs = [os.path.join(_HERE, n) for n in ("dc_oracle.c", "fastmath_probe.cpp", "screening_oracle.cpp",
                                              "Makefile")]
     stale = force or any(not os.path.exists(w) for w in want)
@@ -40,12 +40,13 @@ def _ptr(a, t):
 
 
 class Oracle:
-    """One loaded build of dc_oracle.c (canonical by default, ``fast=True`` = timing build, ``order="avx"`` = the
-    summation order of a reference built with -DCPU_ACCELERATION=AVX, for libraries built with `make CANON=avx`)."""
+    """One loaded build of dc_oracle.c (canonical by default, ``fast=True`` = timing build, ``order="avx"`` / ``"fma"`` = the
+    summation order of a reference built with -DCPU_ACCELERATION=AVX / with -DNATIVE_COMPILATION on an AVX2 + FMA host, for
+    libraries built with `make CANON=avx` / `make CANON=fma`)."""
 
     def __init__(self, fast=False, order="sse2"):
-        assert order in ("sse2", "avx") and not (fast and order != "sse2")
-        name = "libdc_oracle_fast.so" if fast else ("libdc_oracle_avx.so" if order == "avx" else "libdc_oracle.so")
+        assert order in ("sse2", "avx", "fma") and not (fast and order != "sse2")
+        name = "libdc_oracle_fast.so" if fast else {"sse2": "libdc_oracle.so", "avx": "libdc_oracle_avx.so", "fma": "libdc_oracle_fma.so"}[order]
         path = os.path.join(_BUILD, name)
         if not os.path.exists(path):
             build()
@@ -179,11 +180,11 @@ class ScreeningOracle:
 
 class Probe:
     """oracle/fastmath_probe.cpp: the reference's loop shape under the reference's flags (``order="avx"``: with the
-    -mavx that -DCPU_ACCELERATION=AVX adds)."""
+    -mavx that -DCPU_ACCELERATION=AVX adds; ``"fma"``: with -mavx2 -mfma, a -march=native build on such a host)."""
 
     def __init__(self, order="sse2"):
-        assert order in ("sse2", "avx")
-        path = os.path.join(_BUILD, "libfastmath_probe_avx.so" if order == "avx" else "libfastmath_probe.so")
+        assert order in ("sse2", "avx", "fma")
+        path = os.path.join(_BUILD, {"sse2": "libfastmath_probe.so", "avx": "libfastmath_probe_avx.so", "fma": "libfastmath_probe_fma.so"}[order])
         if not os.path.exists(path):
             build()
         self.lib = L = C.CDLL(path)

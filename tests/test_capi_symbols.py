@@ -3,6 +3,8 @@
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -26,19 +28,21 @@ def test_library_exports_every_declared_symbol():
     assert capi.lib.dc_hip_last_error() is not None
 
 
-def test_the_two_builds_say_which_summation_order_they_reproduce():
+@pytest.mark.parametrize("order", ["avx", "fma"])
+def test_the_builds_say_which_summation_order_they_reproduce(order):
     """libdcdensity.so = the reference's default build ("sse2"), lib_avx/libdcdensity.so = a reference built with
-    -DCPU_ACCELERATION=AVX ("avx"); same ABI, same symbols, same source digest"""
+    -DCPU_ACCELERATION=AVX ("avx"), lib_fma/ = with -DNATIVE_COMPILATION on an AVX2 + FMA host ("fma"); same ABI, same
+    symbols, same source digest"""
     import ctypes
     from clustering_amd import capi
     if "DC_LIB_PATH" not in os.environ:
         assert capi.lib.dc_hip_canon_order().decode() == capi.CANON_ORDER
-    other = os.path.join(ROOT, "clustering_amd", "lib_avx", "libdcdensity.so")
-    assert os.path.exists(other), "build() makes both libraries"
+    other = os.path.join(ROOT, "clustering_amd", "lib_" + order, "libdcdensity.so")
+    assert os.path.exists(other), "build() makes all three libraries"
     lib = ctypes.CDLL(other)
     lib.dc_hip_canon_order.restype = ctypes.c_char_p
     lib.dc_hip_build_digest.restype = ctypes.c_char_p
-    assert lib.dc_hip_canon_order().decode() == "avx"
+    assert lib.dc_hip_canon_order().decode() == order
     assert lib.dc_hip_abi_version() == capi.ABI_VERSION
     assert lib.dc_hip_build_digest().decode() == _digest_module().source_digest()
     for name in declared_symbols():

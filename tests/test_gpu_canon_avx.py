@@ -1,6 +1,8 @@
-"""GPU: the library built for the summation order of an AVX build of the reference (`make CANON=avx`,
-clustering_amd/lib_avx/libdcdensity.so, DC_CANON_ORDER=avx) against the oracle of the same order (oracle/dc_oracle.c with
--DDCO_CANON_AVX, pinned in tests/test_oracle.py against g++ -mavx on the reference's loop shape, CMakeLists.txt:73-76):
+"""GPU: the libraries built for the summation order of an AVX build of the reference (`make CANON=avx`,
+clustering_amd/lib_avx/libdcdensity.so, DC_CANON_ORDER=avx) and of a -march=native build on an AVX2 + FMA host (`make
+CANON=fma`, lib_fma/, DC_CANON_ORDER=fma) against the oracle of the same order (oracle/dc_oracle.c with -DDCO_CANON_AVX /
+-DDCO_CANON_FMA, pinned in tests/test_oracle.py against g++ -mavx / -mavx2 -mfma on the reference's loop shape,
+CMakeLists.txt:53-56, 73-76):
 populations, free energies, nn / nn_hd with their d2 bits through every variant -- the exact kernels, the matrix-core
 sweeps with their canonical re-checks (pruned, unpruned, fp32-input), segments of a sharded run."""
 import os
@@ -19,8 +21,9 @@ sys.path.insert(0, sys.argv[1])
 from clustering_amd import capi, density as dens
 from clustering_amd.synth import gaussian_blobs
 from oracle.oracle import Oracle
-assert capi.lib.dc_hip_canon_order().decode() == "avx"
-o, o_def = Oracle(order="avx"), Oracle()
+ORDER = sys.argv[2]
+assert capi.lib.dc_hip_canon_order().decode() == ORDER
+o, o_def = Oracle(order=ORDER), Oracle()
 bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 differ = 0
 for n, d, radii in [(3000, 3, [0.05]), (2500, 5, [0.1, 0.2]), (4000, 8, [0.2]), (4000, 9, [0.2, 0.15]), (6000, 10, [0.2, 0.25, 0.3]),
@@ -50,10 +53,11 @@ print("ok: populations under the two orders differ in", differ, "entries")
 """
 
 
-def test_avx_order_library_against_the_avx_order_oracle():
-    if not os.path.exists(os.path.join(ROOT, "clustering_amd", "lib_avx", "libdcdensity.so")):
-        pytest.fail("clustering_amd/lib_avx/libdcdensity.so is missing: __graft_entry__.build() makes it")
-    env = dict(os.environ, DC_CANON_ORDER="avx")
+@pytest.mark.parametrize("order", ["avx", "fma"])
+def test_other_order_library_against_the_oracle_of_that_order(order):
+    if not os.path.exists(os.path.join(ROOT, "clustering_amd", "lib_" + order, "libdcdensity.so")):
+        pytest.fail(f"clustering_amd/lib_{order}/libdcdensity.so is missing: __graft_entry__.build() makes it")
+    env = dict(os.environ, DC_CANON_ORDER=order)
     env.pop("DC_LIB_PATH", None)
-    r = subprocess.run([sys.executable, "-c", CHILD, ROOT], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, order], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]

@@ -53,49 +53,86 @@ def test_dist2_is_gcc_fastmath_order(oracle, probe, D):
         assert bits(oracle.dist2(c[j], c[i])) == bits(want[i, j])  # bitwise symmetric
 
 
-def _avx_order_d2(x, y):
+def _fma32(a, b, c):
+    """fl32(a * b + c) with ONE rounding, in exact rational arithmetic (round to nearest, ties to even; finite values)"""
+    from fractions import Fraction
+    v = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+    if v == 0:
+        return np.float32(0.0)
+    e = max(int(np.floor(np.log2(float(abs(v))))), -126)
+    while abs(v) >= Fraction(2) ** (e + 1):
+        e += 1
+    while e > -126 and abs(v) < Fraction(2) ** e:
+        e -= 1
+    q = Fraction(2) ** (e - 23)
+    n = v / q
+    lo = n.numerator // n.denominator
+    r = n - lo
+    n_int = lo + (1 if (r > Fraction(1, 2) or (r == Fraction(1, 2) and lo % 2 == 1)) else 0)
+    return np.float32(float(n_int * q))
+
+
+def _avx_order_d2(x, y, fma=False):
     """numpy restatement of the AVX order (independent of dc_oracle.c): eight lane sums, b_i = a_i + a_{i+4}, (b0 + b2) +
-    (b1 + b3); a four-column step (q0 + q2) + (q1 + q3); up to three scalar additions"""
+    (b1 + b3); a four-column step (q0 + q2) + (q1 + q3); up to three scalar additions.  fma: the lane sums and the scalar
+    tail with fused multiply-adds (one rounding), the four-column step unfused -- a -march=native build on AVX2 + FMA"""
     f = np.float32
-    p = [f(f(a - b) * f(a - b)) for a, b in zip(x, y)]
+    c = [f(a - b) for a, b in zip(x, y)]
+    p = [f(v * v) for v in c]
+    acc = (lambda a, k: _fma32(c[k], c[k], a)) if fma else (lambda a, k: f(a + p[k]))
     D, s, k = len(p), f(0.0), 0
     if D >= 8:
         a = [f(0.0)] * 8
         for k0 in range(0, 8 * (D // 8), 8):
-            a = [f(a[l] + p[k0 + l]) for l in range(8)]
+            a = [acc(a[l], k0 + l) for l in range(8)]
         b = [f(a[i] + a[i + 4]) for i in range(4)]
         s, k = f(f(b[0] + b[2]) + f(b[1] + b[3])), 8 * (D // 8)
     if D - k >= 4:
         s, k = f(s + f(f(p[k] + p[k + 2]) + f(p[k + 1] + p[k + 3]))), k + 4
     for kk in range(k, D):
-        s = f(s + p[kk])
+        s = acc(s, kk)
     return s
 
 
+@pytest.mark.parametrize("order", ["avx", "fma"])
 @pytest.mark.parametrize("D", list(range(1, 33)) + [40, 63, 64, 65])
-def test_dist2_avx_order_is_gcc_fastmath_avx_order(D):
-    """The summation order of a reference built with -DCPU_ACCELERATION=AVX (CMakeLists.txt:73-76), which the library
-    reproduces when built with `make CANON=avx`: oracle (order="avx") == what g++ -O3 -ffast-math -mavx gives the
-    reference's loop shape == an independent numpy restatement, bit for bit."""
+def test_dist2_avx_order_is_gcc_fastmath_avx_order(D, order):
+    """The summation orders of a reference built with -DCPU_ACCELERATION=AVX (CMakeLists.txt:73-76) or with
+    -DNATIVE_COMPILATION on an AVX2 + FMA host (:53-56), which the library reproduces when built with `make CANON=avx` /
+    `make CANON=fma`: oracle (order=...) == what g++ -O3 -ffast-math -mavx / -mavx2 -mfma gives the reference's loop shape
+    == an independent numpy restatement, bit for bit."""
     from oracle.oracle import Oracle, Probe
-    o, pr = Oracle(order="avx"), Probe(order="avx")
+    if order == "fma" and not all(f in open("/proc/cpuinfo").read() for f in (" avx2", " fma")):
+        pytest.skip("this host has no AVX2 + FMA: the probe of that order cannot run here")
+    o, pr = Oracle(order=order), Probe(order=order)
     rng = np.random.default_rng(300 + D)
     c = (rng.normal(0, 1, (40, D)) * rng.choice([1e-3, 1.0, 50.0])).astype(np.float32)
     got = pr.pairwise_d2(c)
     for i, j in [(0, 1), (5, 33), (39, 3), (7, 8), (20, 21)]:
-        want = _avx_order_d2(c[i], c[j])
+        want = _avx_order_d2(c[i], c[j], fma=order == "fma")
         assert bits(got[i, j]) == bits(want) == bits(got[j, i])
         assert bits(o.dist2(c[i], c[j])) == bits(want) and bits(o.dist2(c[j], c[i])) == bits(want)
     full = np.array([[o.dist2(c[i], c[j]) if i != j else 0.0 for j in range(40)] for i in range(40)], dtype=np.float32)
     assert (bits(full) == bits(got)).all()
 
 
+def test_fma_order_is_not_the_avx_order():
+    """the fused lane sums round differently: the third build is not a copy of the second"""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(9)
+    c = rng.normal(0, 1, (64, 30)).astype(np.float32)
+    a, b = Oracle(order="avx"), Oracle(order="fma")
+    assert any(bits(a.dist2(c[0], c[j])) != bits(b.dist2(c[0], c[j])) for j in range(1, 64))
+
+
 def test_avx_and_default_orders_differ_only_in_rounding():
     """the two orders are different roundings of the same sum: populations near a radius may differ by a frame or two"""
     from oracle.oracle import Oracle
     c = gaussian_blobs(3000, 10, seed=5)
-    a, b = Oracle().populations(c, [0.2]), Oracle(order="avx").populations(c, [0.2])
-    assert abs(a.astype(np.int64) - b.astype(np.int64)).max() <= 2 and a.sum() > 0
+    a = Oracle().populations(c, [0.2])
+    for order in ("avx", "fma"):
+        b = Oracle(order=order).populations(c, [0.2])
+        assert abs(a.astype(np.int64) - b.astype(np.int64)).max() <= 2 and a.sum() > 0
 
 
 @pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 7, 10, 12, 30])
