@@ -289,17 +289,16 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   // and added to this lane's accumulator of the tile's slot
   auto credit = [&](uint32_t acc_slot) {
     unsigned long long* a_lane = acc + (size_t)acc_slot * (NR * 64) + lane;
+    // (no "anything inside?" test per radius and no test for the radii the call does not use -- their strings are all-outside,
+    //  the host leaves -1 in their squared radii: a wave-level test is a compare, a scalar hand-off and a branch, and the
+    //  sixteen branches of a tile's credit cost more wave time than its eight LDS additions -- round 6, cycle stamps)
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-      if (rr < n_rad) {
-        const uint32_t s0 = sb[rr][0], s1 = sb[rr][1];
-        const uint32_t hi = s0 & s1 & kSignBits, lo = (s0 ^ s1) & kSignBits;
-        const uint32_t x = hi | (lo >> 1);                       // element r: 0..2 at bits 31-2r, 30-2r
-        if (__builtin_amdgcn_ballot_w64(x != 0u) != 0) {         // (small radii: most tiles hold nothing inside)
-          const uint32_t A = x & 0x33333333u, B = (x >> 2) & 0x33333333u;
-          __hip_atomic_fetch_add(a_lane + rr * 64, ((unsigned long long)B << 32) | A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
+      const uint32_t s0 = sb[rr][0], s1 = sb[rr][1];
+      const uint32_t hi = s0 & s1 & kSignBits, lo = (s0 ^ s1) & kSignBits;
+      const uint32_t x = hi | (lo >> 1);                       // element r: 0..2 at bits 31-2r, 30-2r
+      const uint32_t A = x & 0x33333333u, B = (x >> 2) & 0x33333333u;
+      __hip_atomic_fetch_add(a_lane + rr * 64, ((unsigned long long)B << 32) | A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   };
   // reduce the accumulators of a retired window: its (tile, pair of radii) units are dealt to the four waves;
@@ -412,28 +411,47 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     }
     if (lane == 0) list_cnt[wib] = cnt;
     __syncthreads();
-    const uint32_t o1 = list_cnt[0], o2 = o1 + list_cnt[1], o3 = o2 + list_cnt[2], total = o3 + list_cnt[3];
+    // (wave-uniform values held in scalar registers: what the compiler cannot see of an LDS read)
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[0]);
+    const uint32_t o2 = o1 + (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[1]);
+    const uint32_t o3 = o2 + (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[2]);
+    const uint32_t total = o3 + (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[3]);
     if (total != 0) {
+      // (scalar arithmetic, no branches: the list of wave w starts at w * kShareSub, its entries are o_w .. o_{w+1} - 1 of the round)
+      const uint32_t d21 = o2 - o1, d32 = o3 - o2;
       auto entry = [&](uint32_t i) {
-        i = i < total ? i : total - 1;
-        const uint32_t w = (i >= o1 ? 1u : 0u) + (i >= o2 ? 1u : 0u) + (i >= o3 ? 1u : 0u);
-        const uint32_t off = i - (w == 0 ? 0u : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
-        return (uint32_t)__builtin_amdgcn_readfirstlane(lists[w][off]);
+        i = min(i, total - 1u);
+        const uint32_t g1 = 0u - (uint32_t)(i >= o1), g2 = 0u - (uint32_t)(i >= o2), g3 = 0u - (uint32_t)(i >= o3);   // 0 / ~0
+        const uint32_t first = (o1 & g1) + (d21 & g2) + (d32 & g3);             // o_w
+        const uint32_t w_base = (uint32_t)kShareSub & g1;                         // w * kShareSub
+        const uint32_t idx = w_base + ((uint32_t)kShareSub & g2) + ((uint32_t)kShareSub & g3) + (i - first);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((&lists[0][0])[idx]);
       };
       // the tiles of a window are fetched fragment-wise: the NM + 1 pieces of a tile (its MFMA fragments and its 32
       // row norms) go round the four waves
+      // (branch-free: a tile beyond the end of the list is the list's last tile once more, into a slot nobody reads; the
+      //  pieces of tile k that this wave fetches are m = (wave - k) mod 4 and m + 4 -- a fragment, the norms (eight
+      //  lanes) or nothing, by lane predicate.  As a loop over all pieces with a wave-level test each, a window's fetch
+      //  was 21 branches.)
       auto fetch_window = [&](uint32_t i0) {
+#pragma unroll
         for (uint32_t k = 0; k < (uint32_t)kMsWin; ++k) {
           const uint32_t i = i0 + k;
-          if (i >= total) break;
           const uint32_t t = entry(i);
           const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + (i % kMsRing) * kUnits));
           const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
+          const uint32_t m_a = ((uint32_t)__builtin_amdgcn_readfirstlane(wib) - k) & 3u;   // (wave-uniform: a scalar for M0)
+          const uint4* nrm = reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane;
 #pragma unroll
-          for (int m = 0; m < NM; ++m)
-            if (((m + (int)k) & 3) == wib) lds_dma16(src + m * 64, dst + (uint32_t)m * 1024u);
-          if (((NM + (int)k) & 3) == wib && lane < 8)
-            lds_dma16(reinterpret_cast<const uint4*>(norms_r + (size_t)t * 32) + lane, dst + (uint32_t)NM * 1024u);
+          for (uint32_t j = 0; j < ((uint32_t)NM + 4u) / 4u; ++j) {
+            const uint32_t m = m_a + 4u * j;
+            if (4u * j + 3u < (uint32_t)NM) {   // (a fragment whatever the wave: compile-time)
+              lds_dma16(src + m * 64u, dst + m * 1024u);
+            } else {
+              const void* p_m = (m == (uint32_t)NM) ? (const void*)nrm : (const void*)(src + m * 64u);
+              if ((m < (uint32_t)NM) | ((m == (uint32_t)NM) & (lane < 8))) lds_dma16(p_m, dst + m * 1024u);
+            }
+          }
         }
       };
       fetch_window(0);
@@ -497,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
             credit((((i / kMsWin) & 1u) * kMsWin) + (i % kMsWin));
         }
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the fetch beyond the list's end (into slots nobody reads) has landed too
       __syncthreads();   // every add of this round has landed
       {  // the last window
         const uint32_t n_win = (total + kMsWin - 1) / kMsWin, w = n_win - 1u, j = w * kMsWin;
