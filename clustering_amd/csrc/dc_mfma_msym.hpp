@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   //  phase by phase: all accumulator reads, then the byte sums, then the staged gather, then the atomics.  One unit after the
   //  other was three dependent LDS round trips per unit, 16 % of a C5 rank's sweep.)
   constexpr uint32_t kMsUnits = (kMsWin * (NR / 2) + 3) / 4;
-  auto reduce_window = [&](uint32_t win, auto&& entry_of, uint32_t n_tiles) {
+  // (full_c: the window holds kMsWin tiles -- every one but the last of a round: no unit is missing, nothing to test)
+  auto reduce_window = [&](uint32_t win, auto&& entry_of, uint32_t n_tiles, auto full_c) {
+    constexpr bool kFull = decltype(full_c)::value;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u32x4 LdsU4;
     typedef __attribute__((address_space(3))) unsigned char LdsU8;
@@ -316,44 +318,47 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     const uint32_t n_units = n_tiles * kPairs;
     unsigned long long v[kMsUnits][2];
     uint32_t which[kMsUnits], rr0[kMsUnits];
-    bool have[kMsUnits], nz_u[kMsUnits][2];
-    // phase 1: the lane's fields of every unit and radius
+    bool have[kMsUnits];
+    // (no wave-level "is there anything?" tests: a workgroup's eight chains leave something inside nearly every radius of
+    //  nearly every tile they reach, and a test is a compare, a scalar hand-off and a branch -- round 6, cycle stamps)
+    // phase 1: the lane's fields of every unit and radius; the accumulators are cleared for the window after next
 #pragma unroll
     for (uint32_t j = 0; j < kMsUnits; ++j) {
       const uint32_t p = (uint32_t)wib + 4u * j;
-      have[j] = p < n_units;
+      have[j] = kFull || p < n_units;
       which[j] = have[j] ? p / kPairs : 0u;
       rr0[j] = have[j] ? 2u * (p % kPairs) : 0u;
       const uint32_t slot = (win & 1u) * kMsWin + which[j];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        v[j][u] = have[j] ? acc[(size_t)slot * (NR * 64) + (size_t)(rr0[j] + u) * 64 + lane] : 0ull;
+      for (int u = 0; u < 2; ++u) {
+        unsigned long long* w = acc + (size_t)slot * (NR * 64) + (size_t)(rr0[j] + u) * 64 + lane;
+        v[j][u] = have[j] ? *w : 0ull;
+      }
     }
-    // phase 2: fields -> bytes -> sums over the 16 lanes of a row, left by the row-end lanes in the unit's stage
-    bool any = false;
 #pragma unroll
     for (uint32_t j = 0; j < kMsUnits; ++j) {
       const uint32_t slot = (win & 1u) * kMsWin + which[j];
 #pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (have[j]) acc[(size_t)slot * (NR * 64) + (size_t)(rr0[j] + u) * 64 + lane] = 0ull;
+    }
+    // phase 2: fields -> bytes -> sums over the 16 lanes of a row, left by the row-end lanes in the unit's stage
+#pragma unroll
+    for (uint32_t j = 0; j < kMsUnits; ++j) {
+#pragma unroll
       for (int u = 0; u < 2; ++u) {
         const uint32_t A = (uint32_t)v[j][u], B = (uint32_t)(v[j][u] >> 32);
-        nz_u[j][u] = __builtin_amdgcn_ballot_w64((A | B) != 0u) != 0;
-        if (nz_u[j][u]) {
-          acc[(size_t)slot * (NR * 64) + (size_t)(rr0[j] + u) * 64 + lane] = 0ull;
-          uint32_t W[4] = {A & 0x0F0F0F0Fu, B & 0x0F0F0F0Fu, (A >> 4) & 0x0F0F0F0Fu, (B >> 4) & 0x0F0F0F0Fu};
+        uint32_t W[4] = {A & 0x0F0F0F0Fu, B & 0x0F0F0F0Fu, (A >> 4) & 0x0F0F0F0Fu, (B >> 4) & 0x0F0F0F0Fu};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {   // bytes <= 8 -> <= 128 over the 16 lanes of a row
-            W[e] += dpp_take<0x111>(W[e]);         // row_shr:1
-            W[e] += dpp_take<0x112>(W[e]);         // row_shr:2
-            W[e] += dpp_take<0x114>(W[e]);         // row_shr:4
-            W[e] += dpp_take<0x118>(W[e]);         // row_shr:8
-          }
-          if ((lane & 15) == 15) ((LdsU4*)stage[wib][j][u])[lane >> 4] = u32x4{W[0], W[1], W[2], W[3]};
-          any = true;
+        for (int e = 0; e < 4; ++e) {   // bytes <= 8 -> <= 128 over the 16 lanes of a row
+          W[e] += dpp_take<0x111>(W[e]);         // row_shr:1
+          W[e] += dpp_take<0x112>(W[e]);         // row_shr:2
+          W[e] += dpp_take<0x114>(W[e]);         // row_shr:4
+          W[e] += dpp_take<0x118>(W[e]);         // row_shr:8
         }
+        if ((lane & 15) == 15) ((LdsU4*)stage[wib][j][u])[lane >> 4] = u32x4{W[0], W[1], W[2], W[3]};
       }
     }
-    if (!any) return;   // (wave-uniform)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: its LDS operations execute in order)
     __builtin_amdgcn_wave_barrier();
     // phase 3: lane L: radius rr0 + (L >> 5), reference row L & 31 -- the row lies in half hh = bit 2 of the row index; the
@@ -370,13 +375,12 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     // phase 4: one 256-byte atomic per unit
 #pragma unroll
     for (uint32_t j = 0; j < kMsUnits; ++j) {
-      if (!(nz_u[j][0] | nz_u[j][1])) continue;   // (wave-uniform: nothing staged for this unit)
-      uint32_t c2 = ((lane >> 5) ? nz_u[j][1] : nz_u[j][0]) ? cnt2[j] : 0u;   // (a radius that was all zero staged nothing: stale bytes)
+      const uint32_t c2 = cnt2[j];
       const uint32_t t = entry_of(which[j]);
 #ifdef DC_MS_ABL_NOATOMIC
       if (c2 == 0xFFFFFFFFu)
 #else
-      if (c2 != 0u && rr0[j] + (uint32_t)(lane >> 5) < (uint32_t)n_rad && 32u * t + (uint32_t)(lane & 31) < CV.n_pos)
+      if (have[j] && c2 != 0u && rr0[j] + (uint32_t)(lane >> 5) < (uint32_t)n_rad && 32u * t + (uint32_t)(lane & 31) < CV.n_pos)
 #endif
         atomicAdd(&pops_pos[(size_t)t * (NR * 32) + (size_t)(rr0[j] + (lane >> 5)) * 32 + (uint32_t)(lane & 31)], c2);
     }
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
 #ifndef DC_MS_ABL_NOREDUCE
           if (i >= (uint32_t)kMsWin) {
             const uint32_t j = i - kMsWin;
-            reduce_window(j / kMsWin, [&](uint32_t k) { return entry(j + k); }, (uint32_t)kMsWin);
+            reduce_window(j / kMsWin, [&](uint32_t k) { return entry(j + k); }, (uint32_t)kMsWin, std::true_type{});
           }
 #endif
         }
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
       __syncthreads();   // every add of this round has landed
       {  // the last window
         const uint32_t n_win = (total + kMsWin - 1) / kMsWin, w = n_win - 1u, j = w * kMsWin;
-        reduce_window(w, [&](uint32_t k) { return entry(j + k); }, min((uint32_t)kMsWin, total - j));
+        reduce_window(w, [&](uint32_t k) { return entry(j + k); }, min((uint32_t)kMsWin, total - j), std::false_type{});
       }
       // (the skip test of this wave: worth its compare only where it finds something)
       if (wave_live && total >= 16u && skip_hits * 4u < (uint32_t)TQ * total) skip_thr_now = INFINITY;
