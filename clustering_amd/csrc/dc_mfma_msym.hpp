@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     }
   };
   // reduce the accumulators of a retired window: its (tile, pair of radii) units are dealt to the four waves;
-  // entry_of(k): the k-th reference tile of the window, n_tiles of them
+  // entry_of(k): the k-th reference tile of the window as it comes out of LDS (not yet a scalar), n_tiles of them
   const uint32_t my_byte = ref_credit_byte(lane);   // byte (of the 16 a row-end lane stages) with the count of reference row lane & 31
   // (round 6: the wave's units of a window -- up to kMsUnits = ceil(kMsWin * NR / 2 / 4) -- go through the reducer TOGETHER,
   //  phase by phase: all accumulator reads, then the byte sums, then the staged gather, then the atomics.  One unit after the
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     constexpr uint32_t kPairs = NR / 2;
     const uint32_t n_units = n_tiles * kPairs;
     unsigned long long v[kMsUnits][2];
-    uint32_t which[kMsUnits], rr0[kMsUnits];
+    uint32_t which[kMsUnits], rr0[kMsUnits], t_unit[kMsUnits];
     bool have[kMsUnits];
     // (no wave-level "is there anything?" tests: a workgroup's eight chains leave something inside nearly every radius of
     //  nearly every tile they reach, and a test is a compare, a scalar hand-off and a branch -- round 6, cycle stamps)
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
       have[j] = kFull || p < n_units;
       which[j] = have[j] ? p / kPairs : 0u;
       rr0[j] = have[j] ? 2u * (p % kPairs) : 0u;
+      t_unit[j] = entry_of(which[j]);   // (the LDS read; a scalar in phase 4)
       const uint32_t slot = (win & 1u) * kMsWin + which[j];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
 #pragma unroll
     for (uint32_t j = 0; j < kMsUnits; ++j) {
       const uint32_t c2 = cnt2[j];
-      const uint32_t t = entry_of(which[j]);
+      const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(t_unit[j]);
 #ifdef DC_MS_ABL_NOATOMIC
       if (c2 == 0xFFFFFFFFu)
 #else
@@ -423,14 +424,16 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     if (total != 0) {
       // (scalar arithmetic, no branches: the list of wave w starts at w * kShareSub, its entries are o_w .. o_{w+1} - 1 of the round)
       const uint32_t d21 = o2 - o1, d32 = o3 - o2;
-      auto entry = [&](uint32_t i) {
+      // (entry_raw: the LDS read alone -- issued where the index is known, made a scalar (v_readfirstlane, which waits for it)
+      //  where the tile number is needed: three dependent LDS round trips at the head of a window's fetch are one)
+      auto entry_raw = [&](uint32_t i) {
         i = min(i, total - 1u);
         const uint32_t g1 = 0u - (uint32_t)(i >= o1), g2 = 0u - (uint32_t)(i >= o2), g3 = 0u - (uint32_t)(i >= o3);   // 0 / ~0
         const uint32_t first = (o1 & g1) + (d21 & g2) + (d32 & g3);             // o_w
-        const uint32_t w_base = (uint32_t)kShareSub & g1;                         // w * kShareSub
-        const uint32_t idx = w_base + ((uint32_t)kShareSub & g2) + ((uint32_t)kShareSub & g3) + (i - first);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((&lists[0][0])[idx]);
+        const uint32_t idx = ((uint32_t)kShareSub & g1) + ((uint32_t)kShareSub & g2) + ((uint32_t)kShareSub & g3) + (i - first);
+        return (&lists[0][0])[idx];
       };
+      auto entry = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane(entry_raw(i)); };
       // the tiles of a window are fetched fragment-wise: the NM + 1 pieces of a tile (its MFMA fragments and its 32
       // row norms) go round the four waves
       // (branch-free: a tile beyond the end of the list is the list's last tile once more, into a slot nobody reads; the
@@ -438,10 +441,13 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
       //  lanes) or nothing, by lane predicate.  As a loop over all pieces with a wave-level test each, a window's fetch
       //  was 21 branches.)
       auto fetch_window = [&](uint32_t i0) {
+        uint32_t t_raw[kMsWin];
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)kMsWin; ++k) t_raw[k] = entry_raw(i0 + k);
 #pragma unroll
         for (uint32_t k = 0; k < (uint32_t)kMsWin; ++k) {
           const uint32_t i = i0 + k;
-          const uint32_t t = entry(i);
+          const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(t_raw[k]);
           const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(ring + (i % kMsRing) * kUnits));
           const uint4* src = img_r + (size_t)t * (NM * 64) + lane;
           const uint32_t m_a = ((uint32_t)__builtin_amdgcn_readfirstlane(wib) - k) & 3u;   // (wave-uniform: a scalar for M0)
@@ -475,11 +481,11 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
 #ifndef DC_MS_ABL_NOREDUCE
           if (i >= (uint32_t)kMsWin) {
             const uint32_t j = i - kMsWin;
-            reduce_window(j / kMsWin, [&](uint32_t k) { return entry(j + k); }, (uint32_t)kMsWin, std::true_type{});
+            reduce_window(j / kMsWin, [&](uint32_t k) { return entry_raw(j + k); }, (uint32_t)kMsWin, std::true_type{});
           }
 #endif
         }
-        const uint32_t t = entry(i);
+        const uint32_t t_raw = entry_raw(i);   // (made a scalar behind the first epilogue: nothing before it needs the tile's number)
         const uint4* slot = ring + (i % kMsRing) * kUnits;
         // (operands and accumulators are locals of the tile: kept alive across the reducer above -- as they are when
         //  the first chain of the next tile is started early -- they cost 16 - 44 spilled registers and 20 - 40 ms of 450)
@@ -504,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
             mr_chain_k<NM, NR, K0>(a, b[1], c0, acc1, acc0, P.dl, e);
           });
           keep_alive(c0);
+          const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(t_raw);
           finish(std::integral_constant<int, 0>{}, e, t);
           with_skip(skip_count(acc1), [&](auto k_c) {
             constexpr int K0 = decltype(k_c)::value;
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
       __syncthreads();   // every add of this round has landed
       {  // the last window
         const uint32_t n_win = (total + kMsWin - 1) / kMsWin, w = n_win - 1u, j = w * kMsWin;
-        reduce_window(w, [&](uint32_t k) { return entry(j + k); }, min((uint32_t)kMsWin, total - j), std::false_type{});
+        reduce_window(w, [&](uint32_t k) { return entry_raw(j + k); }, min((uint32_t)kMsWin, total - j), std::false_type{});
       }
       // (the skip test of this wave: worth its compare only where it finds something)
       if (wave_live && total >= 16u && skip_hits * 4u < (uint32_t)TQ * total) skip_thr_now = INFINITY;
