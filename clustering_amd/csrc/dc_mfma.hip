@@ -297,6 +297,7 @@ __global__ void scale_kernel(uint32_t* __restrict__ hdr, float r2max, uint32_t D
   hdr[kHdrMused] = __float_as_uint(M);
   hdr[kHdrOpen] = 0u;
   const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
+  hdr[kHdrShift] = 0u;   // (no in-place threshold shifts under this scale)
   hdr[kHdrScale + 0] = __float_as_uint(e.c);
   hdr[kHdrScale + 1] = __float_as_uint(e.s2);
   hdr[kHdrScale + 2] = (uint32_t)e.g;
@@ -1313,6 +1314,9 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
   // the counts by position of the one-radius symmetric per-wave sweep (the pq region): cleared by this call's preparation
   const bool pos_clean = prep && sink_in == nullptr && n_rad == 1 && !pop_shared_wanted(n_rows, n_cols, n_rad) &&
                          pop_sym_wanted(false, q_mode, q_seg, n_rows, n_rad) && tq <= 6u;
+  // the multi-radius symmetric sweep takes its thresholds off the accumulator in place, one MFMA per radius: the band of
+  // the scale has to pay for those steps (guard_shift; NR - 1 of them, NR = 4 or 8 radii per sweep)
+  const int shift_steps = (sink_in == nullptr && pop_multi_radius(n_rows, n_cols, n_rad)) ? (n_rad > 4 ? 7 : 3) : 0;
   if (prep) {
     // (round 5: the passes of dc_prep.hpp -- twelve launches for the thirty of rounds 3 - 4, same values)
     const uint32_t cookie = data_cookie(d_coords, n_rows, n_cols);
@@ -1334,7 +1338,7 @@ static void pop_pruned_one(const float* d_coords, uint32_t n_rows, uint32_t n_co
                        cnt_tab, 1, perm_p, tile_comp, 32u * T_r);
     // ... where the components start, the scale of the sweep (it follows the components' extents) ...
     hipLaunchKernelGGL(order_meta_kernel, dim3(1), dim3(1024), 0, stream, hdr, comp, (const uint32_t*)cnt_tab, kb_r, start_r, range_r,
-                       base_r, n_rows, group_rows, 1, fmaxf(r2_scale, 0.0f), n_cols);
+                       base_r, n_rows, group_rows, 1, fmaxf(r2_scale, 0.0f), n_cols, shift_steps);
     // ... the sort, whose last pass moves every component to a whole query group of the padded order ...
     {
       const SortRemap remap{start_r, base_r, (uint32_t)kMaxComp, tile_comp};

@@ -340,6 +340,7 @@ constexpr uint32_t kHdrMfmaPop = 6, kHdrMfmaNn = 26;
 constexpr uint32_t kHdrLayoutBad = 18;     // nn_block_unpack_kernel: the gathered blocks were packed under different layouts (nothing was unpacked)
 constexpr uint32_t kHdrStatsBlocks = 25;   // rows of stats_kernel's table that components_kernel has still to add up (dc_prep.hpp)
 constexpr int kMfmaCtrPop = (kHdrMfmaPop - 2) / 2, kMfmaCtrNn = (kHdrMfmaNn - 4) / 2;
+constexpr uint32_t kHdrShift = 32;      // population sweeps: the number of in-place threshold shifts the scale's band pays for (dc_mfma_msym.hpp; 0: none)
 constexpr uint32_t kHdrMloc = 29;       // pruned population sweeps: max |x - origin(component of x)|^2 (float bits, with a rounding margin)
 constexpr int kMidShiftPop = 6, kConstShiftPop = 6, kConstShiftNn = 15;
 constexpr float kThrCapPop = 1048576.0f;      // 2^20 (population scale: eps <= 1 keeps S r^2 below 2^19.2 and
@@ -442,23 +443,34 @@ __host__ __device__ inline GuardBand guard_band(float M, float thr, int D, const
   return gb;
 }
 
+// In-place threshold shifts of the multi-radius symmetric sweep (dc_mfma_msym.hpp): radius k's threshold is taken off the
+// accumulator by ONE MFMA, ones x (three fp16 pieces of -delta_k), steps of them in a row.  A step adds C and three exact
+// products: by the hardware fact of guard_e0 its four addends are truncated to q <= u max|addend| and the sum is rounded
+// once -- |error| <= (4 + 1/2) u max(|acc|, |delta|).  For a pair whose value at its own radius is within the band's
+// reach (|t| <= 2 + the error itself) every earlier accumulator value and every delta is <= span + 4 (span: the largest
+// difference between two scaled thresholds of the launch, here bounded by the largest one); pieces below 2^-14 are
+// stored as zero (subnormal MFMA inputs are not exact): 2^-14 per piece.  With the factor 1.25 of the other terms.
+__host__ __device__ inline double guard_shift(double span, int steps) {   // span: scaled
+  const double u = 5.9604644775390625e-8;
+  return (steps <= 0) ? 0.0 : 1.25 * steps * (4.5 * u * (span + 4.0) + 3.0 * ldexp(1.0, -14));
+}
 // population sweep: one band for all pairs with d2 up to the largest radius of the launch (scaled units)
-__host__ __device__ inline double guard_eps_pop(double M, double r2max, int D, int g, int a, int rounded) {
+__host__ __device__ inline double guard_eps_pop(double M, double r2max, int D, int g, int a, int rounded, int shift_steps = 0) {
   const double cap = (r2max > 0.0) ? r2max : 0.0;
-  return (guard_e0(M, r2max, D, g, a, rounded) + guard_kappa(D, rounded) * cap) * (1.0 + 1.2e-7);
+  return (guard_e0(M, r2max, D, g, a, rounded) + guard_kappa(D, rounded) * cap + guard_shift(cap, shift_steps)) * (1.0 + 1.2e-7);
 }
 
 // the population rule: the largest S with guard_eps_pop(S M, S r2max) <= 1 (M, r2max unscaled; r2max the largest
 // squared radius of the call, so that the images serve every radius of it).  Every term of the band grows at most
 // linearly with S, so S = 2^K / eps(2^K) is admissible when 2^K is; c = sqrt(S) rounded down, s2 = fl(c c).
-__host__ __device__ inline ScaleExp pick_scale_pop(float M_in, float r2_in, int D) {
+__host__ __device__ inline ScaleExp pick_scale_pop(float M_in, float r2_in, int D, int shift_steps = 0) {
   const double M = (M_in > 0.0f) ? (double)M_in : 0.0;
   const double r2 = (r2_in > 0.0f) ? (double)r2_in : 0.0;   // (+inf allowed)
   constexpr int kLo = -120, kHi = 120;
-  auto eps_at = [&](double S) { return guard_eps_pop(S * M, S * r2, D, kMidShiftPop, kConstShiftPop, 1); };
+  auto eps_at = [&](double S) { return guard_eps_pop(S * M, S * r2, D, kMidShiftPop, kConstShiftPop, 1, shift_steps); };
   int K = kHi;
   // eps(S) >= S * lin: an upper bound for K, lowered until the flush part fits as well (a step or two)
-  const double lin = (guard_e0_linear(M, r2, D, 1) + guard_kappa(D, 1) * r2) * (1.0 + 1.2e-7);
+  const double lin = (guard_e0_linear(M, r2, D, 1) + guard_kappa(D, 1) * r2 + (shift_steps > 0 ? 1.25 * shift_steps * 4.5 * 5.9604644775390625e-8 * r2 : 0.0)) * (1.0 + 1.2e-7);
   if (!(lin <= 1.7e308)) {
     K = kLo;
   } else if (lin > 0.0) {
@@ -3074,9 +3086,16 @@ void pop_pruned_launch(const float* coords, uint32_t n_rows, uint32_t n_cols, co
         // norms_s to vals_in of the workspace (the population sweeps leave them alone once the orders are built)
         uint32_t* pops_pos = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(P.norms_s));
         (void)hipMemsetAsync(pops_pos, 0, sizeof(uint32_t) * 32 * (size_t)T * NRV, s);
-        { sweep_timer_mark(0, true, s); hipLaunchKernelGGL((pop_msym_kernel<S, NRV>), grid_s, dim3(256), (msym_smem<S, NRV>()), s, coords, n_rows, n_cols,
+        // (two launches: the instance with the thresholds taken off the accumulator in place, and the one that subtracts on
+        //  the vector unit -- each looks at the scale and the radii and the one they do not ask for returns at once)
+        sweep_timer_mark(0, true, s);
+        hipLaunchKernelGGL((pop_msym_kernel<S, NRV, true>), grid_s, dim3(256), (msym_smem<S, NRV>()), s, coords, n_rows, n_cols,
                            P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
-                           chain_counter, rad2, n_rad, CV, pops_pos); sweep_timer_mark(0, false, s); }
+                           chain_counter, rad2, n_rad, CV, pops_pos);
+        hipLaunchKernelGGL((pop_msym_kernel<S, NRV, false>), grid_s, dim3(256), (msym_smem<S, NRV>()), s, coords, n_rows, n_cols,
+                           P.img_p, P.norms_p, P.box_p, P.coords_p, T, img_q, norms_q, perm_q, box_q, n_q, q_seg, P.hdr,
+                           chain_counter, rad2, n_rad, CV, pops_pos);
+        sweep_timer_mark(0, false, s);
         cross(4u * kTQS, pops_pos, (size_t)NRV, 2);
         hipLaunchKernelGGL((pops_by_frame_ms_kernel<NRV>), dim3((32 * T + 255) / 256), dim3(256), 0, s, (const uint32_t*)pops_pos,
                            P.perm_p, 32u * T, n_rows, n_rad, P.hdr, pops);

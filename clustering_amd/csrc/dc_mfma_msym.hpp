@@ -116,7 +116,9 @@ __device__ __forceinline__ void mr_chain_k(const s16x8 (&a)[NM], const s16x8 (&b
   }
 }
 
-template <int NM, int NR>
+// INPL: the instance that takes the thresholds off the accumulator in place (below).  Both instances are launched; which
+// one runs is decided on the device, from the scale and the radii (the other returns at once, like the gated direct kernel).
+template <int NM, int NR, bool INPL>
 __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     const float* __restrict__ coords, uint32_t n_rows, uint32_t n_cols,
     const uint4* __restrict__ img_r, const float* __restrict__ norms_r,
@@ -194,6 +196,48 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
     }
   };
 
+  // ---- thresholds taken off the accumulator IN PLACE (round 6) ------------------------------------------------------------
+  // Radius k's string needs the top two bits of acc - delta_k: 8 v_pk_add_f32 per radius and chain in front of the 16
+  // v_alignbit.  The matrix pipe is idle nine tenths of this sweep, and acc_k = acc_{k-1} - (delta_k - delta_{k-1}) is ONE
+  // MFMA: A = ones in the first three slots, B = three fp16 pieces of the (negated) step there, C = the accumulator.
+  // The two chains of a tile go through their radii in turn, so that the step of one runs under the 16 v_alignbit of the
+  // other.  What the steps cost in accuracy -- four truncated addends and one rounding each -- is part of the band the
+  // scale was chosen for (guard_shift, kHdrShift); a launch whose steps the band does not cover, or whose steps do not
+  // fit fp16, keeps the subtractions on the vector unit.
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const uint32_t m32 = (lane < 32) ? 0xFFFFFFFFu : 0u;   // (the first eight K slots are the first half-wave's)
+  uint32_t sh0[NR + 1], sh1[NR + 1];   // [k]: radius k-1 -> k (k >= 1); [NR]: radius 0 -> kMsSkip<NR>
+  bool inplace = hdr[kHdrShift] >= (uint32_t)(NR - 1);
+  {
+    auto pieces = [&](float x, uint32_t& w0, uint32_t& w1) {
+      auto fz = [](_Float16 v) { return (fabsf((float)v) < 6.103515625e-5f) ? (_Float16)0.0f : v; };   // (below 2^-14: stored as zero)
+      const _Float16 p0 = fz((_Float16)x);
+      const float r1 = x - (float)p0;
+      const _Float16 p1 = fz((_Float16)r1);
+      const _Float16 p2 = fz((_Float16)(r1 - (float)p1));
+      w0 = (uint32_t)__builtin_bit_cast(unsigned short, p0) | ((uint32_t)__builtin_bit_cast(unsigned short, p1) << 16);
+      w1 = (uint32_t)__builtin_bit_cast(unsigned short, p2);
+      return fabsf(x) < 60000.0f;
+    };
+    sh0[0] = sh1[0] = 0u;
+#pragma unroll
+    for (int k = 1; k <= NR; ++k) {
+      uint32_t w0, w1;
+      // (radii the call does not use -- squared radius -1 -- repeat the string of the last one that it does: no step;
+      //  their counts are never read and their bands are its bands)
+      const float step = (k == NR) ? -P.dl.d[kMsSkip<NR>] : ((k < n_rad) ? -(P.dl.d[k] - P.dl.d[k - 1]) : 0.0f);
+      inplace &= pieces(step, w0, w1);
+      sh0[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0);
+      sh1[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w1);
+    }
+  }
+#ifdef DC_MS_NO_INPLACE
+  inplace = false;
+#endif
+  if (inplace != INPL) return;   // (the other instance's launch; before any barrier)
+  const s16x8 ones_op = __builtin_bit_cast(s16x8, u32x4_t{0x3C003C00u & m32, 0x00003C00u & m32, 0u, 0u});
+  auto shift_op = [&](int k) { return __builtin_bit_cast(s16x8, u32x4_t{sh0[k] & m32, sh1[k] & m32, 0u, 0u}); };
+  uint32_t shifts = 0;   // MFMAs issued for the steps (the executed-flop figure of the bench line counts them)
   for (uint32_t k = tid; k < (uint32_t)(kMsAccSlots * NR * 64); k += 256) acc[k] = 0ull;
   if (tid < 2) flush_flag[tid] = 0u;
 
@@ -325,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
 #pragma unroll
     for (uint32_t j = 0; j < kMsUnits; ++j) {
       const uint32_t p = (uint32_t)wib + 4u * j;
-      have[j] = kFull || p < n_units;
+      // (kFull and a unit count that is a multiple of the four waves: every slot of every wave holds a unit)
+      have[j] = (kFull && (kMsWin * kPairs) % 4u == 0u) || p < n_units;
       which[j] = have[j] ? p / kPairs : 0u;
       rr0[j] = have[j] ? 2u * (p % kPairs) : 0u;
       t_unit[j] = entry_of(which[j]);   // (the LDS read; a scalar in phase 4)
@@ -433,7 +478,6 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
         const uint32_t idx = ((uint32_t)kShareSub & g1) + ((uint32_t)kShareSub & g2) + ((uint32_t)kShareSub & g3) + (i - first);
         return (&lists[0][0])[idx];
       };
-      auto entry = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane(entry_raw(i)); };
       // the tiles of a window are fetched fragment-wise: the NM + 1 pieces of a tile (its MFMA fragments and its 32
       // row norms) go round the four waves
       // (branch-free: a tile beyond the end of the list is the list's last tile once more, into a slot nobody reads; the
@@ -504,20 +548,50 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
           chains += TQ;
           f32x16 acc0 = gram_chain<NM>(a, b[0], c0), acc1;
           MrAcc<NR> e;
-          with_skip(skip_count(acc0), [&](auto k_c) {
-            constexpr int K0 = decltype(k_c)::value;
-            mr_begin_k<NR, K0>(e);
-            mr_chain_k<NM, NR, K0>(a, b[1], c0, acc1, acc0, P.dl, e);
-          });
-          keep_alive(c0);
-          const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane(t_raw);
-          finish(std::integral_constant<int, 0>{}, e, t);
-          with_skip(skip_count(acc1), [&](auto k_c) {
-            constexpr int K0 = decltype(k_c)::value;
-            mr_begin_k<NR, K0>(e);
-            mr_epi_k<NR, K0, 0, 16>(acc1, P.dl, e);
-          });
-          finish(std::integral_constant<int, 1>{}, e, t);
+          uint32_t t;
+          if constexpr (INPL) {
+            acc1 = gram_chain<NM>(a, b[1], c0);
+            keep_alive(c0);
+            MrAcc<NR> e1;
+            const int k0 = skip_count(acc0), k1 = skip_count(acc1);
+            with_skip(min(k0, k1), [&](auto k_c) {   // (one decision for the tile: the radii BOTH chains hold nothing of)
+              constexpr int K0 = decltype(k_c)::value;
+              mr_begin_k<NR, K0>(e);
+              mr_begin_k<NR, K0>(e1);
+              if constexpr (K0 > 0) {
+                acc0 = mfma16(ones_op, shift_op(NR), acc0);
+                acc1 = mfma16(ones_op, shift_op(NR), acc1);
+              }
+#pragma unroll
+              for (int rr = K0; rr < NR; ++rr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e.bits[rr] = __builtin_amdgcn_alignbit(e.bits[rr], __float_as_uint(acc0[r]), 30);
+                if (rr + 1 < NR) acc0 = mfma16(ones_op, shift_op(rr + 1), acc0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e1.bits[rr] = __builtin_amdgcn_alignbit(e1.bits[rr], __float_as_uint(acc1[r]), 30);
+                if (rr + 1 < NR) acc1 = mfma16(ones_op, shift_op(rr + 1), acc1);
+              }
+              shifts += 2u * (uint32_t)(NR - 1 - K0 + (K0 > 0 ? 1 : 0));
+            });
+            t = (uint32_t)__builtin_amdgcn_readfirstlane(t_raw);
+            finish(std::integral_constant<int, 0>{}, e, t);
+            finish(std::integral_constant<int, 1>{}, e1, t);
+          } else {
+            with_skip(skip_count(acc0), [&](auto k_c) {
+              constexpr int K0 = decltype(k_c)::value;
+              mr_begin_k<NR, K0>(e);
+              mr_chain_k<NM, NR, K0>(a, b[1], c0, acc1, acc0, P.dl, e);
+            });
+            keep_alive(c0);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane(t_raw);
+            finish(std::integral_constant<int, 0>{}, e, t);
+            with_skip(skip_count(acc1), [&](auto k_c) {
+              constexpr int K0 = decltype(k_c)::value;
+              mr_begin_k<NR, K0>(e);
+              mr_epi_k<NR, K0, 0, 16>(acc1, P.dl, e);
+            });
+            finish(std::integral_constant<int, 1>{}, e, t);
+          }
 #ifndef DC_MS_ABL_NOCREDIT
           if ((t / (4u * TQ)) != group)   // (not the workgroup's own group)
 #else
@@ -540,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void pop_msym_kernel(
   }
   if (lane == 0 && chain_counter && wave_live) {
     atomicAdd(chain_counter, (unsigned long long)chains);
-    atomicAdd(chain_counter + kMfmaCtrPop, (unsigned long long)chains * NM);
+    atomicAdd(chain_counter + kMfmaCtrPop, (unsigned long long)chains * NM + shifts);
   }
   flush();
 

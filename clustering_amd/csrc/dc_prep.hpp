@@ -481,7 +481,8 @@ __global__ __launch_bounds__(1024) void order_meta_kernel(uint32_t* __restrict__
                                                          uint32_t* __restrict__ start /* [kMaxComp + 1] */,
                                                          uint32_t* __restrict__ range /* [kMaxComp + 1][2] */,
                                                          uint32_t* __restrict__ base /* [kMaxComp + 1] */, uint32_t n,
-                                                         uint32_t group_rows, int do_scale, float r2max, uint32_t D) {
+                                                         uint32_t group_rows, int do_scale, float r2max, uint32_t D,
+                                                         int shift_steps = 0) {
   __shared__ uint32_t part[16][kMaxComp];
   __shared__ uint32_t cnt[kMaxComp];
   {
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(1024) void order_meta_kernel(uint32_t* __restrict__
     if (comp[kCompGrid + 5] > 1u) M = fminf(__uint_as_float(hdr[kHdrMloc]), fmaxf(M, 0.0f) * 4.0f + FLT_MIN);
     hdr[kHdrMused] = __float_as_uint(M);
     hdr[kHdrOpen] = 0u;
-    const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D);
+    const ScaleExp e = (r2max < 0.0f) ? pick_scale_nn(M) : pick_scale_pop(M, r2max, (int)D, shift_steps);
+    hdr[kHdrShift] = (r2max < 0.0f) ? 0u : (uint32_t)shift_steps;   // (what the band of this scale pays for: dc_mfma_msym.hpp)
     hdr[kHdrScale + 0] = __float_as_uint(e.c);
     hdr[kHdrScale + 1] = __float_as_uint(e.s2);
     hdr[kHdrScale + 2] = (uint32_t)e.g;

@@ -454,6 +454,62 @@ int main() {
   const int bad_credit = run_credit<2>(40) + run_credit<4>(40) + run_credit<6>(40);
   printf("reference-side reduction of the symmetric sweep (2, 4, 6 strings): violations %d\n", bad_credit);
   bad += bad_credit;
+  // ---- (5) thresholds taken off the accumulator in place (dc_mfma_msym.hpp): `steps` MFMAs of ones x (three fp16 pieces of
+  //      -delta) on accumulators whose FINAL value lies near the band; bound = guard_shift without its factor 1.25
+  {
+    int bad_shift = 0;
+    double worst_shift = 0;
+    for (int trial = 0; trial < 400; ++trial) {
+      const int steps = (trial & 1) ? 7 : 3;
+      const float span = ldexpf(1.0f + (rand() & 1023) / 1024.0f, 2 + rand() % 14);   // 4 ... 65 000 scaled units
+      float delta[8];
+      double sum = 0;
+      for (int k = 0; k < steps; ++k) {
+        delta[k] = span * (0.02f + (rand() & 1023) / 1024.0f) / (float)steps;
+        if (trial % 5 == 0 && k == 1) delta[k] = -delta[k];   // (radii in any order)
+      }
+      // pieces exactly as the kernel forms them
+      unsigned short pc[8][3];
+      double held[8];
+      for (int k = 0; k < steps; ++k) {
+        const float x = -delta[k];
+        auto fz = [](float v) { return fabsf(v) < 6.103515625e-5f ? 0.0f : v; };
+        const float p0 = fz(bf2f(f2bf(x)));
+        const float r1 = x - p0;
+        const float p1 = fz(bf2f(f2bf(r1)));
+        const float p2 = fz(bf2f(f2bf(r1 - p1)));
+        pc[k][0] = f2bf(p0); pc[k][1] = f2bf(p1); pc[k][2] = f2bf(p2);
+        held[k] = (double)p0 + (double)p1 + (double)p2;
+        sum += (double)x;
+      }
+      for (auto& v : C) v = (float)(-sum) + 8.0f * ((rand() & 0xffff) / 65536.0f - 0.5f);   // final value in [-4, 4)
+      std::vector<float> C0 = C;
+      for (int r = 0; r < 32; ++r)
+        for (int k = 0; k < 16; ++k) A[r * 16 + k] = f2bf(k < 3 ? 1.0f : 0.0f);
+      for (int k = 0; k < steps; ++k) {
+        for (int kk = 0; kk < 16; ++kk)
+          for (int j = 0; j < 32; ++j) B[kk * 32 + j] = (kk < 3) ? pc[k][kk] : f2bf(0.0f);
+        CHECK(hipMemcpy(dA, A.data(), 1024, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dB, B.data(), 1024, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dC, C.data(), 4096, hipMemcpyHostToDevice));
+        one_mfma<<<1, 64>>>(dA, dB, dC, dD);
+        CHECK(hipMemcpy(C.data(), dD, 4096, hipMemcpyDeviceToHost));
+      }
+      const double u = ldexp(1.0, -24);
+      double span_abs = 0, run = 0, run_max = 0;
+      for (int k = 0; k < steps; ++k) { run += fabs((double)delta[k]); run_max = run; }
+      span_abs = run_max;
+      const double bound = steps * (4.5 * u * (span_abs + 4.0) + 3.0 * ldexp(1.0, -14));
+      for (int e = 0; e < 1024; ++e) {
+        const double err = fabs((double)C[e] - ((double)C0[e] + sum));
+        if (err / bound > worst_shift) worst_shift = err / bound;
+        if (err > bound) ++bad_shift;
+      }
+      (void)held;
+    }
+    printf("in-place threshold shifts (3 and 7 steps): worst error / bound = %.3f, violations %d\n", worst_shift, bad_shift);
+    bad += bad_shift;
+  }
   const bool ok = failures == 0 && bad == 0;
   printf("%s\n", ok ? "OK" : "FAILED");
   return ok ? 0 : 1;

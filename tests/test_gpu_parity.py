@@ -641,6 +641,57 @@ def test_shared_operand_population_sweep():
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stderr[-3000:])
 
 
+INPLACE_CHILD = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from clustering_amd import density as dens
+from clustering_amd.synth import gaussian_blobs
+from oracle.oracle import Oracle
+oracle = Oracle()
+seen = set()
+for n, d, radii, in_place in [(7000, 30, [0.40, 0.45, 0.50, 0.55, 0.60], True),          # steps of a few thousand scaled units
+                              (7000, 30, [0.55, 0.40, 0.60, 0.45], True),                # any order: steps of either sign
+                              # (a step is at most S r2max, and the band holds that near 6.5e4 / 7.9e4 / 1.0e5 scaled units at
+                              #  6 / 5 / 4 MFMAs per chain: only a radius far beyond the others AND the data's extent leaves fp16)
+                              (5000, 24, [0.05, 3.0], False),
+                              (4097, 17, [0.05, 3.0, 0.5], False),
+                              (7000, 30, [0.30, 0.35, 0.40, 0.45, 0.50, 0.55, 0.60, 2.5], True),
+                              (5000, 24, [0.30, 0.40, 0.50], True), (3000, 40, [0.5, 0.6, 0.7, 0.8, 0.9, 1.0, 1.1, 1.2], True)]:
+    c = gaussian_blobs(n, d, seed=3 * n + d)
+    c[: n // 7] = c[n // 2: n // 2 + n // 7]            # duplicates: pairs at distance 0, inside every radius
+    ct = torch.from_numpy(c).cuda()
+    got = dens.calculate_populations_partial(ct, radii, variant="pruned")
+    tiles, issued = dens.evaluated_tiles(ct.device)[0], dens.issued_mfmas(ct.device)[0]
+    nm = (3 * d + 2 + 15) // 16
+    assert (issued > tiles * nm) == in_place, (n, d, radii, tiles * nm, issued)   # the steps are MFMAs the kernel counts
+    seen.add(issued > tiles * nm)
+    want = oracle.populations(c, radii)
+    assert (got.cpu().numpy().astype(np.uint32).astype(np.uint64) == want).all(), (n, d, radii)
+    acc = torch.zeros_like(got)
+    for g in range(3):
+        acc += dens.calculate_populations_segment(ct, radii, g, 3)
+    assert (acc.cpu().numpy().astype(np.uint32).astype(np.uint64) == want).all(), (n, d, radii, "segments")
+assert seen == {True, False}
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_multi_radius_thresholds_in_place_and_on_the_vector_unit():
+    """The symmetric multi-radius sweep takes the thresholds of radii 1 .. off the accumulator by one MFMA each (ones x
+    fp16 pieces of the step; the band of the scale pays for the steps: guard_shift) -- unless a step does not fit fp16,
+    then the instance that subtracts on the vector unit runs.  Both against the oracle, all rows and segment sums; which
+    instance ran is read off the kernel's own count of issued MFMAs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", INPLACE_CHILD, root], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, DC_POP_SHARED="1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+
+
 NN_SHARED_CHILD = r"""
 import sys
 import numpy as np, torch
