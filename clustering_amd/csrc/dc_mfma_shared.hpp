@@ -315,13 +315,20 @@ __global__ __launch_bounds__(256, 2) void pop_shared_kernel(
     }
     if (lane == 0) list_cnt[wib] = cnt;
     __syncthreads();
-    const uint32_t o1 = list_cnt[0], o2 = o1 + list_cnt[1], o3 = o2 + list_cnt[2], total = o3 + list_cnt[3];
+    // (wave-uniform values held in scalar registers, the survivor list addressed by scalar arithmetic: as compares and
+    //  selects on what an LDS read returned this was four or five branches per call -- dc_mfma_msym.hpp, round 6)
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[0]);
+    const uint32_t o2 = o1 + (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[1]);
+    const uint32_t o3 = o2 + (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[2]);
+    const uint32_t total = o3 + (uint32_t)__builtin_amdgcn_readfirstlane((int)list_cnt[3]);
     if (total != 0) {
+      const uint32_t d21 = o2 - o1, d32 = o3 - o2;
       auto entry = [&](uint32_t i) {
-        i = i < total ? i : total - 1;
-        const uint32_t w = (i >= o1 ? 1u : 0u) + (i >= o2 ? 1u : 0u) + (i >= o3 ? 1u : 0u);
-        const uint32_t off = i - (w == 0 ? 0u : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
-        return (uint32_t)__builtin_amdgcn_readfirstlane(lists[w][off]);
+        i = min(i, total - 1u);
+        const uint32_t g1 = 0u - (uint32_t)(i >= o1), g2 = 0u - (uint32_t)(i >= o2), g3 = 0u - (uint32_t)(i >= o3);   // 0 / ~0
+        const uint32_t first = (o1 & g1) + (d21 & g2) + (d32 & g3);             // o_w: where the list of wave w starts in the round
+        const uint32_t idx = ((uint32_t)kShareSub & g1) + ((uint32_t)kShareSub & g2) + ((uint32_t)kShareSub & g3) + (i - first);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((&lists[0][0])[idx]);
       };
       // reference tile t -> ring slot, by this wave alone: NM fragments of 1 KB (lane l lands at +16 l) and the
       // 32 row norms (lanes 0..7)
