@@ -448,11 +448,13 @@ __host__ __device__ inline GuardBand guard_band(float M, float thr, int D, const
 // products: by the hardware fact of guard_e0 its four addends are truncated to q <= u max|addend| and the sum is rounded
 // once -- |error| <= (4 + 1/2) u max(|acc|, |delta|).  For a pair whose value at its own radius is within the band's
 // reach (|t| <= 2 + the error itself) every earlier accumulator value and every delta is <= span + 4 (span: the largest
-// difference between two scaled thresholds of the launch, here bounded by the largest one); pieces below 2^-14 are
-// stored as zero (subnormal MFMA inputs are not exact): 2^-14 per piece.  With the factor 1.25 of the other terms.
+// difference between two scaled thresholds of the launch, here bounded by the largest one); the steps themselves are
+// float differences of float deltas (two roundings, <= u span each step: the thresholds the steps add up to are that far
+// from the ones the exact path compares with); pieces below 2^-14 are stored as zero (subnormal MFMA inputs are not
+// exact): 2^-14 per piece.  With the factor 1.25 of the other terms.
 __host__ __device__ inline double guard_shift(double span, int steps) {   // span: scaled
   const double u = 5.9604644775390625e-8;
-  return (steps <= 0) ? 0.0 : 1.25 * steps * (4.5 * u * (span + 4.0) + 3.0 * ldexp(1.0, -14));
+  return (steps <= 0) ? 0.0 : 1.25 * steps * (5.5 * u * (span + 4.0) + 3.0 * ldexp(1.0, -14));
 }
 // population sweep: one band for all pairs with d2 up to the largest radius of the launch (scaled units)
 __host__ __device__ inline double guard_eps_pop(double M, double r2max, int D, int g, int a, int rounded, int shift_steps = 0) {
@@ -470,7 +472,7 @@ __host__ __device__ inline ScaleExp pick_scale_pop(float M_in, float r2_in, int 
   auto eps_at = [&](double S) { return guard_eps_pop(S * M, S * r2, D, kMidShiftPop, kConstShiftPop, 1, shift_steps); };
   int K = kHi;
   // eps(S) >= S * lin: an upper bound for K, lowered until the flush part fits as well (a step or two)
-  const double lin = (guard_e0_linear(M, r2, D, 1) + guard_kappa(D, 1) * r2 + (shift_steps > 0 ? 1.25 * shift_steps * 4.5 * 5.9604644775390625e-8 * r2 : 0.0)) * (1.0 + 1.2e-7);
+  const double lin = (guard_e0_linear(M, r2, D, 1) + guard_kappa(D, 1) * r2 + (shift_steps > 0 ? 1.25 * shift_steps * 5.5 * 5.9604644775390625e-8 * r2 : 0.0)) * (1.0 + 1.2e-7);
   if (!(lin <= 1.7e308)) {
     K = kLo;
   } else if (lin > 0.0) {
