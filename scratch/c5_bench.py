@@ -61,8 +61,9 @@ line = {
                            "nn": nn_tiles * 1024.0 / (float(rows) * n),
                            "full sweep": full_tiles * 1024.0 / (float(n) * n)},
     "roofline_pop": roof(pop_tiles, pop_mfma, pop_ms), "roofline_nn": roof(nn_tiles, nn_mfma, nn_ms),
-    "note_pop": "eight radii in ONE symmetric sweep (pop_msym_kernel<6, 8>): every unordered tile pair once for all radii, both "
-                "frames credited; the time is the per-radius epilogue (~300 VALU instructions per tile pair), not the matrix pipe",
+    "note_pop": "eight radii in ONE symmetric sweep (pop_msym_kernel<6, 8, in place>): every unordered tile pair once for all radii, both "
+                "frames credited, the thresholds of radii 1..7 taken off the accumulator by rank-1 MFMAs (mfma_issued counts them); the time "
+                "is the per-radius epilogue and the reference-side bookkeeping (~250 vector instructions per tile pair), not the matrix pipe",
     "hbm_model": {"Q_res": rows, "note": "all query rows of the rank are resident in one launch (TQ*32 per wave, every wave "
                   "streams the surviving reference tiles), so the streamed model of SURVEY 8(d) is one pass over the coordinates",
                   "algorithmic_bytes_per_sweep": n * d * 4 + rows * 16,
